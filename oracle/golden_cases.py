@@ -1,0 +1,53 @@
+"""TEST INFRASTRUCTURE (oracle) -- shared definition of the golden-fixture cases.
+
+Used by oracle/make_golden.py (runs the REAL reference FlashDiffusion, build container only)
+and by the tests that replay the fixtures (oracle restatement on CPU; HIP path on the GPU)."""
+from __future__ import annotations
+
+import copy
+
+import numpy as np
+import torch
+
+from .sched_cpu import DDPMSchedulerRef, DPMSolverMultistepSchedulerRef
+from .unet_cpu import UNet2DConditionRef, make_discriminator, seeded_init_, tiny_config
+
+LORA_RANK = 8
+SCHEDS = {"dpm": DPMSolverMultistepSchedulerRef, "ddpm": DDPMSchedulerRef}
+
+CASES = {
+    # name: (config kwargs, scheduler, step, seed)
+    "g_dmd_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform",
+                         distill_loss_type="l2", gan_loss_type="lsgan", use_dmd_loss=True,
+                         guidance_scale_min=3.0, guidance_scale_max=13.0,
+                         dmd_loss_scale=0.3, adversarial_loss_scale=0.1), "dpm", 0, 11),
+    "d_hinge": (dict(K=[8], num_iterations_per_K=[10], timestep_distribution="mixture",
+                     distill_loss_type="l1", gan_loss_type="hinge", use_dmd_loss=False,
+                     mixture_num_components=4, mixture_var=0.5,
+                     mode_probs=[[0.1, 0.3, 0.3, 0.3]]), "dpm", 1, 12),
+    "g_nonsat_teacher_real": (dict(K=[6], num_iterations_per_K=[10], timestep_distribution="gaussian",
+                                   distill_loss_type="l2", gan_loss_type="non-saturating",
+                                   use_dmd_loss=True, use_teacher_as_real=True), "dpm", 0, 13),
+    "g_noreg_vanilla": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform",
+                             distill_loss_scale=0.0, gan_loss_type="vanilla"), "dpm", 0, 14),
+}
+
+
+def build_models(unet_cfg=None, lora_rank=LORA_RANK, disc_kw=None):
+    unet_cfg = unet_cfg or tiny_config()
+    teacher = seeded_init_(UNet2DConditionRef(unet_cfg), 1)
+    student = copy.deepcopy(teacher)
+    student.add_adapter(lora_rank)
+    seeded_init_(student, 2)
+    student.load_state_dict(dict(teacher.state_dict()), strict=False)
+    teacher.freeze()
+    disc_kw = disc_kw or dict(kind="sd15", color_dim=unet_cfg.block_out_channels[-1], feat=16, last_k=2)
+    disc = seeded_init_(make_discriminator(**disc_kw), 3)
+    return teacher, student, disc
+
+
+def make_batch(B=2, hw=32, ctx_dim=64, seed=5):
+    rs = np.random.RandomState(seed)
+    z = torch.from_numpy(rs.standard_normal((B, 4, hw, hw)).astype(np.float32))
+    c = torch.from_numpy(rs.standard_normal((B, 77, ctx_dim)).astype(np.float32))
+    return {"image": z, "crossattn": c, "text": ["a"] * B}

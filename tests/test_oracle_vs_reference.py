@@ -1,0 +1,76 @@
+"""Pins oracle/flash_ref.py against the reference's OWN FlashDiffusion (imported unmodified
+from /root/reference/src via oracle/shim_import.py).  Skipped where the reference is absent
+(the GPU box); there tests/golden/*.npz (made by the real reference) carry the pin."""
+import copy
+
+import pytest
+import torch
+
+from oracle import shim_import
+from oracle.flash_ref import FlashConfigRef, FlashDiffusionRef, TensorConditioner
+from oracle.sched_cpu import DDPMSchedulerRef, DPMSolverMultistepSchedulerRef
+from oracle.unet_cpu import UNet2DConditionRef, make_discriminator, seeded_init_, tiny_config
+
+pytestmark = pytest.mark.skipif(not shim_import.reference_available(), reason="reference absent")
+
+
+def _build(cls, cfg_cls, sched_cls, **cfg_kw):
+    torch.manual_seed(0)
+    teacher = seeded_init_(UNet2DConditionRef(tiny_config()), 1)
+    student = copy.deepcopy(teacher)
+    student.add_adapter(8)
+    seeded_init_(student, 2)
+    student.load_state_dict({k: v for k, v in teacher.state_dict().items()}, strict=False)
+    teacher.freeze()
+    disc = seeded_init_(make_discriminator("sd15", color_dim=64, feat=16, last_k=2), 3)
+    cfg = cfg_cls(**cfg_kw)
+    m = cls(cfg, student_denoiser=student, teacher_denoiser=teacher,
+            teacher_noise_scheduler=sched_cls(), conditioner=TensorConditioner(), discriminator=disc)
+    return m
+
+
+def _batch():
+    g = torch.Generator().manual_seed(5)
+    return {"image": torch.randn(2, 4, 32, 32, generator=g),
+            "crossattn": torch.randn(2, 77, 64, generator=g), "text": ["a", "b"]}
+
+
+CASES = [
+    dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="l2",
+         gan_loss_type="lsgan", use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=13.0),
+    dict(K=[8], num_iterations_per_K=[10], timestep_distribution="mixture", distill_loss_type="l1",
+         gan_loss_type="hinge", use_dmd_loss=False, mixture_num_components=4, mixture_var=0.5,
+         mode_probs=[[0.1, 0.3, 0.3, 0.3]]),
+    dict(K=[6], num_iterations_per_K=[10], timestep_distribution="gaussian", distill_loss_type="l2",
+         gan_loss_type="non-saturating", use_dmd_loss=True, use_teacher_as_real=True),
+    dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="wgan"),
+    dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="vanilla"),
+]
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+@pytest.mark.parametrize("step", [0, 1])
+@pytest.mark.parametrize("sched", [DPMSolverMultistepSchedulerRef, DDPMSchedulerRef])
+def test_restatement_is_bit_identical(case, step, sched):
+    FD, FDC = shim_import.import_reference()
+    kw = CASES[case]
+    ref = _build(FD, FDC, sched, **kw)
+    ora = _build(FlashDiffusionRef, FlashConfigRef, sched, **kw)
+    outs = []
+    for m in (ref, ora):
+        torch.manual_seed(1234 + case)
+        out = m(_batch(), step=step, device="cpu")
+        loss = out["loss"][step]
+        loss.backward()
+        grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+        outs.append((out, grads))
+    (o1, g1), (o2, g2) = outs
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert torch.equal(o1[k], o2[k]), k
+    assert o1["start_timestep"] == o2["start_timestep"]
+    for i in (0, 1):
+        a, b = o1["loss"][i], o2["loss"][i]
+        assert float(a) == float(b)
+    assert set(g1) == set(g2) and len(g1) > 0
+    for n in g1:
+        assert torch.equal(g1[n], g2[n]), n
