@@ -1,0 +1,95 @@
+"""ctypes binding of libfdmi.so (include/fdmi.h).  Fails loudly when the library is missing --
+there is deliberately no fallback path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfdmi.so")
+_lib = None
+
+i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", i32), ("N", i32), ("K", i32),
+        ("A", vp), ("lda", i64), ("W", vp), ("ldw", i64),
+        ("mode", i32),
+        ("Hin", i32), ("Win", i32), ("Cin", i32), ("Hout", i32), ("Wout", i32), ("KH", i32), ("KW", i32),
+        ("stride", i32), ("pad", i32), ("ups", i32), ("dgrad", i32),
+        ("bias", vp),
+        ("rowvec", vp), ("rowvec_ld", i64), ("rows_per_batch", i32),
+        ("residual", vp), ("ldr", i64),
+        ("act", i32),
+        ("preact", vp), ("ldp", i64),
+        ("C", vp), ("ldc", i64), ("out_f32", i32),
+        ("alpha", f32),
+        ("splitk", i32), ("ws", vp),
+        ("accum_atomic", i32), ("force_tile", i32), ("use_glds", i32),
+    ]
+
+
+_SIGS = {
+    "fdmi_version": (i32, []),
+    "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),
+    "fdmi_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "fdmi_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "fdmi_layernorm_fwd": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
+    "fdmi_layernorm_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32, i32, vp]),
+    "fdmi_attn_tr_elems": (i64, [i32, i32, i32, i32]),
+    "fdmi_attn_bwd_ws_bytes": (i64, [i32, i32, i32, i32, i32]),
+    "fdmi_attn_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp]),
+    "fdmi_attn_bwd": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i64, vp, i64, vp, i64, vp,
+                            i32, i32, i32, i32, i32, f32, vp]),
+    "fdmi_nchw_to_nhwc": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "fdmi_nhwc_to_nchw": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    "fdmi_timestep_embed": (i32, [vp, vp, i32, i32, i32, f32, vp]),
+    "fdmi_geglu_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
+    "fdmi_pool2x2_sum": (i32, [vp, vp, i32, i32, i32, i32, i32, vp]),
+    "fdmi_cast_transpose": (i32, [vp, vp, vp, i32, i32, vp]),
+    "fdmi_transpose2d": (i32, [vp, i64, vp, i64, i64, i32, vp]),
+    "fdmi_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
+    "fdmi_add_noise": (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),
+    "fdmi_axpby4": (i32, [vp, f32, vp, f32, vp, f32, vp, f32, vp, i64, vp]),
+}
+# extended lazily by unet.py for the plan API
+EXTRA_SIGS = {}
+
+
+def declared_symbols():
+    return sorted(list(_SIGS) + list(EXTRA_SIGS) + ["fdmi_last_error"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(make -C flash_diffusion_amd/csrc). There is no fallback path.")
+        l = C.CDLL(LIB_PATH)
+        l.fdmi_last_error.restype = C.c_char_p
+        l.fdmi_last_error.argtypes = []
+        for name, (res, args) in list(_SIGS.items()) + list(EXTRA_SIGS.items()):
+            fn = getattr(l, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise RuntimeError("fdmi: " + lib().fdmi_last_error().decode())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t):
+    """device pointer of a torch tensor (or None)"""
+    return None if t is None else C.c_void_p(t.data_ptr())

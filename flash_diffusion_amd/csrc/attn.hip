@@ -1,0 +1,647 @@
+// Fused (flash-style) attention for gfx950: forward, dQ and dK/dV kernels, MFMA 16x16x32 bf16.
+//
+// Layout: Q/K/V/O are token-major [B, S, H*d] (the GEMM outputs, no permutes); the PV-type products
+// contract over the sequence index, so their "row" operand comes from head-transposed copies
+// XT[B,H,dvpad,spad] (zero padded) written by transpose_heads_kernel.
+//
+// The score product is computed SWAPPED (S^T = K Q^T) so that a lane owns one query column:
+// lane (g = lane>>4, j = lane&15) of fragment (kf, qf) holds S^T[kv = 16kf+4g+r][q = 16qf+j].
+// Row max / row sum then need only two cross-lane steps (xor 16, 32) and the probabilities feed
+// the second MFMA straight from registers as its B operand (k index 8g+i <-> kv = 32s+4g+i for
+// i<4, 32s+16+4g+(i-4) otherwise; the A operand applies the same permutation when it reads X^T).
+// K/V tiles (64 keys) are staged through LDS with 16-B padded rows (conflict-free ds_read_b128),
+// prefetched into registers one tile ahead so the HBM latency hides under the MFMAs.
+#include "ops.h"
+
+namespace {
+
+constexpr int KVB = 64;           // keys per tile
+constexpr int TROWB = KVB * 2 + 16;  // bytes per row of a transposed [dd][64] tile
+
+template <int DK> struct RowTile {
+  static constexpr int CPRW = DK / 8;
+  static constexpr int ROWB = DK * 2 + 16;
+  static constexpr int BYTES = KVB * ROWB;
+  static constexpr int NREG = (KVB * CPRW + 255) / 256;
+};
+template <int DV> struct TrTile {
+  static constexpr int BYTES = DV * TROWB;
+  static constexpr int NREG = (DV * 8 + 255) / 256;
+};
+
+// ---- global -> registers -> LDS tile movers --------------------------------------------------
+template <int DK>
+__device__ __forceinline__ void rows_g2r(uint4 (&reg)[RowTile<DK>::NREG], const bf16_t* X, int64_t ld,
+                                         int b, int S, int s0, int hoff, int d, int tid) {
+  constexpr int CPRW = RowTile<DK>::CPRW;
+#pragma unroll
+  for (int k = 0; k < RowTile<DK>::NREG; ++k) {
+    const int i = tid + 256 * k;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i < KVB * CPRW) {
+      const int r = i / CPRW, c = i - r * CPRW, s = s0 + r;
+      if (s < S && c * 8 < d) v = *(const uint4*)(X + ((int64_t)b * S + s) * ld + hoff + c * 8);
+    }
+    reg[k] = v;
+  }
+}
+template <int DK>
+__device__ __forceinline__ void rows_r2s(char* lds, const uint4 (&reg)[RowTile<DK>::NREG], int tid) {
+  constexpr int CPRW = RowTile<DK>::CPRW;
+#pragma unroll
+  for (int k = 0; k < RowTile<DK>::NREG; ++k) {
+    const int i = tid + 256 * k;
+    if (i < KVB * CPRW) {
+      const int r = i / CPRW, c = i - r * CPRW;
+      *(uint4*)(lds + r * RowTile<DK>::ROWB + c * 16) = reg[k];
+    }
+  }
+}
+template <int DV>
+__device__ __forceinline__ void tr_g2r(uint4 (&reg)[TrTile<DV>::NREG], const bf16_t* XT, int b, int H,
+                                       int h, int SP, int s0, int tid) {
+#pragma unroll
+  for (int k = 0; k < TrTile<DV>::NREG; ++k) {
+    const int i = tid + 256 * k;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (i < DV * 8) {
+      const int r = i >> 3, c = i & 7;
+      v = *(const uint4*)(XT + (((int64_t)b * H + h) * DV + r) * SP + s0 + c * 8);
+    }
+    reg[k] = v;
+  }
+}
+template <int DV>
+__device__ __forceinline__ void tr_r2s(char* lds, const uint4 (&reg)[TrTile<DV>::NREG], int tid) {
+#pragma unroll
+  for (int k = 0; k < TrTile<DV>::NREG; ++k) {
+    const int i = tid + 256 * k;
+    if (i < DV * 8) *(uint4*)(lds + (i >> 3) * TROWB + (i & 7) * 16) = reg[k];
+  }
+}
+
+// ---- fragment readers --------------------------------------------------------------------------
+template <int DK>
+__device__ __forceinline__ bf16x8 row_frag(const char* lds, int f, int ks, int g, int j) {
+  return *(const bf16x8*)(lds + (16 * f + j) * RowTile<DK>::ROWB + (4 * ks + g) * 16);
+}
+__device__ __forceinline__ bf16x8 tr_frag(const char* lds, int df, int s2, int g, int j) {
+  const char* p = lds + (16 * df + j) * TROWB + (32 * s2 + 4 * g) * 2;
+  const uint2 lo = *(const uint2*)p;
+  const uint2 hi = *(const uint2*)(p + 32);
+  union { uint4 u; bf16x8 v; } t;
+  t.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return t.v;
+}
+// this block's own rows as an MFMA B operand: X[row0 + j][32ks + 8g .. +8]
+__device__ __forceinline__ bf16x8 own_frag(const bf16_t* X, int64_t ld, int b, int S, int row, int hoff,
+                                           int d, int ks, int g) {
+  union { uint4 u; bf16x8 v; } t;
+  t.u = make_uint4(0, 0, 0, 0);
+  const int c = 32 * ks + 8 * g;
+  if (row < S && c < d) t.u = *(const uint4*)(X + ((int64_t)b * S + row) * ld + hoff + c);
+  return t.v;
+}
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  union { uint4 u; bf16x8 v; } t;
+  t.u = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3]));
+  return t.v;
+}
+__device__ __forceinline__ float xor_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
+}
+__device__ __forceinline__ float xor_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  v = fmaxf(v, __shfl_xor(v, 32, 64));
+  return v;
+}
+
+#define MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+constexpr float NEG_BIG = -1.0e30f;
+
+// =============================================================================================
+// forward:  O = softmax(scale Q K^T) V ;  lse (log2 domain) optional
+// block = 4 waves, each wave QF query fragments (16 rows each)
+// =============================================================================================
+template <int DK, int DV, int QF>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sV = smem + RowTile<DK>::BYTES;
+  constexpr int KS = DK / 32, DF = DV / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int hoff = h * a.d;
+  const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+  const int SP = attn_spad(a.Skv);
+  const float sc = a.scale * 1.4426950408889634f;
+
+  bf16x8 qf[QF][KS];
+#pragma unroll
+  for (int f = 0; f < QF; ++f)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[f][ks] = own_frag(a.Q, a.ldq, b, a.Sq, q0 + 16 * f + j, hoff, a.d, ks, g);
+
+  f32x4 acc_o[DF][QF];
+  float m[QF], l[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    m[f] = NEG_BIG;
+    l[f] = 0.f;
+#pragma unroll
+    for (int df = 0; df < DF; ++df) acc_o[df][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+
+  uint4 rk[RowTile<DK>::NREG], rv[TrTile<DV>::NREG];
+  const int nt = (a.Skv + KVB - 1) / KVB;
+  rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, 0, hoff, a.d, tid);
+  tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, 0, tid);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    rows_r2s<DK>(sK, rk, tid);
+    tr_r2s<DV>(sV, rv, tid);
+    __syncthreads();
+    if (t + 1 < nt) {
+      rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, (t + 1) * KVB, hoff, a.d, tid);
+      tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, (t + 1) * KVB, tid);
+    }
+    // ---- S^T = K Q^T ----
+    f32x4 s[4][QF];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int f = 0; f < QF; ++f) s[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 kfr[4];
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) kfr[kf] = row_frag<DK>(sK, kf, ks, g, j);
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int f = 0; f < QF; ++f) s[kf][f] = MFMA(kfr[kf], qf[f][ks], s[kf][f]);
+    }
+    // ---- online softmax (per query column j of each fragment) ----
+    const int kvbase = t * KVB + 4 * g;
+    const bool tail = (t + 1) * KVB > a.Skv;
+    bf16x8 pb[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+      float mx = NEG_BIG;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = s[kf][f][r] * sc;
+          if (tail && kvbase + 16 * kf + r >= a.Skv) v = NEG_BIG;
+          s[kf][f][r] = v;
+          mx = fmaxf(mx, v);
+        }
+      mx = xor_max(mx);
+      const float mn = fmaxf(m[f], mx);
+      const float alpha = exp2f(m[f] - mn);
+      m[f] = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[kf][f][r] - mn);
+          s[kf][f][r] = p;
+          ps += p;
+        }
+      l[f] = l[f] * alpha + ps;
+#pragma unroll
+      for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc_o[df][f][r] *= alpha;
+      pb[f][0] = pack8(s[0][f], s[1][f]);
+      pb[f][1] = pack8(s[2][f], s[3][f]);
+    }
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const bf16x8 vfr = tr_frag(sV, df, s2, g, j);
+#pragma unroll
+        for (int f = 0; f < QF; ++f) acc_o[df][f] = MFMA(vfr, pb[f][s2], acc_o[df][f]);
+      }
+  }
+  // ---- epilogue ----
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int q = q0 + 16 * f + j;
+    const float lt = xor_sum(l[f]);
+    const float inv = 1.f / lt;
+    if (q < a.Sq) {
+      if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Sq + q] = m[f] + log2f(lt);
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const int dd = 16 * df + 4 * g;
+        if (dd < a.d) {
+          uint2 pk;
+          pk.x = pack2bf(acc_o[df][f][0] * inv, acc_o[df][f][1] * inv);
+          pk.y = pack2bf(acc_o[df][f][2] * inv, acc_o[df][f][3] * inv);
+          *(uint2*)(a.out + ((int64_t)b * a.Sq + q) * a.ldout + hoff + dd) = pk;
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// backward dQ:  per query block, loop over key tiles.
+//   P^T = exp2(sc K Q^T - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta) scale,  dQ^T += K^T dS^T
+// =============================================================================================
+template <int DK, int DV, int QF>
+__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sK = smem;
+  char* sVr = sK + RowTile<DK>::BYTES;
+  char* sKT = sVr + RowTile<DK>::BYTES;
+  constexpr int KS = DK / 32, DF = DV / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int hoff = h * a.d;
+  const int q0 = blockIdx.x * (64 * QF) + wave * (16 * QF);
+  const int SP = attn_spad(a.Skv);
+  const float sc = a.scale * 1.4426950408889634f;
+
+  bf16x8 qf[QF][KS], dof[QF][KS];
+  float lse[QF], dl[QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int q = q0 + 16 * f + j;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[f][ks] = own_frag(a.Q, a.ldq, b, a.Sq, q, hoff, a.d, ks, g);
+      dof[f][ks] = own_frag(a.dO, a.lddo, b, a.Sq, q, hoff, a.d, ks, g);
+    }
+    const bool ok = q < a.Sq;
+    lse[f] = ok ? a.lse[((int64_t)b * a.H + h) * a.Sq + q] : 1.0e30f;
+    dl[f] = ok ? a.delta[((int64_t)b * a.H + h) * a.Sq + q] : 0.f;
+  }
+  f32x4 acc[DF][QF];
+#pragma unroll
+  for (int f = 0; f < QF; ++f)
+#pragma unroll
+    for (int df = 0; df < DF; ++df) acc[df][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  uint4 rk[RowTile<DK>::NREG], rv[RowTile<DK>::NREG], rt[TrTile<DV>::NREG];
+  const int nt = (a.Skv + KVB - 1) / KVB;
+  for (int t = 0; t < nt; ++t) {
+    rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, t * KVB, hoff, a.d, tid);
+    rows_g2r<DK>(rv, a.V, a.ldv, b, a.Skv, t * KVB, hoff, a.d, tid);
+    tr_g2r<DV>(rt, a.KT, b, a.H, h, SP, t * KVB, tid);
+    __syncthreads();
+    rows_r2s<DK>(sK, rk, tid);
+    rows_r2s<DK>(sVr, rv, tid);
+    tr_r2s<DV>(sKT, rt, tid);
+    __syncthreads();
+    f32x4 s[4][QF], dp[4][QF];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int f = 0; f < QF; ++f) {
+        s[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) {
+        const bf16x8 kfr = row_frag<DK>(sK, kf, ks, g, j);
+        const bf16x8 vfr = row_frag<DK>(sVr, kf, ks, g, j);
+#pragma unroll
+        for (int f = 0; f < QF; ++f) {
+          s[kf][f] = MFMA(kfr, qf[f][ks], s[kf][f]);
+          dp[kf][f] = MFMA(vfr, dof[f][ks], dp[kf][f]);
+        }
+      }
+    }
+    const int kvbase = t * KVB + 4 * g;
+    bf16x8 ds[QF][2];
+#pragma unroll
+    for (int f = 0; f < QF; ++f) {
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = exp2f(s[kf][f][r] * sc - lse[f]);
+          if (kvbase + 16 * kf + r >= a.Skv) p = 0.f;
+          s[kf][f][r] = p * (dp[kf][f][r] - dl[f]) * a.scale;
+        }
+      ds[f][0] = pack8(s[0][f], s[1][f]);
+      ds[f][1] = pack8(s[2][f], s[3][f]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const bf16x8 ktf = tr_frag(sKT, df, s2, g, j);
+#pragma unroll
+        for (int f = 0; f < QF; ++f) acc[df][f] = MFMA(ktf, ds[f][s2], acc[df][f]);
+      }
+  }
+#pragma unroll
+  for (int f = 0; f < QF; ++f) {
+    const int q = q0 + 16 * f + j;
+    if (q < a.Sq) {
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const int dd = 16 * df + 4 * g;
+        if (dd < a.d) {
+          uint2 pk;
+          pk.x = pack2bf(acc[df][f][0], acc[df][f][1]);
+          pk.y = pack2bf(acc[df][f][2], acc[df][f][3]);
+          *(uint2*)(a.out + ((int64_t)b * a.Sq + q) * a.ldout + hoff + dd) = pk;
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// backward dK/dV: per key block (each wave KF key fragments), loop over query tiles.
+//   S = Q K^T (un-swapped: lane (g, j=kv) holds q = 16qf+4g+r),  P = exp2(sc S - lse[q])
+//   dP = dO V^T,  dS = P (dP - delta[q]) scale,  dV^T += dO^T P,  dK^T += Q^T dS
+// =============================================================================================
+template <int DK, int DV, int KF>
+__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sQ = smem;
+  char* sdO = sQ + RowTile<DK>::BYTES;
+  char* sQT = sdO + RowTile<DK>::BYTES;
+  char* sdOT = sQT + TrTile<DV>::BYTES;
+  float* sL = (float*)(sdOT + TrTile<DV>::BYTES);  // [64] lse, [64] delta
+  constexpr int KS = DK / 32, DF = DV / 16;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
+  const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+  const int hoff = h * a.d;
+  const int kv0 = blockIdx.x * (64 * KF) + wave * (16 * KF);
+  const int SPq = attn_spad(a.Sq);
+  const float sc = a.scale * 1.4426950408889634f;
+
+  bf16x8 kf_[KF][KS], vf_[KF][KS];
+#pragma unroll
+  for (int f = 0; f < KF; ++f)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf_[f][ks] = own_frag(a.K, a.ldk, b, a.Skv, kv0 + 16 * f + j, hoff, a.d, ks, g);
+      vf_[f][ks] = own_frag(a.V, a.ldv, b, a.Skv, kv0 + 16 * f + j, hoff, a.d, ks, g);
+    }
+  f32x4 adk[DF][KF], adv[DF][KF];
+#pragma unroll
+  for (int f = 0; f < KF; ++f)
+#pragma unroll
+    for (int df = 0; df < DF; ++df) {
+      adk[df][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      adv[df][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+  uint4 rq[RowTile<DK>::NREG], rdo[RowTile<DK>::NREG], rqt[TrTile<DV>::NREG], rdot[TrTile<DV>::NREG];
+  const int nt = (a.Sq + KVB - 1) / KVB;
+  for (int t = 0; t < nt; ++t) {
+    rows_g2r<DK>(rq, a.Q, a.ldq, b, a.Sq, t * KVB, hoff, a.d, tid);
+    rows_g2r<DK>(rdo, a.dO, a.lddo, b, a.Sq, t * KVB, hoff, a.d, tid);
+    tr_g2r<DV>(rqt, a.QT, b, a.H, h, SPq, t * KVB, tid);
+    tr_g2r<DV>(rdot, a.dOT, b, a.H, h, SPq, t * KVB, tid);
+    __syncthreads();
+    rows_r2s<DK>(sQ, rq, tid);
+    rows_r2s<DK>(sdO, rdo, tid);
+    tr_r2s<DV>(sQT, rqt, tid);
+    tr_r2s<DV>(sdOT, rdot, tid);
+    if (tid < 64) {
+      const int q = t * KVB + tid;
+      const bool ok = q < a.Sq;
+      sL[tid] = ok ? a.lse[((int64_t)b * a.H + h) * a.Sq + q] : 1.0e30f;
+      sL[64 + tid] = ok ? a.delta[((int64_t)b * a.H + h) * a.Sq + q] : 0.f;
+    }
+    __syncthreads();
+    f32x4 s[4][KF], dp[4][KF];
+#pragma unroll
+    for (int qf = 0; qf < 4; ++qf)
+#pragma unroll
+      for (int f = 0; f < KF; ++f) {
+        s[qf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        dp[qf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int qf = 0; qf < 4; ++qf) {
+        const bf16x8 qfr = row_frag<DK>(sQ, qf, ks, g, j);
+        const bf16x8 dofr = row_frag<DK>(sdO, qf, ks, g, j);
+#pragma unroll
+        for (int f = 0; f < KF; ++f) {
+          s[qf][f] = MFMA(qfr, kf_[f][ks], s[qf][f]);
+          dp[qf][f] = MFMA(dofr, vf_[f][ks], dp[qf][f]);
+        }
+      }
+    }
+    bf16x8 pb[KF][2], dsb[KF][2];
+#pragma unroll
+    for (int f = 0; f < KF; ++f) {
+#pragma unroll
+      for (int qf = 0; qf < 4; ++qf) {
+        const float4 ls = *(const float4*)(sL + 16 * qf + 4 * g);
+        const float4 dl = *(const float4*)(sL + 64 + 16 * qf + 4 * g);
+        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = exp2f(s[qf][f][r] * sc - lsv[r]);
+          s[qf][f][r] = p;
+          dp[qf][f][r] = p * (dp[qf][f][r] - dlv[r]) * a.scale;
+        }
+      }
+      pb[f][0] = pack8(s[0][f], s[1][f]);
+      pb[f][1] = pack8(s[2][f], s[3][f]);
+      dsb[f][0] = pack8(dp[0][f], dp[1][f]);
+      dsb[f][1] = pack8(dp[2][f], dp[3][f]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const bf16x8 dotf = tr_frag(sdOT, df, s2, g, j);
+        const bf16x8 qtf = tr_frag(sQT, df, s2, g, j);
+#pragma unroll
+        for (int f = 0; f < KF; ++f) {
+          adv[df][f] = MFMA(dotf, pb[f][s2], adv[df][f]);
+          adk[df][f] = MFMA(qtf, dsb[f][s2], adk[df][f]);
+        }
+      }
+  }
+#pragma unroll
+  for (int f = 0; f < KF; ++f) {
+    const int kv = kv0 + 16 * f + j;
+    if (kv < a.Skv) {
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const int dd = 16 * df + 4 * g;
+        if (dd < a.d) {
+          uint2 pk;
+          pk.x = pack2bf(adk[df][f][0], adk[df][f][1]);
+          pk.y = pack2bf(adk[df][f][2], adk[df][f][3]);
+          *(uint2*)(a.dK + ((int64_t)b * a.Skv + kv) * a.lddk + hoff + dd) = pk;
+          pk.x = pack2bf(adv[df][f][0], adv[df][f][1]);
+          pk.y = pack2bf(adv[df][f][2], adv[df][f][3]);
+          *(uint2*)(a.dV + ((int64_t)b * a.Skv + kv) * a.lddv + hoff + dd) = pk;
+        }
+      }
+    }
+  }
+}
+
+// =============================================================================================
+// X[B,S,ld] (head h at column h*d) -> XT[B,H,DVP,SP], zero padded.  64x(16-dd) LDS transpose.
+// =============================================================================================
+__global__ __launch_bounds__(256) void transpose_heads_kernel(const bf16_t* X, int64_t ld, bf16_t* XT,
+                                                              int B, int H, int S, int d) {
+  __shared__ bf16_t tile[64][66];
+  const int DVP = attn_dvpad(d), SP = attn_spad(S);
+  const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
+  const int bh = blockIdx.z, b = bh / H, h = bh - b * H;
+  const int tid = threadIdx.x;
+  // load 64 rows (s) x 64 cols (dd) -> tile[s][dd]
+  for (int i = tid; i < 64 * 8; i += 256) {
+    const int r = i >> 3, c = (i & 7) * 8;
+    const int s = s0 + r, dd = d0 + c;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (s < S && dd < d) v = *(const u16x8*)(X + ((int64_t)b * S + s) * ld + h * d + dd);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) tile[r][c + e] = v[e];
+  }
+  __syncthreads();
+  for (int i = tid; i < 64 * 8; i += 256) {
+    const int r = i >> 3, c = (i & 7) * 8;  // r = dd, c = s offset
+    const int dd = d0 + r;
+    if (dd < DVP) {
+      u16x8 v;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = tile[c + e][r];
+      *(u16x8*)(XT + (((int64_t)b * H + h) * DVP + dd) * SP + s0 + c) = v;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* O, int64_t ldo, const bf16_t* dO,
+                                                         int64_t lddo, float* delta, int B, int H, int S,
+                                                         int d) {
+  // one 8-lane group per (b, s, h)
+  const int64_t gid = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 3;
+  const int sub = threadIdx.x & 7;
+  const int64_t total = (int64_t)B * S * H;
+  float acc = 0.f;
+  if (gid < total) {
+    const int h = (int)(gid % H);
+    const int64_t bs = gid / H;
+    for (int c = sub * 8; c < d; c += 64) {
+      const u16x8 o = *(const u16x8*)(O + bs * ldo + h * d + c);
+      const u16x8 g = *(const u16x8*)(dO + bs * lddo + h * d + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc += bf2f(o[e]) * bf2f(g[e]);
+    }
+  }
+  acc += __shfl_xor(acc, 1, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  if (gid < total && sub == 0) {
+    const int h = (int)(gid % H);
+    const int64_t bs = gid / H;
+    const int b = (int)(bs / S), s = (int)(bs - (int64_t)b * S);
+    delta[((int64_t)b * H + h) * S + s] = acc;
+  }
+}
+
+template <typename KernelT>
+int set_smem(KernelT k, int bytes) {
+  FDMI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+  return 0;
+}
+
+template <int DK, int DV, int NF>
+int fwd_t(const AttnArgs& a, hipStream_t st) {
+  constexpr int smem = RowTile<DK>::BYTES + TrTile<DV>::BYTES;
+  static bool once = false;
+  if (!once) { if (set_smem(attn_fwd_kernel<DK, DV, NF>, smem)) return -2; once = true; }
+  dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
+  hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+template <int DK, int DV, int NF>
+int dq_t(const AttnArgs& a, hipStream_t st) {
+  constexpr int smem = 2 * RowTile<DK>::BYTES + TrTile<DV>::BYTES;
+  static bool once = false;
+  if (!once) { if (set_smem(attn_bwd_dq_kernel<DK, DV, NF>, smem)) return -2; once = true; }
+  dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
+  hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+template <int DK, int DV, int NF>
+int dkv_t(const AttnArgs& a, hipStream_t st) {
+  constexpr int smem = 2 * RowTile<DK>::BYTES + 2 * TrTile<DV>::BYTES + 512;
+  static bool once = false;
+  if (!once) { if (set_smem(attn_bwd_dkv_kernel<DK, DV, NF>, smem)) return -2; once = true; }
+  dim3 grid(cdiv(a.Skv, 64 * NF), a.B * a.H);
+  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+// head-dim dispatch: (d -> DK = ceil32, DV = ceil16)
+#define ATTN_DISPATCH(FN, NF_SMALL, NF_BIG)                                        \
+  const int DKp = (a.d + 31) & ~31, DVp = attn_dvpad(a.d);                          \
+  if (DKp == 32 && DVp == 16) return FN<32, 16, NF_SMALL>(a, st);                  \
+  if (DKp == 32 && DVp == 32) return FN<32, 32, NF_SMALL>(a, st);                  \
+  if (DKp == 64 && DVp == 48) return FN<64, 48, NF_SMALL>(a, st);                  \
+  if (DKp == 64 && DVp == 64) return FN<64, 64, NF_SMALL>(a, st);                  \
+  if (DKp == 96 && DVp == 80) return FN<96, 80, NF_SMALL>(a, st);                  \
+  if (DKp == 96 && DVp == 96) return FN<96, 96, NF_SMALL>(a, st);                  \
+  if (DKp == 128 && DVp == 128) return FN<128, 128, NF_BIG>(a, st);                \
+  if (DKp == 160 && DVp == 160) return FN<160, 160, NF_BIG>(a, st);                \
+  FDMI_CHECK(false, "attention: unsupported head dim " + std::to_string(a.d));
+
+static int check_attn(const AttnArgs& a) {
+  FDMI_CHECK(a.d % 8 == 0 && a.d <= 160, "attention: head dim must be a multiple of 8, <= 160");
+  FDMI_CHECK(a.ldq % 8 == 0 && a.ldk % 8 == 0, "attention: leading dims must be multiples of 8");
+  FDMI_CHECK(a.Sq > 0 && a.Skv > 0, "attention: empty sequence");
+  return 0;
+}
+
+int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
+  if (check_attn(a)) return -1;
+  ATTN_DISPATCH(fwd_t, 2, 1)
+}
+int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st) {
+  if (check_attn(a)) return -1;
+  ATTN_DISPATCH(dq_t, 2, 1)
+}
+int launch_attn_bwd_dkv(const AttnArgs& a, hipStream_t st) {
+  if (check_attn(a)) return -1;
+  ATTN_DISPATCH(dkv_t, 2, 1)
+}
+
+int launch_transpose_heads(const bf16_t* X, int64_t ld, bf16_t* XT, int B, int H, int S, int d,
+                           hipStream_t st) {
+  FDMI_CHECK(d % 8 == 0 && ld % 8 == 0, "transpose_heads: d, ld must be multiples of 8");
+  dim3 grid(attn_spad(S) / 64, cdiv(attn_dvpad(d), 64), B * H);
+  hipLaunchKernelGGL(transpose_heads_kernel, grid, dim3(256), 0, st, X, ld, XT, B, H, S, d);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+
+int launch_attn_delta(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, float* delta, int B,
+                      int H, int S, int d, hipStream_t st) {
+  const int64_t groups = (int64_t)B * S * H;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((groups * 8 + 255) / 256)), dim3(256), 0, st, O, ldo,
+                     dO, lddo, delta, B, H, S, d);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}

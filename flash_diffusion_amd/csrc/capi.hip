@@ -1,0 +1,138 @@
+// extern "C" surface of libfdmi.so (op-level entry points).  See include/fdmi.h.
+#include "../../include/fdmi.h"
+#include "ops.h"
+
+static thread_local std::string g_err;
+void fdmi_set_error(const std::string& msg) { g_err = msg; }
+
+extern "C" {
+
+const char* fdmi_last_error(void) { return g_err.c_str(); }
+int fdmi_version(void) { return 1; }
+
+int fdmi_gemm(const fdmi_gemm_desc* d, void* stream) {
+  FDMI_CHECK(d != nullptr, "null descriptor");
+  GemmArgs a;
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.A = (const bf16_t*)d->A; a.lda = d->lda;
+  a.W = (const bf16_t*)d->W; a.ldw = d->ldw;
+  a.mode = d->mode;
+  a.Hin = d->Hin; a.Win = d->Win; a.Cin = d->Cin; a.Hout = d->Hout; a.Wout = d->Wout;
+  a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.ups = d->ups; a.dgrad = d->dgrad;
+  a.bias = d->bias;
+  a.rowvec = (const bf16_t*)d->rowvec; a.rowvec_ld = d->rowvec_ld; a.rows_per_batch = d->rows_per_batch;
+  a.residual = (const bf16_t*)d->residual; a.ldr = d->ldr;
+  a.act = d->act;
+  a.preact = (bf16_t*)d->preact; a.ldp = d->ldp;
+  a.C = d->C; a.ldc = d->ldc; a.out_f32 = d->out_f32;
+  a.alpha = d->alpha;
+  a.splitk = d->splitk; a.ws = d->ws;
+  a.accum_atomic = d->accum_atomic;
+  a.force_tile = d->force_tile;
+  a.use_glds = d->use_glds;
+  return launch_gemm(a, (hipStream_t)stream);
+}
+
+int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, float* stats, void* y, int B,
+                       int HW, int C, int G, float eps, int silu, void* stream) {
+  return launch_groupnorm_fwd((const bf16_t*)x, gamma, beta, stats, (bf16_t*)y, B, HW, C, G, eps, silu,
+                              (hipStream_t)stream);
+}
+int fdmi_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
+                       const float* stats, float* bstats, void* dx, int B, int HW, int C, int G, float eps,
+                       int silu, int accumulate, void* stream) {
+  return launch_groupnorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, beta, stats, bstats, (bf16_t*)dx, B,
+                              HW, C, G, eps, silu, accumulate, (hipStream_t)stream);
+}
+int fdmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int C,
+                       float eps, void* stream) {
+  return launch_layernorm_fwd((const bf16_t*)x, gamma, beta, nullptr, nullptr, 0, 1, (bf16_t*)y, rows, C, eps,
+                              (hipStream_t)stream);
+}
+int fdmi_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, int64_t rows, int C,
+                       float eps, int accumulate, void* stream) {
+  return launch_layernorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, nullptr, 0, 1, (bf16_t*)dx, rows, C,
+                              eps, accumulate, (hipStream_t)stream);
+}
+
+int64_t fdmi_attn_tr_elems(int B, int H, int S, int d) {
+  return (int64_t)B * H * attn_dvpad(d) * attn_spad(S);
+}
+static int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+int64_t fdmi_attn_bwd_ws_bytes(int B, int H, int Sq, int Skv, int d) {
+  // QT, dOT (Sq), KT (Skv), delta
+  return align256(fdmi_attn_tr_elems(B, H, Sq, d) * 2) * 2 + align256(fdmi_attn_tr_elems(B, H, Skv, d) * 2) +
+         align256((int64_t)B * H * Sq * 4);
+}
+int fdmi_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv, void* O,
+                  int64_t ldo, void* VT, float* lse, int B, int H, int Sq, int Skv, int d, float scale,
+                  void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  int rc = launch_transpose_heads((const bf16_t*)V, ldv, (bf16_t*)VT, B, H, Skv, d, st);
+  if (rc) return rc;
+  AttnArgs a{};
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+  a.VT = (const bf16_t*)VT; a.lse = lse; a.out = (bf16_t*)O; a.ldout = ldo;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = scale;
+  return launch_attn_fwd(a, st);
+}
+int fdmi_attn_bwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const void* V, int64_t ldv,
+                  const void* O, int64_t ldo, const void* dO, int64_t lddo, const float* lse, void* dQ,
+                  int64_t lddq, void* dK, int64_t lddk, void* dV, int64_t lddv, void* ws, int B, int H, int Sq,
+                  int Skv, int d, float scale, void* stream) {
+  hipStream_t st = (hipStream_t)stream;
+  char* w = (char*)ws;
+  bf16_t* QT = (bf16_t*)w;  w += align256(fdmi_attn_tr_elems(B, H, Sq, d) * 2);
+  bf16_t* dOT = (bf16_t*)w; w += align256(fdmi_attn_tr_elems(B, H, Sq, d) * 2);
+  bf16_t* KT = (bf16_t*)w;  w += align256(fdmi_attn_tr_elems(B, H, Skv, d) * 2);
+  float* delta = (float*)w;
+  int rc;
+  if ((rc = launch_transpose_heads((const bf16_t*)Q, ldq, QT, B, H, Sq, d, st))) return rc;
+  if ((rc = launch_transpose_heads((const bf16_t*)dO, lddo, dOT, B, H, Sq, d, st))) return rc;
+  if ((rc = launch_transpose_heads((const bf16_t*)K, ldk, KT, B, H, Skv, d, st))) return rc;
+  if ((rc = launch_attn_delta((const bf16_t*)O, ldo, (const bf16_t*)dO, lddo, delta, B, H, Sq, d, st))) return rc;
+  AttnArgs a{};
+  a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
+  a.dO = (const bf16_t*)dO; a.lddo = lddo; a.QT = QT; a.KT = KT; a.dOT = dOT;
+  a.lse = (float*)lse; a.delta = delta;
+  a.out = (bf16_t*)dQ; a.ldout = lddq; a.dK = (bf16_t*)dK; a.lddk = lddk; a.dV = (bf16_t*)dV; a.lddv = lddv;
+  a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = scale;
+  if ((rc = launch_attn_bwd_dq(a, st))) return rc;
+  return launch_attn_bwd_dkv(a, st);
+}
+
+int fdmi_nchw_to_nhwc(const float* x, void* y, int B, int C, int HW, int Cpad, void* stream) {
+  return launch_nchw_to_nhwc(x, (bf16_t*)y, B, C, HW, Cpad, (hipStream_t)stream);
+}
+int fdmi_nhwc_to_nchw(const void* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate, void* stream) {
+  return launch_nhwc_to_nchw((const bf16_t*)x, ldx, y, B, C, HW, accumulate, (hipStream_t)stream);
+}
+int fdmi_timestep_embed(const float* t, void* out, int B, int dim, int flip, float shift, void* stream) {
+  return launch_timestep_embed(t, (bf16_t*)out, B, dim, flip, shift, (hipStream_t)stream);
+}
+int fdmi_geglu_bwd(const void* pre, const void* dout, void* dpre, int64_t M, int F, void* stream) {
+  return launch_geglu_bwd((const bf16_t*)pre, (const bf16_t*)dout, (bf16_t*)dpre, M, F, (hipStream_t)stream);
+}
+int fdmi_pool2x2_sum(const void* dy, void* dx, int B, int H, int W, int C, int accumulate, void* stream) {
+  return launch_pool2x2_sum((const bf16_t*)dy, (bf16_t*)dx, B, H, W, C, accumulate, (hipStream_t)stream);
+}
+int fdmi_cast_transpose(const float* w, void* wb, void* wtb, int rows, int cols, void* stream) {
+  return launch_cast_transpose(w, (bf16_t*)wb, (bf16_t*)wtb, rows, cols, (hipStream_t)stream);
+}
+int fdmi_transpose2d(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, void* stream) {
+  return launch_transpose2d((const bf16_t*)in, ldi, (bf16_t*)out, ldo, rows, cols, (hipStream_t)stream);
+}
+int fdmi_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, float grad_scale, void* stream) {
+  return launch_adamw(p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, step, grad_scale, (hipStream_t)stream);
+}
+int fdmi_add_noise(const float* z, const float* noise, const float* sa, const float* sb, float* out, int B,
+                   int64_t per, void* stream) {
+  return launch_add_noise(z, noise, sa, sb, out, B, per, (hipStream_t)stream);
+}
+int fdmi_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
+                const float* x3, float c3, float* out, int64_t n, void* stream) {
+  return launch_axpby4(x0, c0, x1, c1, x2, c2, x3, c3, out, n, (hipStream_t)stream);
+}
+
+}  // extern "C"

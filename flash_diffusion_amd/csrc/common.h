@@ -1,0 +1,68 @@
+// Shared device/host helpers for the fdmi kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(8))) short bf16x8;   // MFMA A/B fragment (8 bf16, 4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;    // MFMA 16x16 C/D fragment
+typedef __attribute__((ext_vector_type(4))) unsigned short u16x4;
+typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
+
+#define FDMI_WAVE 64
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN-preserving
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+__device__ __forceinline__ float dsilu_f(float x) {
+  float s = 1.f / (1.f + __expf(-x));
+  return s * (1.f + x * (1.f - s));
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float dgelu_f(float x) {
+  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
+  return cdf + x * pdf;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+
+// ---- host side -------------------------------------------------------------------------
+void fdmi_set_error(const std::string& msg);
+#define FDMI_CHECK(cond, msg)                                                         \
+  do {                                                                                \
+    if (!(cond)) {                                                                    \
+      fdmi_set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " + (msg)); \
+      return -1;                                                                      \
+    }                                                                                 \
+  } while (0)
+#define FDMI_HIP(call)                                                                \
+  do {                                                                                \
+    hipError_t e_ = (call);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      fdmi_set_error(std::string(__FILE__) + ":" + std::to_string(__LINE__) + ": " +   \
+                     hipGetErrorString(e_));                                          \
+      return -2;                                                                      \
+    }                                                                                 \
+  } while (0)
+
+static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

@@ -1,0 +1,299 @@
+// HBM-bound element-wise / layout kernels around the MFMA ops (16-byte vector accesses where the
+// layout allows), the GEGLU backward, the LoRA refresh (cast + transpose) and fused AdamW.
+#include "ops.h"
+
+#define GRID_STRIDE(i, total) \
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < (total); i += (int64_t)gridDim.x * 256)
+
+static inline int nblocks(int64_t total, int cap = 8192) {
+  int64_t b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// latents: NCHW f32 -> NHWC bf16 with the channel dim zero-padded to Cpad (multiple of 8)
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* x, bf16_t* y, int B, int C, int HW,
+                                                           int Cpad) {
+  const int64_t total = (int64_t)B * HW * Cpad;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % Cpad);
+    const int64_t p = i / Cpad;
+    const int b = (int)(p / HW);
+    const int s = (int)(p - (int64_t)b * HW);
+    y[i] = c < C ? f2bf(x[((int64_t)b * C + c) * HW + s]) : (bf16_t)0;
+  }
+}
+// NHWC bf16 (row stride ldx) -> NCHW f32
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const bf16_t* x, int64_t ldx, float* y, int B, int C,
+                                                           int HW, int accumulate) {
+  const int64_t total = (int64_t)B * C * HW;
+  GRID_STRIDE(i, total) {
+    const int s = (int)(i % HW);
+    const int64_t bc = i / HW;
+    const int c = (int)(bc % C);
+    const int b = (int)(bc / C);
+    const float v = bf2f(x[((int64_t)b * HW + s) * ldx + c]);
+    y[i] = accumulate ? y[i] + v : v;
+  }
+}
+// NCHW f32 gradient -> NHWC bf16 rows of width ldy (columns >= C zeroed)
+__global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* g, bf16_t* y, int64_t ldy, int B,
+                                                                int C, int HW) {
+  const int64_t total = (int64_t)B * HW * ldy;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % ldy);
+    const int64_t p = i / ldy;
+    const int b = (int)(p / HW);
+    const int s = (int)(p - (int64_t)b * HW);
+    y[i] = c < C ? f2bf(g[((int64_t)b * C + c) * HW + s]) : (bf16_t)0;
+  }
+}
+
+// sinusoidal timestep embedding (diffusers Timesteps: [sin | cos], flipped to [cos | sin])
+__global__ __launch_bounds__(256) void timestep_embed_kernel(const float* t, bf16_t* out, int B, int dim,
+                                                             int flip, float shift) {
+  const int half = dim / 2;
+  const int64_t total = (int64_t)B * half;
+  GRID_STRIDE(i, total) {
+    const int k = (int)(i % half);
+    const int b = (int)(i / half);
+    const float freq = expf(-9.210340371976184f * (float)k / ((float)half - shift));
+    const float arg = t[b] * freq;
+    const float sn = sinf(arg), cs = cosf(arg);
+    bf16_t* o = out + (int64_t)b * dim;
+    if (flip) {
+      o[k] = f2bf(cs);
+      o[half + k] = f2bf(sn);
+    } else {
+      o[k] = f2bf(sn);
+      o[half + k] = f2bf(cs);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void silu_kernel(const bf16_t* x, bf16_t* y, int64_t n) {
+  GRID_STRIDE(i, n) y[i] = f2bf(silu_f(bf2f(x[i])));
+}
+__global__ __launch_bounds__(256) void f32_to_bf16_kernel(const float* x, bf16_t* y, int64_t n) {
+  GRID_STRIDE(i, n) y[i] = f2bf(x[i]);
+}
+
+// strided 2-D copy / accumulate in 8-channel chunks
+__global__ __launch_bounds__(256) void copy2d_kernel(const bf16_t* src, int64_t lds, int sc0, bf16_t* dst,
+                                                     int64_t ldd, int dc0, int64_t rows, int cols,
+                                                     int accumulate) {
+  const int cpr = cols >> 3;
+  const int64_t total = rows * cpr;
+  GRID_STRIDE(i, total) {
+    const int64_t r = i / cpr;
+    const int c = (int)(i - r * cpr) * 8;
+    u16x8 v = *(const u16x8*)(src + r * lds + sc0 + c);
+    bf16_t* d = dst + r * ldd + dc0 + c;
+    if (accumulate) {
+      const u16x8 o = *(const u16x8*)d;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = f2bf(bf2f(v[e]) + bf2f(o[e]));
+    }
+    *(u16x8*)d = v;
+  }
+}
+
+__global__ __launch_bounds__(256) void pool2x2_sum_kernel(const bf16_t* dy, bf16_t* dx, int B, int H, int W,
+                                                          int C, int accumulate) {
+  const int cpr = C >> 3;
+  const int64_t total = (int64_t)B * H * W * cpr;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % cpr) * 8;
+    const int64_t p = i / cpr;
+    const int x = (int)(p % W);
+    const int y = (int)((p / W) % H);
+    const int b = (int)(p / ((int64_t)W * H));
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int dy_ = 0; dy_ < 2; ++dy_)
+#pragma unroll
+      for (int dx_ = 0; dx_ < 2; ++dx_) {
+        const u16x8 v =
+            *(const u16x8*)(dy + (((int64_t)b * 2 * H + 2 * y + dy_) * 2 * W + 2 * x + dx_) * C + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += bf2f(v[e]);
+      }
+    bf16_t* d = dx + p * C + c;
+    u16x8 o;
+    if (accumulate) {
+      const u16x8 prev = *(const u16x8*)d;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += bf2f(prev[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(acc[e]);
+    *(u16x8*)d = o;
+  }
+}
+
+// GEGLU backward on the 16-wide (value | gate) interleaved pre-activation layout.
+//   out = val * gelu(gate);  dval = dout * gelu(gate);  dgate = dout * val * gelu'(gate)
+__global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* pre, const bf16_t* dout, bf16_t* dpre,
+                                                        int64_t M, int F) {
+  const int cpr = F >> 3;  // 8 output columns per thread (half a 16-block)
+  const int64_t total = M * cpr;
+  GRID_STRIDE(i, total) {
+    const int64_t m = i / cpr;
+    const int c = (int)(i - m * cpr) * 8;           // output column
+    const int pc = (c >> 4) * 32 + (c & 15);        // value column in the interleaved layout
+    const u16x8 v = *(const u16x8*)(pre + m * 2 * F + pc);
+    const u16x8 g = *(const u16x8*)(pre + m * 2 * F + pc + 16);
+    const u16x8 d = *(const u16x8*)(dout + m * F + c);
+    u16x8 dv, dg;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gf = bf2f(g[e]), vf = bf2f(v[e]), df = bf2f(d[e]);
+      dv[e] = f2bf(df * gelu_f(gf));
+      dg[e] = f2bf(df * vf * dgelu_f(gf));
+    }
+    *(u16x8*)(dpre + m * 2 * F + pc) = dv;
+    *(u16x8*)(dpre + m * 2 * F + pc + 16) = dg;
+  }
+}
+
+// bf16 2-D transpose through LDS: out[c][r] = in[r][c]
+__global__ __launch_bounds__(256) void transpose2d_kernel(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo,
+                                                          int64_t rows, int cols) {
+  __shared__ bf16_t tile[64][66];
+  const int64_t r0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    tile[r][c] = (r0 + r < rows && c0 + c < cols) ? in[(r0 + r) * ldi + c0 + c] : (bf16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < rows) out[(int64_t)(c0 + c) * ldo + r0 + r] = tile[r][c];
+  }
+}
+
+// LoRA refresh: f32 master w[rows][cols] -> bf16 wb[rows][cols] and bf16 wtb[cols][rows]
+__global__ __launch_bounds__(256) void cast_transpose_kernel(const float* w, bf16_t* wb, bf16_t* wtb, int rows,
+                                                             int cols) {
+  __shared__ bf16_t tile[64][66];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    bf16_t v = 0;
+    if (r0 + r < rows && c0 + c < cols) {
+      v = f2bf(w[(int64_t)(r0 + r) * cols + c0 + c]);
+      wb[(int64_t)(r0 + r) * cols + c0 + c] = v;
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < rows) wtb[(int64_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
+
+// fused AdamW (torch.optim.AdamW semantics, decoupled weight decay, bias correction)
+__global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n,
+                                                    float lr, float b1, float b2, float eps, float wd,
+                                                    float bc1, float bc2, float grad_scale) {
+  GRID_STRIDE(i, n) {
+    const float gi = g[i] * grad_scale;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrtf(bc2) + eps;
+    pi -= (lr / bc1) * mi / denom;
+    p[i] = pi;
+  }
+}
+
+// fused scheduler / CFG element-wise helpers (fp32 latents, [B,4,H,W])
+__global__ __launch_bounds__(256) void add_noise_kernel(const float* z, const float* noise, const float* sa,
+                                                        const float* sb, float* out, int B, int64_t per) {
+  const int64_t total = (int64_t)B * per;
+  GRID_STRIDE(i, total) {
+    const int b = (int)(i / per);
+    out[i] = sa[b] * z[i] + sb[b] * noise[i];
+  }
+}
+__global__ __launch_bounds__(256) void axpby4_kernel(const float* x0, float c0, const float* x1, float c1,
+                                                     const float* x2, float c2, const float* x3, float c3,
+                                                     float* out, int64_t n) {
+  GRID_STRIDE(i, n) {
+    float v = c0 * x0[i];
+    if (x1) v += c1 * x1[i];
+    if (x2) v += c2 * x2[i];
+    if (x3) v += c3 * x3[i];
+    out[i] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+#define LAUNCH(kern, total, ...)                                                     \
+  hipLaunchKernelGGL(kern, dim3(nblocks(total)), dim3(256), 0, st, __VA_ARGS__);     \
+  FDMI_HIP(hipGetLastError());                                                       \
+  return 0;
+
+int launch_nchw_to_nhwc(const float* x, bf16_t* y, int B, int C, int HW, int Cpad, hipStream_t st) {
+  LAUNCH(nchw_to_nhwc_kernel, (int64_t)B * HW * Cpad, x, y, B, C, HW, Cpad)
+}
+int launch_nhwc_to_nchw(const bf16_t* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate,
+                        hipStream_t st) {
+  LAUNCH(nhwc_to_nchw_kernel, (int64_t)B * C * HW, x, ldx, y, B, C, HW, accumulate)
+}
+int launch_nchw_grad_to_nhwc(const float* g, bf16_t* y, int64_t ldy, int B, int C, int HW, hipStream_t st) {
+  LAUNCH(nchw_grad_to_nhwc_kernel, (int64_t)B * HW * ldy, g, y, ldy, B, C, HW)
+}
+int launch_timestep_embed(const float* t, bf16_t* out, int B, int dim, int flip, float shift, hipStream_t st) {
+  LAUNCH(timestep_embed_kernel, (int64_t)B * (dim / 2), t, out, B, dim, flip, shift)
+}
+int launch_silu(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t st) { LAUNCH(silu_kernel, n, x, y, n) }
+int launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t st) {
+  LAUNCH(f32_to_bf16_kernel, n, x, y, n)
+}
+int launch_copy2d(const bf16_t* src, int64_t lds, int sc0, bf16_t* dst, int64_t ldd, int dc0, int64_t rows,
+                  int cols, int accumulate, hipStream_t st) {
+  FDMI_CHECK(cols % 8 == 0 && lds % 8 == 0 && ldd % 8 == 0 && sc0 % 8 == 0 && dc0 % 8 == 0,
+             "copy2d: 8-element alignment required");
+  LAUNCH(copy2d_kernel, rows * (cols / 8), src, lds, sc0, dst, ldd, dc0, rows, cols, accumulate)
+}
+int launch_pool2x2_sum(const bf16_t* dy, bf16_t* dx, int B, int H, int W, int C, int accumulate,
+                       hipStream_t st) {
+  FDMI_CHECK(C % 8 == 0, "pool2x2: C must be a multiple of 8");
+  LAUNCH(pool2x2_sum_kernel, (int64_t)B * H * W * (C / 8), dy, dx, B, H, W, C, accumulate)
+}
+int launch_geglu_bwd(const bf16_t* pre, const bf16_t* dout, bf16_t* dpre, int64_t M, int F, hipStream_t st) {
+  FDMI_CHECK(F % 16 == 0, "geglu_bwd: F must be a multiple of 16");
+  LAUNCH(geglu_bwd_kernel, M * (F / 8), pre, dout, dpre, M, F)
+}
+int launch_transpose2d(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo, int64_t rows, int cols,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)((rows + 63) / 64), cdiv(cols, 64)), dim3(256), 0, st,
+                     in, ldi, out, ldo, rows, cols);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(rows, 64), cdiv(cols, 64)), dim3(256), 0, st, w, wb, wtb,
+                     rows, cols);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                 float eps, float wd, int step, float grad_scale, hipStream_t st) {
+  const float bc1 = 1.f - powf(b1, (float)step), bc2 = 1.f - powf(b2, (float)step);
+  LAUNCH(adamw_kernel, n, p, g, m, v, n, lr, b1, b2, eps, wd, bc1, bc2, grad_scale)
+}
+int launch_add_noise(const float* z, const float* noise, const float* sa, const float* sb, float* out, int B,
+                     int64_t per, hipStream_t st) {
+  LAUNCH(add_noise_kernel, (int64_t)B * per, z, noise, sa, sb, out, B, per)
+}
+int launch_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
+                  const float* x3, float c3, float* out, int64_t n, hipStream_t st) {
+  LAUNCH(axpby4_kernel, n, x0, c0, x1, c1, x2, c2, x3, c3, out, n)
+}

@@ -1,0 +1,35 @@
+// bf16 MFMA GEMM / implicit-GEMM convolution for gfx950.  out[M,N] = A[M,K] * W[N,K]^T (+epilogue)
+#pragma once
+#include "common.h"
+
+enum { GEMM_ROW = 0, GEMM_CONV = 1 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2 };
+
+struct GemmArgs {
+  int M = 0, N = 0, K = 0;
+  const bf16_t* A = nullptr; int64_t lda = 0;   // ROW: A[M][lda]; CONV: NHWC activation base
+  const bf16_t* W = nullptr; int64_t ldw = 0;   // W[N][ldw], reduction index contiguous
+  int mode = GEMM_ROW;
+  // CONV geometry.  forward: X[B,Hin,Win,Cin] (virtually 2x nearest-upsampled when ups) ->
+  // Y[B,Hout,Wout,N].  dgrad: "X" is dY of a forward conv with the same KH/KW/stride/pad and
+  // Y is dX (gather form of the transposed convolution).
+  int Hin = 0, Win = 0, Cin = 0, Hout = 0, Wout = 0, KH = 1, KW = 1, stride = 1, pad = 0;
+  int ups = 0, dgrad = 0;
+  // epilogue:  v = alpha*acc + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n]; act
+  const float* bias = nullptr;
+  const bf16_t* rowvec = nullptr; int64_t rowvec_ld = 0; int rows_per_batch = 1;
+  const bf16_t* residual = nullptr; int64_t ldr = 0;
+  int act = ACT_NONE;             // ACT_GEGLU: N pre-activation columns in 16-wide (value|gate)
+                                  // interleave -> N/2 output columns
+  bf16_t* preact = nullptr; int64_t ldp = 0;   // optional save of the pre-activation (GEGLU bwd)
+  void* C = nullptr; int64_t ldc = 0; int out_f32 = 0;
+  float alpha = 1.f;
+  int splitk = 1; float* ws = nullptr;  // splitk>1: raw f32 partial sums accumulate into ws[M][N]
+  int accum_atomic = 0;           // C is f32 and receives atomicAdd(alpha*acc) (wgrad accumulation)
+  int force_tile = 0;             // 0 auto; else (BM<<16 | BN)
+  int use_glds = 1;               // LDS-DMA staging (1) or register staging (0)
+};
+
+int launch_gemm(const GemmArgs& a, hipStream_t stream);
+// algorithmic flops of one launch (2*M*N*K)
+static inline double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }

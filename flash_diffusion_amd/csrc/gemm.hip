@@ -1,0 +1,482 @@
+// Hand-written bf16 MFMA GEMM / implicit-GEMM convolution for gfx950 (CDNA4).
+//
+//   out[M,N] = A[M,K] * W[N,K]^T  (+ bias, + per-batch row vector, + residual, SiLU / GEGLU)
+//
+// * A operand: plain row-major activations, or an implicit im2col gather from an NHWC tensor
+//   (3x3 / 4x4 / 1x1, stride 1|2, zero padding, optional fused nearest-2x upsample, and the
+//   gather form of the transposed convolution for dgrad).  One 16-byte chunk = 8 channels.
+// * Tiles: BM x BN x 64, 256 threads = 4 waves (2x2), each wave (BM/2)x(BN/2) as 16x16x32 bf16
+//   MFMA fragments, fp32 accumulation.  Operands are swapped (D = Wfrag * Afrag^T) so that every
+//   lane owns 4 consecutive output channels of one row -> 8-byte bf16 stores.
+// * Staging: global -> LDS by LDS-DMA (global_load_lds, 16 B/lane), double buffered.  The DMA
+//   destination is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE
+//   address (logical chunk = slot ^ ((row>>1)&7)) and again on the ds_read_b128 address.
+//   Out-of-range rows / K tail / conv padding read a 16-byte zero page instead.
+// * blockIdx -> tile mapping is XCD-aware (8 XCDs, private L2s): consecutive tiles (same A rows,
+//   successive N tiles) are placed on one XCD.
+#include "gemm.h"
+
+static __device__ uint4 g_zero16[4] = {};
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+// ---------------------------------------------------------------------------------------------
+// epilogue helpers (shared by the GEMM kernel and the split-K finalize kernel)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void epi_terms(const GemmArgs& a, int64_t m, int n, float v[4]) {
+  // v = alpha*v + bias + rowvec + residual   (n..n+3, caller guarantees n+3 < N or handles tail)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] *= a.alpha;
+  if (a.bias) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.N) v[r] += a.bias[n + r];
+  }
+  if (a.rowvec) {
+    const bf16_t* rv = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.N) v[r] += bf2f(rv[r]);
+  }
+}
+
+__device__ __forceinline__ void epi_store(const GemmArgs& a, int act, int64_t m, int nout, int Nout, float v[4]) {
+  // + residual (indexed in OUTPUT columns), activation, store 4 consecutive output columns
+  if (a.residual) {
+    const bf16_t* rs = a.residual + m * a.ldr + nout;
+    if (nout + 3 < Nout && ((a.ldr | nout) & 3) == 0) {
+      u16x4 t = *(const u16x4*)rs;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bf2f(t[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nout + r < Nout) v[r] += bf2f(rs[r]);
+    }
+  }
+  if (act == ACT_SILU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+  }
+  if (a.out_f32) {
+    float* c = (float*)a.C + m * a.ldc + nout;
+    if (nout + 3 < Nout && ((a.ldc | nout) & 3) == 0) {
+      *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nout + r < Nout) c[r] = v[r];
+    }
+  } else {
+    bf16_t* c = (bf16_t*)a.C + m * a.ldc + nout;
+    if (nout + 3 < Nout && ((a.ldc | nout) & 3) == 0) {
+      uint2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      *(uint2*)c = pk;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nout + r < Nout) c[r] = f2bf(v[r]);
+    }
+  }
+}
+
+__device__ __forceinline__ void save_preact(const GemmArgs& a, int64_t m, int n, const float v[4]) {
+  bf16_t* p = a.preact + m * a.ldp + n;
+  if (n + 3 < a.N && ((a.ldp | n) & 3) == 0) {
+    uint2 pk;
+    pk.x = pack2bf(v[0], v[1]);
+    pk.y = pack2bf(v[2], v[3]);
+    *(uint2*)p = pk;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.N) p[r] = f2bf(v[r]);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int MODE, bool GLDS>
+__global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int AROWS = BM / 32, WROWS = BN / 32;  // 16-B chunks per thread per K tile
+  constexpr int STAGE = (BM + BN) * 128;           // bytes per pipeline stage
+  constexpr int MF = BM / 32, NF = BN / 32;        // 16x16 fragments per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, j = lane & 15;
+
+  // ---- XCD-aware tile mapping (bijective for any tile count) ----
+  const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
+  const int T = tilesM * tilesN;
+  int idx;
+  {
+    const int b = blockIdx.x, xcd = b & 7, q = T >> 3, r = T & 7;
+    idx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tn = idx % tilesN, tm = idx / tilesN;
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  // ---- K range (split-K over blockIdx.y) ----
+  int kbeg = 0, kend = a.K;
+  if (a.splitk > 1) {
+    const int ktiles = (a.K + 63) >> 6, per = (ktiles + a.splitk - 1) / a.splitk;
+    kbeg = blockIdx.y * per * 64;
+    kend = min(a.K, kbeg + per * 64);
+    if (kbeg >= kend) return;
+  }
+  const int nk = (kend - kbeg + 63) >> 6;
+
+  // ---- loader state: thread owns slot p of rows lr + 32*i; logical chunk c is row-group invariant
+  const int p = tid & 7, lr = tid >> 3;
+  const int c = p ^ ((lr >> 1) & 7);
+  int kcur = kbeg + c * 8;
+  int ky = 0, kx = 0, cc = 0;
+  if (MODE == GEMM_CONV) {
+    const int tap = kcur / a.Cin;
+    cc = kcur - tap * a.Cin;
+    ky = tap / a.KW;
+    kx = tap - ky * a.KW;
+  }
+  const bf16_t* arow[AROWS];
+  int abase_y[AROWS], abase_x[AROWS], apix[AROWS];
+  bool avalid[AROWS];
+#pragma unroll
+  for (int i = 0; i < AROWS; ++i) {
+    const int m = m0 + lr + 32 * i;
+    avalid[i] = m < a.M;
+    if (MODE == GEMM_ROW) {
+      arow[i] = a.A + (int64_t)(avalid[i] ? m : 0) * a.lda;
+      abase_y[i] = abase_x[i] = apix[i] = 0;
+    } else {
+      const int hw = a.Hout * a.Wout;
+      const int mm = avalid[i] ? m : 0;
+      const int b = mm / hw, rem = mm - b * hw;
+      const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+      arow[i] = a.A;
+      apix[i] = b * a.Hin * a.Win;
+      abase_y[i] = a.dgrad ? (oy + a.pad) : (oy * a.stride - a.pad);
+      abase_x[i] = a.dgrad ? (ox + a.pad) : (ox * a.stride - a.pad);
+    }
+  }
+  const bf16_t* wrow[WROWS];
+  bool wvalid[WROWS];
+#pragma unroll
+  for (int i = 0; i < WROWS; ++i) {
+    const int n = n0 + lr + 32 * i;
+    wvalid[i] = n < a.N;
+    wrow[i] = a.W + (int64_t)(wvalid[i] ? n : 0) * a.ldw;
+  }
+  const bf16_t* zero = (const bf16_t*)g_zero16;
+  uint4 areg[AROWS], wreg[WROWS];  // register staging (GLDS == false)
+
+  auto src_a = [&](int i) -> const bf16_t* {
+    if (!avalid[i] || kcur >= kend) return zero;
+    if (MODE == GEMM_ROW) return arow[i] + kcur;
+    if (ky >= a.KH) return zero;
+    int sy, sx;
+    if (a.dgrad) {
+      const int ty = abase_y[i] - ky, tx = abase_x[i] - kx;
+      if (ty < 0 || tx < 0) return zero;
+      if (a.stride == 2) {
+        if ((ty | tx) & 1) return zero;
+        sy = ty >> 1;
+        sx = tx >> 1;
+      } else {
+        sy = ty;
+        sx = tx;
+      }
+      if (sy >= a.Hin || sx >= a.Win) return zero;
+    } else {
+      const int iy = abase_y[i] + ky, ix = abase_x[i] + kx;
+      const int Hv = a.Hin << a.ups, Wv = a.Win << a.ups;
+      if (iy < 0 || ix < 0 || iy >= Hv || ix >= Wv) return zero;
+      sy = iy >> a.ups;
+      sx = ix >> a.ups;
+    }
+    return arow[i] + ((int64_t)(apix[i] + sy * a.Win + sx) * a.Cin + cc);
+  };
+  auto src_w = [&](int i) -> const bf16_t* {
+    if (!wvalid[i] || kcur >= kend) return zero;
+    return wrow[i] + kcur;
+  };
+  auto advance = [&]() {
+    kcur += 64;
+    if (MODE == GEMM_CONV) {
+      cc += 64;
+      while (cc >= a.Cin) {
+        cc -= a.Cin;
+        if (++kx == a.KW) {
+          kx = 0;
+          ++ky;
+        }
+      }
+    }
+  };
+  auto issue = [&](int stage) {  // global -> LDS (DMA) or global -> regs
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) {
+      const bf16_t* s = src_a(i);
+      if (GLDS) {
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)s,
+            (LDS_AS void*)(smem + stage * STAGE + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+      } else {
+        areg[i] = *(const uint4*)s;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i) {
+      const bf16_t* s = src_w(i);
+      if (GLDS) {
+        __builtin_amdgcn_global_load_lds((const GLOBAL_AS void*)s,
+            (LDS_AS void*)(smem + stage * STAGE + BM * 128 + (wave * 64 + 256 * i) * 16), 16, 0, 0);
+      } else {
+        wreg[i] = *(const uint4*)s;
+      }
+    }
+    advance();
+  };
+  auto commit = [&](int stage) {  // regs -> LDS (register staging only)
+#pragma unroll
+    for (int i = 0; i < AROWS; ++i) *(uint4*)(smem + stage * STAGE + (tid + 256 * i) * 16) = areg[i];
+#pragma unroll
+    for (int i = 0; i < WROWS; ++i)
+      *(uint4*)(smem + stage * STAGE + BM * 128 + (tid + 256 * i) * 16) = wreg[i];
+  };
+
+  f32x4 acc[NF][MF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  auto compute = [&](int stage) {
+    const char* sa = smem + stage * STAGE;
+    const char* sw = sa + BM * 128;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int pc = (ks * 4 + g) ^ (j >> 1);  // swizzled slot of logical chunk ks*4+g
+      bf16x8 af[MF], wf[NF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf)
+        af[mf] = *(const bf16x8*)(sa + ((wm * (BM / 2) + mf * 16 + j) * 8 + pc) * 16);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+        wf[nf] = *(const bf16x8*)(sw + ((wn * (BN / 2) + nf * 16 + j) * 8 + pc) * 16);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+          acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], af[mf], acc[nf][mf], 0, 0, 0);
+    }
+  };
+
+  // ---- main loop: 2-stage pipeline, one barrier per K tile ----
+  int stage = 0;
+  if (GLDS) {
+    issue(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) issue(stage ^ 1);
+      compute(stage);
+      __syncthreads();
+      stage ^= 1;
+    }
+  } else {
+    issue(0);
+    commit(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+      if (kt + 1 < nk) issue(stage ^ 1);
+      compute(stage);
+      if (kt + 1 < nk) commit(stage ^ 1);
+      __syncthreads();
+      stage ^= 1;
+    }
+  }
+
+  // ---- epilogue: lane (g, j) owns rows m = ..+j, columns n = ..+4g..4g+3 of each fragment ----
+  if (a.splitk > 1 || a.accum_atomic) {
+    float* dst = a.accum_atomic ? (float*)a.C : a.ws;
+    const int64_t ld = a.accum_atomic ? a.ldc : (int64_t)a.N;
+    const float sc = a.accum_atomic ? a.alpha : 1.f;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = m0 + wm * (BM / 2) + mf * 16 + j;
+        const int n = n0 + wn * (BN / 2) + nf * 16 + g * 4;
+        if (m < a.M) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) atomicAdd(dst + m * ld + n + r, acc[nf][mf][r] * sc);
+        }
+      }
+    return;
+  }
+  if (a.act == ACT_GEGLU) {
+    const int Nout = a.N >> 1;
+#pragma unroll
+    for (int q = 0; q < NF / 2; ++q)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = m0 + wm * (BM / 2) + mf * 16 + j;
+        const int n = n0 + wn * (BN / 2) + q * 32 + g * 4;  // value cols n.., gate cols n+16..
+        if (m < a.M && n < a.N) {
+          float val[4], gate[4], o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            val[r] = acc[2 * q][mf][r];
+            gate[r] = acc[2 * q + 1][mf][r];
+          }
+          epi_terms(a, m, n, val);
+          epi_terms(a, m, n + 16, gate);
+          if (a.preact) {
+            save_preact(a, m, n, val);
+            save_preact(a, m, n + 16, gate);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
+          epi_store(a, ACT_NONE, m, ((n0 + wn * (BN / 2)) >> 1) + q * 16 + g * 4, Nout, o);
+        }
+      }
+    return;
+  }
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t m = m0 + wm * (BM / 2) + mf * 16 + j;
+      const int n = n0 + wn * (BN / 2) + nf * 16 + g * 4;
+      if (m < a.M && n < a.N) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[nf][mf][r];
+        epi_terms(a, m, n, v);
+        epi_store(a, a.act, m, n, a.N, v);
+      }
+    }
+}
+
+// split-K finalize: ws[M][N] f32 raw sums -> epilogue -> C
+__global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs a) {
+  const int ngrp = (a.N + 3) >> 2;
+  const int64_t total = (int64_t)a.M * ngrp;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / ngrp;
+    const int n = (int)(i - m * ngrp) * 4;
+    if (a.act == ACT_GEGLU) {
+      // process (value, gate) 16-blocks: n indexes within a 32-wide pair block
+      const int blk = n >> 5, off = n & 31;
+      if (off >= 16) continue;
+      float val[4], gate[4], o[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        val[r] = (n + r < a.N) ? a.ws[m * a.N + n + r] : 0.f;
+        gate[r] = (n + 16 + r < a.N) ? a.ws[m * a.N + n + 16 + r] : 0.f;
+      }
+      epi_terms(a, m, n, val);
+      epi_terms(a, m, n + 16, gate);
+      if (a.preact) {
+        save_preact(a, m, n, val);
+        save_preact(a, m, n + 16, gate);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
+      epi_store(a, ACT_NONE, m, blk * 16 + off, a.N >> 1, o);
+    } else {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] = (n + r < a.N) ? a.ws[m * a.N + n + r] : 0.f;
+      epi_terms(a, m, n, v);
+      epi_store(a, a.act, m, n, a.N, v);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+template <int BM, int BN, int MODE, bool GLDS>
+static int launch_t(const GemmArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  constexpr int smem = 2 * (BM + BN) * 128;
+  if (!attr_set) {
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm_kernel<BM, BN, MODE, GLDS>,
+                                 hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+  dim3 grid(tiles, a.splitk > 1 ? a.splitk : 1, 1);
+  hipLaunchKernelGGL((gemm_kernel<BM, BN, MODE, GLDS>), grid, dim3(256), smem, stream, a);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int MODE, bool GLDS>
+static int launch_tile(const GemmArgs& a, int BM, int BN, hipStream_t stream) {
+  if (BM == 128 && BN == 128) return launch_t<128, 128, MODE, GLDS>(a, stream);
+  if (BM == 128 && BN == 64) return launch_t<128, 64, MODE, GLDS>(a, stream);
+  if (BM == 64 && BN == 128) return launch_t<64, 128, MODE, GLDS>(a, stream);
+  if (BM == 64 && BN == 64) return launch_t<64, 64, MODE, GLDS>(a, stream);
+  FDMI_CHECK(false, "gemm: unsupported tile");
+}
+
+int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
+  GemmArgs a = a_in;
+  FDMI_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
+  FDMI_CHECK((a.K % 8) == 0 && (a.ldw % 8) == 0, "gemm: K and ldw must be multiples of 8");
+  FDMI_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "gemm: operands must be 16-B aligned");
+  if (a.mode == GEMM_ROW) {
+    FDMI_CHECK((a.lda % 8) == 0, "gemm: lda must be a multiple of 8");
+  } else {
+    FDMI_CHECK((a.Cin % 8) == 0, "conv: Cin must be a multiple of 8");
+    FDMI_CHECK(a.K == a.KH * a.KW * a.Cin, "conv: K != KH*KW*Cin");
+    FDMI_CHECK(a.stride == 1 || a.stride == 2, "conv: stride must be 1 or 2");
+    FDMI_CHECK(!(a.ups && a.dgrad), "conv: ups+dgrad unsupported (dgrad at the upsampled size, then pool)");
+  }
+  if (a.act == ACT_GEGLU) FDMI_CHECK((a.N % 32) == 0, "geglu: N must be a multiple of 32");
+  if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
+  int BM, BN;
+  if (a.force_tile) {
+    BM = a.force_tile >> 16;
+    BN = a.force_tile & 0xffff;
+  } else {
+    if (a.N <= 64) BN = 64;
+    else if ((a.N % 128) == 0) BN = 128;
+    else BN = ((double)cdiv(a.N, 128) * 128 / a.N <= 1.07) ? 128 : 64;
+    BM = 128;
+    if (a.M <= 64 || cdiv(a.M, 128) * cdiv(a.N, BN) < 192) BM = 64;
+  }
+  if (a.splitk <= 0) {  // auto: fill the chip when the tile grid is small and K is long
+    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
+    int sk = 1;
+    if ((a.ws || a.accum_atomic) && tiles < 256) {
+      sk = 512 / tiles;
+      const int ktiles = cdiv(a.K, 64);
+      if (sk > ktiles / 4) sk = ktiles / 4;
+      if (sk > 32) sk = 32;
+      if (sk < 1) sk = 1;
+    }
+    a.splitk = sk;
+  }
+  if (a.splitk > 1 && !a.accum_atomic) {
+    FDMI_CHECK(a.ws != nullptr, "gemm: split-K needs a workspace");
+    FDMI_HIP(hipMemsetAsync(a.ws, 0, (size_t)a.M * a.N * sizeof(float), stream));
+  }
+  int rc;
+  if (a.mode == GEMM_ROW)
+    rc = a.use_glds ? launch_tile<GEMM_ROW, true>(a, BM, BN, stream) : launch_tile<GEMM_ROW, false>(a, BM, BN, stream);
+  else
+    rc = a.use_glds ? launch_tile<GEMM_CONV, true>(a, BM, BN, stream) : launch_tile<GEMM_CONV, false>(a, BM, BN, stream);
+  if (rc) return rc;
+  if (a.splitk > 1 && !a.accum_atomic) {
+    const int64_t total = (int64_t)a.M * ((a.N + 3) >> 2);
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(gemm_finalize_kernel, dim3(blocks), dim3(256), 0, stream, a);
+    FDMI_HIP(hipGetLastError());
+  }
+  return 0;
+}

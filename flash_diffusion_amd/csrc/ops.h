@@ -1,0 +1,76 @@
+// Internal launcher declarations (one per hand-written kernel family).
+#pragma once
+#include "common.h"
+#include "gemm.h"
+
+// ---- norm.hip ----
+int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta, float* stats,
+                         bf16_t* y, int B, int HW, int C, int G, float eps, int silu, hipStream_t st);
+int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta,
+                         const float* stats, float* bstats, bf16_t* dx, int B, int HW, int C, int G,
+                         float eps, int silu, int accumulate, hipStream_t st);
+int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, const bf16_t* shift,
+                         const bf16_t* scale, int64_t mod_ld, int rows_per_batch, bf16_t* y,
+                         int64_t rows, int C, float eps, hipStream_t st);
+int launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const bf16_t* scale,
+                         int64_t mod_ld, int rows_per_batch, bf16_t* dx, int64_t rows, int C,
+                         float eps, int accumulate, hipStream_t st);
+
+// ---- attn.hip ----
+__host__ __device__ static inline int attn_spad(int S) { return (S + 63) & ~63; }      // padded sequence length
+__host__ __device__ static inline int attn_dvpad(int d) { return (d + 15) & ~15; }     // padded head dim (rows of X^T)
+struct AttnArgs {
+  // row-major operands [B, S, ld] with head h at column offset h*d
+  const bf16_t* Q; int64_t ldq;
+  const bf16_t* K; int64_t ldk;
+  const bf16_t* V; int64_t ldv;
+  const bf16_t* O; int64_t ldo;     // forward output (bwd: saved output, only for delta)
+  const bf16_t* dO; int64_t lddo;
+  // head-transposed copies [B, H, dvpad, spad] (zero padded), produced by launch_transpose_heads
+  const bf16_t* QT; const bf16_t* KT; const bf16_t* VT; const bf16_t* dOT;
+  float* lse;        // [B, H, Sq] log2-domain log-sum-exp of scale*log2e*QK^T
+  const float* delta;  // [B, H, Sq] rowsum(dO * O)
+  bf16_t* out;  int64_t ldout;     // fwd: O; dq kernel: dQ
+  bf16_t* dK; int64_t lddk; bf16_t* dV; int64_t lddv;
+  int B, H, Sq, Skv, d; float scale;
+};
+int launch_attn_fwd(const AttnArgs& a, hipStream_t st);
+int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st);
+int launch_attn_bwd_dkv(const AttnArgs& a, hipStream_t st);
+// X[B,S,ld] (head h at h*d) -> XT[B,H,dvpad,spad], zero padded
+int launch_transpose_heads(const bf16_t* X, int64_t ld, bf16_t* XT, int B, int H, int S, int d,
+                           hipStream_t st);
+// delta[b,h,s] = sum_d dO*O
+int launch_attn_delta(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, float* delta,
+                      int B, int H, int S, int d, hipStream_t st);
+
+// ---- elem.hip ----
+int launch_nchw_to_nhwc(const float* x, bf16_t* y, int B, int C, int HW, int Cpad, hipStream_t st);
+int launch_nhwc_to_nchw(const bf16_t* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate,
+                        hipStream_t st);
+int launch_nchw_grad_to_nhwc(const float* g, bf16_t* y, int64_t ldy, int B, int C, int HW, hipStream_t st);
+int launch_timestep_embed(const float* t, bf16_t* out, int B, int dim, int flip, float shift, hipStream_t st);
+int launch_silu(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t st);
+// dst[m][dc0 + c] (=|+=) src[m][sc0 + c], c < cols
+int launch_copy2d(const bf16_t* src, int64_t lds, int sc0, bf16_t* dst, int64_t ldd, int dc0,
+                  int64_t rows, int cols, int accumulate, hipStream_t st);
+int launch_f32_to_bf16(const float* x, bf16_t* y, int64_t n, hipStream_t st);
+// dX[B,H,W,C] (=|+=) sum of the 2x2 block of dY[B,2H,2W,C]
+int launch_pool2x2_sum(const bf16_t* dy, bf16_t* dx, int B, int H, int W, int C, int accumulate, hipStream_t st);
+// GEGLU backward: pre[M][2F] in 16-wide (value|gate) interleave, dout[M][F] -> dpre[M][2F]
+int launch_geglu_bwd(const bf16_t* pre, const bf16_t* dout, bf16_t* dpre, int64_t M, int F, hipStream_t st);
+// out[c][r] = in[r][c]  (bf16 matrix transpose; in ld = ldi, out ld = ldo)
+int launch_transpose2d(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo, int64_t rows, int cols,
+                       hipStream_t st);
+// LoRA refresh: f32 master W[rows][cols] -> bf16 copy and bf16 transpose
+int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int cols, hipStream_t st);
+// fused AdamW on a flat f32 buffer
+int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
+                 float eps, float wd, int step, float grad_scale, hipStream_t st);
+
+// ---- flashstep.hip (fused scheduler / loss element-wise math, K6) ----
+struct StepCoef { float a, b, c, d; };
+int launch_add_noise(const float* z, const float* noise, const float* sa, const float* sb, float* out,
+                     int B, int64_t per, hipStream_t st);
+int launch_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
+                  const float* x3, float c3, float* out, int64_t n, hipStream_t st);

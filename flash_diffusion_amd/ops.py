@@ -1,0 +1,230 @@
+"""Thin Python wrappers over the op-level C-ABI (include/fdmi.h).  torch is used only for device
+memory and the current stream; every computation below runs in a hand-written HIP kernel."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from ._lib import GemmDesc, check, lib, ptr, stream_ptr
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+
+
+def _dev(t):
+    assert t.is_cuda, "fdmi ops need device tensors (no CPU fallback)"
+    return t
+
+
+# ---- weight packing (one-off, init time) ---------------------------------------------------------
+def pack_conv_weight(w):
+    """OIHW f32 -> [O][KH][KW][I] bf16 rows (K = KH*KW*I contiguous); I zero-padded to a multiple of 8."""
+    O, I, KH, KW = w.shape
+    Ip = (I + 7) // 8 * 8
+    p = torch.zeros(O, KH, KW, Ip, dtype=torch.float32, device=w.device)
+    p[..., :I] = w.permute(0, 2, 3, 1)
+    return p.reshape(O, KH * KW * Ip).to(BF16).contiguous()
+
+
+def pack_conv_weight_dgrad(w):
+    """OIHW f32 -> dgrad operand [I][KH][KW][O] bf16 (rows = input channels)."""
+    O, I, KH, KW = w.shape
+    Op = (O + 7) // 8 * 8
+    p = torch.zeros(I, KH, KW, Op, dtype=torch.float32, device=w.device)
+    p[..., :O] = w.permute(1, 2, 3, 0)
+    return p.reshape(I, KH * KW * Op).to(BF16).contiguous()
+
+
+def geglu_perm(n_half, device=None):
+    """Row permutation putting (value, gate) rows of a GEGLU projection into 16-wide interleave."""
+    idx = torch.arange(2 * n_half, device=device)
+    blk, off = idx // 32, idx % 32
+    return torch.where(off < 16, blk * 16 + off, n_half + blk * 16 + off - 16)
+
+
+# ---- GEMM / conv -------------------------------------------------------------------------------
+def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows_per_batch=1, residual=None,
+         act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1, ws=None, accum_atomic=False,
+         force_tile=0, use_glds=True, conv=None):
+    """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue).  conv: dict(Hin,Win,Cin,Hout,Wout,KH,KW,stride,pad,ups,dgrad)
+    with A the NHWC activation."""
+    _dev(A)
+    d = GemmDesc()
+    N = W.shape[0] if N is None else N
+    K = W.shape[1] if K is None else K
+    if conv is None:
+        M = A.shape[0] if M is None else M
+        d.mode = 0
+        d.lda = A.stride(0) if lda is None else lda
+    else:
+        d.mode = 1
+        for k in ("Hin", "Win", "Cin", "Hout", "Wout", "KH", "KW", "stride", "pad", "ups", "dgrad"):
+            setattr(d, k, int(conv.get(k, 0)))
+        assert M is not None
+    d.M, d.N, d.K = M, N, K
+    d.A, d.W, d.ldw = ptr(A), ptr(W), W.stride(0)
+    d.bias = ptr(bias)
+    d.rowvec, d.rowvec_ld, d.rows_per_batch = ptr(rowvec), (rowvec.stride(0) if rowvec is not None else 0), rows_per_batch
+    d.residual, d.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
+    d.act = act
+    d.preact, d.ldp = ptr(preact), (preact.stride(0) if preact is not None else 0)
+    Nout = N // 2 if act == ACT_GEGLU else N
+    if out is None:
+        out = torch.empty(M, Nout, dtype=torch.float32 if out_f32 else BF16, device=A.device)
+    d.C, d.ldc, d.out_f32 = ptr(out), out.stride(0), int(out.dtype == torch.float32)
+    d.alpha = alpha
+    d.splitk, d.ws = splitk, ptr(ws)
+    d.accum_atomic, d.force_tile, d.use_glds = int(accum_atomic), force_tile, int(use_glds)
+    check(lib().fdmi_gemm(C.byref(d), stream_ptr()))
+    return out
+
+
+def conv2d_nhwc(x, w_packed, *, KH, KW, stride=1, pad=0, ups=0, dgrad=0, out_hw=None, **kw):
+    """x [B,H,W,C] bf16 NHWC -> [B,Ho,Wo,N] (as [M,N])."""
+    B, H, Wd, Cin = x.shape
+    if out_hw is None:
+        Hv, Wv = H << ups, Wd << ups
+        Ho = (Hv + 2 * pad - KH) // stride + 1
+        Wo = (Wv + 2 * pad - KW) // stride + 1
+    else:
+        Ho, Wo = out_hw
+    conv = dict(Hin=H, Win=Wd, Cin=Cin, Hout=Ho, Wout=Wo, KH=KH, KW=KW, stride=stride, pad=pad, ups=ups,
+                dgrad=dgrad)
+    y = gemm(x, w_packed, M=B * Ho * Wo, conv=conv, **kw)
+    return y.view(B, Ho, Wo, -1)
+
+
+# ---- norms -------------------------------------------------------------------------------------
+def groupnorm_fwd(x, gamma, beta, G, eps, silu):
+    """x [B,HW,C] bf16 -> (y, stats[B,G,2])"""
+    B, HW, Cc = x.shape
+    y = torch.empty_like(x)
+    stats = torch.empty(B, G, 2, dtype=torch.float32, device=x.device)
+    check(lib().fdmi_groupnorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(y), B, HW, Cc, G, eps,
+                                   int(silu), stream_ptr()))
+    return y, stats
+
+
+def groupnorm_bwd(x, dy, gamma, beta, stats, G, eps, silu, dx=None):
+    B, HW, Cc = x.shape
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    bstats = torch.empty(B, G, 2, dtype=torch.float32, device=x.device)
+    check(lib().fdmi_groupnorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(stats), ptr(bstats), ptr(dx), B,
+                                   HW, Cc, G, eps, int(silu), int(acc), stream_ptr()))
+    return dx
+
+
+def layernorm_fwd(x, gamma, beta, eps):
+    y = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    check(lib().fdmi_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), rows, x.shape[-1], eps, stream_ptr()))
+    return y
+
+
+def layernorm_bwd(x, dy, gamma, eps, dx=None):
+    acc = dx is not None
+    if dx is None:
+        dx = torch.empty_like(x)
+    rows = x.numel() // x.shape[-1]
+    check(lib().fdmi_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(dx), rows, x.shape[-1], eps, int(acc),
+                                   stream_ptr()))
+    return dx
+
+
+# ---- attention ---------------------------------------------------------------------------------
+def attn_fwd(q, k, v, H, scale, need_lse=False):
+    """q [B,Sq,H*d], k/v [B,Skv,H*d] bf16 -> o [B,Sq,H*d] (, lse [B,H,Sq])"""
+    B, Sq, Cc = q.shape
+    Skv = k.shape[1]
+    d = Cc // H
+    o = torch.empty_like(q)
+    vt = torch.empty(lib().fdmi_attn_tr_elems(B, H, Skv, d), dtype=BF16, device=q.device)
+    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
+    check(lib().fdmi_attn_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
+                              ptr(vt), ptr(lse), B, H, Sq, Skv, d, scale, stream_ptr()))
+    return (o, lse) if need_lse else o
+
+
+def attn_bwd(q, k, v, o, do, lse, H, scale):
+    B, Sq, Cc = q.shape
+    Skv = k.shape[1]
+    d = Cc // H
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    ws = torch.empty(lib().fdmi_attn_bwd_ws_bytes(B, H, Sq, Skv, d), dtype=torch.uint8, device=q.device)
+    check(lib().fdmi_attn_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
+                              ptr(do), do.stride(1), ptr(lse), ptr(dq), dq.stride(1), ptr(dk), dk.stride(1),
+                              ptr(dv), dv.stride(1), ptr(ws), B, H, Sq, Skv, d, scale, stream_ptr()))
+    return dq, dk, dv
+
+
+# ---- misc --------------------------------------------------------------------------------------
+def nchw_to_nhwc(x, Cpad):
+    B, Cc, H, W = x.shape
+    y = torch.empty(B, H, W, Cpad, dtype=BF16, device=x.device)
+    check(lib().fdmi_nchw_to_nhwc(ptr(x.contiguous()), ptr(y), B, Cc, H * W, Cpad, stream_ptr()))
+    return y
+
+
+def nhwc_to_nchw(x, Cc):
+    B, H, W, ld = x.shape
+    y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
+    check(lib().fdmi_nhwc_to_nchw(ptr(x), ld, ptr(y), B, Cc, H * W, 0, stream_ptr()))
+    return y
+
+
+def timestep_embed(t, dim, flip=True, shift=0.0):
+    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
+    check(lib().fdmi_timestep_embed(ptr(t.float().contiguous()), ptr(out), t.shape[0], dim, int(flip), shift,
+                                    stream_ptr()))
+    return out
+
+
+def geglu_bwd(pre, dout):
+    M, F2 = pre.shape
+    dpre = torch.empty_like(pre)
+    check(lib().fdmi_geglu_bwd(ptr(pre), ptr(dout), ptr(dpre), M, F2 // 2, stream_ptr()))
+    return dpre
+
+
+def pool2x2_sum(dy):
+    B, H2, W2, Cc = dy.shape
+    dx = torch.empty(B, H2 // 2, W2 // 2, Cc, dtype=BF16, device=dy.device)
+    check(lib().fdmi_pool2x2_sum(ptr(dy), ptr(dx), B, H2 // 2, W2 // 2, Cc, 0, stream_ptr()))
+    return dx
+
+
+def cast_transpose(w):
+    rows, cols = w.shape
+    wb = torch.empty(rows, cols, dtype=BF16, device=w.device)
+    wtb = torch.empty(cols, rows, dtype=BF16, device=w.device)
+    check(lib().fdmi_cast_transpose(ptr(w), ptr(wb), ptr(wtb), rows, cols, stream_ptr()))
+    return wb, wtb
+
+
+def transpose2d(x):
+    rows, cols = x.shape
+    out = torch.empty(cols, rows, dtype=BF16, device=x.device)
+    check(lib().fdmi_transpose2d(ptr(x), x.stride(0), ptr(out), rows, rows, cols, stream_ptr()))
+    return out
+
+
+def adamw_(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=1, grad_scale=1.0):
+    check(lib().fdmi_adamw(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), lr, beta1, beta2, eps, weight_decay, step,
+                           grad_scale, stream_ptr()))
+
+
+def add_noise(z, noise, sa, sb):
+    out = torch.empty_like(z)
+    B = z.shape[0]
+    check(lib().fdmi_add_noise(ptr(z), ptr(noise), ptr(sa), ptr(sb), ptr(out), B, z.numel() // B, stream_ptr()))
+    return out
+
+
+def axpby(x0, c0, x1=None, c1=0.0, x2=None, c2=0.0, x3=None, c3=0.0, out=None):
+    if out is None:
+        out = torch.empty_like(x0)
+    check(lib().fdmi_axpby4(ptr(x0), c0, ptr(x1), c1, ptr(x2), c2, ptr(x3), c3, ptr(out), x0.numel(), stream_ptr()))
+    return out

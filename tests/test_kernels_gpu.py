@@ -1,0 +1,322 @@
+"""GPU parity tests of the individual HIP kernels (through the C-ABI) against plain PyTorch fp32
+references computed on the host from the same bf16-rounded inputs.
+
+Tolerance (stated): outputs are bf16 with fp32 accumulation, so |out - ref| <= 2^-7 * max|ref|
+element-wise (one bf16 ulp at the tensor scale plus accumulation-order noise) and the relative
+Frobenius error must be < 4e-3.  fp32 outputs: relative Frobenius error < 1e-4.
+Mismatch diagnostics are appended to gpurun_out/kernel_diag.txt."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DIAG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "kernel_diag.txt")
+
+
+def _ops():
+    from flash_diffusion_amd import ops
+    return ops
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale)
+
+
+def b16(x):
+    return x.to(torch.bfloat16)
+
+
+def close(name, out, ref, tol_el=2 ** -7, tol_fro=4e-3):
+    out = out.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert out.shape == ref.shape, (name, out.shape, ref.shape)
+    err = (out - ref).abs()
+    scale = ref.abs().max().item() + 1e-30
+    fro = (out - ref).norm().item() / (ref.norm().item() + 1e-30)
+    bad = err > tol_el * scale
+    ok = (not bad.any().item()) and fro < tol_fro and torch.isfinite(out).all().item()
+    if not ok:
+        os.makedirs(os.path.dirname(DIAG), exist_ok=True)
+        with open(DIAG, "a") as f:
+            f.write(f"\n=== {name}: shape {tuple(out.shape)} fro {fro:.3e} maxerr {err.max().item():.3e} "
+                    f"scale {scale:.3e} bad {bad.float().mean().item():.4f} nonfinite "
+                    f"{(~torch.isfinite(out)).sum().item()}\n")
+            o2, r2, b2 = out.reshape(-1, out.shape[-1]), ref.reshape(-1, ref.shape[-1]), bad.reshape(-1, out.shape[-1])
+            rows = b2.any(dim=1).nonzero().flatten()
+            cols = b2.any(dim=0).nonzero().flatten()
+            f.write(f"bad rows ({len(rows)}): {rows[:40].tolist()}\nbad cols ({len(cols)}): {cols[:40].tolist()}\n")
+            f.write(f"bad by row%16: {[int(b2[i::16].sum()) for i in range(16)]}\n")
+            f.write(f"bad by col%16: {[int(b2[:, i::16].sum()) for i in range(min(16, b2.shape[1]))]}\n")
+            for r in rows[:3].tolist():
+                f.write(f"row {r} out {o2[r, :12].tolist()}\nrow {r} ref {r2[r, :12].tolist()}\n")
+    assert ok, f"{name}: fro {fro:.3e}, max err {err.max().item():.3e} (scale {scale:.3e}), bad {bad.float().mean().item():.4f}"
+
+
+# ------------------------------------------------------------------------------------------------
+GEMM_SHAPES = [(128, 128, 64), (200, 72, 136), (1232, 320, 768), (4096, 320, 320), (64, 640, 2560), (16, 1280, 320)]
+
+
+@pytest.mark.parametrize("shape", GEMM_SHAPES)
+@pytest.mark.parametrize("glds", [True, False])
+@pytest.mark.parametrize("tile", [0, (128 << 16) | 128, (128 << 16) | 64, (64 << 16) | 128, (64 << 16) | 64])
+def test_gemm_row(shape, glds, tile):
+    ops = _ops()
+    M, N, K = shape
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    out = ops.gemm(A.cuda(), W.cuda(), use_glds=glds, force_tile=tile)
+    close(f"gemm_row{shape}_glds{glds}_tile{tile:x}", out, A.float() @ W.float().t())
+
+
+def test_gemm_identity_asymmetric():
+    """A = I with an asymmetric W catches transposed / permuted fragment layouts."""
+    ops = _ops()
+    n = 128
+    A = b16(torch.eye(n))
+    W = b16((torch.arange(n)[:, None] * 0.5 + torch.arange(n)[None, :] * 0.01))
+    out = ops.gemm(A.cuda(), W.cuda())
+    close("gemm_identity", out, W.float().t(), tol_el=1e-6, tol_fro=1e-6)
+
+
+@pytest.mark.parametrize("glds", [True, False])
+def test_gemm_epilogues(glds):
+    ops = _ops()
+    M, N, K, rpb = 192, 328, 256, 64
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    rowvec = b16(rnd(M // rpb, N, seed=4))
+    res = b16(rnd(M, N, seed=5))
+    ref = 0.5 * (A.float() @ W.float().t()) + bias + rowvec.float().repeat_interleave(rpb, 0) + res.float()
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), rowvec=rowvec.cuda(), rows_per_batch=rpb,
+                   residual=res.cuda(), alpha=0.5, use_glds=glds)
+    close("gemm_epi_full", out, ref)
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_SILU, use_glds=glds)
+    close("gemm_epi_silu", out, F.silu(A.float() @ W.float().t() + bias))
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), out_f32=True, use_glds=glds)
+    close("gemm_epi_f32", out, A.float() @ W.float().t() + bias, tol_el=1e-4, tol_fro=1e-4)
+
+
+def test_gemm_geglu():
+    ops = _ops()
+    M, K, Fh = 200, 64, 96
+    A = b16(rnd(M, K, seed=1))
+    W = b16(rnd(2 * Fh, K, seed=2, scale=K ** -0.5))
+    bias = rnd(2 * Fh, seed=3)
+    res = b16(rnd(M, Fh, seed=5))
+    perm = ops.geglu_perm(Fh)
+    h = A.float() @ W.float().t() + bias
+    ref = h[:, :Fh] * F.gelu(h[:, Fh:]) + res.float()
+    pre = torch.empty(M, 2 * Fh, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(A.cuda(), W[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(),
+                   act=ops.ACT_GEGLU, preact=pre, residual=res.cuda())
+    close("gemm_geglu", out, ref)
+    close("gemm_geglu_preact", pre, h[:, perm])
+    # backward of the gate on the interleaved layout
+    dout = b16(rnd(M, Fh, seed=7))
+    dpre = ops.geglu_bwd(pre, dout.cuda())
+    hp = pre.float().cpu()
+    inv = torch.empty_like(perm)
+    inv[perm] = torch.arange(2 * Fh)
+    hh = hp[:, inv]
+    val, gate = hh[:, :Fh].requires_grad_(), hh[:, Fh:].requires_grad_()
+    (val * F.gelu(gate)).backward(dout.float())
+    ref_d = torch.cat([val.grad, gate.grad], 1)[:, perm]
+    close("geglu_bwd", dpre, ref_d)
+
+
+def test_gemm_splitk_and_atomic():
+    ops = _ops()
+    M, N, K = 96, 200, 4096
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    ref = A.float() @ W.float().t()
+    ws = torch.empty(M, N, dtype=torch.float32, device="cuda")
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), splitk=4, ws=ws)
+    close("gemm_splitk", out, ref + bias)
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), splitk=0, ws=ws)
+    close("gemm_splitk_auto", out, ref + bias)
+    acc = torch.ones(M, N, dtype=torch.float32, device="cuda")
+    ops.gemm(A.cuda(), W.cuda(), out=acc, accum_atomic=True, splitk=8, alpha=2.0)
+    close("gemm_atomic", acc, 1.0 + 2.0 * ref, tol_el=1e-4, tol_fro=1e-4)
+
+
+CONVS = [
+    # (B, H, W, Cin, Cout, k, stride, pad, ups)
+    (2, 8, 8, 32, 64, 3, 1, 1, 0),
+    (1, 16, 12, 64, 40, 3, 1, 1, 0),
+    (2, 16, 16, 32, 32, 3, 2, 1, 0),
+    (2, 8, 8, 64, 64, 3, 1, 1, 1),
+    (2, 16, 16, 8, 32, 3, 1, 1, 0),
+    (2, 8, 8, 128, 16, 4, 2, 1, 0),
+    (2, 4, 4, 32, 4, 4, 1, 0, 0),
+    (3, 8, 8, 320, 320, 3, 1, 1, 0),
+    (2, 8, 8, 96, 64, 1, 1, 0, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+@pytest.mark.parametrize("glds", [True, False])
+def test_conv_fwd_and_dgrad(cfg, glds):
+    ops = _ops()
+    B, H, W, Ci, Co, k, s, p, ups = cfg
+    x = b16(rnd(B, Ci, H, W, seed=1))
+    w = b16(rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5))
+    bias = rnd(Co, seed=3)
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    xin.requires_grad_()
+    ref = F.conv2d(xin, w.float(), bias, stride=s, padding=p)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    y = ops.conv2d_nhwc(xn, ops.pack_conv_weight(w.float()).cuda(), KH=k, KW=k, stride=s, pad=p, ups=ups,
+                        bias=bias.cuda(), use_glds=glds)
+    close(f"conv_fwd{cfg}_glds{glds}", y.permute(0, 3, 1, 2), ref)
+    # dgrad: gather form of the transposed conv with the [I][KH][KW][O] operand
+    if Co % 8 == 0:
+        dy = b16(rnd(*ref.shape, seed=4))
+        ref.backward(dy.float())
+        dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+        dx = ops.conv2d_nhwc(dyn, ops.pack_conv_weight_dgrad(w.float()).cuda(), KH=k, KW=k, stride=s, pad=p,
+                             dgrad=1, out_hw=(H << ups, W << ups), use_glds=glds)
+        close(f"conv_dgrad{cfg}_glds{glds}", dx.permute(0, 3, 1, 2), xin.grad)
+        if ups:
+            dxl = ops.pool2x2_sum(dx.contiguous())
+            g_low = xin.grad.reshape(B, Ci, H, 2, W, 2).sum((3, 5))
+            close(f"pool2x2{cfg}", dxl.permute(0, 3, 1, 2), g_low)
+
+
+GNS = [(2, 64, 32, 32), (2, 256, 320, 32), (1, 100, 960, 32), (2, 16, 2560, 32), (3, 64, 128, 4), (2, 1024, 640, 32)]
+
+
+@pytest.mark.parametrize("cfg", GNS)
+@pytest.mark.parametrize("silu", [0, 1])
+def test_groupnorm(cfg, silu):
+    ops = _ops()
+    B, HW, Cc, G = cfg
+    x = b16(rnd(B, HW, Cc, seed=1) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.1 * rnd(Cc, seed=2), 0.1 * rnd(Cc, seed=3)
+    xr = x.float().permute(0, 2, 1).requires_grad_()
+    ref = F.group_norm(xr, G, gamma, beta, 1e-5)
+    if silu:
+        ref = F.silu(ref)
+    y, stats = ops.groupnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), G, 1e-5, silu)
+    close(f"gn_fwd{cfg}_{silu}", y, ref.permute(0, 2, 1))
+    dy = b16(rnd(B, HW, Cc, seed=4))
+    ref.backward(dy.float().permute(0, 2, 1))
+    dx = ops.groupnorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), stats, G, 1e-5, silu)
+    close(f"gn_bwd{cfg}_{silu}", dx, xr.grad.permute(0, 2, 1), tol_el=2 ** -6, tol_fro=6e-3)
+
+
+@pytest.mark.parametrize("cfg", [(200, 320), (64, 1280), (33, 64), (128, 1152)])
+def test_layernorm(cfg):
+    ops = _ops()
+    rows, Cc = cfg
+    x = b16(rnd(rows, Cc, seed=1) * 2 + 0.5)
+    gamma, beta = 1 + 0.1 * rnd(Cc, seed=2), 0.1 * rnd(Cc, seed=3)
+    xr = x.float().requires_grad_()
+    ref = F.layer_norm(xr, (Cc,), gamma, beta, 1e-5)
+    y = ops.layernorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), 1e-5)
+    close(f"ln_fwd{cfg}", y, ref)
+    dy = b16(rnd(rows, Cc, seed=4))
+    ref.backward(dy.float())
+    dx = ops.layernorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), 1e-5)
+    close(f"ln_bwd{cfg}", dx, xr.grad, tol_el=2 ** -6, tol_fro=6e-3)
+    prev = b16(rnd(rows, Cc, seed=9))
+    dx2 = prev.cuda().clone()
+    ops.layernorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), 1e-5, dx=dx2)
+    close(f"ln_bwd_acc{cfg}", dx2, xr.grad + prev.float(), tol_el=2 ** -6, tol_fro=6e-3)
+
+
+ATTN = [
+    # (B, H, Sq, Skv, d)
+    (2, 2, 64, 64, 16), (1, 2, 128, 128, 32), (2, 8, 256, 256, 40), (1, 3, 100, 100, 64), (2, 8, 256, 77, 40),
+    (1, 8, 64, 77, 160), (1, 8, 256, 256, 80), (1, 2, 1024, 1024, 40), (1, 4, 200, 120, 72), (1, 2, 64, 64, 160),
+    (1, 2, 130, 70, 8),
+]
+
+
+def _attn_ref(q, k, v, H, scale):
+    B, Sq, Cc = q.shape
+    d = Cc // H
+    qh = q.view(B, Sq, H, d).transpose(1, 2)
+    kh = k.view(B, -1, H, d).transpose(1, 2)
+    vh = v.view(B, -1, H, d).transpose(1, 2)
+    p = ((qh @ kh.transpose(-1, -2)) * scale).softmax(-1)
+    return (p @ vh).transpose(1, 2).reshape(B, Sq, Cc)
+
+
+@pytest.mark.parametrize("cfg", ATTN)
+def test_attention_fwd_bwd(cfg):
+    ops = _ops()
+    B, H, Sq, Skv, d = cfg
+    scale = d ** -0.5
+    q = b16(rnd(B, Sq, H * d, seed=1))
+    k = b16(rnd(B, Skv, H * d, seed=2))
+    v = b16(rnd(B, Skv, H * d, seed=3))
+    qr, kr, vr = (t.float().requires_grad_() for t in (q, k, v))
+    ref = _attn_ref(qr, kr, vr, H, scale)
+    o, lse = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, scale, need_lse=True)
+    close(f"attn_fwd{cfg}", o, ref)
+    do = b16(rnd(B, Sq, H * d, seed=4))
+    ref.backward(do.float())
+    dq, dk, dv = ops.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o, do.cuda(), lse, H, scale)
+    close(f"attn_dq{cfg}", dq, qr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
+    close(f"attn_dk{cfg}", dk, kr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
+    close(f"attn_dv{cfg}", dv, vr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
+
+
+def test_attention_spike_forces_rescale():
+    """One key dominates one query late in the sequence: the online-softmax rescale branch must fire."""
+    ops = _ops()
+    B, H, S, d = 1, 2, 256, 40
+    q, k, v = rnd(B, S, H * d, seed=1), rnd(B, S, H * d, seed=2), rnd(B, S, H * d, seed=3)
+    k[0, 200, :d] = q[0, 17, :d] * 6.0
+    q, k, v = b16(q), b16(k), b16(v)
+    ref = _attn_ref(q.float(), k.float(), v.float(), H, d ** -0.5)
+    o = ops.attn_fwd(q.cuda(), k.cuda(), v.cuda(), H, d ** -0.5)
+    close("attn_spike", o, ref)
+
+
+def test_layout_and_misc_kernels():
+    ops = _ops()
+    x = rnd(2, 4, 8, 8, seed=1)
+    y = ops.nchw_to_nhwc(x.cuda(), 8)
+    ref = torch.zeros(2, 8, 8, 8)
+    ref[..., :4] = x.permute(0, 2, 3, 1)
+    close("nchw_to_nhwc", y, b16(ref).float(), tol_el=1e-6, tol_fro=1e-6)
+    back = ops.nhwc_to_nchw(y, 4)
+    close("nhwc_to_nchw", back, b16(x).float(), tol_el=1e-6, tol_fro=1e-6)
+    t = torch.tensor([999.0, 1.0, 500.0])
+    emb = ops.timestep_embed(t.cuda(), 320)
+    half = 160
+    e = t[:, None] * torch.exp(-math.log(10000) * torch.arange(half) / half)[None]
+    close("timestep_embed", emb, torch.cat([torch.cos(e), torch.sin(e)], -1), tol_el=2 ** -7, tol_fro=5e-3)
+    w = rnd(100, 72, seed=3)
+    wb, wtb = ops.cast_transpose(w.cuda())
+    close("cast", wb, b16(w).float(), tol_el=1e-6, tol_fro=1e-6)
+    close("cast_t", wtb, b16(w).float().t(), tol_el=1e-6, tol_fro=1e-6)
+    xb = b16(rnd(130, 200, seed=4))
+    close("transpose2d", ops.transpose2d(xb.cuda()), xb.float().t(), tol_el=1e-6, tol_fro=1e-6)
+    z, n = rnd(3, 4, 8, 8, seed=5), rnd(3, 4, 8, 8, seed=6)
+    sa, sb = torch.tensor([0.9, 0.5, 0.1]), torch.tensor([0.1, 0.7, 0.99])
+    close("add_noise", ops.add_noise(z.cuda(), n.cuda(), sa.cuda(), sb.cuda()),
+          sa.view(-1, 1, 1, 1) * z + sb.view(-1, 1, 1, 1) * n, tol_el=1e-6, tol_fro=1e-6)
+    close("axpby", ops.axpby(z.cuda(), 2.0, n.cuda(), -0.5, z.cuda(), 0.25), 2.25 * z - 0.5 * n, tol_el=1e-6,
+          tol_fro=1e-6)
+
+
+def test_adamw_matches_torch():
+    ops = _ops()
+    p0, g = rnd(1000, seed=1), rnd(1000, seed=2)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([p], lr=1e-3, weight_decay=0.01)
+    pd, m, v = p0.cuda().clone(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for step in (1, 2, 3):
+        p.grad = g.clone() * step
+        opt.step()
+        ops.adamw_(pd, (g * step).cuda(), m, v, 1e-3, step=step)
+    close("adamw", pd, p.detach(), tol_el=1e-5, tol_fro=1e-5)
