@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const bf16_t* pre, const
 
 // bf16 2-D transpose through LDS: out[c][r] = in[r][c]
 __global__ __launch_bounds__(256) void transpose2d_kernel(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo,
-                                                          int64_t rows, int cols) {
+                                                          int64_t rows, int cols, int64_t rows_pad) {
   __shared__ bf16_t tile[64][66];
   const int64_t r0 = (int64_t)blockIdx.x * 64;
   const int c0 = blockIdx.y * 64;
@@ -170,7 +170,17 @@ __global__ __launch_bounds__(256) void transpose2d_kernel(const bf16_t* in, int6
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int c = i >> 6, r = i & 63;
-    if (c0 + c < cols && r0 + r < rows) out[(int64_t)(c0 + c) * ldo + r0 + r] = tile[r][c];
+    if (c0 + c < cols && r0 + r < rows_pad) out[(int64_t)(c0 + c) * ldo + r0 + r] = tile[r][c];
+  }
+}
+
+__global__ __launch_bounds__(256) void pad_cols_kernel(const bf16_t* src, int cols, bf16_t* dst, int cols_pad,
+                                                       int64_t rows) {
+  const int64_t total = rows * cols_pad;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % cols_pad);
+    const int64_t r = i / cols_pad;
+    dst[i] = c < cols ? src[r * cols + c] : (bf16_t)0;
   }
 }
 
@@ -273,10 +283,17 @@ int launch_geglu_bwd(const bf16_t* pre, const bf16_t* dout, bf16_t* dpre, int64_
 }
 int launch_transpose2d(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo, int64_t rows, int cols,
                        hipStream_t st) {
-  hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)((rows + 63) / 64), cdiv(cols, 64)), dim3(256), 0, st,
-                     in, ldi, out, ldo, rows, cols);
+  return launch_transpose2d_pad(in, ldi, out, ldo, rows, cols, rows, st);
+}
+int launch_transpose2d_pad(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo, int64_t rows, int cols,
+                           int64_t rows_pad, hipStream_t st) {
+  hipLaunchKernelGGL(transpose2d_kernel, dim3((unsigned)((rows_pad + 63) / 64), cdiv(cols, 64)), dim3(256), 0, st,
+                     in, ldi, out, ldo, rows, cols, rows_pad);
   FDMI_HIP(hipGetLastError());
   return 0;
+}
+int launch_pad_cols(const bf16_t* src, int cols, bf16_t* dst, int cols_pad, int64_t rows, hipStream_t st) {
+  LAUNCH(pad_cols_kernel, rows * cols_pad, src, cols, dst, cols_pad, rows)
 }
 int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int cols, hipStream_t st) {
   hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(rows, 64), cdiv(cols, 64)), dim3(256), 0, st, w, wb, wtb,

@@ -62,6 +62,10 @@ int launch_geglu_bwd(const bf16_t* pre, const bf16_t* dout, bf16_t* dpre, int64_
 // out[c][r] = in[r][c]  (bf16 matrix transpose; in ld = ldi, out ld = ldo)
 int launch_transpose2d(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo, int64_t rows, int cols,
                        hipStream_t st);
+int launch_transpose2d_pad(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t ldo, int64_t rows, int cols,
+                           int64_t rows_pad, hipStream_t st);
+// dst[rows][cols_pad] = src[rows][cols] zero padded
+int launch_pad_cols(const bf16_t* src, int cols, bf16_t* dst, int cols_pad, int64_t rows, hipStream_t st);
 // LoRA refresh: f32 master W[rows][cols] -> bf16 copy and bf16 transpose
 int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int cols, hipStream_t st);
 // fused AdamW on a flat f32 buffer

@@ -1,0 +1,1012 @@
+// UNet2DCondition plan executor for libfdmi.so: the native replacement of
+//   DiffusersUNet2DCondWrapper.forward -> UNet2DConditionModel.forward(...).sample
+//   (/root/reference/src/flash/models/unets/unet.py:66-119) and of its autograd backward.
+//
+// One plan = one denoiser (architecture hyper-parameters as pinned in
+// /root/reference/examples/train_flash_sd.py:56-114 / train_flash_sdxl.py:66-118, weights registered by
+// their diffusers state_dict names and packed once into bf16 MFMA operand layouts: forward [N][K] and
+// the dgrad layout).  forward() walks the network launching the hand-written kernels on NHWC bf16
+// activations bump-allocated from a caller-owned workspace; when `save` is set it records a tape of
+// backward closures (dgrad everywhere -- base weights are frozen -- and wgrad for the LoRA A/B
+// matrices only), which backward() replays in reverse.
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "../../include/fdmi.h"
+#include "ops.h"
+
+namespace {
+
+struct Arena {
+  char* base = nullptr;
+  size_t cap = 0, off = 0, peak = 0;
+  bool dry = false;
+  void* alloc(size_t bytes) {
+    size_t a = (off + 255) & ~(size_t)255;
+    if (!dry && a + bytes > cap) return nullptr;
+    off = a + bytes;
+    if (off > peak) peak = off;
+    return dry ? (void*)(uintptr_t)256 : (void*)(base + a);
+  }
+};
+
+struct T {  // NHWC / token-major bf16 activation [rows][cols] (+ lazily allocated gradient)
+  bf16_t* p = nullptr;
+  bf16_t* g = nullptr;
+  bf16_t* tr = nullptr;  // cached transpose [cols][rows_pad] (LoRA wgrad)
+  int64_t rows = 0;
+  int cols = 0;
+  int B = 0, H = 0, W = 0;
+  bool ginit = false;
+};
+
+struct Weight {
+  bf16_t* w = nullptr;   // forward operand [N][K]
+  bf16_t* wt = nullptr;  // dgrad operand: linear [K][N]; conv [Cin][KH][KW][Cout_pad]
+  float* bias = nullptr;
+  int N = 0, K = 0;      // forward GEMM dims (conv: K = KH*KW*Cin_pad)
+  int Cin = 0, Cout = 0, KH = 1, KW = 1, Cin_pad = 0, Cout_pad = 0;
+  bool geglu = false;
+  int set = 0;           // bit0 weight, bit1 bias
+  bool has_bias = true;
+};
+struct Norm {
+  float* gamma = nullptr;
+  float* beta = nullptr;
+  int C = 0, set = 0;
+};
+struct Lora {
+  const float *A_master = nullptr, *B_master = nullptr;
+  float *A_grad = nullptr, *B_grad = nullptr;
+  bf16_t *A = nullptr, *AT = nullptr, *B = nullptr, *BT = nullptr;
+  int r = 0, in = 0, out = 0;
+  bool on = false;
+};
+struct LinearW {
+  Weight w;
+  Lora lora;
+};
+struct ResnetW {
+  Norm n1, n2;
+  Weight c1, c2, sc;
+  bool has_sc = false;
+  int cin = 0, cout = 0, temb_off = 0;
+};
+struct AttnW { LinearW q, k, v, o; };
+struct TBlockW {
+  Norm ln1, ln2, ln3;
+  AttnW a1, a2;
+  Weight ff1, ff2;
+};
+struct TransformerW {
+  Norm gn;
+  Weight pin, pout;
+  std::vector<std::unique_ptr<TBlockW>> blocks;
+  int heads = 0, C = 0;
+};
+struct StageW {
+  std::vector<std::unique_ptr<ResnetW>> res;
+  std::vector<std::unique_ptr<TransformerW>> attn;
+  bool has_attn = false, has_resample = false;
+  Weight resample;  // downsample (stride 2) or upsample conv
+};
+
+enum SlotKind { S_CONV_W, S_LIN_W, S_BIAS, S_GAMMA, S_BETA, S_TEMB_W, S_TEMB_B };
+struct Slot {
+  SlotKind kind;
+  Weight* w = nullptr;
+  Norm* n = nullptr;
+  int64_t numel = 0;
+  int row_off = 0, rows = 0;  // S_TEMB_*
+};
+
+struct Exec;
+struct Run {
+  Arena arena;
+  std::deque<T> tensors;
+  std::vector<std::function<int(Exec&)>> tape;
+  bool save = false;
+  hipStream_t st = nullptr;
+  T* x0 = nullptr;   // NHWC input (grad wrt the sample)
+  T* out = nullptr;  // output tensor
+  int outC = 0;
+  T* mk(int64_t rows, int cols, int B = 0, int H = 0, int W = 0) {
+    tensors.emplace_back();
+    T* t = &tensors.back();
+    t->rows = rows; t->cols = cols; t->B = B; t->H = H; t->W = W;
+    t->p = (bf16_t*)arena.alloc((size_t)rows * cols * 2);
+    return t->p ? t : nullptr;
+  }
+  bool dry() const { return arena.dry; }
+};
+
+}  // namespace
+
+struct fdmi_unet {
+  fdmi_unet_config cfg;
+  int nl = 0, temb_ch = 0, temb_total = 0;
+  Weight conv_in, conv_out, te1, te2, ce1, ce2, temb_proj;
+  Norm norm_out;
+  std::vector<std::unique_ptr<StageW>> down, up;
+  std::unique_ptr<ResnetW> mid_r0, mid_r1;
+  std::unique_ptr<TransformerW> mid_attn;
+  std::map<std::string, Slot> slots;
+  std::map<std::string, LinearW*> lora_targets;
+  std::vector<void*> owned;  // hipMalloc'ed packed weights
+  std::vector<Lora*> loras;
+  Run runs[8];
+  double last_flops = 0;     // algorithmic MFMA flops of the last forward/backward call
+
+  ~fdmi_unet() {
+    for (void* p : owned) (void)hipFree(p);
+  }
+};
+
+namespace {
+
+#define RET_IF(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+#define NULL_IF(x) do { if ((x)) return nullptr; } while (0)
+#define FDMI_CHECK_NULL(cond, msg) do { if (!(cond)) { fdmi_set_error(msg); return nullptr; } } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// weight packing kernels (init time)
+// ---------------------------------------------------------------------------------------------
+// conv OIHW f32 -> out[rows][KH][KW][cpad] bf16; transpose=0: rows=O, ch=I ; transpose=1: rows=I, ch=O
+__global__ void pack_conv_kernel(const float* w, bf16_t* out, int O, int I, int KH, int KW, int cpad,
+                                 int transpose) {
+  const int rows = transpose ? I : O, ch = transpose ? O : I;
+  const int64_t total = (int64_t)rows * KH * KW * cpad;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cpad);
+    int64_t t = i / cpad;
+    const int kx = (int)(t % KW); t /= KW;
+    const int ky = (int)(t % KH); t /= KH;
+    const int r = (int)t;
+    float v = 0.f;
+    if (c < ch) {
+      const int o = transpose ? c : r, ii = transpose ? r : c;
+      v = w[(((int64_t)o * I + ii) * KH + ky) * KW + kx];
+    }
+    out[i] = f2bf(v);
+  }
+}
+// linear [N][K] f32 -> w[N][K] bf16 (rows optionally GEGLU-permuted) and wt[K][N] bf16
+__global__ void pack_linear_kernel(const float* w, bf16_t* out, bf16_t* outT, int N, int K, int geglu) {
+  const int64_t total = (int64_t)N * K;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int k = (int)(i % K);
+    const int n = (int)(i / K);  // packed row
+    int src = n;
+    if (geglu) {
+      const int blk = n >> 5, off = n & 31;
+      src = off < 16 ? blk * 16 + off : N / 2 + blk * 16 + off - 16;
+    }
+    const bf16_t v = f2bf(w[(int64_t)src * K + k]);
+    out[i] = v;
+    outT[(int64_t)k * N + n] = v;
+  }
+}
+__global__ void pack_vec_kernel(const float* b, float* out, int N, int geglu) {
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < N; n += gridDim.x * 256) {
+    int src = n;
+    if (geglu) {
+      const int blk = n >> 5, off = n & 31;
+      src = off < 16 ? blk * 16 + off : N / 2 + blk * 16 + off - 16;
+    }
+    out[n] = b[src];
+  }
+}
+__global__ void f32_to_bf16_rows(const float* x, bf16_t* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = f2bf(x[i]);
+}
+static inline int gridfor(int64_t n) {
+  int64_t b = (n + 255) / 256;
+  return (int)(b > 4096 ? 4096 : (b < 1 ? 1 : b));
+}
+
+// ---------------------------------------------------------------------------------------------
+// plan construction
+// ---------------------------------------------------------------------------------------------
+struct Builder {
+  fdmi_unet* U;
+  void conv(const std::string& name, Weight& w, int cout, int cin, int k, bool bias = true) {
+    w.Cin = cin; w.Cout = cout; w.KH = w.KW = k;
+    w.Cin_pad = (cin + 7) & ~7; w.Cout_pad = (cout + 7) & ~7;
+    w.N = cout; w.K = k * k * w.Cin_pad; w.has_bias = bias;
+    U->slots[name + ".weight"] = Slot{S_CONV_W, &w, nullptr, (int64_t)cout * cin * k * k};
+    if (bias) U->slots[name + ".bias"] = Slot{S_BIAS, &w, nullptr, cout};
+  }
+  void linear(const std::string& name, Weight& w, int out, int in, bool bias, bool geglu = false) {
+    w.Cin = in; w.Cout = out; w.N = out; w.K = in; w.has_bias = bias; w.geglu = geglu;
+    U->slots[name + ".weight"] = Slot{S_LIN_W, &w, nullptr, (int64_t)out * in};
+    if (bias) U->slots[name + ".bias"] = Slot{S_BIAS, &w, nullptr, out};
+  }
+  void norm(const std::string& name, Norm& n, int C) {
+    n.C = C;
+    U->slots[name + ".weight"] = Slot{S_GAMMA, nullptr, &n, C};
+    U->slots[name + ".bias"] = Slot{S_BETA, nullptr, &n, C};
+  }
+  void lin_lora(const std::string& name, LinearW& l, int out, int in, bool bias) {
+    linear(name, l.w, out, in, bias);
+    U->lora_targets[name] = &l;
+  }
+  std::unique_ptr<ResnetW> resnet(const std::string& name, int cin, int cout) {
+    auto r = std::make_unique<ResnetW>();
+    r->cin = cin; r->cout = cout;
+    norm(name + ".norm1", r->n1, cin);
+    conv(name + ".conv1", r->c1, cout, cin, 3);
+    r->temb_off = U->temb_total;
+    Slot sw{S_TEMB_W, &U->temb_proj, nullptr, (int64_t)cout * U->temb_ch};
+    sw.row_off = r->temb_off; sw.rows = cout;
+    U->slots[name + ".time_emb_proj.weight"] = sw;
+    Slot sb{S_TEMB_B, &U->temb_proj, nullptr, cout};
+    sb.row_off = r->temb_off; sb.rows = cout;
+    U->slots[name + ".time_emb_proj.bias"] = sb;
+    U->temb_total += cout;
+    norm(name + ".norm2", r->n2, cout);
+    conv(name + ".conv2", r->c2, cout, cout, 3);
+    r->has_sc = cin != cout;
+    if (r->has_sc) conv(name + ".conv_shortcut", r->sc, cout, cin, 1);
+    return r;
+  }
+  std::unique_ptr<TransformerW> transformer(const std::string& name, int C, int heads, int layers) {
+    auto t = std::make_unique<TransformerW>();
+    t->C = C; t->heads = heads;
+    norm(name + ".norm", t->gn, C);
+    linear(name + ".proj_in", t->pin, C, C, true);
+    linear(name + ".proj_out", t->pout, C, C, true);
+    const int cd = U->cfg.cross_dim;
+    for (int k = 0; k < layers; ++k) {
+      auto b = std::make_unique<TBlockW>();
+      const std::string bn = name + ".transformer_blocks." + std::to_string(k);
+      norm(bn + ".norm1", b->ln1, C);
+      norm(bn + ".norm2", b->ln2, C);
+      norm(bn + ".norm3", b->ln3, C);
+      lin_lora(bn + ".attn1.to_q", b->a1.q, C, C, false);
+      lin_lora(bn + ".attn1.to_k", b->a1.k, C, C, false);
+      lin_lora(bn + ".attn1.to_v", b->a1.v, C, C, false);
+      lin_lora(bn + ".attn1.to_out.0", b->a1.o, C, C, true);
+      lin_lora(bn + ".attn2.to_q", b->a2.q, C, C, false);
+      lin_lora(bn + ".attn2.to_k", b->a2.k, C, cd, false);
+      lin_lora(bn + ".attn2.to_v", b->a2.v, C, cd, false);
+      lin_lora(bn + ".attn2.to_out.0", b->a2.o, C, C, true);
+      linear(bn + ".ff.net.0.proj", b->ff1, 8 * C, C, true, true);
+      linear(bn + ".ff.net.2", b->ff2, C, 4 * C, true);
+      t->blocks.push_back(std::move(b));
+    }
+    return t;
+  }
+};
+
+int build_plan(fdmi_unet* U) {
+  const fdmi_unet_config& c = U->cfg;
+  FDMI_CHECK(c.n_levels >= 1 && c.n_levels <= 4, "unet: n_levels must be 1..4");
+  U->nl = c.n_levels;
+  U->temb_ch = c.block_out[0] * 4;
+  Builder b{U};
+  b.conv("conv_in", U->conv_in, c.block_out[0], c.in_channels, 3);
+  b.linear("time_embedding.linear_1", U->te1, U->temb_ch, c.block_out[0], true);
+  b.linear("time_embedding.linear_2", U->te2, U->temb_ch, U->temb_ch, true);
+  if (c.class_embed_dim > 0) {
+    b.linear("class_embedding.linear_1", U->ce1, U->temb_ch, c.class_embed_dim, true);
+    b.linear("class_embedding.linear_2", U->ce2, U->temb_ch, U->temb_ch, true);
+  }
+  int out_ch = c.block_out[0];
+  for (int i = 0; i < U->nl; ++i) {
+    auto s = std::make_unique<StageW>();
+    const int in_ch = out_ch;
+    out_ch = c.block_out[i];
+    s->has_attn = c.down_attn[i] != 0;
+    const std::string bn = "down_blocks." + std::to_string(i);
+    for (int j = 0; j < c.layers_per_block; ++j) {
+      s->res.push_back(b.resnet(bn + ".resnets." + std::to_string(j), j == 0 ? in_ch : out_ch, out_ch));
+      if (s->has_attn)
+        s->attn.push_back(b.transformer(bn + ".attentions." + std::to_string(j), out_ch, c.heads[i], c.tlayers[i]));
+    }
+    s->has_resample = i != U->nl - 1;
+    if (s->has_resample) b.conv(bn + ".downsamplers.0.conv", s->resample, out_ch, out_ch, 3);
+    U->down.push_back(std::move(s));
+  }
+  const int cm = c.block_out[U->nl - 1];
+  U->mid_r0 = b.resnet("mid_block.resnets.0", cm, cm);
+  U->mid_attn = b.transformer("mid_block.attentions.0", cm, c.heads[U->nl - 1], c.tlayers[U->nl - 1]);
+  U->mid_r1 = b.resnet("mid_block.resnets.1", cm, cm);
+  out_ch = cm;
+  for (int i = 0; i < U->nl; ++i) {
+    auto s = std::make_unique<StageW>();
+    const int ri = U->nl - 1 - i;
+    const int prev = out_ch;
+    out_ch = c.block_out[ri];
+    const int in_ch = c.block_out[ri - 1 >= 0 ? ri - 1 : 0];
+    s->has_attn = c.up_attn[i] != 0;
+    const std::string bn = "up_blocks." + std::to_string(i);
+    const int n = c.layers_per_block + 1;
+    for (int j = 0; j < n; ++j) {
+      const int skip = j == n - 1 ? in_ch : out_ch;
+      const int rin = j == 0 ? prev : out_ch;
+      s->res.push_back(b.resnet(bn + ".resnets." + std::to_string(j), rin + skip, out_ch));
+      if (s->has_attn)
+        s->attn.push_back(b.transformer(bn + ".attentions." + std::to_string(j), out_ch, c.heads[ri], c.tlayers[ri]));
+    }
+    s->has_resample = i != U->nl - 1;
+    if (s->has_resample) b.conv(bn + ".upsamplers.0.conv", s->resample, out_ch, out_ch, 3);
+    U->up.push_back(std::move(s));
+  }
+  b.norm("conv_norm_out", U->norm_out, c.block_out[0]);
+  b.conv("conv_out", U->conv_out, c.out_channels, c.block_out[0], 3);
+  // batched time_emb_proj: one [sum Cout][temb_ch] operand
+  U->temb_proj.N = U->temb_total;
+  U->temb_proj.K = U->temb_ch;
+  return 0;
+}
+
+template <typename Tp>
+int dmalloc(fdmi_unet* U, Tp** p, size_t n) {
+  void* q = nullptr;
+  FDMI_HIP(hipMalloc(&q, n * sizeof(Tp)));
+  FDMI_HIP(hipMemset(q, 0, n * sizeof(Tp)));
+  U->owned.push_back(q);
+  *p = (Tp*)q;
+  return 0;
+}
+
+int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t numel, hipStream_t st) {
+  auto it = U->slots.find(name);
+  FDMI_CHECK(it != U->slots.end(), "unet: unknown parameter '" + name + "'");
+  Slot& s = it->second;
+  FDMI_CHECK(s.numel == numel, "unet: parameter '" + name + "' has " + std::to_string(numel) +
+                                   " elements, expected " + std::to_string(s.numel));
+  switch (s.kind) {
+    case S_CONV_W: {
+      Weight& w = *s.w;
+      if (!w.w) {
+        RET_IF(dmalloc(U, &w.w, (size_t)w.Cout * w.KH * w.KW * w.Cin_pad));
+        RET_IF(dmalloc(U, &w.wt, (size_t)w.Cin * w.KH * w.KW * w.Cout_pad));
+      }
+      hipLaunchKernelGGL(pack_conv_kernel, dim3(gridfor((int64_t)w.Cout * w.K)), dim3(256), 0, st, src, w.w,
+                         w.Cout, w.Cin, w.KH, w.KW, w.Cin_pad, 0);
+      hipLaunchKernelGGL(pack_conv_kernel, dim3(gridfor((int64_t)w.Cin * w.KH * w.KW * w.Cout_pad)), dim3(256), 0,
+                         st, src, w.wt, w.Cout, w.Cin, w.KH, w.KW, w.Cout_pad, 1);
+      w.set |= 1;
+      break;
+    }
+    case S_LIN_W: {
+      Weight& w = *s.w;
+      if (!w.w) {
+        RET_IF(dmalloc(U, &w.w, (size_t)w.N * w.K));
+        RET_IF(dmalloc(U, &w.wt, (size_t)w.N * w.K));
+      }
+      hipLaunchKernelGGL(pack_linear_kernel, dim3(gridfor((int64_t)w.N * w.K)), dim3(256), 0, st, src, w.w, w.wt,
+                         w.N, w.K, w.geglu ? 1 : 0);
+      w.set |= 1;
+      break;
+    }
+    case S_BIAS: {
+      Weight& w = *s.w;
+      if (!w.bias) RET_IF(dmalloc(U, &w.bias, (size_t)w.N));
+      hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(w.N)), dim3(256), 0, st, src, w.bias, w.N, w.geglu ? 1 : 0);
+      w.set |= 2;
+      break;
+    }
+    case S_GAMMA:
+    case S_BETA: {
+      Norm& n = *s.n;
+      float** dst = s.kind == S_GAMMA ? &n.gamma : &n.beta;
+      if (!*dst) RET_IF(dmalloc(U, dst, (size_t)n.C));
+      hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(n.C)), dim3(256), 0, st, src, *dst, n.C, 0);
+      n.set |= s.kind == S_GAMMA ? 1 : 2;
+      break;
+    }
+    case S_TEMB_W:
+    case S_TEMB_B: {
+      Weight& w = *s.w;
+      if (!w.w) {
+        RET_IF(dmalloc(U, &w.w, (size_t)w.N * w.K));
+        RET_IF(dmalloc(U, &w.bias, (size_t)w.N));
+      }
+      if (s.kind == S_TEMB_W) {
+        hipLaunchKernelGGL(f32_to_bf16_rows, dim3(gridfor((int64_t)s.rows * w.K)), dim3(256), 0, st, src,
+                           w.w + (size_t)s.row_off * w.K, (int64_t)s.rows * w.K);
+      } else {
+        hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(s.rows)), dim3(256), 0, st, src, w.bias + s.row_off,
+                           s.rows, 0);
+      }
+      break;
+    }
+  }
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// ops with tape (forward + recorded input-gradient closure)
+// ---------------------------------------------------------------------------------------------
+struct Exec {
+  fdmi_unet* U;
+  Run& R;
+  hipStream_t st;
+  double flops = 0;
+
+  bf16_t* grad_of(T* t) {  // lazily allocate the gradient buffer
+    if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * 2);
+    return t->g;
+  }
+  int gemm(GemmArgs& a) {
+    flops += gemm_flops(a);
+    if (R.dry()) return 0;
+    return launch_gemm(a, st);
+  }
+  // ---- C = A W^T style helper; accumulate=true adds into C (residual = C) ----
+  int gemm_rows(const bf16_t* A, int64_t lda, int64_t M, const bf16_t* W, int N, int K, const float* bias,
+                bf16_t* C, int64_t ldc, const bf16_t* residual, int64_t ldr, int act = ACT_NONE,
+                bf16_t* preact = nullptr) {
+    GemmArgs a;
+    a.M = (int)M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias;
+    a.C = C; a.ldc = ldc; a.residual = residual; a.ldr = ldr; a.act = act;
+    a.preact = preact; a.ldp = N;
+    return gemm(a);
+  }
+
+  int lora_refresh() {
+    if (R.dry()) return 0;
+    for (Lora* l : U->loras) {
+      RET_IF(launch_cast_transpose(l->A_master, l->A, l->AT, l->r, l->in, st));
+      RET_IF(launch_cast_transpose(l->B_master, l->B, l->BT, l->out, l->r, st));
+    }
+    return 0;
+  }
+
+  // transposed copy [cols][rows_pad] of a token tensor (cached), zero padded
+  bf16_t* transposed(T* x) {
+    if (x->tr) return x->tr;
+    const int64_t rp = (x->rows + 7) & ~(int64_t)7;
+    x->tr = (bf16_t*)R.arena.alloc((size_t)x->cols * rp * 2);
+    if (!x->tr) return nullptr;
+    if (!R.dry() && launch_transpose2d_pad(x->p, x->cols, x->tr, rp, x->rows, x->cols, rp, st)) return nullptr;
+    return x->tr;
+  }
+
+  // y = x W^T + b (+ residual) (+ LoRA)
+  T* linear(T* x, LinearW& L, T* residual = nullptr) { return linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr); }
+  T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true) {
+    T* y = R.mk(x->rows, w.N, x->B, x->H, x->W);
+    if (!y) return nullptr;
+    NULL_IF(gemm_rows(x->p, x->cols, x->rows, w.w, w.N, w.K, w.bias, y->p, w.N, residual ? residual->p : nullptr,
+                      residual ? residual->cols : 0));
+    T* t = nullptr;
+    if (lo) {
+      t = R.mk(x->rows, lo->r);
+      if (!t) return nullptr;
+      NULL_IF(gemm_rows(x->p, x->cols, x->rows, lo->A, lo->r, lo->in, nullptr, t->p, lo->r, nullptr, 0));
+      NULL_IF(gemm_rows(t->p, lo->r, x->rows, lo->B, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N));
+    }
+    if (R.save) {
+      R.tape.push_back([x, y, residual, lo, t, need_dx, &w](Exec& E) -> int {
+        if (!y->g) return 0;  // no gradient reached this output
+        if (residual) RET_IF(E.add_grad(residual, y->g, y->cols, 0, y->cols));
+        if (need_dx) {
+          bf16_t* dx = E.grad_of(x);
+          FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
+          RET_IF(E.gemm_rows(y->g, w.N, x->rows, w.wt, w.K, w.N, nullptr, dx, x->cols, x->ginit ? dx : nullptr,
+                           x->cols));
+          x->ginit = true;
+        }
+        if (lo) {
+          // dt = dy B ; dB += dy^T t ; dA += dt^T x ; dx += dt A
+          T* dt = E.R.mk(x->rows, lo->r);
+          FDMI_CHECK(dt, "unet: workspace exhausted (lora)");
+          RET_IF(E.gemm_rows(y->g, w.N, x->rows, lo->BT, lo->r, lo->out, nullptr, dt->p, lo->r, nullptr, 0));
+          T ygrad = *y;
+          ygrad.p = y->g; ygrad.tr = nullptr;
+          bf16_t* dyT = E.transposed(&ygrad);
+          bf16_t* tT = E.transposed(t);
+          bf16_t* dtT = E.transposed(dt);
+          bf16_t* xT = E.transposed(x);
+          FDMI_CHECK(dyT && tT && dtT && xT, "unet: workspace exhausted (lora transposes)");
+          const int64_t rp = (x->rows + 7) & ~(int64_t)7;
+          GemmArgs a;
+          a.M = lo->out; a.N = lo->r; a.K = (int)rp; a.A = dyT; a.lda = rp; a.W = tT; a.ldw = rp;
+          a.C = lo->B_grad; a.ldc = lo->r; a.out_f32 = 1; a.accum_atomic = 1; a.splitk = 0;
+          RET_IF(E.gemm(a));
+          GemmArgs b;
+          b.M = lo->r; b.N = lo->in; b.K = (int)rp; b.A = dtT; b.lda = rp; b.W = xT; b.ldw = rp;
+          b.C = lo->A_grad; b.ldc = lo->in; b.out_f32 = 1; b.accum_atomic = 1; b.splitk = 0;
+          RET_IF(E.gemm(b));
+          if (need_dx) {
+            bf16_t* dx = E.grad_of(x);
+            RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
+          }
+        }
+        return 0;
+      });
+    }
+    return y;
+  }
+
+  // dst->g[:, c0:c0+cols] (+)= src[:, sc0:sc0+cols]
+  int add_grad(T* dst, const bf16_t* src, int64_t ld_src, int sc0, int cols, int dc0 = 0) {
+    bf16_t* g = grad_of(dst);
+    FDMI_CHECK(g, "unet: workspace exhausted (grad)");
+    if (!R.dry()) {
+      if (!dst->ginit && (dc0 != 0 || cols != dst->cols))
+        FDMI_HIP(hipMemsetAsync(g, 0, (size_t)dst->rows * dst->cols * 2, st));
+      RET_IF(launch_copy2d(src, ld_src, sc0, g, dst->cols, dc0, dst->rows, cols, dst->ginit ? 1 : 0, st));
+    }
+    dst->ginit = true;
+    return 0;
+  }
+
+  // 3x3 (or kxk) convolution on NHWC; stride 1|2, optional fused nearest-2x upsample of the input
+  T* conv(T* x, Weight& w, int stride, int ups, const bf16_t* rowvec, int64_t rowvec_ld, T* residual) {
+    const int pad = w.KH / 2;
+    const int Hv = x->H << ups, Wv = x->W << ups;
+    const int Ho = (Hv + 2 * pad - w.KH) / stride + 1, Wo = (Wv + 2 * pad - w.KW) / stride + 1;
+    T* y = R.mk((int64_t)x->B * Ho * Wo, w.N, x->B, Ho, Wo);
+    if (!y) return nullptr;
+    FDMI_CHECK_NULL(x->cols == w.Cin_pad, "conv: channel mismatch");
+    GemmArgs a;
+    a.mode = GEMM_CONV; a.M = (int)y->rows; a.N = w.N; a.K = w.K; a.A = x->p; a.W = w.w; a.ldw = w.K;
+    a.Hin = x->H; a.Win = x->W; a.Cin = w.Cin_pad; a.Hout = Ho; a.Wout = Wo; a.KH = w.KH; a.KW = w.KW;
+    a.stride = stride; a.pad = pad; a.ups = ups; a.bias = w.bias;
+    a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = Ho * Wo;
+    a.residual = residual ? residual->p : nullptr; a.ldr = residual ? residual->cols : 0;
+    a.C = y->p; a.ldc = w.N;
+    NULL_IF(gemm(a));
+    if (R.save) {
+      R.tape.push_back([x, y, residual, &w, stride, ups, pad, Hv, Wv, Ho, Wo](Exec& E) -> int {
+        if (!y->g) return 0;
+        if (residual) RET_IF(E.add_grad(residual, y->g, y->cols, 0, y->cols));
+        // dgrad: gather form of the transposed conv over dY (channels padded to 8)
+        const bf16_t* dy = y->g;
+        int64_t dy_cols = y->cols;
+        if (y->cols != w.Cout_pad) {  // e.g. conv_out (4 -> 8 channels): zero-padded copy
+          bf16_t* pd = (bf16_t*)E.R.arena.alloc((size_t)y->rows * w.Cout_pad * 2);
+          FDMI_CHECK(pd, "unet: workspace exhausted");
+          if (!E.R.dry()) RET_IF(launch_pad_cols(y->g, y->cols, pd, w.Cout_pad, y->rows, E.st));
+          dy = pd;
+          dy_cols = w.Cout_pad;
+        }
+        GemmArgs d;
+        d.mode = GEMM_CONV; d.dgrad = 1; d.M = (int)((int64_t)x->B * Hv * Wv); d.N = w.Cin; d.K = w.KH * w.KW * w.Cout_pad;
+        d.A = dy; d.W = w.wt; d.ldw = d.K;
+        d.Hin = Ho; d.Win = Wo; d.Cin = (int)dy_cols; d.Hout = Hv; d.Wout = Wv; d.KH = w.KH; d.KW = w.KW;
+        d.stride = stride; d.pad = pad;
+        bf16_t* dx = E.grad_of(x);
+        FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
+        if (ups) {
+          bf16_t* tmp = (bf16_t*)E.R.arena.alloc((size_t)d.M * x->cols * 2);
+          FDMI_CHECK(tmp, "unet: workspace exhausted");
+          d.C = tmp; d.ldc = x->cols;
+          RET_IF(E.gemm(d));
+          if (!E.R.dry()) RET_IF(launch_pool2x2_sum(tmp, dx, x->B, x->H, x->W, x->cols, x->ginit ? 1 : 0, E.st));
+        } else {
+          d.C = dx; d.ldc = x->cols;
+          if (x->ginit) { d.residual = dx; d.ldr = x->cols; }
+          if (w.Cin != x->cols && !x->ginit && !E.R.dry())  // padded input channels (conv_in): zero the pad
+            FDMI_HIP(hipMemsetAsync(dx, 0, (size_t)x->rows * x->cols * 2, E.st));
+          RET_IF(E.gemm(d));
+        }
+        x->ginit = true;
+        return 0;
+      });
+    }
+    return y;
+  }
+
+  T* groupnorm(T* x, Norm& n, float eps, int silu) {
+    T* y = R.mk(x->rows, x->cols, x->B, x->H, x->W);
+    float* stats = (float*)R.arena.alloc((size_t)x->B * U->cfg.groups * 2 * sizeof(float));
+    if (!y || !stats) return nullptr;
+    const int HW = x->H * x->W, G = U->cfg.groups;
+    if (!R.dry()) NULL_IF(launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st));
+    if (R.save) {
+      R.tape.push_back([x, y, &n, stats, HW, G, eps, silu](Exec& E) -> int {
+        if (!y->g) return 0;
+        bf16_t* dx = E.grad_of(x);
+        float* bst = (float*)E.R.arena.alloc((size_t)x->B * G * 2 * sizeof(float));
+        FDMI_CHECK(dx && bst, "unet: workspace exhausted (grad)");
+        if (!E.R.dry())
+          RET_IF(launch_groupnorm_bwd(x->p, y->g, n.gamma, n.beta, stats, bst, dx, x->B, HW, x->cols, G, eps, silu,
+                                      x->ginit ? 1 : 0, E.st));
+        x->ginit = true;
+        return 0;
+      });
+    }
+    return y;
+  }
+
+  T* layernorm(T* x, Norm& n) {
+    T* y = R.mk(x->rows, x->cols, x->B, x->H, x->W);
+    if (!y) return nullptr;
+    if (!R.dry()) NULL_IF(launch_layernorm_fwd(x->p, n.gamma, n.beta, nullptr, nullptr, 0, 1, y->p, x->rows, x->cols, 1e-5f, st));
+    if (R.save) {
+      R.tape.push_back([x, y, &n](Exec& E) -> int {
+        if (!y->g) return 0;
+        bf16_t* dx = E.grad_of(x);
+        FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
+        if (!E.R.dry())
+          RET_IF(launch_layernorm_bwd(x->p, y->g, n.gamma, nullptr, 0, 1, dx, x->rows, x->cols, 1e-5f, x->ginit ? 1 : 0, E.st));
+        x->ginit = true;
+        return 0;
+      });
+    }
+    return y;
+  }
+
+  T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv) {
+    const int d = q->cols / H;
+    T* o = R.mk(q->rows, q->cols, q->B, q->H, q->W);
+    const int64_t tr_kv = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Skv);
+    const int64_t tr_q = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Sq);
+    bf16_t* VT = (bf16_t*)R.arena.alloc((size_t)tr_kv * 2);
+    float* lse = R.save ? (float*)R.arena.alloc((size_t)Bn * H * Sq * 4) : nullptr;
+    if (!o || !VT || (R.save && !lse)) return nullptr;
+    AttnArgs a{};
+    a.Q = q->p; a.ldq = q->cols; a.K = k->p; a.ldk = k->cols; a.V = v->p; a.ldv = v->cols; a.VT = VT;
+    a.lse = lse; a.out = o->p; a.ldout = o->cols;
+    a.B = Bn; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.f / sqrtf((float)d);
+    flops += 4.0 * Bn * H * (double)Sq * Skv * d;
+    if (!R.dry()) {
+      NULL_IF(launch_transpose_heads(v->p, v->cols, VT, Bn, H, Skv, d, st));
+      NULL_IF(launch_attn_fwd(a, st));
+    }
+    if (R.save) {
+      R.tape.push_back([o, q, k, v, a, Bn, H, Sq, Skv, d, tr_q, tr_kv](Exec& E) -> int {
+        if (!o->g) return 0;
+        bf16_t* QT = (bf16_t*)E.R.arena.alloc((size_t)tr_q * 2);
+        bf16_t* dOT = (bf16_t*)E.R.arena.alloc((size_t)tr_q * 2);
+        bf16_t* KT = (bf16_t*)E.R.arena.alloc((size_t)tr_kv * 2);
+        float* delta = (float*)E.R.arena.alloc((size_t)Bn * H * Sq * 4);
+        bf16_t *dq = E.grad_of(q), *dk = E.grad_of(k), *dv = E.grad_of(v);
+        FDMI_CHECK(QT && dOT && KT && delta && dq && dk && dv, "unet: workspace exhausted (attn bwd)");
+        E.flops += 2.0 * 4.0 * Bn * H * (double)Sq * Skv * d;  // algorithmic: 2x forward
+        if (!E.R.dry()) {
+          RET_IF(launch_transpose_heads(q->p, q->cols, QT, Bn, H, Sq, d, E.st));
+          RET_IF(launch_transpose_heads(o->g, o->cols, dOT, Bn, H, Sq, d, E.st));
+          RET_IF(launch_transpose_heads(k->p, k->cols, KT, Bn, H, Skv, d, E.st));
+          RET_IF(launch_attn_delta(o->p, o->cols, o->g, o->cols, delta, Bn, H, Sq, d, E.st));
+          AttnArgs b = a;
+          b.dO = o->g; b.lddo = o->cols; b.QT = QT; b.KT = KT; b.dOT = dOT; b.delta = delta;
+          b.out = dq; b.ldout = q->cols; b.dK = dk; b.lddk = k->cols; b.dV = dv; b.lddv = v->cols;
+          RET_IF(launch_attn_bwd_dq(b, E.st));
+          RET_IF(launch_attn_bwd_dkv(b, E.st));
+        }
+        q->ginit = k->ginit = v->ginit = true;
+        return 0;
+      });
+    }
+    return o;
+  }
+
+  // GEGLU feed-forward input projection: [M,C] -> [M,4C]
+  T* geglu(T* x, Weight& w) {
+    const int F = w.N / 2;
+    T* y = R.mk(x->rows, F, x->B, x->H, x->W);
+    T* pre = R.save ? R.mk(x->rows, w.N) : nullptr;
+    if (!y || (R.save && !pre)) return nullptr;
+    NULL_IF(gemm_rows(x->p, x->cols, x->rows, w.w, w.N, w.K, w.bias, y->p, F, nullptr, 0, ACT_GEGLU,
+                      pre ? pre->p : nullptr));
+    if (R.save) {
+      R.tape.push_back([x, y, &w, pre, F](Exec& E) -> int {
+        if (!y->g) return 0;
+        T* dpre = E.R.mk(x->rows, w.N);
+        bf16_t* dx = E.grad_of(x);
+        FDMI_CHECK(dpre && dx, "unet: workspace exhausted (geglu bwd)");
+        if (!E.R.dry()) RET_IF(launch_geglu_bwd(pre->p, y->g, dpre->p, x->rows, F, E.st));
+        RET_IF(E.gemm_rows(dpre->p, w.N, x->rows, w.wt, w.K, w.N, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
+        x->ginit = true;
+        return 0;
+      });
+    }
+    return y;
+  }
+
+  T* cat(T* a, T* b) {
+    T* y = R.mk(a->rows, a->cols + b->cols, a->B, a->H, a->W);
+    if (!y) return nullptr;
+    if (!R.dry()) {
+      NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0, st));
+      NULL_IF(launch_copy2d(b->p, b->cols, 0, y->p, y->cols, a->cols, b->rows, b->cols, 0, st));
+    }
+    if (R.save) {
+      R.tape.push_back([y, a, b](Exec& E) -> int {
+        if (!y->g) return 0;
+        RET_IF(E.add_grad(a, y->g, y->cols, 0, a->cols));
+        RET_IF(E.add_grad(b, y->g, y->cols, a->cols, b->cols));
+        return 0;
+      });
+    }
+    return y;
+  }
+
+  // ---- blocks ----------------------------------------------------------------------------------
+  T* resnet(T* x, ResnetW& r, T* temb_all) {
+    const fdmi_unet_config& c = U->cfg;
+    T* a = groupnorm(x, r.n1, c.eps, 1);
+    if (!a) return nullptr;
+    T* h = conv(a, r.c1, 1, 0, temb_all->p + r.temb_off, temb_all->cols, nullptr);
+    if (!h) return nullptr;
+    T* a2 = groupnorm(h, r.n2, c.eps, 1);
+    if (!a2) return nullptr;
+    T* sc = x;
+    if (r.has_sc) {
+      sc = linear_w(x, r.sc);
+      if (!sc) return nullptr;
+    }
+    return conv(a2, r.c2, 1, 0, nullptr, 0, sc);
+  }
+
+  T* transformer(T* x, TransformerW& t, T* ctx, int L) {
+    const int Bn = x->B, S = x->H * x->W;
+    T* hn = groupnorm(x, t.gn, 1e-6f, 0);
+    if (!hn) return nullptr;
+    T* h = linear_w(hn, t.pin);
+    if (!h) return nullptr;
+    for (auto& bp : t.blocks) {
+      TBlockW& b = *bp;
+      T* n = layernorm(h, b.ln1);
+      if (!n) return nullptr;
+      T *q = linear(n, b.a1.q), *k = linear(n, b.a1.k), *v = linear(n, b.a1.v);
+      if (!q || !k || !v) return nullptr;
+      T* o = attention(q, k, v, Bn, t.heads, S, S);
+      if (!o) return nullptr;
+      h = linear(o, b.a1.o, h);
+      if (!h) return nullptr;
+      n = layernorm(h, b.ln2);
+      if (!n) return nullptr;
+      q = linear(n, b.a2.q);
+      k = linear_w(ctx, b.a2.k.w, nullptr, b.a2.k.lora.on ? &b.a2.k.lora : nullptr, false);
+      v = linear_w(ctx, b.a2.v.w, nullptr, b.a2.v.lora.on ? &b.a2.v.lora : nullptr, false);
+      if (!q || !k || !v) return nullptr;
+      o = attention(q, k, v, Bn, t.heads, S, L);
+      if (!o) return nullptr;
+      h = linear(o, b.a2.o, h);
+      if (!h) return nullptr;
+      n = layernorm(h, b.ln3);
+      if (!n) return nullptr;
+      T* f = geglu(n, b.ff1);
+      if (!f) return nullptr;
+      h = linear_w(f, b.ff2, h);
+      if (!h) return nullptr;
+    }
+    return linear_w(h, t.pout, x);
+  }
+};
+
+#define FAIL_IF_NULL(p) FDMI_CHECK((p) != nullptr, "unet: op failed or workspace exhausted")
+
+int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const float* ctx, const float* cls,
+                float* out, int B, int H, int W, int L, int flags) {
+  const fdmi_unet_config& c = U->cfg;
+  Exec E{U, R, R.st};
+  R.tensors.clear();
+  R.tape.clear();
+  R.arena.off = 0;
+  R.save = (flags & FDMI_UNET_SAVE) != 0;
+  const bool inter = (flags & FDMI_UNET_INTERMEDIATE) != 0;
+  hipStream_t st = R.st;
+  if (!U->loras.empty()) RET_IF(E.lora_refresh());
+  const int cin_pad = U->conv_in.Cin_pad;
+  // ---- inputs ----
+  T* x0 = R.mk((int64_t)B * H * W, cin_pad, B, H, W);
+  T* ctxb = R.mk((int64_t)B * L, c.cross_dim);
+  float* tf = (float*)R.arena.alloc((size_t)B * 4);
+  FAIL_IF_NULL(x0); FAIL_IF_NULL(ctxb); FAIL_IF_NULL(tf);
+  R.x0 = x0;
+  if (!R.dry()) {
+    RET_IF(launch_nchw_to_nhwc(x, x0->p, B, c.in_channels, H * W, cin_pad, st));
+    RET_IF(launch_f32_to_bf16(ctx, ctxb->p, (int64_t)B * L * c.cross_dim, st));
+  }
+  // ---- time embedding ----
+  T* te = R.mk(B, c.block_out[0]);
+  T* e1 = R.mk(B, U->temb_ch);
+  T* emb = R.mk(B, U->temb_ch);
+  FAIL_IF_NULL(te); FAIL_IF_NULL(e1); FAIL_IF_NULL(emb);
+  if (!R.dry()) RET_IF(launch_timestep_embed(t, te->p, B, c.block_out[0], c.flip_sin_to_cos, c.freq_shift, st));
+  RET_IF(E.gemm_rows(te->p, te->cols, B, U->te1.w, U->te1.N, U->te1.K, U->te1.bias, e1->p, e1->cols, nullptr, 0, ACT_SILU));
+  RET_IF(E.gemm_rows(e1->p, e1->cols, B, U->te2.w, U->te2.N, U->te2.K, U->te2.bias, emb->p, emb->cols, nullptr, 0));
+  if (c.class_embed_dim > 0) {
+    FDMI_CHECK(cls != nullptr, "unet: class_labels (vector conditioning) required");
+    T* cb = R.mk(B, c.class_embed_dim);
+    T* c1 = R.mk(B, U->temb_ch);
+    FAIL_IF_NULL(cb); FAIL_IF_NULL(c1);
+    if (!R.dry()) RET_IF(launch_f32_to_bf16(cls, cb->p, (int64_t)B * c.class_embed_dim, st));
+    RET_IF(E.gemm_rows(cb->p, cb->cols, B, U->ce1.w, U->ce1.N, U->ce1.K, U->ce1.bias, c1->p, c1->cols, nullptr, 0, ACT_SILU));
+    RET_IF(E.gemm_rows(c1->p, c1->cols, B, U->ce2.w, U->ce2.N, U->ce2.K, U->ce2.bias, emb->p, emb->cols, emb->p, emb->cols));
+  }
+  T* semb = R.mk(B, U->temb_ch);
+  T* temb_all = R.mk(B, U->temb_total);
+  FAIL_IF_NULL(semb); FAIL_IF_NULL(temb_all);
+  if (!R.dry()) RET_IF(launch_silu(emb->p, semb->p, (int64_t)B * U->temb_ch, st));
+  RET_IF(E.gemm_rows(semb->p, semb->cols, B, U->temb_proj.w, U->temb_proj.N, U->temb_proj.K, U->temb_proj.bias,
+                     temb_all->p, temb_all->cols, nullptr, 0));
+  // ---- down ----
+  T* h = E.conv(x0, U->conv_in, 1, 0, nullptr, 0, nullptr);
+  FAIL_IF_NULL(h);
+  std::vector<T*> skips{h};
+  for (auto& sp : U->down) {
+    StageW& s = *sp;
+    for (size_t j = 0; j < s.res.size(); ++j) {
+      h = E.resnet(h, *s.res[j], temb_all);
+      FAIL_IF_NULL(h);
+      if (s.has_attn) {
+        h = E.transformer(h, *s.attn[j], ctxb, L);
+        FAIL_IF_NULL(h);
+      }
+      skips.push_back(h);
+    }
+    if (s.has_resample) {
+      h = E.conv(h, s.resample, 2, 0, nullptr, 0, nullptr);
+      FAIL_IF_NULL(h);
+      skips.push_back(h);
+    }
+  }
+  // ---- mid ----
+  h = E.resnet(h, *U->mid_r0, temb_all);
+  FAIL_IF_NULL(h);
+  h = E.transformer(h, *U->mid_attn, ctxb, L);
+  FAIL_IF_NULL(h);
+  h = E.resnet(h, *U->mid_r1, temb_all);
+  FAIL_IF_NULL(h);
+  if (!inter) {
+    for (auto& sp : U->up) {
+      StageW& s = *sp;
+      for (size_t j = 0; j < s.res.size(); ++j) {
+        T* sk = skips.back();
+        skips.pop_back();
+        T* hc = E.cat(h, sk);
+        FAIL_IF_NULL(hc);
+        h = E.resnet(hc, *s.res[j], temb_all);
+        FAIL_IF_NULL(h);
+        if (s.has_attn) {
+          h = E.transformer(h, *s.attn[j], ctxb, L);
+          FAIL_IF_NULL(h);
+        }
+      }
+      if (s.has_resample) {
+        h = E.conv(h, s.resample, 1, 1, nullptr, 0, nullptr);
+        FAIL_IF_NULL(h);
+      }
+    }
+    T* a = E.groupnorm(h, U->norm_out, c.eps, 1);
+    FAIL_IF_NULL(a);
+    h = E.conv(a, U->conv_out, 1, 0, nullptr, 0, nullptr);
+    FAIL_IF_NULL(h);
+  }
+  R.out = h;
+  R.outC = h->cols;
+  if (!R.dry()) RET_IF(launch_nhwc_to_nchw(h->p, h->cols, out, B, h->cols, h->H * h->W, 0, st));
+  U->last_flops = E.flops;
+  return 0;
+}
+
+int run_backward(fdmi_unet* U, Run& R, const float* grad_out, float* grad_x) {
+  FDMI_CHECK(R.save && R.out, "unet: backward without a saved forward in this slot");
+  Exec E{U, R, R.st};
+  T* o = R.out;
+  bf16_t* g = E.grad_of(o);
+  FDMI_CHECK(g, "unet: workspace exhausted (grad)");
+  if (!R.dry()) RET_IF(launch_nchw_grad_to_nhwc(grad_out, g, o->cols, o->B, o->cols, o->H * o->W, R.st));
+  o->ginit = true;
+  for (auto it = R.tape.rbegin(); it != R.tape.rend(); ++it) RET_IF((*it)(E));
+  if (grad_x) {
+    FDMI_CHECK(R.x0->g && R.x0->ginit, "unet: no gradient reached the input");
+    if (!R.dry())
+      RET_IF(launch_nhwc_to_nchw(R.x0->g, R.x0->cols, grad_x, R.x0->B, U->cfg.in_channels, R.x0->H * R.x0->W, 0, R.st));
+  }
+  R.save = false;  // tape consumed
+  R.tape.clear();
+  U->last_flops = E.flops;
+  return 0;
+}
+
+int check_ready(fdmi_unet* U) {
+  for (auto& kv : U->slots) {
+    const Slot& s = kv.second;
+    bool ok = true;
+    if (s.kind == S_CONV_W || s.kind == S_LIN_W) ok = (s.w->set & 1) != 0;
+    else if (s.kind == S_BIAS) ok = (s.w->set & 2) != 0;
+    else if (s.kind == S_GAMMA) ok = (s.n->set & 1) != 0;
+    else if (s.kind == S_BETA) ok = (s.n->set & 2) != 0;
+    else ok = U->temb_proj.w != nullptr;
+    FDMI_CHECK(ok, "unet: parameter '" + kv.first + "' was never set");
+  }
+  return 0;
+}
+
+}  // namespace
+
+// =============================================================================================
+// C ABI
+// =============================================================================================
+extern "C" {
+
+fdmi_unet* fdmi_unet_create(const fdmi_unet_config* cfg) {
+  if (!cfg) { fdmi_set_error("null config"); return nullptr; }
+  auto* U = new fdmi_unet();
+  U->cfg = *cfg;
+  if (build_plan(U)) { delete U; return nullptr; }
+  return U;
+}
+void fdmi_unet_destroy(fdmi_unet* U) { delete U; }
+
+int64_t fdmi_unet_num_params(fdmi_unet* U) { return U ? (int64_t)U->slots.size() : -1; }
+int fdmi_unet_param_name(fdmi_unet* U, int64_t i, char* buf, int64_t buflen, int64_t* numel) {
+  FDMI_CHECK(U && i >= 0 && i < (int64_t)U->slots.size(), "param index out of range");
+  auto it = U->slots.begin();
+  std::advance(it, i);
+  FDMI_CHECK((int64_t)it->first.size() + 1 <= buflen, "param name buffer too small");
+  memcpy(buf, it->first.c_str(), it->first.size() + 1);
+  if (numel) *numel = it->second.numel;
+  return 0;
+}
+int fdmi_unet_set_param(fdmi_unet* U, const char* name, const float* data, int64_t numel, void* stream) {
+  FDMI_CHECK(U && name && data, "null argument");
+  return set_param(U, name, data, numel, (hipStream_t)stream);
+}
+int fdmi_unet_set_lora(fdmi_unet* U, const char* target, const float* A, const float* B, float* A_grad,
+                       float* B_grad, int rank) {
+  FDMI_CHECK(U && target && A && B, "null argument");
+  auto it = U->lora_targets.find(target);
+  FDMI_CHECK(it != U->lora_targets.end(), std::string("unet: '") + target + "' is not a LoRA-capable linear");
+  FDMI_CHECK(rank > 0 && rank % 8 == 0, "unet: LoRA rank must be a positive multiple of 8");
+  Lora& l = it->second->lora;
+  const Weight& w = it->second->w;
+  l.A_master = A; l.B_master = B; l.A_grad = A_grad; l.B_grad = B_grad;
+  if (!l.on) {
+    l.r = rank; l.in = w.K; l.out = w.N;
+    RET_IF(dmalloc(U, &l.A, (size_t)rank * l.in));
+    RET_IF(dmalloc(U, &l.AT, (size_t)rank * l.in));
+    RET_IF(dmalloc(U, &l.B, (size_t)rank * l.out));
+    RET_IF(dmalloc(U, &l.BT, (size_t)rank * l.out));
+    l.on = true;
+    U->loras.push_back(&l);
+  }
+  FDMI_CHECK(l.r == rank, "unet: LoRA rank changed");
+  return 0;
+}
+int fdmi_unet_ready(fdmi_unet* U) {
+  FDMI_CHECK(U, "null plan");
+  return check_ready(U);
+}
+
+int64_t fdmi_unet_workspace_bytes(fdmi_unet* U, int B, int H, int W, int L, int flags) {
+  if (!U) return -1;
+  Run R;
+  R.arena.dry = true;
+  if (run_forward(U, R, nullptr, nullptr, nullptr, (const float*)(uintptr_t)256, nullptr, B, H, W, L, flags)) return -1;
+  if (flags & FDMI_UNET_SAVE) {
+    if (run_backward(U, R, nullptr, (flags & FDMI_UNET_INPUT_GRAD) ? (float*)(uintptr_t)256 : nullptr)) return -1;
+  }
+  return (int64_t)R.arena.peak + (1 << 20);
+}
+
+int fdmi_unet_forward(fdmi_unet* U, int slot, const float* sample, const float* timestep, const float* ctx,
+                      const float* class_labels, float* out, int B, int H, int W, int L, void* workspace,
+                      int64_t workspace_bytes, int flags, void* stream) {
+  FDMI_CHECK(U && slot >= 0 && slot < 8, "bad plan / slot");
+  FDMI_CHECK(sample && timestep && ctx && out && workspace, "null argument");
+  FDMI_CHECK(H % (1 << (U->nl - 1)) == 0 && W % (1 << (U->nl - 1)) == 0, "unet: H, W must be divisible by 2^(levels-1)");
+  Run& R = U->runs[slot];
+  R.arena.base = (char*)workspace;
+  R.arena.cap = (size_t)workspace_bytes;
+  R.arena.dry = false;
+  R.st = (hipStream_t)stream;
+  return run_forward(U, R, sample, timestep, ctx, class_labels, out, B, H, W, L, flags);
+}
+
+int fdmi_unet_backward(fdmi_unet* U, int slot, const float* grad_out, float* grad_sample, void* stream) {
+  FDMI_CHECK(U && slot >= 0 && slot < 8 && grad_out, "bad plan / slot / null grad");
+  Run& R = U->runs[slot];
+  R.st = (hipStream_t)stream;
+  return run_backward(U, R, grad_out, grad_sample);
+}
+
+double fdmi_unet_last_flops(fdmi_unet* U) { return U ? U->last_flops : 0.0; }
+
+}  // extern "C"

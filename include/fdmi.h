@@ -99,6 +99,56 @@ int fdmi_add_noise(const float* z, const float* noise, const float* sqrt_ac, con
 int fdmi_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
                 const float* x3, float c3, float* out, int64_t n, void* stream);
 
+/* ---------------- UNet2DCondition plan: forward + input/LoRA-gradient backward -------------------
+ * Replaces DiffusersUNet2DCondWrapper.forward -> UNet2DConditionModel.forward(...).sample
+ * (/root/reference/src/flash/models/unets/unet.py:66-119) and its autograd backward.  Architecture
+ * hyper-parameters as pinned in examples/train_flash_sd.py:56-114 / train_flash_sdxl.py:66-118.
+ * Parameters are registered by their diffusers state_dict names as fp32 device tensors in the
+ * diffusers layout (conv OIHW, linear [out][in]); the plan packs them once into its own bf16 operand
+ * storage (forward + dgrad layouts).  LoRA A/B (peft semantics, scale alpha/r = 1,
+ * examples/train_flash_sd.py:191-200) stay fp32 master tensors owned by the caller; their bf16
+ * operand copies are refreshed at every forward and their gradients are ACCUMULATED (+=) into the
+ * caller's fp32 grad buffers by backward.                                                          */
+typedef struct fdmi_unet fdmi_unet;
+typedef struct fdmi_unet_config {
+  int32_t in_channels, out_channels;
+  int32_t n_levels;             /* 1..4 */
+  int32_t block_out[4];
+  int32_t down_attn[4];         /* CrossAttnDownBlock2D (1) or DownBlock2D (0) per level */
+  int32_t up_attn[4];           /* per up block, in up_blocks order */
+  int32_t layers_per_block;
+  int32_t tlayers[4];           /* transformer_layers_per_block, per level */
+  int32_t heads[4];             /* number of attention heads per level (diffusers' attention_head_dim) */
+  int32_t cross_dim;
+  int32_t groups; float eps;    /* norm_num_groups, norm_eps */
+  int32_t class_embed_dim;      /* projection_class_embeddings_input_dim, 0 = no class embedding */
+  int32_t flip_sin_to_cos; float freq_shift;
+} fdmi_unet_config;
+enum { FDMI_UNET_SAVE = 1,          /* record what backward needs (student / GAN backbone) */
+       FDMI_UNET_INTERMEDIATE = 2,  /* return_intermediate=True: output the mid-block features */
+       FDMI_UNET_INPUT_GRAD = 4     /* (workspace query only) backward will also produce d/d sample */ };
+
+fdmi_unet* fdmi_unet_create(const fdmi_unet_config* cfg);   /* NULL on error */
+void fdmi_unet_destroy(fdmi_unet* u);
+int64_t fdmi_unet_num_params(fdmi_unet* u);
+int fdmi_unet_param_name(fdmi_unet* u, int64_t i, char* buf, int64_t buflen, int64_t* numel);
+int fdmi_unet_set_param(fdmi_unet* u, const char* name, const float* data, int64_t numel, void* stream);
+int fdmi_unet_set_lora(fdmi_unet* u, const char* target /* e.g. "...attn1.to_q" */, const float* A /*[r][in]*/,
+                       const float* B /*[out][r]*/, float* A_grad, float* B_grad, int rank);
+int fdmi_unet_ready(fdmi_unet* u);   /* 0 when every parameter has been set */
+/* bytes of caller workspace one forward (+ backward when flags has SAVE) needs at this shape */
+int64_t fdmi_unet_workspace_bytes(fdmi_unet* u, int B, int H, int W, int L, int flags);
+/* sample [B,C,H,W] f32 NCHW, timestep [B] f32, ctx [B,L,cross_dim] f32, class_labels [B,class_embed_dim]
+ * f32 or NULL -> out f32 NCHW ([B,out_channels,H,W], or the mid-block features with INTERMEDIATE).
+ * `slot` (0..7) names the run state: the workspace handed to a SAVE forward must stay untouched until
+ * the matching fdmi_unet_backward(slot).                                                           */
+int fdmi_unet_forward(fdmi_unet* u, int slot, const float* sample, const float* timestep, const float* ctx,
+                      const float* class_labels, float* out, int B, int H, int W, int L, void* workspace,
+                      int64_t workspace_bytes, int flags, void* stream);
+/* grad_out: f32 NCHW gradient of the forward's output; grad_sample: f32 NCHW or NULL */
+int fdmi_unet_backward(fdmi_unet* u, int slot, const float* grad_out, float* grad_sample, void* stream);
+double fdmi_unet_last_flops(fdmi_unet* u);  /* algorithmic MFMA flops of the last forward/backward */
+
 #ifdef __cplusplus
 }
 #endif
