@@ -1,0 +1,414 @@
+"""FlashDiffusion -- MI355X drop-in for the reference's distillation model
+(/root/reference/src/flash/models/flash/flash_diffusion_model.py:38, "FD"): same constructor
+(FD:40-60), same forward(batch, batch_idx=0, step=0, *args, **kwargs) -> dict contract (FD:179,
+360-366), same loss semantics (FD:368-667), same config fields (flash_diffusion_config.py:9-105).
+
+What differs is where the work runs: the denoisers are MiUNet2DConditionModel plans (hand-written
+HIP kernels behind libfdmi.so), the teacher loop fuses CFG + DPM-Solver++ update into one kernel per
+step, and the teacher pass is issued BEFORE the student pass (legal: the teacher is frozen and its
+inputs do not depend on the student, FD:282-324; the SD3 twin of the reference already orders it this
+way, flash_sd3/flash_diffusion_model.py:281-323) so that a data-parallel trainer can overlap the
+previous step's gradient all-reduce + AdamW with it.
+
+Random draws go through `Draws` so tests can inject the exact values the reference consumed."""
+from __future__ import annotations
+
+from copy import deepcopy
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------------------------------
+@dataclass
+class FlashDiffusionConfig:
+    """Field-for-field mirror of the reference FlashDiffusionConfig (flash_diffusion_config.py:9-105),
+    including the scalar -> per-stage list broadcasting of its __post_init__."""
+    K: List[int] = field(default_factory=lambda: [32, 32, 32, 32, 32])
+    num_iterations_per_K: List[int] = field(default_factory=lambda: [5000, 10000, 15000, 20000, 25000])
+    guidance_scale_min: Any = 3.0
+    guidance_scale_max: Any = 7.0
+    distill_loss_type: str = "l2"
+    ucg_keys: List[str] = field(default_factory=lambda: ["text"])
+    timestep_distribution: str = "mixture"
+    mixture_num_components: Any = 4
+    mixture_var: Any = 0.5
+    adapter_conditioning_scale: float = 1.0
+    adapter_input_key: Optional[str] = None
+    use_dmd_loss: bool = False
+    dmd_loss_scale: Any = 1.0
+    distill_loss_scale: Any = 1.0
+    adversarial_loss_scale: Any = 1.0
+    gan_loss_type: str = "hinge"
+    mode_probs: Optional[List[List[float]]] = None
+    use_teacher_as_real: bool = False
+    use_empty_prompt: bool = False
+    input_key: str = "image"
+
+    def __post_init__(self):
+        n = len(self.K)
+        assert self.distill_loss_type in ("l2", "l1", "lpips")
+        assert self.timestep_distribution in ("gaussian", "uniform", "mixture")
+        assert self.gan_loss_type in ("hinge", "vanilla", "non-saturating", "wgan", "lsgan")
+        if isinstance(self.mixture_num_components, int):
+            self.mixture_num_components = [self.mixture_num_components] * n
+        for f in ("guidance_scale_min", "guidance_scale_max", "mixture_var", "distill_loss_scale",
+                  "dmd_loss_scale", "adversarial_loss_scale"):
+            if isinstance(getattr(self, f), float):
+                setattr(self, f, [getattr(self, f)] * n)
+        if self.mode_probs is None:
+            self.mode_probs = [[1 / m] * m for m in self.mixture_num_components]
+        for i in range(n):
+            assert len(self.mode_probs[i]) == self.mixture_num_components[i], \
+                f"Number of mode probabilities must match number of mixture components for stage {i}"
+        assert len(self.K) == len(self.num_iterations_per_K), "Number of timesteps must match number of iterations"
+        assert len(self.K) == len(self.mode_probs), "Number of timesteps must match number of mode probabilities"
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+
+class Draws:
+    """Source of every random draw of one forward.  values=None: draw from torch's RNG (noise on the
+    input's device, categorical / uniform scalars on the host like the reference, FD:167, 285, 454, 528)
+    and record; values=dict: replay (parity tests inject what the reference consumed)."""
+
+    def __init__(self, values: Optional[Dict[str, torch.Tensor]] = None):
+        self.inject = values is not None
+        self.values: Dict[str, torch.Tensor] = dict(values) if values else {}
+        self._count: Dict[str, int] = {}
+
+    def _get(self, name, make):
+        i = self._count.get(name, 0)
+        self._count[name] = i + 1
+        k = name if i == 0 else f"{name}#{i}"
+        if self.inject:
+            return self.values[k]
+        v = make()
+        self.values[k] = v
+        return v
+
+    def randn_like(self, name, x):
+        return self._get(name, lambda: torch.randn_like(x)).to(device=x.device, dtype=x.dtype)
+
+    def multinomial(self, name, prob, n, replacement=False):
+        return self._get(name, lambda: torch.multinomial(prob, n, replacement=replacement))
+
+    def rand1(self, name):
+        return self._get(name, lambda: torch.rand(1))
+
+    def randint(self, name, lo, hi, shape, device):
+        return self._get(name, lambda: torch.randint(lo, hi, shape)).to(device)
+
+
+class TensorConditioner(nn.Module):
+    """Stand-in for ConditionerWrapper (embedders/conditioners_wrapper.py:39-91) when the batch already
+    carries the embeddings (`crossattn` [B,L,D], optional `vector`, `concat`).  Keys listed in `ucg_keys`
+    are zeroed -- what force_zero_embedding yields for a dropped conditioner
+    (clip_embedder_model.py:93-94).  Text encoders themselves are out of scope."""
+
+    def __init__(self, input_key="text"):
+        super().__init__()
+        self.input_key = input_key
+
+    def forward(self, batch, ucg_keys=None, set_ucg_rate_zero=False, *args, **kwargs):
+        drop = ucg_keys is not None and self.input_key in ucg_keys
+        cond = {}
+        for k in ("crossattn", "vector", "concat"):
+            if batch.get(k, None) is not None:
+                cond[k] = torch.zeros_like(batch[k]) if drop else batch[k]
+        return {"cond": cond}
+
+
+# ----------------------------------------------------------------------------------------------------
+class _PerSampleAffine(torch.autograd.Function):
+    """out[b] = ca[b] * x[b] + cb[b] * eps[b]  (fused; gradient flows to eps only)."""
+
+    @staticmethod
+    def forward(ctx, eps, x, ca, cb):
+        ctx.save_for_backward(cb)
+        return ops.add_noise(x.contiguous(), eps.contiguous(), ca, cb)
+
+    @staticmethod
+    def backward(ctx, g):
+        (cb,) = ctx.saved_tensors
+        g = g.contiguous()
+        return ops.add_noise(g, g, cb, torch.zeros_like(cb)), None, None, None
+
+
+def gaussian_mixture_pmf(K, locs, var, mode_probs):
+    p = [sum(mode_probs[j] * torch.exp(-torch.tensor([(i - loc) ** 2 / var])) for j, loc in enumerate(locs))
+         for i in range(K)]
+    p = torch.tensor(p)
+    return p / torch.sum(p)
+
+
+class FlashDiffusion(nn.Module):
+    def __init__(self, config: FlashDiffusionConfig, student_denoiser, teacher_denoiser=None,
+                 teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
+                 vae=None, conditioner=None, adapter=None, discriminator: nn.Module = None):
+        super().__init__()
+        if vae is not None or adapter is not None:
+            raise NotImplementedError("VAE / T2I-adapter are outside the hot-path scope (SURVEY.md 2.1 rows 5-6)")
+        self.config = config
+        self.input_key = config.input_key
+        self.student_denoiser = student_denoiser
+        self.teacher_denoiser = teacher_denoiser
+        self.teacher_noise_scheduler = teacher_noise_scheduler
+        self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
+        self.sampling_noise_scheduler = sampling_noise_scheduler
+        self.vae = None
+        self.adapter = None
+        self.conditioner = conditioner
+        self.discriminator = discriminator
+        for f in ("guidance_scale_min", "guidance_scale_max", "ucg_keys", "K", "num_iterations_per_K",
+                  "distill_loss_type", "timestep_distribution", "mixture_num_components", "mixture_var",
+                  "use_dmd_loss", "dmd_loss_scale", "distill_loss_scale", "adversarial_loss_scale", "gan_loss_type",
+                  "mode_probs", "use_teacher_as_real", "use_empty_prompt"):
+            setattr(self, f, getattr(config, f))
+        if self.distill_loss_type == "lpips":
+            raise NotImplementedError("lpips distill loss needs pretrained VAE+VGG weights: a 'next' row (SURVEY.md 8f)")
+        self.iter_steps = 0
+        self.disc_update_counter = 0
+        self.disc_backbone = self.teacher_denoiser
+        self.K_steps = np.cumsum(self.num_iterations_per_K)
+        self.K_prev = self.K[0]
+        ac = teacher_noise_scheduler.alphas_cumprod
+        self.register_buffer("sqrt_alpha_cumprod", torch.sqrt(ac))
+        self.register_buffer("sigmas", torch.sqrt(1 - ac))
+        self.draws: Optional[Draws] = None
+        self.last_draws: Optional[Draws] = None
+        self.terms: Dict[str, Any] = {}
+        self.fixed_start_idx: Optional[int] = None     # benchmark / DDP: pin the teacher-step count
+        self.fixed_guidance: Optional[float] = None
+
+    # ---- helpers -----------------------------------------------------------------------------------
+    def freeze(self):
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def on_train_batch_end(self, batch, *a, **k):
+        pass
+
+    def _get_conditioning(self, batch, ucg_keys=None, set_ucg_rate_zero=False, *args, **kwargs):
+        if self.conditioner is None:
+            return None
+        return self.conditioner(batch, ucg_keys=ucg_keys, set_ucg_rate_zero=set_ucg_rate_zero, vae=self.vae,
+                                *args, **kwargs)
+
+    def _timestep_pmf(self, K, K_step):
+        """FD:141-165"""
+        if self.timestep_distribution == "uniform":
+            return torch.ones(K) / K
+        if self.timestep_distribution == "gaussian":
+            p = torch.tensor([torch.exp(-torch.tensor([(i - K / 2) ** 2 / K])) for i in range(K)])
+            return p / torch.sum(p)
+        M = self.mixture_num_components[K_step]
+        locs = [i * (K // M) for i in range(M)]
+        return gaussian_mixture_pmf(K, locs, self.mixture_var[K_step], self.mode_probs[K_step])
+
+    def _get_timesteps(self, d: Draws, num_samples, K, K_step, device):
+        """FD:135-177: ONE start index per batch, drawn on the host."""
+        self.teacher_noise_scheduler.set_timesteps(K)
+        if self.fixed_start_idx is not None:
+            start_idx = torch.tensor([self.fixed_start_idx])
+        else:
+            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
+        t0 = self.teacher_noise_scheduler.timesteps[start_idx]
+        return start_idx, t0.to(device).repeat(num_samples)
+
+    @staticmethod
+    def _scalings_for_boundary_conditions(timestep, sigma_data=0.5):
+        """FD:710-716"""
+        c_skip = sigma_data ** 2 / ((timestep / 0.1) ** 2 + sigma_data ** 2)
+        c_out = (timestep / 0.1) / ((timestep / 0.1) ** 2 + sigma_data ** 2) ** 0.5
+        return c_skip, c_out
+
+    def _x0_coeffs(self, t):
+        """per-sample (1/alpha_t, -sigma_t/alpha_t) of the epsilon-branch of _predicted_x_0 (FD:731-742)."""
+        al = self.sqrt_alpha_cumprod[t]
+        sg = self.sigmas[t]
+        assert bool((al > 0).all()), "alpha_t == 0 never occurs on the trailing schedules of the reference configs"
+        return 1.0 / al, -sg / al
+
+    # ---- forward (FD:179-366) ------------------------------------------------------------------------
+    def forward(self, batch: Dict[str, Any], batch_idx=0, step=0, *args, **kwargs):
+        sch = self.teacher_noise_scheduler
+        d = self.draws if self.draws is not None else Draws()
+        self.last_draws = d
+        self.iter_steps += 1
+        z = batch[self.input_key].float().contiguous()
+        B = z.shape[0]
+        conditioning = self._get_conditioning(batch, set_ucg_rate_zero=True, *args, **kwargs)
+        student_conditioning = self._get_conditioning(batch, *args, **kwargs)
+        if self.use_empty_prompt and "text" in self.ucg_keys:
+            ub = dict(batch)
+            ub["text"] = [""] * len(batch["text"])
+            uncond = self._get_conditioning(ub, set_ucg_rate_zero=True, *args, **kwargs)
+        else:
+            uncond = self._get_conditioning(batch, ucg_keys=self.ucg_keys, *args, **kwargs)
+        if self.iter_steps > self.K_steps[-1]:
+            K_step = len(self.K) - 1
+        else:
+            K_step = int(np.argmax(self.iter_steps < self.K_steps))
+        K = self.K[K_step]
+        g_min, g_max = self.guidance_scale_min[K_step], self.guidance_scale_max[K_step]
+        if K != self.K_prev:
+            self.K_prev = K
+            if getattr(self, "switch_teacher", False):  # the reference reads an attribute it never sets (FD:230)
+                self.teacher_denoiser = deepcopy(self.student_denoiser)
+                self.teacher_denoiser.freeze()
+
+        noise = d.randn_like("noise", z)
+        start_idx, start_t = self._get_timesteps(d, B, K, K_step, z.device)
+        si = int(start_idx)
+        if si == 0:
+            x_init = noise if sch.init_noise_sigma == 1.0 else noise * sch.init_noise_sigma
+        else:
+            with torch.no_grad():
+                x_init = sch.add_noise(z, noise, start_t)
+        x_in = sch.scale_model_input(x_init, start_t)
+        if self.fixed_guidance is not None:
+            g = float(self.fixed_guidance)
+        else:
+            g = float(d.rand1("guidance")) * (g_max - g_min) + g_min
+
+        # ---- teacher: n = K - start_idx CFG denoising steps, no grad (FD:288-324) ----
+        with torch.no_grad():
+            x = x_init
+            fused = hasattr(sch, "fused_cfg_step")
+            for t in sch.timesteps[si:]:
+                tt = torch.full((B,), float(t), device=z.device)
+                x_ = sch.scale_model_input(x, t)
+                e_c = self.teacher_denoiser(sample=x_, timestep=tt, conditioning=conditioning,
+                                            down_intrablock_additional_residuals=None, *args, **kwargs)
+                e_u = self.teacher_denoiser(sample=x_, timestep=tt, conditioning=uncond,
+                                            down_intrablock_additional_residuals=None, *args, **kwargs)
+                if fused:
+                    x = sch.fused_cfg_step(e_c, e_u, g, t, x)
+                else:
+                    e = ops.axpby(e_c, g, e_u, 1.0 - g)
+                    x = sch.step(e, t, x, return_dict=False)[0]
+            teacher_output = x
+
+        # ---- student: one step with grad (FD:255-280, 328) ----
+        hook = getattr(self, "before_student", None)
+        if hook is not None:
+            hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
+        eps_s = self.student_denoiser(sample=x_in, timestep=start_t, conditioning=student_conditioning,
+                                      down_intrablock_additional_residuals=None)
+        c_skip, c_out = self._scalings_for_boundary_conditions(start_t.float())
+        inv_a, ms_a = self._x0_coeffs(start_t.long())
+        # student_output = c_skip x + c_out (x - sigma eps)/alpha
+        ca = (c_skip + c_out * inv_a).float().contiguous()
+        cb = (c_out * ms_a).float().contiguous()
+        student_output = _PerSampleAffine.apply(eps_s, x_init, ca, cb)
+
+        l_distill = self._distill_loss(student_output, teacher_output)
+        loss = l_distill * self.distill_loss_scale[K_step]
+        self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": g, "n_teacher_steps": K - si}
+        if self.use_dmd_loss:
+            l_dmd = self._dmd_loss(d, student_output, student_conditioning, conditioning, uncond, K_step)
+            self.terms["dmd"] = l_dmd.detach()
+            loss = loss + l_dmd * self.dmd_loss_scale[K_step]
+        if self.discriminator is not None:
+            gan = self._gan_loss(d, z, student_output, teacher_output, conditioning, step)
+        else:
+            gan = [0, 0]  # the reference cannot run without a discriminator (FD:347); we degrade gracefully
+        self.terms["gan_G"] = gan[0].detach() if torch.is_tensor(gan[0]) else gan[0]
+        self.terms["gan_D"] = gan[1].detach() if torch.is_tensor(gan[1]) else gan[1]
+        loss = loss + self.adversarial_loss_scale[K_step] * gan[0]
+        return {"loss": [loss, gan[1]], "teacher_output": teacher_output, "student_output": student_output,
+                "noisy_sample": x_init, "start_timestep": int(start_t[0].item())}
+
+    # ---- losses --------------------------------------------------------------------------------------
+    def _distill_loss(self, s, t):
+        """FD:368-382"""
+        if self.distill_loss_type == "l2":
+            return torch.mean(((s - t) ** 2).reshape(s.shape[0], -1), 1).mean()
+        return torch.mean(torch.abs(s - t).reshape(s.shape[0], -1), 1).mean()
+
+    def _dmd_loss(self, d, s, student_cond, cond, uncond, K_step):
+        """FD:401-499"""
+        sch = self.teacher_noise_scheduler
+        B = s.shape[0]
+        noise = d.randn_like("dmd_noise", s)
+        t = d.randint("dmd_t", 0, sch.config.num_train_timesteps, (B,), s.device)
+        noisy = sch.add_noise(s, noise, t)
+        with torch.no_grad():
+            tf = t.float()
+            e_c = self.teacher_denoiser(sample=noisy, timestep=tf, conditioning=cond,
+                                        down_intrablock_additional_residuals=None)
+            e_u = self.teacher_denoiser(sample=noisy, timestep=tf, conditioning=uncond,
+                                        down_intrablock_additional_residuals=None)
+            e_f = self.student_denoiser(sample=noisy, timestep=tf, conditioning=student_cond,
+                                        down_intrablock_additional_residuals=None)
+            g = (float(d.rand1("dmd_guidance")) * (self.guidance_scale_max[K_step] - self.guidance_scale_min[K_step])
+                 + self.guidance_scale_min[K_step])
+            real = ops.axpby(e_c, g, e_u, 1.0 - g)
+            a = sch.alphas_cumprod.to(s.device)[t]
+            coeff = (real - e_f) * ((1.0 - a) ** 0.5 / a ** 0.5).view(-1, 1, 1, 1)   # (score_fake - score_real) ...
+            inv_a, ms_a = self._x0_coeffs(t)
+            x0 = ops.add_noise(noisy.detach().contiguous(), real, inv_a.float().contiguous(), ms_a.float().contiguous())
+            w = 1.0 / ((s.detach() - x0).abs().mean([1, 2, 3], keepdim=True) + 1e-5)
+            target = s.detach() - w * coeff
+        return F.mse_loss(s, target, reduction="mean")
+
+    def _gan_loss(self, d, z, s, teacher_output, conditioning, step):
+        """FD:501-667"""
+        sch = self.teacher_noise_scheduler
+        self.disc_update_counter += 1
+        B = s.shape[0]
+        noise = d.randn_like("gan_noise", s)
+        real = teacher_output if self.use_teacher_as_real else z
+        idx = d.multinomial("gan_idx", torch.tensor([0.25, 0.25, 0.25, 0.25]), B, replacement=True).to(s.device)
+        ts = torch.tensor([10, 250, 500, 750], device=s.device, dtype=torch.long)[idx]
+        gen = step % 2 == 0
+        s_in = s if gen else s.detach()          # D-step: fake branch is detached (FD:583, 602, 616, 638, 659)
+        noisy_fake = sch.add_noise(s_in, noise, ts)
+        with torch.no_grad():
+            noisy_real = sch.add_noise(real, noise, ts)
+        x = torch.cat([noisy_fake, noisy_real], dim=0)
+        if conditioning is not None:
+            conditioning = {"cond": {k: torch.cat([v, v], dim=0) for k, v in conditioning["cond"].items()}}
+        t2 = torch.cat([ts, ts], dim=0).float()
+        feat = self.disc_backbone(sample=x, timestep=t2, conditioning=conditioning,
+                                  down_intrablock_additional_residuals=None, return_intermediate=True)
+        f_fake, f_real = feat.chunk(2, dim=0)
+        disc = self.discriminator
+        kind = self.gan_loss_type
+        dev = s.device
+        if kind == "wgan":
+            for p in disc.parameters():
+                p.data.clamp_(-0.01, 0.01)
+            if gen:
+                return [-disc(f_fake).mean(), 0]
+            return [0, -disc(f_real).mean() + disc(f_fake.detach()).mean()]
+        if kind == "lsgan":
+            valid, fake = torch.ones(B, 1, device=dev), torch.zeros(B, 1, device=dev)
+            if gen:
+                return [F.mse_loss(torch.sigmoid(disc(f_fake)), valid), 0]
+            return [0, 0.5 * (F.mse_loss(torch.sigmoid(disc(f_real)), valid)
+                              + F.mse_loss(torch.sigmoid(disc(f_fake.detach())), fake))]
+        if kind == "hinge":
+            if gen:
+                return [-disc(f_fake).mean(), 0]
+            return [0, F.relu(1.0 - disc(f_real)).mean() + F.relu(1.0 + disc(f_fake.detach())).mean()]
+        if kind == "non-saturating":
+            if gen:
+                return [-torch.mean(torch.log(torch.sigmoid(disc(f_fake)) + 1e-8)), 0]
+            return [0, -torch.mean(torch.log(torch.sigmoid(disc(f_real)) + 1e-8)
+                                   + torch.log(1 - torch.sigmoid(disc(f_fake.detach())) + 1e-8))]
+        valid = torch.ones(B, 1, device=dev)
+        if gen:
+            return [F.binary_cross_entropy_with_logits(disc(f_fake), valid), 0]
+        fake = torch.zeros(B, 1, device=dev)
+        return [0, F.binary_cross_entropy_with_logits(disc(f_real), valid)
+                + F.binary_cross_entropy_with_logits(disc(f_fake.detach()), fake)]

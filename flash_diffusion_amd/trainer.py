@@ -1,0 +1,260 @@
+"""TrainingPipeline -- Lightning-free twin of the reference trainer
+(/root/reference/src/flash/trainer/trainer.py:16-251, "TR") for the distillation hot path:
+  * configure_optimizers: regex-selected parameter groups per optimizer, everything unmatched frozen
+    (TR:76-139);
+  * training_step: one optimizer -> single backward; several optimizers -> the manual loop that runs
+    the FULL model forward once per optimizer with step=i (TR:187-218);
+  * data parallel: one process per GPU, gradients of the trainable (LoRA / discriminator) tensors are
+    summed with ONE RCCL all-reduce per optimizer on a flat buffer (the reference gets bucketed NCCL
+    all-reduces from Lightning's DDP strategy, examples/train_flash_sd.py:386).  Because the teacher is
+    frozen, the all-reduce + AdamW of iteration i run on a side stream concurrently with the teacher
+    loop of iteration i+1; the student forward waits on that stream (FlashDiffusion.before_student).
+AdamW itself is the fused HIP kernel fdmi_adamw (torch.optim.AdamW semantics)."""
+from __future__ import annotations
+
+import logging
+import re
+import time
+from dataclasses import dataclass, field
+from typing import Any, Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+@dataclass
+class TrainingConfig:
+    """Mirror of the fields of the reference TrainingConfig that the hot path reads
+    (trainer/training_config.py:10-136)."""
+    experiment_id: Optional[str] = None
+    optimizers_name: List[str] = field(default_factory=lambda: ["AdamW"])
+    optimizers_kwargs: List[dict] = field(default_factory=lambda: [{}])
+    learning_rates: List[float] = field(default_factory=lambda: [1e-3])
+    lr_schedulers_name: List[Optional[str]] = field(default_factory=lambda: [None])
+    trainable_params: List[List[str]] = field(default_factory=lambda: [[".*"]])
+    log_keys: Any = "txt"
+    log_samples_model_kwargs: dict = field(default_factory=dict)
+
+    def __post_init__(self):
+        if self.optimizers_kwargs == [{}]:
+            self.optimizers_kwargs = [{} for _ in self.optimizers_name]
+        assert len(self.optimizers_name) == len(self.optimizers_kwargs)
+        if self.trainable_params == [[".*"]]:
+            self.trainable_params = [[".*"] for _ in self.optimizers_name]
+        assert len(self.optimizers_name) == len(self.trainable_params)
+        assert len(self.optimizers_name) == len(self.learning_rates)
+
+
+class FusedAdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW semantics (decoupled weight decay 1e-2, betas (0.9, 0.999), eps 1e-8), one
+    fdmi_adamw launch per contiguous fp32 buffer.  Parameters that are views into one flat buffer
+    (the LoRA tensors) are updated with a single launch."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flat=None, flat_grad=None):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        self.flat, self.flat_grad = flat, flat_grad
+        self.grad_scale = 1.0
+        self._flat_state = None
+        self.step_count = 0
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        self.step_count += 1
+        for grp in self.param_groups:
+            b1, b2 = grp["betas"]
+            if self.flat is not None:
+                if self._flat_state is None:
+                    self._flat_state = (torch.zeros_like(self.flat), torch.zeros_like(self.flat))
+                m, v = self._flat_state
+                ops.adamw_(self.flat, self.flat_grad, m, v, grp["lr"], b1, b2, grp["eps"], grp["weight_decay"],
+                           self.step_count, self.grad_scale)
+                continue
+            for p in grp["params"]:
+                if p.grad is None:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["m"], st["v"] = torch.zeros_like(p), torch.zeros_like(p)
+                assert p.is_contiguous() and p.grad.is_contiguous()
+                ops.adamw_(p.data, p.grad, st["m"], st["v"], grp["lr"], b1, b2, grp["eps"], grp["weight_decay"],
+                           self.step_count, self.grad_scale)
+
+
+class TrainingPipeline(nn.Module):
+    def __init__(self, model: nn.Module, pipeline_config: TrainingConfig, verbose: bool = False, overlap: bool = True,
+                 **kwargs):
+        super().__init__()
+        self.model = model
+        self.pipeline_config = pipeline_config
+        self.log_samples_model_kwargs = pipeline_config.log_samples_model_kwargs
+        self.verbose = verbose
+        self.automatic_optimization = True
+        self.optims: List[torch.optim.Optimizer] = []
+        self.overlap = overlap
+        self._comm_stream = None
+        self._pending = None      # event recorded on the comm stream after the deferred optimizer step
+        self.global_rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
+        self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        self.timer = None
+
+    @property
+    def device(self):
+        return next(self.model.parameters()).device
+
+    # ---- TR:76-139 -------------------------------------------------------------------------------
+    def configure_optimizers(self):
+        cfg = self.pipeline_config
+        optimizers = []
+        student = getattr(self.model, "student_denoiser", None)
+        for i, name in enumerate(cfg.optimizers_name):
+            params, n_params, names = [], 0, []
+            for pname, p in self.model.named_parameters():
+                if any(re.match(re.compile(rx), pname) for rx in cfg.trainable_params[i]) and p.requires_grad:
+                    params.append(p)
+                    names.append(pname)
+                    n_params += p.numel()
+            logging.info(f"Number of trainable parameters for optimizer {i}: {n_params}")
+            kw = dict(cfg.optimizers_kwargs[i])
+            if name == "AdamW" and params and all(p.is_cuda for p in params):
+                flat = flat_grad = None
+                lora = student.lora_parameters() if (student is not None and getattr(student, "lora_rank", 0)) else []
+                if lora and len(lora) == len(params) and all(a is b for a, b in zip(lora, params)):
+                    student._reflatten_lora(params[0].device)
+                    flat, flat_grad = student.lora_flat(), student.lora_flat_grad()
+                opt = FusedAdamW(params, lr=cfg.learning_rates[i], flat=flat, flat_grad=flat_grad, **kw)
+            else:
+                opt = getattr(torch.optim, name)(params, lr=cfg.learning_rates[i], **kw)
+            optimizers.append(opt)
+        if len(optimizers) > 1:
+            self.automatic_optimization = False
+        self.optims = optimizers
+        for pname, p in self.model.named_parameters():
+            keep = any(re.match(re.compile(rx), pname) for rxs in cfg.trainable_params for rx in rxs) and p.requires_grad
+            if not keep:
+                p.requires_grad = False
+        logging.info("Number of trainable parameters: %d",
+                     sum(p.numel() for p in self.model.parameters() if p.requires_grad))
+        if self.overlap and torch.cuda.is_available():
+            self._comm_stream = torch.cuda.Stream()
+            self.model.before_student = self._wait_pending
+        return optimizers
+
+    def optimizers(self):
+        return self.optims
+
+    # ---- gradient exchange + optimizer step ---------------------------------------------------------
+    def _wait_pending(self):
+        if self._pending is not None and torch.cuda.is_available():
+            torch.cuda.current_stream().wait_event(self._pending)
+            self._pending = None
+
+    def _reduce_and_step(self, opt):
+        """All-reduce (sum) the optimizer's gradients over the data-parallel ranks, then step.  Runs on
+        the comm stream when overlap is on; the 1/world mean is folded into the fused AdamW."""
+        side = self._comm_stream if (self.overlap and self._comm_stream is not None) else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream())
+        ctx = torch.cuda.stream(side) if side is not None else _null()
+        with ctx:
+            if self.world > 1:
+                if isinstance(opt, FusedAdamW) and opt.flat_grad is not None:
+                    torch.distributed.all_reduce(opt.flat_grad)
+                else:
+                    grads = [p.grad for g in opt.param_groups for p in g["params"] if p.grad is not None]
+                    if grads:
+                        flat = torch._utils._flatten_dense_tensors(grads)
+                        torch.distributed.all_reduce(flat)
+                        for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
+                            g.copy_(f)
+                if isinstance(opt, FusedAdamW):
+                    opt.grad_scale = 1.0 / self.world
+                else:
+                    for g in opt.param_groups:
+                        for p in g["params"]:
+                            if p.grad is not None:
+                                p.grad.div_(self.world)
+            opt.step()
+            if side is not None:
+                self._pending = torch.cuda.Event()
+                self._pending.record(side)
+
+    def _zero_grad(self, opt):
+        if isinstance(opt, FusedAdamW) and opt.flat_grad is not None:
+            self._wait_pending()  # the deferred step of the previous iteration still reads the grads
+            opt.flat_grad.zero_()
+        else:
+            self._wait_pending()
+            opt.zero_grad()
+
+    # ---- TR:169-218 ------------------------------------------------------------------------------------
+    def training_step(self, train_batch: Dict[str, Any], batch_idx: int = 0) -> dict:
+        if not self.optims:
+            self.configure_optimizers()
+        if self.automatic_optimization:
+            opt = self.optims[0]
+            out = self.model(train_batch, device=self.device)
+            loss = out["loss"][0] if isinstance(out["loss"], (list, tuple)) else out["loss"]
+            # zero_grad may only run once the deferred step has consumed the previous gradients;
+            # model.before_student already waited for it.
+            self._zero_grad(opt)
+            loss.backward()
+            self._reduce_and_step(opt)
+            return {"loss": loss.detach(), "batch_idx": batch_idx, "start_timestep": out.get("start_timestep")}
+        outputs = {"batch_idx": batch_idx}
+        for i, opt in enumerate(self.optims):
+            model_output = self.model(train_batch, device=self.device, step=i, batch_idx=batch_idx)
+            loss = model_output["loss"]
+            if "start_timestep" in model_output:
+                outputs["start_timestep"] = model_output["start_timestep"]
+            outputs[f"loss_optimizer_{i}"] = loss[i].detach() if torch.is_tensor(loss[i]) else loss[i]
+            self._toggle(i)
+            self._zero_grad(opt)
+            if torch.is_tensor(loss[i]) and loss[i].requires_grad:
+                loss[i].backward()
+                self._reduce_and_step(opt)
+            self._untoggle()
+        return outputs
+
+    def _toggle(self, i):
+        """Lightning's toggle_optimizer: only optimizer i's parameters require grad during its backward."""
+        mine = {id(p) for g in self.optims[i].param_groups for p in g["params"]}
+        self._toggled = []
+        for j, o in enumerate(self.optims):
+            if j == i:
+                continue
+            for g in o.param_groups:
+                for p in g["params"]:
+                    if id(p) not in mine and p.requires_grad:
+                        p.requires_grad = False
+                        self._toggled.append(p)
+
+    def _untoggle(self):
+        for p in self._toggled:
+            p.requires_grad = True
+        self._toggled = []
+
+    def finish(self):
+        """Drain the deferred optimizer step (end of training / before reading parameters)."""
+        self._wait_pending()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+
+    # ---- TR:58-74 --------------------------------------------------------------------------------------
+    def on_train_start(self):
+        self.timer = time.perf_counter()
+
+    def on_train_batch_end(self, outputs, batch, batch_idx):
+        self.model.on_train_batch_end(batch)
+        if self.global_rank == 0 and batch_idx % 10 == 0 and self.timer is not None:
+            delta = time.perf_counter() - self.timer
+            logging.info(f"Average time per batch {batch_idx} took {delta / (batch_idx + 1)} seconds")
+
+
+class _null:
+    def __enter__(self):
+        return None
+
+    def __exit__(self, *a):
+        return False

@@ -1,0 +1,133 @@
+"""GPU parity of the full distillation step (FlashDiffusion.forward + backward on the HIP path) against
+the fixtures the REAL reference produced (tests/golden/*.npz, oracle/make_golden.py), on identical noised
+latents (every random draw injected), plus the reference's own invariants
+(tests/test_flash/test_flash_diffusion.py:146-222) re-expressed on the new path.
+
+Tolerance (stated): bf16 activations vs the reference's fp32 CPU run: student/teacher outputs rel.
+Frobenius < 4e-2, each loss term |rel| < 6e-2 (north_star asks 1e-3 for an fp32-equivalent path; the
+bf16 figure is what precision="bf16-mixed" gives -- measured values in gpurun_out/flash_parity.txt),
+LoRA / discriminator gradient tensors: cosine similarity > 0.98 and norm ratio within 10 %."""
+import copy
+import os
+
+import pytest
+import torch
+
+from oracle.golden_cases import CASES, LORA_RANK, build_models
+from tests.golden_util import load_case, rel_err
+from tests.unet_util import mi_from_oracle
+
+pytestmark = pytest.mark.gpu
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "flash_parity.txt")
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(msg + "\n")
+
+
+def build_product(kw, sched="dpm"):
+    from flash_diffusion_amd.flash import FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DDPMScheduler, DPMSolverMultistepScheduler
+    teacher_o, student_o, disc_o = build_models()
+    teacher = mi_from_oracle(teacher_o)
+    teacher.freeze()
+    student = mi_from_oracle(student_o, lora_rank=LORA_RANK)
+    disc = copy.deepcopy(disc_o).cuda()
+    sch = DPMSolverMultistepScheduler() if sched == "dpm" else DDPMScheduler()
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=sch, conditioner=TensorConditioner(), discriminator=disc).cuda()
+    return m
+
+
+def cos(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_step_matches_reference_golden(name):
+    from flash_diffusion_amd.flash import Draws
+    kw, sched, step, _ = CASES[name]
+    g = load_case(name)
+    m = build_product(kw, sched)
+    m.draws = Draws(g["draws"])
+    B = g["z"].shape[0]
+    batch = {"image": g["z"].cuda(), "crossattn": g["crossattn"].cuda(), "text": ["a"] * B}
+    out = m(batch, step=step, device="cuda")
+    assert out["start_timestep"] == g["start_timestep"]
+    errs = {k: rel_err(out[k], g["out"][k]) for k in ("teacher_output", "student_output", "noisy_sample")}
+    lerr = []
+    for i in (0, 1):
+        ref = g["loss"][i]
+        got = float(out["loss"][i])
+        lerr.append(abs(got - ref) / max(abs(ref), 1e-12) if ref != 0 else abs(got))
+    log(f"{name}: " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + f" loss_rel={lerr[0]:.3e},{lerr[1]:.3e}"
+        + f" terms={ {k: (float(v) if torch.is_tensor(v) else v) for k, v in m.terms.items()} } ref_terms={g['terms']}")
+    assert errs["noisy_sample"] < 1e-6
+    assert errs["teacher_output"] < 4e-2 and errs["student_output"] < 4e-2
+    assert lerr[0] < 6e-2 and lerr[1] < 6e-2
+    out["loss"][step].backward()
+    torch.cuda.synchronize()
+    n, worst_cos, worst_ratio = 0, 1.0, 0.0
+    for pn, p in m.named_parameters():
+        key = pn
+        if pn.startswith("student_denoiser.") and ".lora_" not in pn:
+            continue
+        cand = [k for k in g["grads"] if k.replace(".base_layer.", ".") == key]
+        if p.grad is None:
+            assert not cand or float(g["grads"][cand[0]].abs().max()) == 0.0, pn
+            continue
+        assert cand, pn
+        ref = g["grads"][cand[0]]
+        if float(ref.norm()) < 1e-12:
+            continue
+        c = cos(p.grad, ref)
+        r = float(p.grad.float().norm().cpu() / ref.norm())
+        worst_cos, worst_ratio = min(worst_cos, c), max(worst_ratio, abs(r - 1))
+        n += 1
+    log(f"{name}: {n} grad tensors, worst cosine {worst_cos:.4f}, worst |norm ratio - 1| {worst_ratio:.3e}")
+    assert n > 0 and worst_cos > 0.98 and worst_ratio < 0.10
+
+
+def test_reference_invariants_forward_signs():
+    """T-FD:146-153: step=0 -> loss[0] > 0, loss[1] == 0 ; step=1 -> both > 0."""
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="gaussian", gan_loss_type="hinge")
+    m = build_product(kw)
+    g = torch.Generator().manual_seed(0)
+    batch = {"image": torch.randn(2, 4, 32, 32, generator=g).cuda(), "crossattn": torch.randn(2, 77, 64, generator=g).cuda(),
+             "text": ["x", "y"]}
+    with torch.no_grad():
+        o0 = m(batch, device="cuda", step=0)
+        assert o0["loss"][0] > 0.0 and o0["loss"][1] == 0.0
+        o1 = m(batch, device="cuda", step=1)
+        assert o1["loss"][0] > 0.0 and o1["loss"][1] > 0.0
+
+
+@pytest.mark.parametrize("distill_scale", [1.0, 0.0])
+def test_reference_invariants_optimizers(distill_scale):
+    """T-FD:155-222: after one G-step and one D-step (2 optimizers, manual loop) the student changed, the
+    teacher is bit-identical, the discriminator changed -- also with distill_loss_scale=[0.0], i.e. the GAN
+    generator gradient alone reaches the student THROUGH the frozen teacher backbone."""
+    from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="gaussian", gan_loss_type="hinge",
+              distill_loss_scale=[distill_scale])
+    m = build_product(kw)
+    # peft inits LoRA B = 0; the golden models use non-zero B so the student really depends on A too
+    pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-3, 1e-3],
+                                              trainable_params=[["student_denoiser"], ["discriminator."]]))
+    pipe.configure_optimizers()
+    before = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    g = torch.Generator().manual_seed(0)
+    batch = {"image": torch.randn(2, 4, 32, 32, generator=g).cuda(), "crossattn": torch.randn(2, 77, 64, generator=g).cuda(),
+             "text": ["x", "y"]}
+    pipe.training_step(batch, 0)
+    pipe.finish()
+    after = m.state_dict()
+    changed = lambda pre: [k for k in after if k.startswith(pre) and not torch.equal(before[k], after[k])]
+    same = lambda pre: all(torch.equal(before[k], after[k]) for k in after if k.startswith(pre))
+    assert same("teacher_denoiser."), "teacher must stay bit-identical"
+    stu = changed("student_denoiser.")
+    assert stu and all(".lora_" in k for k in stu), "only LoRA tensors of the student may change"
+    assert changed("discriminator."), "discriminator must be updated by the D-step"

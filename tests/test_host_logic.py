@@ -1,0 +1,138 @@
+"""CPU tests of the host-side logic of the product package (no GPU, no kernels): config broadcasting,
+timestep pmf, scheduler coefficients vs the oracle, optimizer parameter selection (TR:76-139), and the
+data-parallel gradient exchange on a 2-process gloo group."""
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+from flash_diffusion_amd.flash import FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
+from oracle.flash_ref import FlashConfigRef, timestep_pmf
+from oracle.sched_cpu import DPMSolverMultistepSchedulerRef
+
+
+def test_config_broadcast_matches_reference_post_init():
+    c = FlashDiffusionConfig(K=[8, 8], num_iterations_per_K=[5, 5], guidance_scale_min=3.0, mixture_var=0.5)
+    assert c.guidance_scale_min == [3.0, 3.0] and c.mixture_num_components == [4, 4]
+    assert c.mode_probs == [[0.25] * 4] * 2 and c.distill_loss_type == "l2" and c.gan_loss_type == "hinge"
+    with pytest.raises(AssertionError):
+        FlashDiffusionConfig(K=[8], num_iterations_per_K=[5, 5])
+
+
+class _Dummy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = nn.Parameter(torch.zeros(3))
+
+
+@pytest.mark.parametrize("dist,kw", [("uniform", {}), ("gaussian", {}),
+                                     ("mixture", dict(mixture_num_components=4, mixture_var=0.5, mode_probs=[[0.1, 0.3, 0.3, 0.3]]))])
+def test_timestep_pmf_matches_oracle(dist, kw):
+    cfg = FlashDiffusionConfig(K=[16], num_iterations_per_K=[3], timestep_distribution=dist, **kw)
+    m = FlashDiffusion(cfg, _Dummy(), _Dummy(), DPMSolverMultistepScheduler())
+    ref = timestep_pmf(FlashConfigRef(K=[16], num_iterations_per_K=[3], timestep_distribution=dist, **kw), 16, 0)
+    assert torch.equal(m._timestep_pmf(16, 0), ref)
+
+
+@pytest.mark.parametrize("K", [1, 4, 8, 32])
+def test_dpm_coefficients_match_oracle(K):
+    a, b = DPMSolverMultistepScheduler(), DPMSolverMultistepSchedulerRef()
+    a.set_timesteps(K)
+    b.set_timesteps(K)
+    assert a.timesteps.tolist() == b.timesteps.tolist()
+    assert torch.equal(a.sigmas, b.sigmas)
+    for i in range(K):
+        for lo in (0, 1):
+            if lo == 1 and i == 0:
+                continue
+            assert a.step_coefficients(i, lo) == b.step_coefficients(i, lo)
+    assert torch.equal(a.alphas_cumprod, b.alphas_cumprod)
+
+
+class _Toy(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.student_denoiser = nn.Linear(4, 4)
+        self.teacher_denoiser = nn.Linear(4, 4)
+        self.discriminator = nn.Sequential(nn.Linear(4, 1))
+        for p in self.teacher_denoiser.parameters():
+            p.requires_grad = False
+
+    def on_train_batch_end(self, b):
+        pass
+
+    def forward(self, batch, step=0, **kw):
+        s = self.student_denoiser(batch["x"])
+        t = self.teacher_denoiser(batch["x"]).detach()
+        lg = ((s - t) ** 2).mean() - self.discriminator(s).mean()
+        ld = self.discriminator(s.detach()).mean() - self.discriminator(t).mean()
+        return {"loss": [lg, 0] if step % 2 == 0 else [0, ld], "start_timestep": 1}
+
+
+def test_configure_optimizers_regex_selection_and_manual_loop():
+    m = _Toy()
+    pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-2, 1e-2],
+                                              trainable_params=[["student_denoiser"], ["discriminator."]]), overlap=False)
+    opts = pipe.configure_optimizers()
+    assert not pipe.automatic_optimization and len(opts) == 2
+    assert sum(p.numel() for p in opts[0].param_groups[0]["params"]) == 20
+    assert sum(p.numel() for p in opts[1].param_groups[0]["params"]) == 5
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    out = pipe.training_step({"x": torch.randn(8, 4)}, 0)
+    assert "loss_optimizer_0" in out and "loss_optimizer_1" in out
+    after = m.state_dict()
+    assert all(torch.equal(before[k], after[k]) for k in after if k.startswith("teacher"))
+    assert any(not torch.equal(before[k], after[k]) for k in after if k.startswith("student"))
+    assert any(not torch.equal(before[k], after[k]) for k in after if k.startswith("discriminator"))
+
+
+def _ddp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = _Toy()  # identical replicas
+    pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-2],
+                                              trainable_params=[["student_denoiser"]]), overlap=False)
+    pipe.configure_optimizers()
+    g = torch.Generator().manual_seed(100 + rank)  # each rank its own shard
+    pipe.training_step({"x": torch.randn(8, 4, generator=g)}, 0)
+    q.put((rank, {k: v.numpy().copy() for k, v in m.student_denoiser.state_dict().items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_all_reduce_gloo_world2():
+    """world_size-2 gloo run: replicas stay identical and equal a single process that averages both shards."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in range(2))
+    res = {r: {k: torch.from_numpy(v) for k, v in d.items()} for r, d in res.items()}
+    for p in procs:
+        p.join(60)
+    for k in res[0]:
+        assert torch.equal(res[0][k], res[1][k]), "replicas diverged"
+    # single-process reference: mean of the two shard gradients
+    torch.manual_seed(0)
+    m = _Toy()
+    opt = torch.optim.AdamW(m.student_denoiser.parameters(), lr=1e-2)
+    grads = []
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        opt.zero_grad()
+        m({"x": torch.randn(8, 4, generator=g)})["loss"][0].backward()
+        grads.append([p.grad.clone() for p in m.student_denoiser.parameters()])
+    for p, a, b in zip(m.student_denoiser.parameters(), *grads):
+        p.grad = (a + b) / 2
+    opt.step()
+    for k, v in m.student_denoiser.state_dict().items():
+        assert torch.allclose(v, res[0][k], atol=1e-6), k
