@@ -1,0 +1,180 @@
+#!/usr/bin/env python
+"""bench.py -- distillation images/s on MI355X for BASELINE.json's headline config (C2):
+SD1.5 UNet teacher + LoRA-r128 student, per-GPU batch 16, 64x64 latents, 4 teacher CFG steps, bf16 MFMA
+compute.  One "step" = one generator iteration of the reference: FlashDiffusion.forward
+(step=0) [1 student fwd (grad) + 2n teacher fwd] + backward of loss[0] + AdamW on the LoRA tensors
+(+ RCCL all-reduce of the flat LoRA gradient when N > 1).  Synthetic latents / text embeddings and
+random-init weights (no network); inputs are resident in HBM before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W
+N > 1 is launched by the driver with torch.distributed.run (one rank per GPU, RCCL).
+Prints ONE JSON line on rank 0."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_BF16 = 2.5e15  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF; 2:1 sparse figures excluded)
+BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<64,128,row>", "gemm_kernel<64,64,row>",
+           "gemm_kernel<128,128,conv>", "gemm_kernel<128,64,conv>", "gemm_kernel<64,128,conv>", "gemm_kernel<64,64,conv>",
+           "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel"]
+
+
+def cpu_baseline(n_teacher_steps):
+    """The oracle (CPU fp32 restatement of the reference step, oracle/flash_ref.py -- kind "port") timed on
+    this box's host cores on a bounded sample of the SAME workload: SD1.5, r128 LoRA, 64x64 latents, n teacher
+    steps, but B=1 and ONE generator iteration."""
+    import copy
+    import torch
+    from oracle.flash_ref import FlashConfigRef, FlashDiffusionRef, TensorConditioner
+    from oracle.sched_cpu import DPMSolverMultistepSchedulerRef
+    from oracle.unet_cpu import UNet2DConditionRef, sd15_config
+    B = 1
+    torch.manual_seed(0)
+    teacher = UNet2DConditionRef(sd15_config())
+    student = copy.deepcopy(teacher)
+    student.add_adapter(128)
+    teacher.freeze()
+    m = FlashDiffusionRef(FlashConfigRef(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform"),
+                          student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=DPMSolverMultistepSchedulerRef(), conditioner=TensorConditioner())
+    from oracle.flash_ref import Draws
+    batch = {"image": torch.randn(B, 4, 64, 64), "crossattn": torch.randn(B, 77, 768), "text": ["s"] * B}
+    m.draws = Draws({"noise": torch.randn(B, 4, 64, 64), "start_idx": torch.tensor([0]), "guidance": torch.tensor([0.5])})
+    opt = torch.optim.AdamW([p for p in student.parameters() if p.requires_grad], lr=1e-5)
+    t0 = time.perf_counter()
+    out = m(batch, step=0)
+    out["loss"][0].backward()
+    opt.step()
+    dt = time.perf_counter() - t0
+    return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 generator iteration (fwd+bwd+AdamW) of the same SD1.5 r128 step at B={B}, {n_teacher_steps} teacher "
+                      f"CFG steps, fp32 PyTorch-CPU oracle, {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
+    ap.add_argument("--hw", type=int, default=64, help="latent height = width")
+    ap.add_argument("--teacher-steps", type=int, default=4)
+    ap.add_argument("--arch", default="sd15", choices=["sd15", "tiny"])
+    ap.add_argument("--lora-rank", type=int, default=128)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from flash_diffusion_amd import _lib, unet as _unet
+    from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
+    from flash_diffusion_amd.workloads import SD15, TINY, build_flash, synthetic_batch
+    arch = SD15 if args.arch == "sd15" else TINY
+    rank_r = args.lora_rank if args.arch == "sd15" else 8
+    model = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0)
+    pipe = TrainingPipeline(model, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-5],
+                                                  trainable_params=[["student_denoiser"]]),
+                            overlap=not args.no_overlap)
+    pipe.configure_optimizers()
+    B = args.batch
+    batches = [synthetic_batch(B, args.hw, arch["cross_attention_dim"], seed=1234 + rank + 1000 * i) for i in range(4)]
+
+    def run(n, counter=None):
+        for i in range(n):
+            pipe.training_step(batches[i % len(batches)], i)
+            if counter is not None:
+                counter[0] += model.student_denoiser.step_flops + model.teacher_denoiser.step_flops
+                model.student_denoiser.step_flops = model.teacher_denoiser.step_flops = 0.0
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(args.warmup)
+    pipe.finish()
+    model.student_denoiser.step_flops = model.teacher_denoiser.step_flops = 0.0
+    flops = [0.0]
+    barrier()
+    t0 = time.perf_counter()
+    run(args.steps, flops)
+    pipe.finish()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    ms_per_step = dt / args.steps * 1e3
+    value = B * world * args.steps / dt
+    step_flops = flops[0] / args.steps
+
+    # ---- roofline leg: per-launch HIP events on the launch stream, one extra (untimed) step ----
+    roofline = None
+    if rank == 0:
+        L = _lib.lib()
+        L.fdmi_prof_enable(1)
+        run(1)
+        pipe.finish()
+        L.fdmi_prof_enable(0)
+        nb = 16
+        ms = (C.c_double * nb)()
+        fl = (C.c_double * nb)()
+        ln = (C.c_int64 * nb)()
+        _lib.check(L.fdmi_prof_collect(nb, ms, fl, ln))
+        rows = [(BUCKETS[i], ms[i], fl[i], ln[i]) for i in range(len(BUCKETS)) if ln[i] > 0]
+        rows.sort(key=lambda r: -r[1])
+        name, tms, tfl, tln = rows[0]
+        ach = tfl / (tms * 1e-3) / 1e12
+        gemm_ms = sum(r[1] for r in rows if r[0].startswith("gemm"))
+        gemm_fl = sum(r[2] for r in rows if r[0].startswith("gemm"))
+        roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                    "frac": ach / (PEAK_BF16 / 1e12), "traffic": None, "launches_per_step": int(tln),
+                    "avg_launch_us": tms * 1e3 / tln, "algorithmic_gflop_per_launch": tfl / tln / 1e9,
+                    "all_mfma_kernels": {r[0]: {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),
+                                                "launches": int(r[3])} for r in rows},
+                    "whole_step": {"algorithmic_tflop_per_step_per_gpu": step_flops / 1e12,
+                                   "achieved_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
+                                   "frac_of_peak": step_flops / (ms_per_step * 1e-3) / PEAK_BF16}}
+    if world > 1:
+        dist.barrier()
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.arch == "sd15":
+        cpu = cpu_baseline(args.teacher_steps)
+    if rank == 0:
+        line = {
+            "metric": "distillation images/sec/GPU (SD1.5 64x64 latent, bs=16); 1->8 GPU scaling",
+            "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"C2: Flash-{args.arch.upper()} UNet teacher + LoRA r{rank_r} student, {B} images/GPU, "
+                                   f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
+                                   "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
+                       "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,8 @@ class GemmDesc(C.Structure):
 
 _SIGS = {
     "fdmi_version": (i32, []),
+    "fdmi_prof_enable": (i32, [i32]),
+    "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "fdmi_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "fdmi_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),

@@ -568,7 +568,10 @@ int fwd_t(const AttnArgs& a, hipStream_t st) {
   static bool once = false;
   if (!once) { if (set_smem(attn_fwd_kernel<DK, DV, NF>, smem)) return -2; once = true; }
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
   hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
@@ -578,7 +581,10 @@ int dq_t(const AttnArgs& a, hipStream_t st) {
   static bool once = false;
   if (!once) { if (set_smem(attn_bwd_dq_kernel<DK, DV, NF>, smem)) return -2; once = true; }
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DQ, 6.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
   hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
@@ -588,7 +594,10 @@ int dkv_t(const AttnArgs& a, hipStream_t st) {
   static bool once = false;
   if (!once) { if (set_smem(attn_bwd_dkv_kernel<DK, DV, NF>, smem)) return -2; once = true; }
   dim3 grid(cdiv(a.Skv, 64 * NF), a.B * a.H);
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DKV, 8.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
   hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;
 }

@@ -5,7 +5,44 @@
 static thread_local std::string g_err;
 void fdmi_set_error(const std::string& msg) { g_err = msg; }
 
+// ---- per-launch event profiling -------------------------------------------------------------
+#include <vector>
+namespace {
+struct ProfRec { hipEvent_t a, b; double flops; int bucket; };
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
+std::vector<hipEvent_t> g_pool;
+hipEvent_t prof_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+}  // namespace
+bool fdmi_prof_on() { return g_prof; }
+void fdmi_prof_begin(hipStream_t st, int bucket, double flops) {
+  ProfRec r{prof_event(), prof_event(), flops, bucket};
+  (void)hipEventRecord(r.a, st);
+  g_recs.push_back(r);
+}
+void fdmi_prof_end(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); }
+
 extern "C" {
+
+int fdmi_prof_enable(int on) { g_prof = on != 0; return 0; }
+int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches) {
+  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= 11 buckets");
+  for (int i = 0; i < nbuckets; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  for (auto& r : g_recs) {
+    FDMI_HIP(hipEventSynchronize(r.b));
+    float t = 0;
+    FDMI_HIP(hipEventElapsedTime(&t, r.a, r.b));
+    ms[r.bucket] += t; flops[r.bucket] += r.flops; launches[r.bucket] += 1;
+    g_pool.push_back(r.a); g_pool.push_back(r.b);
+  }
+  g_recs.clear();
+  return 0;
+}
 
 const char* fdmi_last_error(void) { return g_err.c_str(); }
 int fdmi_version(void) { return 1; }

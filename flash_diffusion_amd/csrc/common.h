@@ -65,4 +65,10 @@ void fdmi_set_error(const std::string& msg);
     }                                                                                 \
   } while (0)
 
+// optional per-launch HIP-event profiling (bench.py roofline leg); see capi.hip
+enum { PROF_GEMM0 = 0 /* +mode*4 + tile */, PROF_ATTN_FWD = 8, PROF_ATTN_DQ = 9, PROF_ATTN_DKV = 10, PROF_NBUCKETS = 11 };
+bool fdmi_prof_on();
+void fdmi_prof_begin(hipStream_t st, int bucket, double flops);
+void fdmi_prof_end(hipStream_t st);
+
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

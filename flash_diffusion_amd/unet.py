@@ -224,6 +224,8 @@ class MiUNet2DConditionModel(nn.Module):
             leaf.register_parameter(parts[-1], nn.Parameter(v))
         self.lora_rank = 0
         self._lora_targets: List[str] = []
+        self.last_flops = 0.0
+        self.step_flops = 0.0   # running sum of algorithmic MFMA flops (bench.py resets it)
 
     # ---- plan management ---------------------------------------------------------------------------
     _PLANS: Dict[int, _Plan] = {}
@@ -473,6 +475,7 @@ class MiUNet2DConditionModel(nn.Module):
         check(L.fdmi_unet_forward(plan.handle, slot, ptr(sample), ptr(t), ptr(enc), ptr(vec), ptr(out), B, H, W, Lc,
                                   ptr(ws), ws.numel(), flags, stream_ptr()))
         self.last_flops = L.fdmi_unet_last_flops(plan.handle)
+        self.step_flops += self.last_flops
         return out, slot
 
     def _run_backward(self, slot, grad_out, needs_x, xshape):
@@ -487,6 +490,7 @@ class MiUNet2DConditionModel(nn.Module):
         finally:
             plan.busy.discard(slot)
         self.last_flops = L.fdmi_unet_last_flops(plan.handle)
+        self.step_flops += self.last_flops
         return gx
 
     def release_saved(self):

@@ -1,0 +1,45 @@
+"""Synthetic BASELINE.json workloads: random-init weights of the pinned
+architectures, synthetic latents / text embeddings, pinned teacher-step count."""
+from __future__ import annotations
+
+import copy
+
+import torch
+
+from .flash import FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+from .schedulers import DPMSolverMultistepScheduler
+from .unet import MiUNet2DConditionModel
+
+SD15 = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+            cross_attention_dim=768, attention_head_dim=8, transformer_layers_per_block=1)
+TINY = dict(in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64), layers_per_block=2,
+            cross_attention_dim=64, attention_head_dim=2, transformer_layers_per_block=1)
+
+
+def build_flash(arch=SD15, lora_rank=128, n_teacher_steps=4, device="cuda", seed=0, discriminator=None,
+                use_dmd_loss=False, gan_loss_type="lsgan", guidance=8.0):
+    """teacher (frozen) + student = copy + LoRA (peft init: A gaussian, B = 0), DPM-Solver++ trailing schedule
+    with K = n_teacher_steps and start index pinned to 0 (so every step runs exactly n teacher CFG steps)."""
+    torch.manual_seed(seed)
+    teacher = MiUNet2DConditionModel(**arch)
+    student = copy.deepcopy(teacher)
+    teacher = teacher.to(device)
+    teacher.freeze()
+    student = student.to(device)
+    student.add_adapter(lora_rank)
+    cfg = FlashDiffusionConfig(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform",
+                               distill_loss_type="l2", use_dmd_loss=use_dmd_loss, gan_loss_type=gan_loss_type,
+                               guidance_scale_min=3.0, guidance_scale_max=13.0, adversarial_loss_scale=0.1,
+                               dmd_loss_scale=0.3)
+    m = FlashDiffusion(cfg, student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                       discriminator=discriminator).to(device)
+    m.fixed_start_idx = 0
+    m.fixed_guidance = guidance
+    return m
+
+
+def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return {"image": torch.randn(B, 4, hw, hw, generator=g).to(device),
+            "crossattn": torch.randn(B, L, ctx_dim, generator=g).to(device), "text": ["synthetic"] * B}

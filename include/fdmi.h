@@ -29,6 +29,11 @@ extern "C" {
 
 const char* fdmi_last_error(void);
 int fdmi_version(void);
+/* Optional per-launch HIP-event timing of the MFMA kernels on the stream they are launched on
+ * (bench.py roofline leg).  Buckets 0-7: gemm_kernel<BM,BN,mode> = mode*4 + (BM==64)*2 + (BN==64);
+ * 8: attention fwd, 9: attention dQ, 10: attention dK/dV.  collect() synchronises, sums and resets. */
+int fdmi_prof_enable(int on);
+int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches);
 
 /* ---------------- GEMM / implicit-GEMM convolution (bf16 MFMA, fp32 accumulate) ----------------
  * out[M,N] = A[M,K] * W[N,K]^T ; epilogue v = alpha*acc + bias[n] + rowvec[m/rows_per_batch][n]

@@ -292,7 +292,10 @@ class FlashDiffusionRef(torch.nn.Module):
             l_dmd = self.dmd_loss(d, student_output, student_conditioning, conditioning, uncond, K_step)
             self.terms["dmd"] = l_dmd.detach()
             loss = loss + l_dmd * cfg.dmd_loss_scale[K_step]
-        gan = self.gan_loss(d, z, student_output, teacher_output, conditioning, step)   # FD:347
+        if self.discriminator is not None:
+            gan = self.gan_loss(d, z, student_output, teacher_output, conditioning, step)   # FD:347
+        else:
+            gan = [0, 0]   # the reference crashes here without a discriminator; used by bench.py's cpu_baseline
         self.terms["gan_G"] = gan[0].detach() if torch.is_tensor(gan[0]) else gan[0]
         self.terms["gan_D"] = gan[1].detach() if torch.is_tensor(gan[1]) else gan[1]
         loss = loss + cfg.adversarial_loss_scale[K_step] * gan[0]             # FD:357

@@ -93,7 +93,7 @@ def test_step_matches_reference_golden(name):
 
 def test_reference_invariants_forward_signs():
     """T-FD:146-153: step=0 -> loss[0] > 0, loss[1] == 0 ; step=1 -> both > 0."""
-    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="gaussian", gan_loss_type="hinge")
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="gaussian", gan_loss_type="lsgan")
     m = build_product(kw)
     g = torch.Generator().manual_seed(0)
     batch = {"image": torch.randn(2, 4, 32, 32, generator=g).cuda(), "crossattn": torch.randn(2, 77, 64, generator=g).cuda(),
