@@ -22,7 +22,8 @@ sys.path.insert(0, ROOT)
 PEAK_BF16 = 2.5e15  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF; 2:1 sparse figures excluded)
 BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<64,128,row>", "gemm_kernel<64,64,row>",
            "gemm_kernel<128,128,conv>", "gemm_kernel<128,64,conv>", "gemm_kernel<64,128,conv>", "gemm_kernel<64,64,conv>",
-           "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel"]
+           "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
+           "gemm3_kernel<256x160,row>", "gemm3_kernel<256x128,row>", "gemm3_kernel<256x160,conv>", "gemm3_kernel<256x128,conv>"]
 
 
 def cpu_baseline(n_teacher_steps):
@@ -144,9 +145,7 @@ def main():
         rows.sort(key=lambda r: -r[1])
         name, tms, tfl, tln = rows[0]
         ach = tfl / (tms * 1e-3) / 1e12
-        gemm_ms = sum(r[1] for r in rows if r[0].startswith("gemm"))
-        gemm_fl = sum(r[2] for r in rows if r[0].startswith("gemm"))
-        roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+                roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": ach / (PEAK_BF16 / 1e12), "traffic": None, "launches_per_step": int(tln),
                     "avg_launch_us": tms * 1e3 / tln, "algorithmic_gflop_per_launch": tfl / tln / 1e9,
                     "all_mfma_kernels": {r[0]: {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),

@@ -27,9 +27,18 @@ __device__ __forceinline__ float dsilu_f(float x) {
   float s = 1.f / (1.f + __expf(-x));
   return s * (1.f + x * (1.f - s));
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erff(x * 0.70710678118654752f)); }
+// erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, below bf16/fp32-epilogue resolution): one exp,
+// one rcp and five fmas instead of the ~40-instruction branchy libm erff in the GEGLU epilogues.
+__device__ __forceinline__ float erf_fast(float x) {
+  const float ax = fabsf(x);
+  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float r = 1.f - poly * __expf(-ax * ax);
+  return copysignf(r, x);
+}
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
 __device__ __forceinline__ float dgelu_f(float x) {
-  float cdf = 0.5f * (1.f + erff(x * 0.70710678118654752f));
+  float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752f));
   float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);
   return cdf + x * pdf;
 }
@@ -66,7 +75,8 @@ void fdmi_set_error(const std::string& msg);
   } while (0)
 
 // optional per-launch HIP-event profiling (bench.py roofline leg); see capi.hip
-enum { PROF_GEMM0 = 0 /* +mode*4 + tile */, PROF_ATTN_FWD = 8, PROF_ATTN_DQ = 9, PROF_ATTN_DKV = 10, PROF_NBUCKETS = 11 };
+enum { PROF_GEMM0 = 0 /* +mode*4 + tile */, PROF_ATTN_FWD = 8, PROF_ATTN_DQ = 9, PROF_ATTN_DKV = 10,
+       PROF_GEMM3 = 11 /* + mode*2 + (BN==128) */, PROF_NBUCKETS = 15 };
 bool fdmi_prof_on();
 void fdmi_prof_begin(hipStream_t st, int bucket, double flops);
 void fdmi_prof_end(hipStream_t st);

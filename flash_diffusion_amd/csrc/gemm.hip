@@ -15,6 +15,7 @@
 // * blockIdx -> tile mapping is XCD-aware (8 XCDs, private L2s): consecutive tiles (same A rows,
 //   successive N tiles) are placed on one XCD.
 #include "gemm.h"
+#include <math.h>
 
 static __device__ uint4 g_zero16[4] = {};
 
@@ -299,10 +300,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
   }
 
   // ---- epilogue: lane (g, j) owns rows m = ..+j, columns n = ..+4g..4g+3 of each fragment ----
-  if (a.splitk > 1 || a.accum_atomic) {
-    float* dst = a.accum_atomic ? (float*)a.C : a.ws;
-    const int64_t ld = a.accum_atomic ? a.ldc : (int64_t)a.N;
-    const float sc = a.accum_atomic ? a.alpha : 1.f;
+  if (a.accum_atomic) {
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -312,7 +310,28 @@ __global__ __launch_bounds__(256) void gemm_kernel(const GemmArgs a) {
         if (m < a.M) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (n + r < a.N) atomicAdd(dst + m * ld + n + r, acc[nf][mf][r] * sc);
+            if (n + r < a.N) atomicAdd((float*)a.C + m * a.ldc + n + r, acc[nf][mf][r] * a.alpha);
+        }
+      }
+    return;
+  }
+  if (a.splitk > 1) {  // raw partial sums -> this split's fp32 slab (plain stores, deterministic)
+    float* slab = a.ws + (int64_t)blockIdx.y * a.M * a.N;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = m0 + wm * (BM / 2) + mf * 16 + j;
+        const int n = n0 + wn * (BN / 2) + nf * 16 + g * 4;
+        if (m < a.M && n < a.N) {
+          float* d = slab + m * a.N + n;
+          if (n + 3 < a.N && (a.N & 3) == 0) {
+            *(float4*)d = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < a.N) d[r] = acc[nf][mf][r];
+          }
         }
       }
     return;
@@ -375,8 +394,12 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs a) {
       float val[4], gate[4], o[4];
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        val[r] = (n + r < a.N) ? a.ws[m * a.N + n + r] : 0.f;
-        gate[r] = (n + 16 + r < a.N) ? a.ws[m * a.N + n + 16 + r] : 0.f;
+        val[r] = gate[r] = 0.f;
+        for (int s = 0; s < a.splitk; ++s) {
+          const float* slab = a.ws + (int64_t)s * a.M * a.N + m * a.N;
+          if (n + r < a.N) val[r] += slab[n + r];
+          if (n + 16 + r < a.N) gate[r] += slab[n + 16 + r];
+        }
       }
       epi_terms(a, m, n, val);
       epi_terms(a, m, n + 16, gate);
@@ -388,9 +411,18 @@ __global__ __launch_bounds__(256) void gemm_finalize_kernel(const GemmArgs a) {
       for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
       epi_store(a, ACT_NONE, m, blk * 16 + off, a.N >> 1, o);
     } else {
-      float v[4];
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int s = 0; s < a.splitk; ++s) {
+        const float* slab = a.ws + (int64_t)s * a.M * a.N + m * a.N + n;
+        if (n + 3 < a.N && (a.N & 3) == 0) {
+          const float4 t = *(const float4*)slab;
+          v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] = (n + r < a.N) ? a.ws[m * a.N + n + r] : 0.f;
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) v[r] += slab[r];
+        }
+      }
       epi_terms(a, m, n, v);
       epi_store(a, a.act, m, n, a.N, v);
     }
@@ -426,6 +458,59 @@ static int launch_tile(const GemmArgs& a, int BM, int BN, hipStream_t stream) {
   FDMI_CHECK(false, "gemm: unsupported tile");
 }
 
+// ---- kernel / tile / split-K selection by a small cost model -------------------------------------
+// block rates calibrated on MI355X (scripts/kbench.py): the 256-row ring kernel sustains ~3.4 TFLOP/s
+// per CU (1 block/CU), the 128x128 kernel ~1.05 per block (2/CU), 128x64 ~0.6 (3/CU), 64-row ~0.45.
+static double est_us(double M, double N, double K, int BM, int BN, int slots, double rate_tf, int sk, bool atomic) {
+  const double tiles = (double)cdiv((int64_t)M, BM) * cdiv((int64_t)N, BN);
+  const double rounds = ceil(tiles * sk / slots);
+  const double kt = ceil(K / 64.0 / sk);
+  double t = rounds * (2.0 * BM * BN * 64.0 * kt / (rate_tf * 1e6) + 2.0 + 0.3 * 3);  // us; +fill/drain
+  if (sk > 1 && !atomic) t += sk * M * N * 8.0 / 3.0e6 + 3.0;  // slab write + read at ~3 TB/s, + finalize launch
+  return t;
+}
+
+GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
+  GemmPlan p;
+  const int ktiles = cdiv(a.K, 64);
+  if (a.force_tile) {
+    p.BM = a.force_tile >> 16;
+    p.BN = a.force_tile & 0xffff;
+    p.big = p.BM == 256;
+    p.splitk = a.splitk > 0 ? a.splitk : 1;
+    return p;
+  }
+  const bool can_split = ws_available && a.splitk <= 0;
+  const int forced_sk = a.splitk > 0 ? a.splitk : 0;
+  double best = 1e30;
+  auto consider = [&](int big, int BM, int BN, int slots, double rate) {
+    for (int sk = 1; sk <= 16; ++sk) {
+      if (forced_sk && sk != forced_sk) continue;
+      if (!forced_sk && sk > 1 && (!can_split || ktiles / sk < 6)) break;
+      const double t = est_us(a.M, a.N, a.K, BM, BN, slots, rate, sk, a.accum_atomic != 0);
+      if (t < best * 0.97) {
+        best = t;
+        p.big = big; p.BM = BM; p.BN = BN; p.splitk = sk;
+      }
+    }
+  };
+  if (gemm3_eligible(a)) consider(1, 256, gemm3_pick_bn(a), 256, 3.4);
+  const bool geglu = a.act == ACT_GEGLU;
+  consider(0, 128, 128, 512, 1.05);
+  consider(0, 128, 64, 768, 0.60);
+  consider(0, 64, 128, 768, 0.50);
+  if (a.N <= 64 || a.M <= 64) consider(0, 64, 64, 1280, 0.22);
+  (void)geglu;
+  return p;
+}
+
+size_t gemm_ws_bytes(const GemmArgs& a) {
+  GemmArgs b = a;
+  b.splitk = 0;
+  const GemmPlan p = plan_gemm(b, true);
+  return p.splitk > 1 ? (size_t)p.splitk * a.M * a.N * sizeof(float) : 0;
+}
+
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
   FDMI_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
@@ -441,38 +526,23 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   }
   if (a.act == ACT_GEGLU) FDMI_CHECK((a.N % 32) == 0, "geglu: N must be a multiple of 32");
   if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
-  int BM, BN;
-  if (a.force_tile) {
-    BM = a.force_tile >> 16;
-    BN = a.force_tile & 0xffff;
-  } else {
-    if (a.N <= 64) BN = 64;
-    else if ((a.N % 128) == 0) BN = 128;
-    else BN = ((double)cdiv(a.N, 128) * 128 / a.N <= 1.07) ? 128 : 64;
-    BM = 128;
-    if (a.M <= 64 || cdiv(a.M, 128) * cdiv(a.N, BN) < 192) BM = 64;
-  }
-  if (a.splitk <= 0) {  // auto: fill the chip when the tile grid is small and K is long
-    const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
-    int sk = 1;
-    if ((a.ws || a.accum_atomic) && tiles < 256) {
-      sk = 512 / tiles;
-      const int ktiles = cdiv(a.K, 64);
-      if (sk > ktiles / 4) sk = ktiles / 4;
-      if (sk > 32) sk = 32;
-      if (sk < 1) sk = 1;
-    }
-    a.splitk = sk;
+  const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic);
+  if (p.big) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
+  a.splitk = p.splitk;
+  {  // every split must own at least one K tile (slabs of empty splits would stay uninitialised)
+    const int kt = cdiv(a.K, 64);
+    while (a.splitk > 1 && (a.splitk - 1) * cdiv(kt, a.splitk) >= kt) --a.splitk;
   }
   if (a.splitk > 1 && !a.accum_atomic) {
-    FDMI_CHECK(a.ws != nullptr, "gemm: split-K needs a workspace");
-    FDMI_HIP(hipMemsetAsync(a.ws, 0, (size_t)a.M * a.N * sizeof(float), stream));
+    FDMI_CHECK(a.ws != nullptr, "gemm: split-K needs a workspace of splitk*M*N floats");
   }
   int rc;
-  if (a.mode == GEMM_ROW)
-    rc = a.use_glds ? launch_tile<GEMM_ROW, true>(a, BM, BN, stream) : launch_tile<GEMM_ROW, false>(a, BM, BN, stream);
+  if (p.big)
+    rc = launch_gemm3(a, p.BN, stream);
+  else if (a.mode == GEMM_ROW)
+    rc = a.use_glds ? launch_tile<GEMM_ROW, true>(a, p.BM, p.BN, stream) : launch_tile<GEMM_ROW, false>(a, p.BM, p.BN, stream);
   else
-    rc = a.use_glds ? launch_tile<GEMM_CONV, true>(a, BM, BN, stream) : launch_tile<GEMM_CONV, false>(a, BM, BN, stream);
+    rc = a.use_glds ? launch_tile<GEMM_CONV, true>(a, p.BM, p.BN, stream) : launch_tile<GEMM_CONV, false>(a, p.BM, p.BN, stream);
   if (rc) return rc;
   if (a.splitk > 1 && !a.accum_atomic) {
     const int64_t total = (int64_t)a.M * ((a.N + 3) >> 2);

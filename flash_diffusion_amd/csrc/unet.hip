@@ -438,6 +438,14 @@ struct Exec {
   }
   int gemm(GemmArgs& a) {
     flops += gemm_flops(a);
+    if (!a.accum_atomic && a.splitk == 1) {  // let the launcher split K when the tile grid under-fills the chip
+      const size_t wsb = gemm_ws_bytes(a);
+      if (wsb) {
+        a.ws = (float*)R.arena.alloc(wsb);
+        FDMI_CHECK(a.ws, "unet: workspace exhausted (split-K)");
+        a.splitk = 0;
+      }
+    }
     if (R.dry()) return 0;
     return launch_gemm(a, st);
   }

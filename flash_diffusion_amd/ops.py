@@ -74,6 +74,8 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
         out = torch.empty(M, Nout, dtype=torch.float32 if out_f32 else BF16, device=A.device)
     d.C, d.ldc, d.out_f32 = ptr(out), out.stride(0), int(out.dtype == torch.float32)
     d.alpha = alpha
+    if splitk != 1 and not accum_atomic and ws is None:  # fp32 slabs [splitk][M][N] (auto: up to 16)
+        ws = torch.empty((splitk if splitk > 1 else 16) * M * N, dtype=torch.float32, device=A.device)
     d.splitk, d.ws = splitk, ptr(ws)
     d.accum_atomic, d.force_tile, d.use_glds = int(accum_atomic), force_tile, int(use_glds)
     check(lib().fdmi_gemm(C.byref(d), stream_ptr()))

@@ -134,10 +134,9 @@ def test_gemm_splitk_and_atomic():
     A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
     bias = rnd(N, seed=3)
     ref = A.float() @ W.float().t()
-    ws = torch.empty(M, N, dtype=torch.float32, device="cuda")
-    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), splitk=4, ws=ws)
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), splitk=4)
     close("gemm_splitk", out, ref + bias)
-    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), splitk=0, ws=ws)
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), splitk=0)
     close("gemm_splitk_auto", out, ref + bias)
     acc = torch.ones(M, N, dtype=torch.float32, device="cuda")
     ops.gemm(A.cuda(), W.cuda(), out=acc, accum_atomic=True, splitk=8, alpha=2.0)
@@ -320,3 +319,78 @@ def test_adamw_matches_torch():
         opt.step()
         ops.adamw_(pd, (g * step).cuda(), m, v, 1e-3, step=step)
     close("adamw", pd, p.detach(), tol_el=1e-5, tol_fro=1e-5)
+
+
+# ---- 256-row tile kernel (gemm3: 3-stage LDS-DMA ring, counted vmcnt) ---------------------------------
+BIG = [(256 << 16) | 160, (256 << 16) | 128]
+
+
+@pytest.mark.parametrize("shape", [(1232, 320, 768), (4096, 320, 320), (512, 640, 2560), (300, 1280, 128), (256, 160, 64),
+                                   (2048, 200, 192)])
+@pytest.mark.parametrize("tile", BIG)
+def test_gemm3_row(shape, tile):
+    ops = _ops()
+    M, N, K = shape
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    res = b16(rnd(M, N, seed=5))
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=tile)
+    close(f"gemm3_row{shape}_{tile:x}", out, A.float() @ W.float().t() + bias + res.float())
+    if K >= 512:
+        out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), force_tile=tile, splitk=3)
+        close(f"gemm3_row_splitk{shape}_{tile:x}", out, A.float() @ W.float().t() + bias)
+
+
+def test_gemm3_geglu_and_auto_plan():
+    ops = _ops()
+    M, K, Fh = 520, 128, 256
+    A = b16(rnd(M, K, seed=1))
+    W = b16(rnd(2 * Fh, K, seed=2, scale=K ** -0.5))
+    bias = rnd(2 * Fh, seed=3)
+    perm = ops.geglu_perm(Fh)
+    h = A.float() @ W.float().t() + bias
+    ref = h[:, :Fh] * F.gelu(h[:, Fh:])
+    pre = torch.empty(M, 2 * Fh, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(A.cuda(), W[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), act=ops.ACT_GEGLU,
+                   preact=pre, force_tile=(256 << 16) | 128)
+    close("gemm3_geglu", out, ref)
+    close("gemm3_geglu_preact", pre, h[:, perm])
+    out = ops.gemm(A.cuda(), W[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), act=ops.ACT_GEGLU)
+    close("gemm_auto_geglu", out, ref)
+    acc = torch.zeros(M, 2 * Fh, dtype=torch.float32, device="cuda")
+    ops.gemm(A.cuda(), W.cuda(), out=acc, accum_atomic=True, splitk=2, force_tile=(256 << 16) | 128)
+    close("gemm3_atomic", acc, A.float() @ W.float().t(), tol_el=1e-4, tol_fro=1e-4)
+
+
+CONVS3 = [
+    (3, 8, 8, 320, 320, 3, 1, 1, 0), (2, 16, 16, 64, 640, 3, 1, 1, 0), (2, 16, 16, 128, 160, 3, 2, 1, 0),
+    (2, 8, 8, 64, 128, 3, 1, 1, 1), (2, 16, 16, 192, 128, 1, 1, 0, 0), (4, 8, 8, 128, 256, 4, 2, 1, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS3)
+@pytest.mark.parametrize("tile", BIG)
+def test_gemm3_conv_fwd_and_dgrad(cfg, tile):
+    ops = _ops()
+    B, H, W, Ci, Co, k, s, p, ups = cfg
+    x = b16(rnd(B, Ci, H, W, seed=1))
+    w = b16(rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5))
+    bias = rnd(Co, seed=3)
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    xin.requires_grad_()
+    ref = F.conv2d(xin, w.float(), bias, stride=s, padding=p)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    Mout = ref.shape[0] * ref.shape[2] * ref.shape[3]
+    if Mout >= 256:
+        y = ops.conv2d_nhwc(xn, ops.pack_conv_weight(w.float()).cuda(), KH=k, KW=k, stride=s, pad=p, ups=ups,
+                            bias=bias.cuda(), force_tile=tile)
+        close(f"conv3_fwd{cfg}_{tile:x}", y.permute(0, 3, 1, 2), ref)
+    if Co % 64 == 0 and Ci >= 128 and B * (H << ups) * (W << ups) >= 256:
+        dy = b16(rnd(*ref.shape, seed=4))
+        ref.backward(dy.float())
+        dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+        dx = ops.conv2d_nhwc(dyn, ops.pack_conv_weight_dgrad(w.float()).cuda(), KH=k, KW=k, stride=s, pad=p, dgrad=1,
+                             out_hw=(H << ups, W << ups), force_tile=tile)
+        close(f"conv3_dgrad{cfg}_{tile:x}", dx.permute(0, 3, 1, 2), xin.grad)
