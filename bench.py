@@ -145,7 +145,7 @@ def main():
         rows.sort(key=lambda r: -r[1])
         name, tms, tfl, tln = rows[0]
         ach = tfl / (tms * 1e-3) / 1e12
-                roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
+        roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": ach / (PEAK_BF16 / 1e12), "traffic": None, "launches_per_step": int(tln),
                     "avg_launch_us": tms * 1e3 / tln, "algorithmic_gflop_per_launch": tfl / tln / 1e9,
                     "all_mfma_kernels": {r[0]: {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),

@@ -33,6 +33,7 @@ class GemmDesc(C.Structure):
 
 _SIGS = {
     "fdmi_version": (i32, []),
+    "fdmi_tune_set": (i32, [i32, i32]),
     "fdmi_prof_enable": (i32, [i32]),
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),

@@ -11,6 +11,8 @@
 // i<4, 32s+16+4g+(i-4) otherwise; the A operand applies the same permutation when it reads X^T).
 // K/V tiles (64 keys) are staged through LDS with 16-B padded rows (conflict-free ds_read_b128),
 // prefetched into registers one tile ahead so the HBM latency hides under the MFMAs.
+#include <type_traits>
+
 #include "ops.h"
 
 namespace {
@@ -125,12 +127,16 @@ constexpr float NEG_BIG = -1.0e30f;
 // forward:  O = softmax(scale Q K^T) V ;  lse (log2 domain) optional
 // block = 4 waves, each wave QF query fragments (16 rows each)
 // =============================================================================================
+// raw v_exp_f32 (2^x); inputs here are <= 0 or the NEG_BIG sentinel, denormal results flush harmlessly
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+
 template <int DK, int DV, int QF>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sV = smem + RowTile<DK>::BYTES;
   constexpr int KS = DK / 32, DF = DV / 16;
+  constexpr int QP = QF >= 2 ? 2 : 1;  // query fragments processed together (bounds live registers)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
   const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
   const int hoff = h * a.d;
@@ -154,8 +160,74 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
     for (int df = 0; df < DF; ++df) acc_o[df][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+  // one KV tile for query fragments [f0, f0+QP); TAIL masks keys >= Skv (last tile only)
+  auto tile_pair = [&](auto tail_tag, int f0, int t) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    f32x4 s[4][QP];
+#pragma unroll
+    for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+      for (int f = 0; f < QP; ++f) s[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      bf16x8 kfr[4];
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf) kfr[kf] = row_frag<DK>(sK, kf, ks, g, j);
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int f = 0; f < QP; ++f) s[kf][f] = MFMA(kfr[kf], qf[f0 + f][ks], s[kf][f]);
+    }
+    bf16x8 pb[QP][2];
+#pragma unroll
+    for (int f = 0; f < QP; ++f) {
+      if (TAIL) {
+        const int kvbase = t * KVB + 4 * g;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kvbase + 16 * kf + r >= a.Skv) s[kf][f][r] = NEG_BIG;
+      }
+      float mx = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), fmaxf(s[0][f][2], s[0][f][3]));
+#pragma unroll
+      for (int kf = 1; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kf][f][r]);
+      mx = xor_max(mx);
+      const float mn = fmaxf(m[f0 + f], mx * sc);
+      const float alpha = fast_exp2(m[f0 + f] - mn);
+      m[f0 + f] = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = fast_exp2(fmaf(s[kf][f][r], sc, -mn));
+          s[kf][f][r] = p;
+          ps += p;
+        }
+      l[f0 + f] = l[f0 + f] * alpha + ps;
+#pragma unroll
+      for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc_o[df][f0 + f][r] *= alpha;
+      pb[f][0] = pack8(s[0][f], s[1][f]);
+      pb[f][1] = pack8(s[2][f], s[3][f]);
+    }
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int df = 0; df < DF; ++df) {
+        const bf16x8 vfr = tr_frag(sV, df, s2, g, j);
+#pragma unroll
+        for (int f = 0; f < QP; ++f) acc_o[df][f0 + f] = MFMA(vfr, pb[f][s2], acc_o[df][f0 + f]);
+      }
+  };
+
   uint4 rk[RowTile<DK>::NREG], rv[TrTile<DV>::NREG];
   const int nt = (a.Skv + KVB - 1) / KVB;
+  const bool ragged = (a.Skv % KVB) != 0;
   rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, 0, hoff, a.d, tid);
   tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, 0, tid);
   for (int t = 0; t < nt; ++t) {
@@ -167,68 +239,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnArgs a) {
       rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, (t + 1) * KVB, hoff, a.d, tid);
       tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, (t + 1) * KVB, tid);
     }
-    // ---- S^T = K Q^T ----
-    f32x4 s[4][QF];
+    if (ragged && t == nt - 1) {
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+      for (int f0 = 0; f0 < QF; f0 += QP) tile_pair(std::true_type{}, f0, t);
+    } else {
 #pragma unroll
-      for (int f = 0; f < QF; ++f) s[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 kfr[4];
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf) kfr[kf] = row_frag<DK>(sK, kf, ks, g, j);
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int f = 0; f < QF; ++f) s[kf][f] = MFMA(kfr[kf], qf[f][ks], s[kf][f]);
+      for (int f0 = 0; f0 < QF; f0 += QP) tile_pair(std::false_type{}, f0, t);
     }
-    // ---- online softmax (per query column j of each fragment) ----
-    const int kvbase = t * KVB + 4 * g;
-    const bool tail = (t + 1) * KVB > a.Skv;
-    bf16x8 pb[QF][2];
-#pragma unroll
-    for (int f = 0; f < QF; ++f) {
-      float mx = NEG_BIG;
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float v = s[kf][f][r] * sc;
-          if (tail && kvbase + 16 * kf + r >= a.Skv) v = NEG_BIG;
-          s[kf][f][r] = v;
-          mx = fmaxf(mx, v);
-        }
-      mx = xor_max(mx);
-      const float mn = fmaxf(m[f], mx);
-      const float alpha = exp2f(m[f] - mn);
-      m[f] = mn;
-      float ps = 0.f;
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[kf][f][r] - mn);
-          s[kf][f][r] = p;
-          ps += p;
-        }
-      l[f] = l[f] * alpha + ps;
-#pragma unroll
-      for (int df = 0; df < DF; ++df)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc_o[df][f][r] *= alpha;
-      pb[f][0] = pack8(s[0][f], s[1][f]);
-      pb[f][1] = pack8(s[2][f], s[3][f]);
-    }
-    // ---- O^T += V^T P^T ----
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-      for (int df = 0; df < DF; ++df) {
-        const bf16x8 vfr = tr_frag(sV, df, s2, g, j);
-#pragma unroll
-        for (int f = 0; f < QF; ++f) acc_o[df][f] = MFMA(vfr, pb[f][s2], acc_o[df][f]);
-      }
   }
   // ---- epilogue ----
 #pragma unroll
@@ -330,7 +347,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = exp2f(s[kf][f][r] * sc - lse[f]);
+          float p = fast_exp2(fmaf(s[kf][f][r], sc, -lse[f]));
           if (kvbase + 16 * kf + r >= a.Skv) p = 0.f;
           s[kf][f][r] = p * (dp[kf][f][r] - dl[f]) * a.scale;
         }
@@ -451,7 +468,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = exp2f(s[qf][f][r] * sc - lsv[r]);
+          const float p = fast_exp2(fmaf(s[qf][f][r], sc, -lsv[r]));
           s[qf][f][r] = p;
           dp[qf][f][r] = p * (dp[qf][f][r] - dlv[r]) * a.scale;
         }
@@ -606,11 +623,13 @@ int dkv_t(const AttnArgs& a, hipStream_t st) {
 
 // head-dim dispatch: (d -> DK = ceil32, DV = ceil16)
 #define ATTN_DISPATCH(FN, NF_SMALL, NF_BIG)                                        \
+  ATTN_DISPATCH4(FN, NF_SMALL, NF_SMALL, NF_BIG)
+#define ATTN_DISPATCH4(FN, NF_TINY, NF_SMALL, NF_BIG)                              \
   const int DKp = (a.d + 31) & ~31, DVp = attn_dvpad(a.d);                          \
-  if (DKp == 32 && DVp == 16) return FN<32, 16, NF_SMALL>(a, st);                  \
-  if (DKp == 32 && DVp == 32) return FN<32, 32, NF_SMALL>(a, st);                  \
-  if (DKp == 64 && DVp == 48) return FN<64, 48, NF_SMALL>(a, st);                  \
-  if (DKp == 64 && DVp == 64) return FN<64, 64, NF_SMALL>(a, st);                  \
+  if (DKp == 32 && DVp == 16) return FN<32, 16, NF_TINY>(a, st);                   \
+  if (DKp == 32 && DVp == 32) return FN<32, 32, NF_TINY>(a, st);                   \
+  if (DKp == 64 && DVp == 48) return FN<64, 48, NF_TINY>(a, st);                   \
+  if (DKp == 64 && DVp == 64) return FN<64, 64, NF_TINY>(a, st);                   \
   if (DKp == 96 && DVp == 80) return FN<96, 80, NF_SMALL>(a, st);                  \
   if (DKp == 96 && DVp == 96) return FN<96, 96, NF_SMALL>(a, st);                  \
   if (DKp == 128 && DVp == 128) return FN<128, 128, NF_BIG>(a, st);                \
@@ -626,6 +645,7 @@ static int check_attn(const AttnArgs& a) {
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
+  if (a.Sq >= 1024 && fdmi_tune_get(0) == 4) { ATTN_DISPATCH4(fwd_t, 4, 2, 1) }
   ATTN_DISPATCH(fwd_t, 2, 1)
 }
 int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st) {

@@ -13,14 +13,14 @@ typedef __attribute__((ext_vector_type(8))) unsigned short u16x8;
 #define FDMI_WAVE 64
 
 __device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
-__device__ __forceinline__ bf16_t f2bf(float f) {  // round-to-nearest-even, NaN-preserving
-  uint32_t u = __float_as_uint(f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
-}
+// fp32 -> bf16 (round-to-nearest-even) through the native __bf16 type: lowers to the gfx950
+// v_cvt_pk_bf16_f32 instruction (one VALU op per PAIR instead of ~6 integer ops per element).
+typedef float fdmi_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 fdmi_b2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(unsigned short, (__bf16)f); }
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
-  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+  const fdmi_f2 v = {lo, hi};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fdmi_b2));
 }
 __device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
@@ -77,6 +77,7 @@ void fdmi_set_error(const std::string& msg);
 // optional per-launch HIP-event profiling (bench.py roofline leg); see capi.hip
 enum { PROF_GEMM0 = 0 /* +mode*4 + tile */, PROF_ATTN_FWD = 8, PROF_ATTN_DQ = 9, PROF_ATTN_DKV = 10,
        PROF_GEMM3 = 11 /* + mode*2 + (BN==128) */, PROF_NBUCKETS = 15 };
+int fdmi_tune_get(int key);   // developer tuning knobs (fdmi_tune_set)
 bool fdmi_prof_on();
 void fdmi_prof_begin(hipStream_t st, int bucket, double flops);
 void fdmi_prof_end(hipStream_t st);

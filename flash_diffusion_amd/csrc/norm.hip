@@ -91,45 +91,76 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_b
   if (tid < a.G * 2) atomicAdd(dst + (int64_t)b * a.G * 2 + tid, sred[tid >> 1][tid & 1]);
 }
 
+// apply pass: thread t owns channel chunk t % CPR for rows t / CPR, +R, +2R, ... of its row block, so
+// the per-channel affine coefficients (mean/rstd/gamma/beta -> a, b) are derived ONCE per thread and
+// the row loop is a 16-byte load, 8 fmas (+SiLU) and a 16-byte store.
 template <bool BWD>
-__global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a) {
+__global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a, int rows_per_block) {
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
   const int CPR = a.C >> 3, cpg = a.C / a.G;
-  const int64_t total = (int64_t)a.B * a.HW * CPR;
+  const int R = CPR <= 256 ? 256 / CPR : 1;
+  const int nslot = (CPR + 255) >> 8;
+  const int row0 = blockIdx.x * rows_per_block;
+  const int row1 = min(a.HW, row0 + rows_per_block);
   const float inv_n = 1.f / ((float)a.HW * cpg);
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
-    const int64_t row = i / CPR;
-    const int c0 = (int)(i - row * CPR) * 8;
-    const int b = (int)(row / a.HW);
-    const u16x8 xv = *(const u16x8*)(a.x + row * a.C + c0);
-    u16x8 dv, ov, prev;
-    if (BWD) {
-      dv = *(const u16x8*)(a.dy + row * a.C + c0);
-      if (a.accumulate) prev = *(const u16x8*)(a.y + row * a.C + c0);
+  for (int s = 0; s < nslot; ++s) {
+    int chunk, roff;
+    if (CPR <= 256) {
+      chunk = tid % CPR;
+      roff = tid / CPR;
+      if (roff >= R) continue;
+    } else {
+      chunk = tid + 256 * s;
+      roff = 0;
+      if (chunk >= CPR) continue;
     }
+    const int c0 = chunk * 8;
+    float ca[8], cb[8], gm[8], bt[8], m1[8], m2[8], mean[8], rstd[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const int gi = (c0 + e) / cpg;
       const float sm = a.stats[((int64_t)b * a.G + gi) * 2 + 0] * inv_n;
       const float sq = a.stats[((int64_t)b * a.G + gi) * 2 + 1] * inv_n;
-      const float rstd = rsqrtf(fmaxf(sq - sm * sm, 0.f) + a.eps);
-      const float xh = (bf2f(xv[e]) - sm) * rstd;
-      const float gm = a.gamma[c0 + e], bt = a.beta[c0 + e];
-      if (!BWD) {
-        float z = gm * xh + bt;
-        if (a.silu) z = silu_f(z);
-        ov[e] = f2bf(z);
-      } else {
-        float dz = bf2f(dv[e]);
-        if (a.silu) dz *= dsilu_f(gm * xh + bt);
-        const float dxh = dz * gm;
-        const float m1 = a.bstats[((int64_t)b * a.G + gi) * 2 + 0] * inv_n;
-        const float m2 = a.bstats[((int64_t)b * a.G + gi) * 2 + 1] * inv_n;
-        float dx = rstd * (dxh - m1 - xh * m2);
-        if (a.accumulate) dx += bf2f(prev[e]);
-        ov[e] = f2bf(dx);
+      mean[e] = sm;
+      rstd[e] = rsqrtf(fmaxf(sq - sm * sm, 0.f) + a.eps);
+      gm[e] = a.gamma[c0 + e];
+      bt[e] = a.beta[c0 + e];
+      ca[e] = rstd[e] * gm[e];            // z = ca * x + cb
+      cb[e] = bt[e] - sm * ca[e];
+      if (BWD) {
+        m1[e] = a.bstats[((int64_t)b * a.G + gi) * 2 + 0] * inv_n;
+        m2[e] = a.bstats[((int64_t)b * a.G + gi) * 2 + 1] * inv_n;
       }
     }
-    *(u16x8*)(a.y + row * a.C + c0) = ov;
+    for (int r = row0 + roff; r < row1; r += R) {
+      const int64_t off = ((int64_t)b * a.HW + r) * a.C + c0;
+      const u16x8 xv = *(const u16x8*)(a.x + off);
+      u16x8 ov;
+      if (!BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float z = fmaf(ca[e], bf2f(xv[e]), cb[e]);
+          if (a.silu) z = silu_f(z);
+          ov[e] = f2bf(z);
+        }
+      } else {
+        const u16x8 dv = *(const u16x8*)(a.dy + off);
+        u16x8 prev;
+        if (a.accumulate) prev = *(const u16x8*)(a.y + off);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float xh = (bf2f(xv[e]) - mean[e]) * rstd[e];
+          float dz = bf2f(dv[e]);
+          if (a.silu) dz *= dsilu_f(fmaf(gm[e], xh, bt[e]));
+          const float dxh = dz * gm[e];
+          float dx = rstd[e] * (dxh - m1[e] - xh * m2[e]);
+          if (a.accumulate) dx += bf2f(prev[e]);
+          ov[e] = f2bf(dx);
+        }
+      }
+      *(u16x8*)(a.y + off) = ov;
+    }
   }
 }
 
@@ -149,10 +180,7 @@ int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
   FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
   hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
-  const int64_t total = (int64_t)B * HW * (C / 8);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
@@ -165,10 +193,7 @@ int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, 
   FDMI_HIP(hipMemsetAsync(bstats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
   hipLaunchKernelGGL(gn_reduce_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
-  const int64_t total = (int64_t)B * HW * (C / 8);
-  int blocks = (int)((total + 255) / 256);
-  if (blocks > 8192) blocks = 8192;
-  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(blocks), dim3(256), 0, st, a);
+  hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
@@ -185,20 +210,32 @@ struct LnArgs {
   bf16_t* y; int64_t rows; int C; float eps; int accumulate;
 };
 
-template <bool BWD>
+// LPR lanes cooperate on one row (LPR = 8..64, a power of two chosen so each lane holds <= 5 chunks of
+// 8 channels); a wavefront therefore streams 64/LPR rows at once with ~5 KB of loads in flight.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <bool BWD, int LPR>
 __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= a.rows) return;
+  constexpr int RPW = 64 / LPR;  // rows per wavefront
+  constexpr int MAXC = 5;
+  const int lane = threadIdx.x & 63, sub = lane % LPR;
+  const int64_t row = ((int64_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+  const bool live = row < a.rows;
+  const int64_t rrow = live ? row : 0;
   const int CPR = a.C >> 3;
-  constexpr int MAXC = 4;
+  const float invC = 1.f / a.C;
   float xv[MAXC][8];
   float sum = 0.f;
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) {
-    const int ch = lane + 64 * s;
+    const int ch = sub + LPR * s;
     if (ch < CPR) {
-      const u16x8 v = *(const u16x8*)(a.x + row * a.C + ch * 8);
+      const u16x8 v = *(const u16x8*)(a.x + rrow * a.C + ch * 8);
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         xv[s][e] = bf2f(v[e]);
@@ -206,11 +243,11 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
       }
     }
   }
-  const float mean = wave_sum(sum) / a.C;
+  const float mean = group_sum<LPR>(sum) * invC;
   float sq = 0.f;
 #pragma unroll
   for (int s = 0; s < MAXC; ++s) {
-    const int ch = lane + 64 * s;
+    const int ch = sub + LPR * s;
     if (ch < CPR) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -219,23 +256,30 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
       }
     }
   }
-  const float rstd = rsqrtf(wave_sum(sq) / a.C + a.eps);
-  const int64_t mrow = a.scale ? (row / a.rows_per_batch) * a.mod_ld : 0;
+  const float rstd = rsqrtf(group_sum<LPR>(sq) * invC + a.eps);
+  const int64_t mrow = a.scale ? (rrow / a.rows_per_batch) * a.mod_ld : 0;
   if (!BWD) {
 #pragma unroll
     for (int s = 0; s < MAXC; ++s) {
-      const int ch = lane + 64 * s;
-      if (ch < CPR) {
+      const int ch = sub + LPR * s;
+      if (ch < CPR && live) {
         u16x8 o;
+        const int c0 = ch * 8;
+        float gmv[8], btv[8];
+        if (a.gamma) {
+          const float4 g0 = *(const float4*)(a.gamma + c0), g1 = *(const float4*)(a.gamma + c0 + 4);
+          const float4 b0 = *(const float4*)(a.beta + c0), b1 = *(const float4*)(a.beta + c0 + 4);
+          gmv[0] = g0.x; gmv[1] = g0.y; gmv[2] = g0.z; gmv[3] = g0.w; gmv[4] = g1.x; gmv[5] = g1.y; gmv[6] = g1.z; gmv[7] = g1.w;
+          btv[0] = b0.x; btv[1] = b0.y; btv[2] = b0.z; btv[3] = b0.w; btv[4] = b1.x; btv[5] = b1.y; btv[6] = b1.z; btv[7] = b1.w;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int c = ch * 8 + e;
           float v = (xv[s][e] - mean) * rstd;
-          if (a.gamma) v = v * a.gamma[c] + a.beta[c];
-          if (a.scale) v = v * (1.f + bf2f(a.scale[mrow + c])) + bf2f(a.shift[mrow + c]);
+          if (a.gamma) v = fmaf(v, gmv[e], btv[e]);
+          if (a.scale) v = fmaf(v, 1.f + bf2f(a.scale[mrow + c0 + e]), bf2f(a.shift[mrow + c0 + e]));
           o[e] = f2bf(v);
         }
-        *(u16x8*)(a.y + row * a.C + ch * 8) = o;
+        *(u16x8*)(a.y + row * a.C + c0) = o;
       }
     }
   } else {
@@ -243,13 +287,18 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int s = 0; s < MAXC; ++s) {
-      const int ch = lane + 64 * s;
+      const int ch = sub + LPR * s;
       if (ch < CPR) {
-        const u16x8 d = *(const u16x8*)(a.dy + row * a.C + ch * 8);
+        const u16x8 d = *(const u16x8*)(a.dy + rrow * a.C + ch * 8);
+        float gmv[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+        if (a.gamma) {
+          const float4 g0 = *(const float4*)(a.gamma + ch * 8), g1 = *(const float4*)(a.gamma + ch * 8 + 4);
+          gmv[0] = g0.x; gmv[1] = g0.y; gmv[2] = g0.z; gmv[3] = g0.w; gmv[4] = g1.x; gmv[5] = g1.y; gmv[6] = g1.z; gmv[7] = g1.w;
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const int c = ch * 8 + e;
-          float gmul = a.gamma ? a.gamma[c] : 1.f;
+          float gmul = gmv[e];
           if (a.scale) gmul *= (1.f + bf2f(a.scale[mrow + c]));
           dxh[s][e] = bf2f(d[e]) * gmul;
           const float xh = (xv[s][e] - mean) * rstd;
@@ -258,11 +307,11 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
         }
       }
     }
-    const float m1 = wave_sum(s1) / a.C, m2 = wave_sum(s2) / a.C;
+    const float m1 = group_sum<LPR>(s1) * invC, m2 = group_sum<LPR>(s2) * invC;
 #pragma unroll
     for (int s = 0; s < MAXC; ++s) {
-      const int ch = lane + 64 * s;
-      if (ch < CPR) {
+      const int ch = sub + LPR * s;
+      if (ch < CPR && live) {
         u16x8 o, prev;
         if (a.accumulate) prev = *(const u16x8*)(a.y + row * a.C + ch * 8);
 #pragma unroll
@@ -278,22 +327,35 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
   }
 }
 
+template <bool BWD>
+static int launch_ln(const LnArgs& a, hipStream_t st) {
+  const int CPR = a.C >> 3;
+  int lpr = 8;
+  while (lpr < 64 && lpr * 5 < CPR) lpr <<= 1;
+  const int rpw = 64 / lpr;
+  const unsigned blocks = (unsigned)((a.rows + 4 * rpw - 1) / (4 * rpw));
+  switch (lpr) {
+    case 8: hipLaunchKernelGGL((ln_kernel<BWD, 8>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 16: hipLaunchKernelGGL((ln_kernel<BWD, 16>), dim3(blocks), dim3(256), 0, st, a); break;
+    case 32: hipLaunchKernelGGL((ln_kernel<BWD, 32>), dim3(blocks), dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL((ln_kernel<BWD, 64>), dim3(blocks), dim3(256), 0, st, a); break;
+  }
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, const bf16_t* shift,
                          const bf16_t* scale, int64_t mod_ld, int rows_per_batch, bf16_t* y,
                          int64_t rows, int C, float eps, hipStream_t st) {
-  FDMI_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
+  FDMI_CHECK(C % 8 == 0 && C <= 2560, "layernorm: C must be a multiple of 8 and <= 2560");
   LnArgs a{x, nullptr, gamma, beta, shift, scale, mod_ld, rows_per_batch, y, rows, C, eps, 0};
-  hipLaunchKernelGGL(ln_kernel<false>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
-  FDMI_HIP(hipGetLastError());
-  return 0;
+  return launch_ln<false>(a, st);
 }
 
 int launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const bf16_t* scale,
                          int64_t mod_ld, int rows_per_batch, bf16_t* dx, int64_t rows, int C,
                          float eps, int accumulate, hipStream_t st) {
-  FDMI_CHECK(C % 8 == 0 && C <= 2048, "layernorm: C must be a multiple of 8 and <= 2048");
+  FDMI_CHECK(C % 8 == 0 && C <= 2560, "layernorm: C must be a multiple of 8 and <= 2560");
   LnArgs a{x, dy, gamma, nullptr, nullptr, scale, mod_ld, rows_per_batch, dx, rows, C, eps, accumulate};
-  hipLaunchKernelGGL(ln_kernel<true>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, a);
-  FDMI_HIP(hipGetLastError());
-  return 0;
+  return launch_ln<true>(a, st);
 }

@@ -60,6 +60,15 @@ def run_gemm(reps, **kw):
 
 
 def run_attn(reps):
+    from flash_diffusion_amd._lib import lib
+    for qf in (0, 4):
+        lib().fdmi_tune_set(0, qf)
+        print("fwd QF knob", qf)
+        _run_attn(reps)
+    lib().fdmi_tune_set(0, 0)
+
+
+def _run_attn(reps):
     B = 16
     for (S, Skv, H, d) in [(4096, 4096, 8, 40), (4096, 77, 8, 40), (1024, 1024, 8, 80), (256, 256, 8, 160), (64, 64, 8, 160)]:
         q = torch.randn(B, S, H * d, device="cuda").to(BF)
