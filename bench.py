@@ -66,7 +66,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
     ap.add_argument("--hw", type=int, default=64, help="latent height = width")
     ap.add_argument("--teacher-steps", type=int, default=4)
-    ap.add_argument("--arch", default="sd15", choices=["sd15", "tiny"])
+    ap.add_argument("--arch", default="sd15", choices=["sd15", "sdxl", "tiny"])
     ap.add_argument("--lora-rank", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
@@ -86,16 +86,17 @@ def main():
 
     from flash_diffusion_amd import _lib, unet as _unet
     from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
-    from flash_diffusion_amd.workloads import SD15, TINY, build_flash, synthetic_batch
-    arch = SD15 if args.arch == "sd15" else TINY
-    rank_r = args.lora_rank if args.arch == "sd15" else 8
+    from flash_diffusion_amd.workloads import SD15, SDXL, TINY, build_flash, synthetic_batch
+    arch = {"sd15": SD15, "sdxl": SDXL, "tiny": TINY}[args.arch]
+    rank_r = args.lora_rank if args.arch != "tiny" else 8
     model = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0)
     pipe = TrainingPipeline(model, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-5],
                                                   trainable_params=[["student_denoiser"]]),
                             overlap=not args.no_overlap)
     pipe.configure_optimizers()
     B = args.batch
-    batches = [synthetic_batch(B, args.hw, arch["cross_attention_dim"], seed=1234 + rank + 1000 * i) for i in range(4)]
+    batches = [synthetic_batch(B, args.hw, arch["cross_attention_dim"], seed=1234 + rank + 1000 * i,
+                               vector_dim=arch.get("projection_class_embeddings_input_dim", 0) or 0) for i in range(4)]
 
     def run(n, counter=None):
         for i in range(n):
@@ -164,7 +165,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"C2: Flash-{args.arch.upper()} UNet teacher + LoRA r{rank_r} student, {B} images/GPU, "
+            "config": {"workload": f"{'C2' if args.arch == 'sd15' else ('C3-single-GPU' if args.arch == 'sdxl' else 'dev')}: Flash-{args.arch.upper()} UNet teacher + LoRA r{rank_r} student, {B} images/GPU, "
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world},

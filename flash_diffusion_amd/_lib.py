@@ -31,7 +31,25 @@ class GemmDesc(C.Structure):
     ]
 
 
+class UNetCfg(C.Structure):
+    _fields_ = [("in_channels", i32), ("out_channels", i32), ("n_levels", i32), ("block_out", i32 * 4),
+                ("down_attn", i32 * 4), ("up_attn", i32 * 4), ("layers_per_block", i32), ("tlayers", i32 * 4),
+                ("heads", i32 * 4), ("cross_dim", i32), ("groups", i32), ("eps", f32), ("class_embed_dim", i32),
+                ("flip_sin_to_cos", i32), ("freq_shift", f32)]
+
+
 _SIGS = {
+    "fdmi_unet_create": (vp, [C.POINTER(UNetCfg)]),
+    "fdmi_unet_destroy": (None, [vp]),
+    "fdmi_unet_num_params": (i64, [vp]),
+    "fdmi_unet_param_name": (i32, [vp, i64, C.c_char_p, i64, C.POINTER(i64)]),
+    "fdmi_unet_set_param": (i32, [vp, C.c_char_p, vp, i64, vp]),
+    "fdmi_unet_set_lora": (i32, [vp, C.c_char_p, vp, vp, vp, vp, i32]),
+    "fdmi_unet_ready": (i32, [vp]),
+    "fdmi_unet_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32]),
+    "fdmi_unet_forward": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, i32, vp]),
+    "fdmi_unet_backward": (i32, [vp, i32, vp, vp, vp]),
+    "fdmi_unet_last_flops": (C.c_double, [vp]),
     "fdmi_version": (i32, []),
     "fdmi_tune_set": (i32, [i32, i32]),
     "fdmi_prof_enable": (i32, [i32]),
@@ -56,6 +74,16 @@ _SIGS = {
     "fdmi_adamw": (i32, [vp, vp, vp, vp, i64, f32, f32, f32, f32, f32, i32, f32, vp]),
     "fdmi_add_noise": (i32, [vp, vp, vp, vp, vp, i32, i64, vp]),
     "fdmi_axpby4": (i32, [vp, f32, vp, f32, vp, f32, vp, f32, vp, i64, vp]),
+    "fdmi_im2col": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "fdmi_silu": (i32, [vp, vp, i64, vp]),
+    "fdmi_silu_bwd": (i32, [vp, vp, vp, i64, vp]),
+    "fdmi_colsum": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, vp]),
+    "fdmi_transpose2d_pad": (i32, [vp, i64, vp, i64, i64, i32, i64, vp]),
+    "fdmi_pad_cols": (i32, [vp, i32, vp, i32, i64, vp]),
+    "fdmi_f32_to_bf16": (i32, [vp, vp, i64, vp]),
+    "fdmi_distill_loss": (i32, [vp, vp, i64, i32, vp, vp]),
+    "fdmi_distill_grad": (i32, [vp, vp, i64, i32, f32, vp, vp]),
+    "fdmi_dmd_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
 }
 # extended lazily by unet.py for the plan API
 EXTRA_SIGS = {}

@@ -179,4 +179,40 @@ int fdmi_axpby4(const float* x0, float c0, const float* x1, float c1, const floa
   return launch_axpby4(x0, c0, x1, c1, x2, c2, x3, c3, out, n, (hipStream_t)stream);
 }
 
+int fdmi_im2col(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                void* stream) {
+  return launch_im2col((const bf16_t*)x, (bf16_t*)out, B, H, W, C, Ho, Wo, KH, KW, stride, pad, (hipStream_t)stream);
+}
+int fdmi_silu(const void* x, void* y, int64_t n, void* stream) {
+  return launch_silu((const bf16_t*)x, (bf16_t*)y, n, (hipStream_t)stream);
+}
+int fdmi_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  return launch_silu_bwd((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, (hipStream_t)stream);
+}
+int fdmi_colsum(const void* dy, const void* x, const float* stats, float* out0, float* out1, int64_t rows, int C, int HW,
+                int G, float eps, void* stream) {
+  return launch_colsum((const bf16_t*)dy, (const bf16_t*)x, stats, out0, out1, rows, C, HW, G, eps, (hipStream_t)stream);
+}
+int fdmi_transpose2d_pad(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int64_t rows_pad,
+                         void* stream) {
+  return launch_transpose2d_pad((const bf16_t*)in, ldi, (bf16_t*)out, ldo, rows, cols, rows_pad, (hipStream_t)stream);
+}
+int fdmi_pad_cols(const void* src, int cols, void* dst, int cols_pad, int64_t rows, void* stream) {
+  return launch_pad_cols((const bf16_t*)src, cols, (bf16_t*)dst, cols_pad, rows, (hipStream_t)stream);
+}
+int fdmi_f32_to_bf16(const float* x, void* y, int64_t n, void* stream) {
+  return launch_f32_to_bf16(x, (bf16_t*)y, n, (hipStream_t)stream);
+}
+int fdmi_distill_loss(const float* s, const float* t, int64_t n, int l1, float* out, void* stream) {
+  return launch_distill_loss(s, t, n, l1, out, (hipStream_t)stream);
+}
+int fdmi_distill_grad(const float* s, const float* t, int64_t n, int l1, float gscale, float* ds, void* stream) {
+  return launch_distill_grad(s, t, n, l1, gscale, ds, (hipStream_t)stream);
+}
+int fdmi_dmd_loss(const float* s, const float* noisy, const float* real, const float* fake, const float* inv_alpha,
+                  const float* msig_alpha, const float* kb, float* w, float* grad, float* loss, int B, int64_t per,
+                  void* stream) {
+  return launch_dmd_loss(s, noisy, real, fake, inv_alpha, msig_alpha, kb, w, grad, loss, B, per, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -314,3 +314,145 @@ int launch_axpby4(const float* x0, float c0, const float* x1, float c1, const fl
                   const float* x3, float c3, float* out, int64_t n, hipStream_t st) {
   LAUNCH(axpby4_kernel, n, x0, c0, x1, c1, x2, c2, x3, c3, out, n)
 }
+
+// =============================================================================================
+// discriminator support (a15: examples/train_flash_sd.py:225-240) and fused loss kernels (a12, a13)
+// =============================================================================================
+// explicit im2col (only for the discriminator's weight gradient; the forward / dgrad paths gather implicitly)
+__global__ __launch_bounds__(256) void im2col_kernel(const bf16_t* x, bf16_t* out, int B, int H, int W, int C,
+                                                     int Ho, int Wo, int KH, int KW, int stride, int pad) {
+  const int cpr = C >> 3;
+  const int64_t K8 = (int64_t)KH * KW * cpr;
+  const int64_t total = (int64_t)B * Ho * Wo * K8;
+  GRID_STRIDE(i, total) {
+    const int64_t m = i / K8;
+    int r = (int)(i - m * K8);
+    const int c = (r % cpr) * 8;
+    r /= cpr;
+    const int kx = r % KW, ky = r / KW;
+    const int ox = (int)(m % Wo), oy = (int)((m / Wo) % Ho), b = (int)(m / ((int64_t)Wo * Ho));
+    const int iy = oy * stride - pad + ky, ix = ox * stride - pad + kx;
+    u16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (iy >= 0 && ix >= 0 && iy < H && ix < W) v = *(const u16x8*)(x + (((int64_t)b * H + iy) * W + ix) * C + c);
+    *(u16x8*)(out + m * (K8 * 8) + (int64_t)(ky * KW + kx) * C + c) = v;
+  }
+}
+__global__ __launch_bounds__(256) void silu_bwd_kernel(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t n) {
+  GRID_STRIDE(i, n) dx[i] = f2bf(bf2f(dy[i]) * dsilu_f(bf2f(x[i])));
+}
+// out0[c] += sum_r dy[r][c] ; out1[c] += sum_r dy[r][c] * xhat[r][c]   (xhat from GroupNorm stats when given)
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, const bf16_t* x, const float* stats, float* out0,
+                                                     float* out1, int64_t rows, int C, int HW, int G, float eps) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rlane = threadIdx.x >> 6;
+  float s0 = 0.f, s1 = 0.f;
+  if (c < C) {
+    const int cpg = stats ? C / G : 1;
+    for (int64_t r = (int64_t)blockIdx.y * 4 + rlane; r < rows; r += (int64_t)gridDim.y * 4) {
+      const float d = bf2f(dy[r * C + c]);
+      s0 += d;
+      if (out1) {
+        float xh = bf2f(x[r * C + c]);
+        if (stats) {
+          const int b = (int)(r / HW), gi = c / cpg;
+          const float inv_n = 1.f / ((float)HW * cpg);
+          const float sm = stats[((int64_t)b * G + gi) * 2] * inv_n, sq = stats[((int64_t)b * G + gi) * 2 + 1] * inv_n;
+          xh = (xh - sm) * rsqrtf(fmaxf(sq - sm * sm, 0.f) + eps);
+        }
+        s1 += d * xh;
+      }
+    }
+    atomicAdd(out0 + c, s0);
+    if (out1) atomicAdd(out1 + c, s1);
+  }
+}
+// distillation loss (FD:368-382): out += sum |s-t|^p / n  (p = 2: l2, p = 1: l1)
+__global__ __launch_bounds__(256) void distill_loss_kernel(const float* s, const float* t, int64_t n, int l1, float* out) {
+  float acc = 0.f;
+  GRID_STRIDE(i, n) {
+    const float d = s[i] - t[i];
+    acc += l1 ? fabsf(d) : d * d;
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, (part[0] + part[1] + part[2] + part[3]) / (float)n);
+}
+__global__ __launch_bounds__(256) void distill_grad_kernel(const float* s, const float* t, int64_t n, int l1, float gscale,
+                                                           float* ds) {
+  GRID_STRIDE(i, n) {
+    const float d = s[i] - t[i];
+    ds[i] = l1 ? gscale * (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) : 2.f * gscale * d;
+  }
+}
+// DMD (FD:459-499), one block per sample for the weight, then the element-wise gradient + loss:
+//   x0 = ia*noisy + ma*real ; w = 1/(mean|s - x0| + 1e-5) ; coeff = (real - fake)*kb
+//   loss = mean((w*coeff)^2) ; dL/ds = 2*w*coeff/N
+__global__ __launch_bounds__(256) void dmd_weight_kernel(const float* s, const float* noisy, const float* real, const float* ia,
+                                                         const float* ma, float* w, int64_t per) {
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  for (int64_t i = threadIdx.x; i < per; i += 256) {
+    const int64_t k = (int64_t)b * per + i;
+    acc += fabsf(s[k] - (ia[b] * noisy[k] + ma[b] * real[k]));
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) w[b] = 1.f / ((part[0] + part[1] + part[2] + part[3]) / (float)per + 1e-5f);
+}
+__global__ __launch_bounds__(256) void dmd_grad_kernel(const float* real, const float* fake, const float* kb, const float* w,
+                                                       float* grad, float* loss, int B, int64_t per) {
+  const int64_t n = (int64_t)B * per;
+  float acc = 0.f;
+  GRID_STRIDE(i, n) {
+    const int b = (int)(i / per);
+    const float wc = w[b] * (real[i] - fake[i]) * kb[b];
+    grad[i] = 2.f * wc / (float)n;
+    acc += wc * wc;
+  }
+  acc = wave_sum(acc);
+  __shared__ float part[4];
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (part[0] + part[1] + part[2] + part[3]) / (float)n);
+}
+
+int launch_im2col(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride,
+                  int pad, hipStream_t st) {
+  FDMI_CHECK(C % 8 == 0, "im2col: C must be a multiple of 8");
+  LAUNCH(im2col_kernel, (int64_t)B * Ho * Wo * KH * KW * (C / 8), x, out, B, H, W, C, Ho, Wo, KH, KW, stride, pad)
+}
+int launch_silu_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t n, hipStream_t st) {
+  LAUNCH(silu_bwd_kernel, n, x, dy, dx, n)
+}
+int launch_colsum(const bf16_t* dy, const bf16_t* x, const float* stats, float* out0, float* out1, int64_t rows, int C,
+                  int HW, int G, float eps, hipStream_t st) {
+  int gy = (int)((rows + 63) / 64);
+  if (gy > 256) gy = 256;
+  if (gy < 1) gy = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, st, dy, x, stats, out0, out1, rows, C, HW, G, eps);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_distill_loss(const float* s, const float* t, int64_t n, int l1, float* out, hipStream_t st) {
+  FDMI_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
+  hipLaunchKernelGGL(distill_loss_kernel, dim3(nblocks(n, 256)), dim3(256), 0, st, s, t, n, l1, out);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_distill_grad(const float* s, const float* t, int64_t n, int l1, float gscale, float* ds, hipStream_t st) {
+  LAUNCH(distill_grad_kernel, n, s, t, n, l1, gscale, ds)
+}
+int launch_dmd_loss(const float* s, const float* noisy, const float* real, const float* fake, const float* ia,
+                    const float* ma, const float* kb, float* w, float* grad, float* loss, int B, int64_t per,
+                    hipStream_t st) {
+  FDMI_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
+  hipLaunchKernelGGL(dmd_weight_kernel, dim3(B), dim3(256), 0, st, s, noisy, real, ia, ma, w, per);
+  hipLaunchKernelGGL(dmd_grad_kernel, dim3(nblocks((int64_t)B * per, 256)), dim3(256), 0, st, real, fake, kb, w, grad, loss, B,
+                     per);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}

@@ -72,7 +72,18 @@ int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float wd, int step, float grad_scale, hipStream_t st);
 
-// ---- flashstep.hip (fused scheduler / loss element-wise math, K6) ----
+// ---- discriminator support + fused loss kernels (elem.hip) ----
+int launch_im2col(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride,
+                  int pad, hipStream_t st);
+int launch_silu_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t n, hipStream_t st);
+int launch_colsum(const bf16_t* dy, const bf16_t* x, const float* stats, float* out0, float* out1, int64_t rows, int C,
+                  int HW, int G, float eps, hipStream_t st);
+int launch_distill_loss(const float* s, const float* t, int64_t n, int l1, float* out, hipStream_t st);
+int launch_distill_grad(const float* s, const float* t, int64_t n, int l1, float gscale, float* ds, hipStream_t st);
+int launch_dmd_loss(const float* s, const float* noisy, const float* real, const float* fake, const float* ia,
+                    const float* ma, const float* kb, float* w, float* grad, float* loss, int B, int64_t per,
+                    hipStream_t st);
+// ---- fused scheduler element-wise math ----
 struct StepCoef { float a, b, c, d; };
 int launch_add_noise(const float* z, const float* noise, const float* sa, const float* sb, float* out,
                      int B, int64_t per, hipStream_t st);

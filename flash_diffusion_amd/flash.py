@@ -142,6 +142,52 @@ class _PerSampleAffine(torch.autograd.Function):
         return ops.add_noise(g, g, cb, torch.zeros_like(cb)), None, None, None
 
 
+class _DistillLoss(torch.autograd.Function):
+    """FD:368-382 as one fused reduction kernel (+ one element-wise kernel for the gradient)."""
+
+    @staticmethod
+    def forward(ctx, s, t, l1):
+        from ._lib import check, lib, ptr, stream_ptr
+        s, t = s.contiguous(), t.contiguous()
+        out = torch.empty(1, dtype=torch.float32, device=s.device)
+        check(lib().fdmi_distill_loss(ptr(s), ptr(t), s.numel(), int(l1), ptr(out), stream_ptr()))
+        ctx.save_for_backward(s, t)
+        ctx.l1 = int(l1)
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from ._lib import check, lib, ptr, stream_ptr
+        s, t = ctx.saved_tensors
+        ds = torch.empty_like(s)
+        check(lib().fdmi_distill_grad(ptr(s), ptr(t), s.numel(), ctx.l1, 1.0 / s.numel(), ptr(ds), stream_ptr()))
+        return ds * g, None, None   # g: device scalar (no host sync)
+
+
+class _DmdLoss(torch.autograd.Function):
+    """FD:459-499 fused: per-sample weight 1/(mean|s - x0(real)| + 1e-5), coefficient
+    (real - fake) sqrt(1-abar)/sqrt(abar), loss mean((w coeff)^2) and dL/ds = 2 w coeff / N."""
+
+    @staticmethod
+    def forward(ctx, s, noisy, real, fake, inv_a, ms_a, kb):
+        from ._lib import check, lib, ptr, stream_ptr
+        B = s.shape[0]
+        s = s.contiguous()
+        w = torch.empty(B, dtype=torch.float32, device=s.device)
+        grad = torch.empty_like(s)
+        loss = torch.empty(1, dtype=torch.float32, device=s.device)
+        check(lib().fdmi_dmd_loss(ptr(s), ptr(noisy.contiguous()), ptr(real.contiguous()), ptr(fake.contiguous()),
+                                  ptr(inv_a), ptr(ms_a), ptr(kb), ptr(w), ptr(grad), ptr(loss), B, s.numel() // B,
+                                  stream_ptr()))
+        ctx.save_for_backward(grad)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (grad,) = ctx.saved_tensors
+        return grad * g, None, None, None, None, None, None
+
+
 def gaussian_mixture_pmf(K, locs, var, mode_probs):
     p = [sum(mode_probs[j] * torch.exp(-torch.tensor([(i - loc) ** 2 / var])) for j, loc in enumerate(locs))
          for i in range(K)]
@@ -166,6 +212,13 @@ class FlashDiffusion(nn.Module):
         self.vae = None
         self.adapter = None
         self.conditioner = conditioner
+        if isinstance(discriminator, nn.Sequential) and not hasattr(discriminator, "convert"):
+            from .discriminator import MiDiscriminator
+            try:   # run the reference's PatchGAN heads on the HIP kernels; anything exotic stays a plain module
+                if all(isinstance(m, (nn.Conv2d, nn.SiLU, nn.GroupNorm, nn.Flatten)) for m in discriminator):
+                    discriminator = MiDiscriminator.convert(discriminator)
+            except Exception:
+                pass
         self.discriminator = discriminator
         for f in ("guidance_scale_min", "guidance_scale_max", "ucg_keys", "K", "num_iterations_per_K",
                   "distill_loss_type", "timestep_distribution", "mixture_num_components", "mixture_var",
@@ -351,9 +404,7 @@ class FlashDiffusion(nn.Module):
     # ---- losses --------------------------------------------------------------------------------------
     def _distill_loss(self, s, t):
         """FD:368-382"""
-        if self.distill_loss_type == "l2":
-            return torch.mean(((s - t) ** 2).reshape(s.shape[0], -1), 1).mean()
-        return torch.mean(torch.abs(s - t).reshape(s.shape[0], -1), 1).mean()
+        return _DistillLoss.apply(s, t.detach(), self.distill_loss_type == "l1")
 
     def _dmd_loss(self, d, s, student_cond, cond, uncond, K_step):
         """FD:401-499"""
@@ -371,12 +422,9 @@ class FlashDiffusion(nn.Module):
                  + self.guidance_scale_min[K_step])
             real = ops.axpby(e_c, g, e_u, 1.0 - g)
             a = sch.alphas_cumprod.to(s.device)[t]
-            coeff = (real - e_f) * ((1.0 - a) ** 0.5 / a ** 0.5).view(-1, 1, 1, 1)   # (score_fake - score_real) ...
+            kb = ((1.0 - a) ** 0.5 / a ** 0.5).float().contiguous()     # (score_fake - score_real) = real - fake
             inv_a, ms_a = self._x0_coeffs(t)
-            x0 = ops.add_noise(noisy.detach().contiguous(), real, inv_a.float().contiguous(), ms_a.float().contiguous())
-            w = 1.0 / ((s.detach() - x0).abs().mean([1, 2, 3], keepdim=True) + 1e-5)
-            target = s.detach() - w * coeff
-        return F.mse_loss(s, target, reduction="mean")
+        return _DmdLoss.apply(s, noisy.detach(), real, e_f, inv_a.float().contiguous(), ms_a.float().contiguous(), kb)
 
     def _gan_loss(self, d, z, s, teacher_output, conditioning, step):
         """FD:501-667"""

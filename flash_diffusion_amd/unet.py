@@ -21,26 +21,7 @@ from ._lib import check, f32, i32, i64, ptr, stream_ptr, vp
 FDMI_UNET_SAVE, FDMI_UNET_INTERMEDIATE, FDMI_UNET_INPUT_GRAD = 1, 2, 4
 
 
-class UNetCfg(C.Structure):
-    _fields_ = [("in_channels", i32), ("out_channels", i32), ("n_levels", i32), ("block_out", i32 * 4),
-                ("down_attn", i32 * 4), ("up_attn", i32 * 4), ("layers_per_block", i32), ("tlayers", i32 * 4),
-                ("heads", i32 * 4), ("cross_dim", i32), ("groups", i32), ("eps", f32), ("class_embed_dim", i32),
-                ("flip_sin_to_cos", i32), ("freq_shift", f32)]
-
-
-_lib.EXTRA_SIGS.update({
-    "fdmi_unet_create": (vp, [C.POINTER(UNetCfg)]),
-    "fdmi_unet_destroy": (None, [vp]),
-    "fdmi_unet_num_params": (i64, [vp]),
-    "fdmi_unet_param_name": (i32, [vp, i64, C.c_char_p, i64, C.POINTER(i64)]),
-    "fdmi_unet_set_param": (i32, [vp, C.c_char_p, vp, i64, vp]),
-    "fdmi_unet_set_lora": (i32, [vp, C.c_char_p, vp, vp, vp, vp, i32]),
-    "fdmi_unet_ready": (i32, [vp]),
-    "fdmi_unet_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32]),
-    "fdmi_unet_forward": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, i32, vp]),
-    "fdmi_unet_backward": (i32, [vp, i32, vp, vp, vp]),
-    "fdmi_unet_last_flops": (C.c_double, [vp]),
-})
+from ._lib import UNetCfg  # noqa: E402  (C struct fdmi_unet_config)
 
 
 class _Node(nn.Module):

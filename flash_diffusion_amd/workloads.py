@@ -12,6 +12,11 @@ from .unet import MiUNet2DConditionModel
 
 SD15 = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
             cross_attention_dim=768, attention_head_dim=8, transformer_layers_per_block=1)
+SDXL = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), layers_per_block=2,
+            down_block_types=("DownBlock2D", "CrossAttnDownBlock2D", "CrossAttnDownBlock2D"),
+            up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), cross_attention_dim=2048,
+            attention_head_dim=(5, 10, 20), transformer_layers_per_block=(1, 2, 10), class_embed_type="projection",
+            projection_class_embeddings_input_dim=2816)   # examples/train_flash_sdxl.py:66-118
 TINY = dict(in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64), layers_per_block=2,
             cross_attention_dim=64, attention_head_dim=2, transformer_layers_per_block=1)
 
@@ -39,7 +44,10 @@ def build_flash(arch=SD15, lora_rank=128, n_teacher_steps=4, device="cuda", seed
     return m
 
 
-def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77):
+def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77, vector_dim=0):
     g = torch.Generator(device="cpu").manual_seed(seed)
-    return {"image": torch.randn(B, 4, hw, hw, generator=g).to(device),
-            "crossattn": torch.randn(B, L, ctx_dim, generator=g).to(device), "text": ["synthetic"] * B}
+    b = {"image": torch.randn(B, 4, hw, hw, generator=g).to(device),
+         "crossattn": torch.randn(B, L, ctx_dim, generator=g).to(device), "text": ["synthetic"] * B}
+    if vector_dim:
+        b["vector"] = torch.randn(B, vector_dim, generator=g).to(device)
+    return b

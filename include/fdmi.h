@@ -105,6 +105,27 @@ int fdmi_add_noise(const float* z, const float* noise, const float* sqrt_ac, con
 int fdmi_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
                 const float* x3, float c3, float* out, int64_t n, void* stream);
 
+/* ---------------- discriminator building blocks (examples/train_flash_sd.py:225-240) and fused losses ----
+ * The PatchGAN head is trainable, so besides fdmi_gemm (forward / dgrad) it needs a weight gradient:
+ * dW = dY^T * im2col(X) as a plain GEMM over the explicit patch matrix (tiny: <= 2B x 8 x 8 pixels).
+ * fdmi_colsum: out0[c] += sum_rows dy ; out1[c] += sum_rows dy * xhat (bias / GroupNorm affine grads).
+ * fdmi_distill_loss/grad: FD:368-382 (l2 / l1).  fdmi_dmd_loss: FD:459-499 (weight, loss and dL/ds). */
+int fdmi_im2col(const void* x, void* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                void* stream);
+int fdmi_silu(const void* x, void* y, int64_t n, void* stream);
+int fdmi_silu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+int fdmi_colsum(const void* dy, const void* x, const float* stats, float* out0, float* out1, int64_t rows, int C, int HW,
+                int G, float eps, void* stream);
+int fdmi_transpose2d_pad(const void* in, int64_t ldi, void* out, int64_t ldo, int64_t rows, int cols, int64_t rows_pad,
+                         void* stream);
+int fdmi_pad_cols(const void* src, int cols, void* dst, int cols_pad, int64_t rows, void* stream);
+int fdmi_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int fdmi_distill_loss(const float* s, const float* t, int64_t n, int l1, float* out, void* stream);
+int fdmi_distill_grad(const float* s, const float* t, int64_t n, int l1, float gscale, float* ds, void* stream);
+int fdmi_dmd_loss(const float* s, const float* noisy, const float* real, const float* fake, const float* inv_alpha,
+                  const float* msig_alpha, const float* kb, float* w, float* grad, float* loss, int B, int64_t per,
+                  void* stream);
+
 /* ---------------- UNet2DCondition plan: forward + input/LoRA-gradient backward -------------------
  * Replaces DiffusersUNet2DCondWrapper.forward -> UNet2DConditionModel.forward(...).sample
  * (/root/reference/src/flash/models/unets/unet.py:66-119) and its autograd backward.  Architecture
