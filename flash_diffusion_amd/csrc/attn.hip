@@ -130,7 +130,9 @@ constexpr float NEG_BIG = -1.0e30f;
 // raw v_exp_f32 (2^x); inputs here are <= 0 or the NEG_BIG sentinel, denormal results flush harmlessly
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
-template <int DK, int DV, int QF>
+// ONES: the V^T copy carries a row of ones at dd = d (spare padded row), so the PV MFMA accumulates the
+// softmax denominator for free and the VALU row-sum disappears.
+template <int DK, int DV, int QF, bool ONES>
 __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
@@ -196,8 +198,16 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kf][f][r]);
       mx = xor_max(mx);
       const float mn = fmaxf(m[f0 + f], mx * sc);
-      const float alpha = fast_exp2(m[f0 + f] - mn);
-      m[f0 + f] = mn;
+      const bool grew = __any(mn > m[f0 + f]);   // wave-uniform: no row max moved -> nothing to rescale
+      float alpha = 1.f;
+      if (grew) {
+        alpha = fast_exp2(m[f0 + f] - mn);
+        m[f0 + f] = mn;
+#pragma unroll
+        for (int df = 0; df < DF; ++df)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc_o[df][f0 + f][r] *= alpha;
+      }
       float ps = 0.f;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
@@ -205,13 +215,9 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
         for (int r = 0; r < 4; ++r) {
           const float p = fast_exp2(fmaf(s[kf][f][r], sc, -mn));
           s[kf][f][r] = p;
-          ps += p;
+          if (!ONES) ps += p;
         }
-      l[f0 + f] = l[f0 + f] * alpha + ps;
-#pragma unroll
-      for (int df = 0; df < DF; ++df)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) acc_o[df][f0 + f][r] *= alpha;
+      if (!ONES) l[f0 + f] = l[f0 + f] * alpha + ps;
       pb[f][0] = pack8(s[0][f], s[1][f]);
       pb[f][1] = pack8(s[2][f], s[3][f]);
     }
@@ -251,7 +257,17 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
     const int q = q0 + 16 * f + j;
-    const float lt = xor_sum(l[f]);
+    float lt;
+    if (ONES) {  // denominator sits in the accumulator row dd = d: fragment d/16, lane group (d%16)/4, reg 0
+      const int dfo = a.d >> 4, go = (a.d & 15) >> 2;
+      float v = 0.f;
+#pragma unroll
+      for (int df = 0; df < DF; ++df)
+        if (df == dfo) v = acc_o[df][f][0];
+      lt = __shfl(v, go * 16 + j, 64);
+    } else {
+      lt = xor_sum(l[f]);
+    }
     const float inv = 1.f / lt;
     if (q < a.Sq) {
       if (a.lse && g == 0) a.lse[((int64_t)b * a.H + h) * a.Sq + q] = m[f] + log2f(lt);
@@ -516,7 +532,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
 // X[B,S,ld] (head h at column h*d) -> XT[B,H,DVP,SP], zero padded.  64x(16-dd) LDS transpose.
 // =============================================================================================
 __global__ __launch_bounds__(256) void transpose_heads_kernel(const bf16_t* X, int64_t ld, bf16_t* XT,
-                                                              int B, int H, int S, int d) {
+                                                              int B, int H, int S, int d, int ones_row) {
   __shared__ bf16_t tile[64][66];
   const int DVP = attn_dvpad(d), SP = attn_spad(S);
   const int s0 = blockIdx.x * 64, d0 = blockIdx.y * 64;
@@ -539,6 +555,10 @@ __global__ __launch_bounds__(256) void transpose_heads_kernel(const bf16_t* X, i
       u16x8 v;
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = tile[c + e][r];
+      if (ones_row && dd == d) {  // bf16 1.0 for valid keys: the PV product then also yields sum_k P
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (s0 + c + e < S) ? (bf16_t)0x3F80 : (bf16_t)0;
+      }
       *(u16x8*)(XT + (((int64_t)b * H + h) * DVP + dd) * SP + s0 + c) = v;
     }
   }
@@ -583,11 +603,18 @@ template <int DK, int DV, int NF>
 int fwd_t(const AttnArgs& a, hipStream_t st) {
   constexpr int smem = RowTile<DK>::BYTES + TrTile<DV>::BYTES;
   static bool once = false;
-  if (!once) { if (set_smem(attn_fwd_kernel<DK, DV, NF>, smem)) return -2; once = true; }
+  if (!once) {
+    if (set_smem(attn_fwd_kernel<DK, DV, NF, false>, smem)) return -2;
+    if (set_smem(attn_fwd_kernel<DK, DV, NF, true>, smem)) return -2;
+    once = true;
+  }
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
-  hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  if (a.vt_ones && a.d < DV)
+    hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, true>), grid, dim3(256), smem, st, a);
+  else
+    hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, false>), grid, dim3(256), smem, st, a);
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -645,8 +672,8 @@ static int check_attn(const AttnArgs& a) {
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
-  if (a.Sq >= 1024 && fdmi_tune_get(0) == 4) { ATTN_DISPATCH4(fwd_t, 4, 2, 1) }
-  ATTN_DISPATCH(fwd_t, 2, 1)
+  // query fragments per wave: 2 for d <= 64; 1 for larger heads (register pressure at 2 waves/SIMD)
+  ATTN_DISPATCH4(fwd_t, 2, 1, 1)
 }
 int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
@@ -658,10 +685,10 @@ int launch_attn_bwd_dkv(const AttnArgs& a, hipStream_t st) {
 }
 
 int launch_transpose_heads(const bf16_t* X, int64_t ld, bf16_t* XT, int B, int H, int S, int d,
-                           hipStream_t st) {
+                           hipStream_t st, int ones_row) {
   FDMI_CHECK(d % 8 == 0 && ld % 8 == 0, "transpose_heads: d, ld must be multiples of 8");
   dim3 grid(attn_spad(S) / 64, cdiv(attn_dvpad(d), 64), B * H);
-  hipLaunchKernelGGL(transpose_heads_kernel, grid, dim3(256), 0, st, X, ld, XT, B, H, S, d);
+  hipLaunchKernelGGL(transpose_heads_kernel, grid, dim3(256), 0, st, X, ld, XT, B, H, S, d, ones_row);
   FDMI_HIP(hipGetLastError());
   return 0;
 }

@@ -112,11 +112,11 @@ int fdmi_attn_fwd(const void* Q, int64_t ldq, const void* K, int64_t ldk, const 
                   int64_t ldo, void* VT, float* lse, int B, int H, int Sq, int Skv, int d, float scale,
                   void* stream) {
   hipStream_t st = (hipStream_t)stream;
-  int rc = launch_transpose_heads((const bf16_t*)V, ldv, (bf16_t*)VT, B, H, Skv, d, st);
+  int rc = launch_transpose_heads((const bf16_t*)V, ldv, (bf16_t*)VT, B, H, Skv, d, st, 1);
   if (rc) return rc;
   AttnArgs a{};
   a.Q = (const bf16_t*)Q; a.ldq = ldq; a.K = (const bf16_t*)K; a.ldk = ldk; a.V = (const bf16_t*)V; a.ldv = ldv;
-  a.VT = (const bf16_t*)VT; a.lse = lse; a.out = (bf16_t*)O; a.ldout = ldo;
+  a.VT = (const bf16_t*)VT; a.lse = lse; a.out = (bf16_t*)O; a.ldout = ldo; a.vt_ones = 1;
   a.B = B; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = scale;
   return launch_attn_fwd(a, st);
 }

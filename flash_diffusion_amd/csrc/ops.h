@@ -33,13 +33,14 @@ struct AttnArgs {
   bf16_t* out;  int64_t ldout;     // fwd: O; dq kernel: dQ
   bf16_t* dK; int64_t lddk; bf16_t* dV; int64_t lddv;
   int B, H, Sq, Skv, d; float scale;
+  int vt_ones;       // VT carries a row of ones at dd = d (written by launch_transpose_heads(..., ones_row=1))
 };
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st);
 int launch_attn_bwd_dkv(const AttnArgs& a, hipStream_t st);
 // X[B,S,ld] (head h at h*d) -> XT[B,H,dvpad,spad], zero padded
 int launch_transpose_heads(const bf16_t* X, int64_t ld, bf16_t* XT, int B, int H, int S, int d,
-                           hipStream_t st);
+                           hipStream_t st, int ones_row = 0);
 // delta[b,h,s] = sum_d dO*O
 int launch_attn_delta(const bf16_t* O, int64_t ldo, const bf16_t* dO, int64_t lddo, float* delta,
                       int B, int H, int S, int d, hipStream_t st);

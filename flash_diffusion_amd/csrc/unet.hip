@@ -656,11 +656,11 @@ struct Exec {
     if (!o || !VT || (R.save && !lse)) return nullptr;
     AttnArgs a{};
     a.Q = q->p; a.ldq = q->cols; a.K = k->p; a.ldk = k->cols; a.V = v->p; a.ldv = v->cols; a.VT = VT;
-    a.lse = lse; a.out = o->p; a.ldout = o->cols;
+    a.lse = lse; a.out = o->p; a.ldout = o->cols; a.vt_ones = 1;
     a.B = Bn; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.f / sqrtf((float)d);
     flops += 4.0 * Bn * H * (double)Sq * Skv * d;
     if (!R.dry()) {
-      NULL_IF(launch_transpose_heads(v->p, v->cols, VT, Bn, H, Skv, d, st));
+      NULL_IF(launch_transpose_heads(v->p, v->cols, VT, Bn, H, Skv, d, st, 1));
       NULL_IF(launch_attn_fwd(a, st));
     }
     if (R.save) {

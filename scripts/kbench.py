@@ -61,7 +61,7 @@ def run_gemm(reps, **kw):
 
 def run_attn(reps):
     from flash_diffusion_amd._lib import lib
-    for qf in (0, 4):
+    for qf in (0, 1):
         lib().fdmi_tune_set(0, qf)
         print("fwd QF knob", qf)
         _run_attn(reps)
