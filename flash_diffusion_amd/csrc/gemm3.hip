@@ -308,25 +308,32 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   };
 
   f32x4 acc[NF][MF];
-  auto compute = [&](int slot) {
+  // fragments of BOTH k-steps are requested right after the barrier, the next tile's LDS-DMA is issued
+  // while they are in flight, then the 2 x NF x MF MFMAs run (a wave issues in order: anything placed
+  // after the MFMAs would only start once they have all been issued)
+  bf16x8 af[2][MF], wf[2][NF];
+  auto load_frags = [&](int slot) {
     const char* sa = smem + slot * STAGE;
     const char* sw = sa + BM * 128;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int pc = (ks * 4 + g) ^ (j >> 1);
-      bf16x8 af[MF], wf[NF];
 #pragma unroll
-      for (int mf = 0; mf < MF; ++mf) af[mf] = *(const bf16x8*)(sa + ((wm * 64 + mf * 16 + j) * 8 + pc) * 16);
+      for (int mf = 0; mf < MF; ++mf) af[ks][mf] = *(const bf16x8*)(sa + ((wm * 64 + mf * 16 + j) * 8 + pc) * 16);
 #pragma unroll
-      for (int nf = 0; nf < NF; ++nf) wf[nf] = *(const bf16x8*)(sw + ((wn * (BN / 2) + nf * 16 + j) * 8 + pc) * 16);
-      __builtin_amdgcn_s_setprio(1);
+      for (int nf = 0; nf < NF; ++nf) wf[ks][nf] = *(const bf16x8*)(sw + ((wn * (BN / 2) + nf * 16 + j) * 8 + pc) * 16);
+    }
+  };
+  auto mma = [&]() {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
-          acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nf], af[mf], acc[nf][mf], 0, 0, 0);
-      __builtin_amdgcn_s_setprio(0);
-    }
+          acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nf], af[ks][mf], acc[nf][mf], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
   };
 
   auto epilogue = [&](const Item& it) {
@@ -508,8 +515,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
         wait_vmcnt<0>();
       }
       __builtin_amdgcn_s_barrier();
-      if (issue_next()) ++inflight;
-      compute(cslot);
+      if (issue_next()) ++inflight;   // (DMA issue first: the asm's memory clobber would drain pending ds_reads)
+      load_frags(cslot);
+      mma();
       cslot = cslot == 2 ? 0 : cslot + 1;
       --inflight;
     }
