@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfdmi.so")
+LIB_PATH = os.environ.get("FDMI_LIB", os.path.join(_HERE, "libfdmi.so"))
 _lib = None
 
 i32, i64, f32, vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p

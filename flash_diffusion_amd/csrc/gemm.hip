@@ -476,7 +476,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   if (a.force_tile) {
     p.BM = a.force_tile >> 16;
     p.BN = a.force_tile & 0xffff;
-    p.big = p.BM == 256;
+    p.big = p.BM == 256 ? (p.BN == 320 ? 2 : 1) : 0;
     p.splitk = a.splitk > 0 ? a.splitk : 1;
     return p;
   }
@@ -495,6 +495,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
     }
   };
   if (gemm3_eligible(a)) consider(1, 256, gemm3_pick_bn(a), 256, 3.4);
+  if (gemm4_eligible(a)) consider(2, 256, 320, 256, 4.8);
   const bool geglu = a.act == ACT_GEGLU;
   consider(0, 128, 128, 512, 1.05);
   consider(0, 128, 64, 768, 0.60);
@@ -510,6 +511,25 @@ size_t gemm_ws_bytes(const GemmArgs& a) {
   const GemmPlan p = plan_gemm(b, true);
   return p.splitk > 1 ? (size_t)p.splitk * a.M * a.N * sizeof(float) : 0;
 }
+
+// developer aid: FDMI_GEMM_LOG=1 prints a histogram of the launched problems at exit
+#include <map>
+#include <tuple>
+#include <cstdlib>
+namespace {
+struct GemmLog {
+  std::map<std::tuple<int, int, int, int, int, int, int, int>, long> n;
+  bool on = getenv("FDMI_GEMM_LOG") != nullptr;
+  ~GemmLog() {
+    if (!on) return;
+    for (auto& kv : n) {
+      const auto& k = kv.first;
+      fprintf(stderr, "GEMMLOG mode=%d M=%d N=%d K=%d act=%d flags=%d kern=%d sk=%d count=%ld\n", std::get<0>(k), std::get<1>(k), std::get<2>(k),
+              std::get<3>(k), std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), kv.second);
+    }
+  }
+} g_gemm_log;
+}  // namespace
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   GemmArgs a = a_in;
@@ -527,7 +547,8 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.act == ACT_GEGLU) FDMI_CHECK((a.N % 32) == 0, "geglu: N must be a multiple of 32");
   if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic);
-  if (p.big) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
+  if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
+  if (p.big == 2) FDMI_CHECK(gemm4_eligible(a), "gemm: 256x320 tile not applicable to this problem");
   a.splitk = p.splitk;
   {  // every split must own at least one K tile (slabs of empty splits would stay uninitialised)
     const int kt = cdiv(a.K, 64);
@@ -536,8 +557,13 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.splitk > 1 && !a.accum_atomic) {
     FDMI_CHECK(a.ws != nullptr, "gemm: split-K needs a workspace of splitk*M*N floats");
   }
+  if (g_gemm_log.on)
+    ++g_gemm_log.n[std::make_tuple(a.mode, a.M, a.N, a.K, a.act, (a.residual ? 1 : 0) | (a.preact ? 2 : 0) | (a.accum_atomic ? 4 : 0) | (a.out_f32 ? 8 : 0) | (a.dgrad ? 16 : 0),
+                                   p.big ? p.big * 1000 + p.BN : p.BM * 1000 + p.BN, a.splitk)];
   int rc;
-  if (p.big)
+  if (p.big == 2)
+    rc = launch_gemm4(a, stream);
+  else if (p.big)
     rc = launch_gemm3(a, p.BN, stream);
   else if (a.mode == GEMM_ROW)
     rc = a.use_glds ? launch_tile<GEMM_ROW, true>(a, p.BM, p.BN, stream) : launch_tile<GEMM_ROW, false>(a, p.BM, p.BN, stream);

@@ -8,132 +8,15 @@
 // the SD/SDXL UNets (320, 640, 1280, 2560, 5120, 10240), BN = 128 covers GEGLU pairs and DiT widths.
 // The im2col gather keeps one 64-bit source pointer per staged row that is re-derived only when the
 // K loop crosses a filter tap (Cin % 64 == 0), so the steady-state loader is an add per row.
-#include "gemm.h"
-
-static __device__ uint4 g_zero16b[4] = {};
-
-#define GLOBAL_AS __attribute__((address_space(1)))
-#define LDS_AS __attribute__((address_space(3)))
+#include "gemm_tile.h"
 
 namespace {
-
-__device__ __forceinline__ void epi_terms3(const GemmArgs& a, int64_t m, int n, float v[4]) {
-#pragma unroll
-  for (int r = 0; r < 4; ++r) v[r] *= a.alpha;
-  if (a.bias) {
-    if (n + 3 < a.N) {
-      const float4 b = *(const float4*)(a.bias + n);
-      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (n + r < a.N) v[r] += a.bias[n + r];
-    }
-  }
-  if (a.rowvec) {
-    const bf16_t* rv = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-      if (n + r < a.N) v[r] += bf2f(rv[r]);
-  }
-}
-__device__ __forceinline__ void epi_store3(const GemmArgs& a, int act, int64_t m, int nout, int Nout, float v[4]) {
-  if (a.residual) {
-    const bf16_t* rs = a.residual + m * a.ldr + nout;
-    if (nout + 3 < Nout && ((a.ldr | nout) & 3) == 0) {
-      const u16x4 t = *(const u16x4*)rs;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) v[r] += bf2f(t[r]);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (nout + r < Nout) v[r] += bf2f(rs[r]);
-    }
-  }
-  if (act == ACT_SILU) {
-#pragma unroll
-    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
-  }
-  if (a.out_f32) {
-    float* c = (float*)a.C + m * a.ldc + nout;
-    if (nout + 3 < Nout && ((a.ldc | nout) & 3) == 0) {
-      *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (nout + r < Nout) c[r] = v[r];
-    }
-  } else {
-    bf16_t* c = (bf16_t*)a.C + m * a.ldc + nout;
-    if (nout + 3 < Nout && ((a.ldc | nout) & 3) == 0) {
-      uint2 pk;
-      pk.x = pack2bf(v[0], v[1]);
-      pk.y = pack2bf(v[2], v[3]);
-      *(uint2*)c = pk;
-    } else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (nout + r < Nout) c[r] = f2bf(v[r]);
-    }
-  }
-}
-__device__ __forceinline__ void save_preact3(const GemmArgs& a, int64_t m, int n, const float v[4]) {
-  bf16_t* p = a.preact + m * a.ldp + n;
-  uint2 pk;
-  pk.x = pack2bf(v[0], v[1]);
-  pk.y = pack2bf(v[2], v[3]);
-  *(uint2*)p = pk;
-}
-
-// ---- 8-wide epilogue: after v_permlane16_swap of a fragment pair every lane owns 8 consecutive output
-// columns of one row, so residual loads and output stores are 16 B per lane (half the store
-// instructions of the native 4-per-lane MFMA layout; the store tail of short-K GEMMs is issue-bound).
-__device__ __forceinline__ void swap16(float& x, float& y) {  // rows 1,3 of x <-> rows 0,2 of y
-  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
-  x = __uint_as_float(r[0]);
-  y = __uint_as_float(r[1]);
-}
-#define SWAP16(X, Y) do { float x_ = (X), y_ = (Y); swap16(x_, y_); (X) = x_; (Y) = y_; } while (0)
-__device__ __forceinline__ void epi_terms8(const GemmArgs& a, int64_t m, int n, float v[8]) {
-#pragma unroll
-  for (int r = 0; r < 8; ++r) v[r] *= a.alpha;
-  if (a.bias) {
-    const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
-    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
-    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-  }
-  if (a.rowvec) {
-    const u16x8 rv = *(const u16x8*)(a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
-  }
-}
-__device__ __forceinline__ void epi_store8(const GemmArgs& a, int act, int64_t m, int nout, float v[8]) {
-  if (a.residual) {
-    const u16x8 t = *(const u16x8*)(a.residual + m * a.ldr + nout);
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] += bf2f(t[r]);
-  }
-  if (act == ACT_SILU) {
-#pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
-  }
-  if (a.out_f32) {
-    float* c = (float*)a.C + m * a.ldc + nout;
-    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
-    *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
-  } else {
-    uint4 pk;
-    pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
-    *(uint4*)((bf16_t*)a.C + m * a.ldc + nout) = pk;
-  }
-}
 
 // LDS-DMA issued from inline asm: hipcc then keeps no scoreboard entry for it, so the ONLY waits on
 // these loads are the counted ones placed by hand below (with the builtin, the waitcnt pass drained
 // the ring with vmcnt(0) at every loop back-edge of the persistent loop).  M0 (the LDS destination
 // base) is written and restored inside the statement; lds_addr is wave-uniform.
-__device__ __forceinline__ void glds16(const void* gptr, unsigned lds_addr) {
+__device__ __forceinline__ void glds16m(const void* gptr, unsigned lds_addr) {
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
@@ -143,7 +26,7 @@ __device__ __forceinline__ void glds16(const void* gptr, unsigned lds_addr) {
 }
 
 template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
+__device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
@@ -262,17 +145,17 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     const unsigned sa = __builtin_amdgcn_readfirstlane(lds0 + slot * STAGE + wave * 1024);
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-      glds16(ap[i], sa + 512 * 16 * i);
+      glds16m(ap[i], sa + 512 * 16 * i);
       ap[i] += ainc[i];
     }
 #pragma unroll
     for (int i = 0; i < WFULL; ++i) {
-      glds16(wp[i], sa + BM * 128 + 512 * 16 * i);
+      glds16m(wp[i], sa + BM * 128 + 512 * 16 * i);
       wp[i] += winc[i];
     }
     if (WODD) {
       if (wave < 4) {
-        glds16(wp[WR - 1], sa + BM * 128 + 512 * 16 * (WR - 1));
+        glds16m(wp[WR - 1], sa + BM * 128 + 512 * 16 * (WR - 1));
         wp[WR - 1] += winc[WR - 1];
       }
     }
@@ -336,161 +219,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  auto epilogue = [&](const Item& it) {
-    const int m0 = it.m0, n0 = it.n0;
-    if (a.accum_atomic) {
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          const int64_t m = m0 + wm * 64 + mf * 16 + j;
-          const int n = n0 + wn * (BN / 2) + nf * 16 + g * 4;
-          if (m < a.M) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (n + r < a.N) atomicAdd((float*)a.C + m * a.ldc + n + r, acc[nf][mf][r] * a.alpha);
-          }
-        }
-      return;
-    }
-    // wide (8 columns per lane) path needs 8-element alignment of every row pointer involved
-    const bool wide = (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
-                      (!a.rowvec || (a.rowvec_ld & 7) == 0) && (!a.preact || (a.ldp & 7) == 0);
-    if (a.splitk > 1) {  // raw partial sums -> this split's fp32 slab (plain stores, deterministic)
-      float* slab = a.ws + (int64_t)it.z * a.M * a.N;
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-        for (int mf = 0; mf < MF; ++mf) {
-          const int64_t m = m0 + wm * 64 + mf * 16 + j;
-          const int n = n0 + wn * (BN / 2) + nf * 16 + g * 4;
-          if (m < a.M && n < a.N) {
-            float* d = slab + m * a.N + n;
-            if (n + 3 < a.N && (a.N & 3) == 0) {
-              *(float4*)d = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
-            } else {
-#pragma unroll
-              for (int r = 0; r < 4; ++r)
-                if (n + r < a.N) d[r] = acc[nf][mf][r];
-            }
-          }
-        }
-      return;
-    }
-    if (a.act == ACT_GEGLU) {
-      if constexpr (NF == 4) {
-        const int Nout = a.N >> 1;
-        if (wide) {
-          // pair value fragments (0,2) and gate fragments (1,3): even lane groups get block q=0, odd q=1
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              SWAP16(acc[0][mf][r], acc[2][mf][r]);
-              SWAP16(acc[1][mf][r], acc[3][mf][r]);
-            }
-            const int64_t m = m0 + wm * 64 + mf * 16 + j;
-            const int q = g & 1;
-            const int n = n0 + wn * 64 + q * 32 + (g >> 1) * 8;  // value cols n..n+7, gate cols n+16..n+23
-            if (m < a.M && n < a.N) {
-              float val[8], gate[8], o[8];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                val[r] = acc[0][mf][r]; val[4 + r] = acc[2][mf][r];
-                gate[r] = acc[1][mf][r]; gate[4 + r] = acc[3][mf][r];
-              }
-              epi_terms8(a, m, n, val);
-              epi_terms8(a, m, n + 16, gate);
-              if (a.preact) {
-                uint4 pk;
-                pk.x = pack2bf(val[0], val[1]); pk.y = pack2bf(val[2], val[3]); pk.z = pack2bf(val[4], val[5]); pk.w = pack2bf(val[6], val[7]);
-                *(uint4*)(a.preact + m * a.ldp + n) = pk;
-                pk.x = pack2bf(gate[0], gate[1]); pk.y = pack2bf(gate[2], gate[3]); pk.z = pack2bf(gate[4], gate[5]); pk.w = pack2bf(gate[6], gate[7]);
-                *(uint4*)(a.preact + m * a.ldp + n + 16) = pk;
-              }
-#pragma unroll
-              for (int r = 0; r < 8; ++r) o[r] = val[r] * gelu_f(gate[r]);
-              epi_store8(a, ACT_NONE, m, ((n0 + wn * 64) >> 1) + q * 16 + (g >> 1) * 8, o);
-            }
-          }
-          return;
-        }
-#pragma unroll
-        for (int q = 0; q < NF / 2; ++q)
-#pragma unroll
-          for (int mf = 0; mf < MF; ++mf) {
-            const int64_t m = m0 + wm * 64 + mf * 16 + j;
-            const int n = n0 + wn * (BN / 2) + q * 32 + g * 4;
-            if (m < a.M && n < a.N) {
-              float val[4], gate[4], o[4];
-#pragma unroll
-              for (int r = 0; r < 4; ++r) {
-                val[r] = acc[2 * q][mf][r];
-                gate[r] = acc[2 * q + 1][mf][r];
-              }
-              epi_terms3(a, m, n, val);
-              epi_terms3(a, m, n + 16, gate);
-              if (a.preact) {
-                save_preact3(a, m, n, val);
-                save_preact3(a, m, n + 16, gate);
-              }
-#pragma unroll
-              for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
-              epi_store3(a, ACT_NONE, m, ((n0 + wn * (BN / 2)) >> 1) + q * 16 + g * 4, Nout, o);
-            }
-          }
-      }
-      return;
-    }
-    if (wide) {
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const int64_t m = m0 + wm * 64 + mf * 16 + j;
-#pragma unroll
-        for (int pr = 0; pr < NF / 2; ++pr) {
-          const int nf = 2 * pr;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
-          const int n = n0 + wn * (BN / 2) + (nf + (g & 1)) * 16 + (g >> 1) * 8;
-          if (m < a.M && n < a.N) {
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-              v[r] = acc[nf][mf][r];
-              v[4 + r] = acc[nf + 1][mf][r];
-            }
-            epi_terms8(a, m, n, v);
-            epi_store8(a, a.act, m, n, v);
-          }
-        }
-        if constexpr ((NF & 1) != 0) {
-          const int n = n0 + wn * (BN / 2) + (NF - 1) * 16 + g * 4;
-          if (m < a.M && n < a.N) {
-            float v[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) v[r] = acc[NF - 1][mf][r];
-            epi_terms3(a, m, n, v);
-            epi_store3(a, a.act, m, n, a.N, v);
-          }
-        }
-      }
-      return;
-    }
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf)
-#pragma unroll
-      for (int mf = 0; mf < MF; ++mf) {
-        const int64_t m = m0 + wm * 64 + mf * 16 + j;
-        const int n = n0 + wn * (BN / 2) + nf * 16 + g * 4;
-        if (m < a.M && n < a.N) {
-          float v[4];
-#pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = acc[nf][mf][r];
-          epi_terms3(a, m, n, v);
-          epi_store3(a, a.act, m, n, a.N, v);
-        }
-      }
-  };
+  auto epilogue = [&](const Item& it) { tile_epilogue<NF, MF>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j); };
 
   // ---- flattened 3-stage ring across items: counted vmcnt, one raw barrier per K tile ----
   int inflight = 0;
@@ -507,12 +236,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
       // the epilogue of the previous item left ordinary loads/stores on the VM counter: drain once
       if (inflight >= 2 && t > 0) {
         if (WODD) {
-          if (wave < 4) wait_vmcnt<AR + WR>(); else wait_vmcnt<AR + WFULL>();
+          if (wave < 4) wait_vm<AR + WR>(); else wait_vm<AR + WFULL>();
         } else {
-          wait_vmcnt<AR + WFULL>();
+          wait_vm<AR + WFULL>();
         }
       } else {
-        wait_vmcnt<0>();
+        wait_vm<0>();
       }
       __builtin_amdgcn_s_barrier();
       if (issue_next()) ++inflight;   // (DMA issue first: the asm's memory clobber would drain pending ds_reads)

@@ -1,0 +1,286 @@
+// 256 x 320 x 64 bf16 MFMA GEMM / implicit-GEMM conv tile for gfx950 (512 threads = 8 waves as 4(M) x 2(N),
+// wave tile 64 x 160 = 4 x 10 accumulator fragments).
+//
+// Why a second large-tile kernel: the 256 x 160 kernel (gemm3.hip) moves 53 KB through the CU's vector
+// L1 per 64-deep K tile (98 flop/B).  One CU's L1 -> LDS path sustains ~42 B/clk (measured: the fill
+// time of a tile does not change from 8 to 256 active CUs), the MFMA pipe ~19 clk per 16x16x32, so
+// fill (~1300 clk) and MFMA (~1500 clk) of a 256 x 160 tile are both near saturation and every
+// imperfection of their overlap shows (measured 2300 clk per tile).  256 x 320 needs 72 KB per
+// 2 x 256 x 320 x 64 flop = 142 flop/B: the fill is 57% of the MFMA time.  N = 320 divides every
+// channel count of the SD / SDXL UNets, M = B*H*W is a multiple of 256 at every level but the deepest.
+//
+// Pipeline: 2-slot LDS ring (2 x 72 KB).  While tile k is multiplied from slot k%2, tile k+1 is
+// fetched into the other slot by LDS-DMA pieces issued one per MFMA group over the first half of the
+// tile; one `s_waitcnt vmcnt(0) lgkmcnt(0)` + `s_barrier` per tile hands the slots over.  W fragments
+// are streamed through a 4-deep register ring (10 W fragments per k-step would not fit beside 160
+// accumulator registers at 2 waves per SIMD); both k-steps' A fragments stay resident.
+#include "gemm_tile.h"
+
+namespace {
+
+template <int MODE>
+__global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int BM = 256, BN = 320;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int AR = 4, WR = 5, NP = AR + WR;  // LDS-DMA pieces (1 KiB per wave) per thread per tile
+  constexpr int MF = 4, NF = 10, NQ = 2 * NF;  // NQ MFMA groups (k-step, W fragment) per tile
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int g = lane >> 4, j = lane & 15;
+
+  // ---- persistent work loop: item = (tile, k-split); block b takes items b, b+G, b+2G, ... ----
+  const int tilesN = a.N / BN, tilesM = a.M / BM;
+  const int sk = a.splitk > 1 ? a.splitk : 1;
+  const int Wtot = tilesM * tilesN * sk;
+  const int G = gridDim.x;
+  const int ktiles = a.K >> 6, kper = (ktiles + sk - 1) / sk;
+  auto remap = [&](int v) {  // XCD-aware (block b runs on XCD b % 8; G % 8 == 0 or G == Wtot)
+    const int xcd = v & 7, q = Wtot >> 3, r = Wtot & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (v >> 3);
+  };
+  struct Item { int m0, n0, kbeg, nk, z; };
+  auto item_of = [&](int v) {
+    const int w = remap(v);
+    const int tile = w / sk, z = w - tile * sk;
+    const int tn = tile % tilesN, tm = tile / tilesN;
+    Item it;
+    it.m0 = tm * BM; it.n0 = tn * BN; it.z = z;
+    it.kbeg = z * kper * 64;
+    const int kend = min(a.K, it.kbeg + kper * 64);
+    it.nk = max(0, (kend - it.kbeg) >> 6);
+    return it;
+  };
+
+  // ---- loader state.  Thread t fills chunk t&7 of row t>>3 of each 64-row group; the chunk holds the
+  // logical k-chunk (t&7) ^ ((row>>1)&7) (source-side swizzle: conflict-free ds_read_b128 below) ----
+  const int p = tid & 7, lr = tid >> 3;
+  const int c8 = (p ^ ((lr >> 1) & 7)) * 8;
+  const bf16_t* zero = (const bf16_t*)g_zero16b;
+  const bf16_t* ap[AR];      // CONV: one source pointer per staged row (re-derived per filter tap)
+  unsigned aok = 0;          // CONV: bit i = row i reads real data (advances along Cin)
+  int ayx[AR], apix[AR];     // CONV: (y << 16 | x) window origin (biased by +256), batch pixel base
+  int ky = 0, kx = 0, cc = 0;
+  const bf16_t* abase = zero;  // ROW: row m0+lr; piece i is 64*i rows further
+  int64_t astep = 0;
+  const bf16_t* wbase = zero;  // W row n0+lr; piece i is 64*i rows further
+  int64_t wstep = 0;
+  auto retap = [&]() {
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+      const int by = (ayx[i] >> 16) - 256, bx = (ayx[i] & 0xffff) - 256;
+      bool ok = true;
+      int sy = 0, sx = 0;
+      if (a.dgrad) {
+        const int ty = by - ky, tx = bx - kx;
+        ok = ty >= 0 && tx >= 0;
+        if (a.stride == 2) {
+          ok = ok && (((ty | tx) & 1) == 0);
+          sy = ty >> 1;
+          sx = tx >> 1;
+        } else {
+          sy = ty;
+          sx = tx;
+        }
+        ok = ok && sy < a.Hin && sx < a.Win;
+      } else {
+        const int iy = by + ky, ix = bx + kx;
+        ok = iy >= 0 && ix >= 0 && iy < (a.Hin << a.ups) && ix < (a.Win << a.ups);
+        sy = iy >> a.ups;
+        sx = ix >> a.ups;
+      }
+      ap[i] = ok ? a.A + ((int64_t)(apix[i] + sy * a.Win + sx) * a.Cin + cc + c8) : zero;
+      aok = ok ? (aok | (1u << i)) : (aok & ~(1u << i));
+    }
+  };
+  auto setup_issue = [&](const Item& it) {
+    if (MODE == GEMM_ROW) {
+      abase = a.A + (int64_t)(it.m0 + lr) * a.lda + it.kbeg + c8;
+      astep = 64 * a.lda;
+    } else {
+      const int tap = it.kbeg / a.Cin;
+      cc = it.kbeg - tap * a.Cin;
+      ky = tap / a.KW;
+      kx = tap - ky * a.KW;
+      const int hw = a.Hout * a.Wout;
+#pragma unroll
+      for (int i = 0; i < AR; ++i) {
+        const int m = it.m0 + lr + 64 * i;
+        const int b = m / hw, rem = m - b * hw;
+        const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
+        apix[i] = b * a.Hin * a.Win;
+        const int by = a.dgrad ? (oy + a.pad) : (oy * a.stride - a.pad);
+        const int bx = a.dgrad ? (ox + a.pad) : (ox * a.stride - a.pad);
+        ayx[i] = ((by + 256) << 16) | (bx + 256);
+      }
+      retap();
+    }
+    wbase = a.W + (int64_t)(it.n0 + lr) * a.ldw + it.kbeg + c8;
+    wstep = 64 * a.ldw;
+  };
+  const unsigned lds0 = (unsigned)(uintptr_t)((LDS_AS char*)smem);
+  int iv = blockIdx.x, ikt = 0, ink = 0, islot = 0;
+  bool ihave = false, idone = false;
+  auto issue_prepare = [&]() -> bool {  // position the cursor on the next k-tile; false when none is left
+    if (idone) return false;
+    while (!ihave || ikt == ink) {
+      if (ihave) iv += G;
+      if (iv >= Wtot) {
+        idone = true;
+        return false;
+      }
+      const Item it = item_of(iv);
+      ihave = true;
+      ikt = 0;
+      ink = it.nk;
+      if (ink > 0) setup_issue(it);
+    }
+    return true;
+  };
+  auto park_issue = [&]() {  // past the last tile: the pieces read a zero page (keeps one instruction stream)
+    abase = zero; astep = 0;
+    wbase = zero; wstep = 0;
+    aok = 0;
+#pragma unroll
+    for (int i = 0; i < AR; ++i) ap[i] = zero;
+  };
+  auto slot_base = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane(lds0 + islot * STAGE + wave * 1024); };
+  auto piece = [&](int i, unsigned sa) {
+    if (i < AR) {
+      if (MODE == GEMM_ROW) {
+        glds16(abase + i * astep, sa + 512 * 16 * i);
+      } else {
+        glds16(ap[i], sa + 512 * 16 * i);
+        ap[i] += ((aok >> i) & 1u) << 6;
+      }
+    } else {
+      glds16(wbase + (i - AR) * wstep, sa + BM * 128 + 512 * 16 * (i - AR));
+    }
+  };
+  auto issue_finish = [&]() {
+    if (MODE == GEMM_ROW) {
+      abase += astep ? 64 : 0;
+    } else {
+      cc += 64;
+      if (cc >= a.Cin) {  // next tile starts a new filter tap (uniform: Cin % 64 == 0)
+        cc = 0;
+        if (++kx == a.KW) {
+          kx = 0;
+          ++ky;
+        }
+        retap();
+      }
+    }
+    wbase += wstep ? 64 : 0;
+    islot ^= 1;
+    ++ikt;
+  };
+
+  // ---- fragments ----
+  f32x4 acc[NF][MF];
+  bf16x8 af[2][MF], wq[4];
+  auto lds_a = [&](int ks, int mf, int slot) -> bf16x8 {
+    const int pc = (ks * 4 + g) ^ (j >> 1);
+    return *(const bf16x8*)(smem + slot * STAGE + ((wm * 64 + mf * 16 + j) * 8 + pc) * 16);
+  };
+  auto lds_w = [&](int q, int slot) -> bf16x8 {  // q = ks * NF + nf
+    const int ks = q / NF, nf = q - ks * NF;
+    const int pc = (ks * 4 + g) ^ (j >> 1);
+    return *(const bf16x8*)(smem + slot * STAGE + BM * 128 + ((wn * (BN / 2) + nf * 16 + j) * 8 + pc) * 16);
+  };
+
+  // prologue: tile 0 -> slot 0
+  if (issue_prepare()) {
+    const unsigned sa = slot_base();
+#pragma unroll
+    for (int i = 0; i < NP; ++i) piece(i, sa);
+    issue_finish();
+  }
+
+  int cslot = 0;
+  for (int cv = blockIdx.x; cv < Wtot; cv += G) {
+    const Item it = item_of(cv);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < it.nk; ++t) {
+      // hand-over: this wave's pieces of tile k have landed and its reads of the other slot are done
+      wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      // fragments of k-step 0 and the head of the W ring
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) af[0][mf] = lds_a(0, mf, cslot);
+#pragma unroll
+      for (int q = 0; q < 3; ++q) wq[q] = lds_w(q, cslot);
+      const bool have = issue_prepare();
+      if (!have) park_issue();
+      const unsigned sa = slot_base();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) {
+        const int ks = q / NF, nf = q % NF;
+        if (q + 3 < NQ) wq[(q + 3) & 3] = lds_w(q + 3, cslot);
+        if (q == 3) {
+#pragma unroll
+          for (int mf = 0; mf < MF; ++mf) af[1][mf] = lds_a(1, mf, cslot);
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf)
+          acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 3], af[ks][mf], acc[nf][mf], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+        if (q < NP) {
+          __builtin_amdgcn_sched_barrier(0);
+          piece(q, sa);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (have) issue_finish();
+      cslot ^= 1;
+    }
+    // the next item's first tile is landing meanwhile
+    tile_epilogue<NF, MF>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+  }
+  wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
+}
+
+template <int MODE>
+int launch4_t(const GemmArgs& a, hipStream_t stream) {
+  static bool attr_set = false;
+  constexpr int smem = 2 * (256 + 320) * 128;
+  if (!attr_set) {
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    attr_set = true;
+  }
+  const int items = (a.M / 256) * (a.N / 320) * (a.splitk > 1 ? a.splitk : 1);
+  static int ncu = 0;
+  if (!ncu) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    FDMI_HIP(hipGetDevice(&dev));
+    FDMI_HIP(hipGetDeviceProperties(&prop, dev));
+    ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount & ~7) : 256;
+    if (ncu < 8) ncu = 8;
+  }
+  dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(stream, PROF_GEMM3 + MODE * 2, gemm_flops(a));
+  hipLaunchKernelGGL((gemm4_kernel<MODE>), grid, dim3(512), smem, stream, a);
+  if (prof) fdmi_prof_end(stream);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+bool gemm4_eligible(const GemmArgs& a) {
+  if ((a.K & 63) != 0 || (a.M & 255) != 0 || (a.N % 320) != 0) return false;
+  if (a.mode == GEMM_CONV && ((a.Cin & 63) != 0 || a.Hout > 2048 || a.Wout > 2048)) return false;
+  if (a.act == ACT_GEGLU && !fdmi_tune_get(9)) return false;  // epilogue-bound at the UNet's K
+  return true;
+}
+int launch_gemm4(const GemmArgs& a, hipStream_t stream) {
+  return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW>(a, stream) : launch4_t<GEMM_CONV>(a, stream);
+}

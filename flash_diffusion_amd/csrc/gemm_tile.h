@@ -1,0 +1,308 @@
+// Shared pieces of the large-tile LDS-DMA GEMM kernels (gemm3.hip: 256 x {128,160}; gemm4.hip: 256 x 320):
+// LDS-DMA issue / counted waits, and the epilogue of one wave's MF x NF block of 16x16 accumulators
+// (swapped operands: lane (g, j) holds output row j, columns g*4..g*4+3 of each fragment).
+#pragma once
+#include "gemm.h"
+#include <type_traits>
+
+static __device__ uint4 g_zero16b[4] = {};
+
+#define GLOBAL_AS __attribute__((address_space(1)))
+#define LDS_AS __attribute__((address_space(3)))
+
+namespace {
+
+__device__ __forceinline__ void epi_terms3(const GemmArgs& a, int64_t m, int n, float v[4]) {
+#pragma unroll
+  for (int r = 0; r < 4; ++r) v[r] *= a.alpha;
+  if (a.bias) {
+    if (n + 3 < a.N) {
+      const float4 b = *(const float4*)(a.bias + n);
+      v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (n + r < a.N) v[r] += a.bias[n + r];
+    }
+  }
+  if (a.rowvec) {
+    const bf16_t* rv = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (n + r < a.N) v[r] += bf2f(rv[r]);
+  }
+}
+__device__ __forceinline__ void epi_store3(const GemmArgs& a, int act, int64_t m, int nout, int Nout, float v[4]) {
+  if (a.residual) {
+    const bf16_t* rs = a.residual + m * a.ldr + nout;
+    if (nout + 3 < Nout && ((a.ldr | nout) & 3) == 0) {
+      const u16x4 t = *(const u16x4*)rs;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[r] += bf2f(t[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nout + r < Nout) v[r] += bf2f(rs[r]);
+    }
+  }
+  if (act == ACT_SILU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+  }
+  if (a.out_f32) {
+    float* c = (float*)a.C + m * a.ldc + nout;
+    if (nout + 3 < Nout && ((a.ldc | nout) & 3) == 0) {
+      *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nout + r < Nout) c[r] = v[r];
+    }
+  } else {
+    bf16_t* c = (bf16_t*)a.C + m * a.ldc + nout;
+    if (nout + 3 < Nout && ((a.ldc | nout) & 3) == 0) {
+      uint2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      *(uint2*)c = pk;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        if (nout + r < Nout) c[r] = f2bf(v[r]);
+    }
+  }
+}
+__device__ __forceinline__ void save_preact3(const GemmArgs& a, int64_t m, int n, const float v[4]) {
+  bf16_t* p = a.preact + m * a.ldp + n;
+  uint2 pk;
+  pk.x = pack2bf(v[0], v[1]);
+  pk.y = pack2bf(v[2], v[3]);
+  *(uint2*)p = pk;
+}
+
+// ---- 8-wide epilogue: after v_permlane16_swap of a fragment pair every lane owns 8 consecutive output
+// columns of one row, so residual loads and output stores are 16 B per lane (half the store
+// instructions of the native 4-per-lane MFMA layout; the store tail of short-K GEMMs is issue-bound).
+__device__ __forceinline__ void swap16(float& x, float& y) {  // rows 1,3 of x <-> rows 0,2 of y
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(y), false, false);
+  x = __uint_as_float(r[0]);
+  y = __uint_as_float(r[1]);
+}
+#define SWAP16(X, Y) do { float x_ = (X), y_ = (Y); swap16(x_, y_); (X) = x_; (Y) = y_; } while (0)
+__device__ __forceinline__ void epi_terms8(const GemmArgs& a, int64_t m, int n, float v[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) v[r] *= a.alpha;
+  if (a.bias) {
+    const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+    v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w;
+    v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+  }
+  if (a.rowvec) {
+    const u16x8 rv = *(const u16x8*)(a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
+  }
+}
+__device__ __forceinline__ void epi_store8(const GemmArgs& a, int act, int64_t m, int nout, float v[8]) {
+  if (a.residual) {
+    const u16x8 t = *(const u16x8*)(a.residual + m * a.ldr + nout);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] += bf2f(t[r]);
+  }
+  if (act == ACT_SILU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+  }
+  if (a.out_f32) {
+    float* c = (float*)a.C + m * a.ldc + nout;
+    *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+    *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+  } else {
+    uint4 pk;
+    pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+    *(uint4*)((bf16_t*)a.C + m * a.ldc + nout) = pk;
+  }
+}
+
+// LDS-DMA issued from inline asm: hipcc then keeps no scoreboard entry for it, so the ONLY waits on
+// these loads are the counted ones placed by hand below (with the builtin, the waitcnt pass drained
+// the ring with vmcnt(0) at every loop back-edge of the persistent loop).  M0 (the LDS destination
+// base) is written and restored inside the statement; lds_addr is wave-uniform.
+__device__ __forceinline__ void glds16(const void* gptr, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gptr), "s"(lds_addr));
+}
+
+// counted wait on the LDS-DMA pieces (plus: every LDS read of this wave has returned, so the ring slot
+// it read from may be refilled once the workgroup has passed the barrier that follows)
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
+}
+
+// epilogue of one wave: rows mw + mf*16 + j, columns nw + nf*16 + g*4 .. +3; z = split-K slab index
+template <int NF, int MF>
+__device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw, int z, f32x4 (&acc)[NF][MF], int g, int j) {
+  if (a.accum_atomic) {
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = mw + mf * 16 + j;
+        const int n = nw + nf * 16 + g * 4;
+        if (m < a.M) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (n + r < a.N) atomicAdd((float*)a.C + m * a.ldc + n + r, acc[nf][mf][r] * a.alpha);
+        }
+      }
+    return;
+  }
+  // wide (8 columns per lane) path needs 8-element alignment of every row pointer involved
+  const bool wide = (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
+                    (!a.rowvec || (a.rowvec_ld & 7) == 0) && (!a.preact || (a.ldp & 7) == 0);
+  if (a.splitk > 1) {  // raw partial sums -> this split's fp32 slab (plain stores, deterministic)
+    float* slab = a.ws + (int64_t)z * a.M * a.N;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = mw + mf * 16 + j;
+        const int n = nw + nf * 16 + g * 4;
+        if (m < a.M && n < a.N) {
+          float* d = slab + m * a.N + n;
+          if (n + 3 < a.N && (a.N & 3) == 0) {
+            *(float4*)d = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
+          } else {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < a.N) d[r] = acc[nf][mf][r];
+          }
+        }
+      }
+    return;
+  }
+  if (a.act == ACT_GEGLU) {
+    // fragment 2q holds 16 value columns, fragment 2q+1 the matching 16 gate columns
+    const int Nout = a.N >> 1;
+    constexpr int NQUAD = NF / 4;  // groups of two (value, gate) pairs that can take the 8-wide path
+    constexpr int QW = NQUAD * 2;  // pairs covered by the 8-wide path when `wide`
+    if (wide) {
+#pragma unroll
+      for (int t = 0; t < NQUAD; ++t) {
+        // pair value fragments (4t, 4t+2) and gate fragments (4t+1, 4t+3): even lane groups get pair 2t, odd 2t+1
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            SWAP16(acc[4 * t][mf][r], acc[4 * t + 2][mf][r]);
+            SWAP16(acc[4 * t + 1][mf][r], acc[4 * t + 3][mf][r]);
+          }
+          const int64_t m = mw + mf * 16 + j;
+          const int q = g & 1;
+          const int n = nw + t * 64 + q * 32 + (g >> 1) * 8;  // value cols n..n+7, gate cols n+16..n+23
+          if (m < a.M && n < a.N) {
+            float val[8], gate[8], o[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              val[r] = acc[4 * t][mf][r]; val[4 + r] = acc[4 * t + 2][mf][r];
+              gate[r] = acc[4 * t + 1][mf][r]; gate[4 + r] = acc[4 * t + 3][mf][r];
+            }
+            epi_terms8(a, m, n, val);
+            epi_terms8(a, m, n + 16, gate);
+            if (a.preact) {
+              uint4 pk;
+              pk.x = pack2bf(val[0], val[1]); pk.y = pack2bf(val[2], val[3]); pk.z = pack2bf(val[4], val[5]); pk.w = pack2bf(val[6], val[7]);
+              *(uint4*)(a.preact + m * a.ldp + n) = pk;
+              pk.x = pack2bf(gate[0], gate[1]); pk.y = pack2bf(gate[2], gate[3]); pk.z = pack2bf(gate[4], gate[5]); pk.w = pack2bf(gate[6], gate[7]);
+              *(uint4*)(a.preact + m * a.ldp + n + 16) = pk;
+            }
+#pragma unroll
+            for (int r = 0; r < 8; ++r) o[r] = val[r] * gelu_f(gate[r]);
+            epi_store8(a, ACT_NONE, m, (nw >> 1) + t * 32 + q * 16 + (g >> 1) * 8, o);
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NF / 2; ++q) {
+      if (wide && q < QW) continue;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = mw + mf * 16 + j;
+        const int n = nw + q * 32 + g * 4;
+        if (m < a.M && n < a.N) {
+          float val[4], gate[4], o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            val[r] = acc[2 * q][mf][r];
+            gate[r] = acc[2 * q + 1][mf][r];
+          }
+          epi_terms3(a, m, n, val);
+          epi_terms3(a, m, n + 16, gate);
+          if (a.preact) {
+            save_preact3(a, m, n, val);
+            save_preact3(a, m, n + 16, gate);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
+          epi_store3(a, ACT_NONE, m, (nw >> 1) + q * 16 + g * 4, Nout, o);
+        }
+      }
+    }
+    return;
+  }
+  if (wide) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t m = mw + mf * 16 + j;
+#pragma unroll
+      for (int pr = 0; pr < NF / 2; ++pr) {
+        const int nf = 2 * pr;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
+        const int n = nw + (nf + (g & 1)) * 16 + (g >> 1) * 8;
+        if (m < a.M && n < a.N) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = acc[nf][mf][r];
+            v[4 + r] = acc[nf + 1][mf][r];
+          }
+          epi_terms8(a, m, n, v);
+          epi_store8(a, a.act, m, n, v);
+        }
+      }
+      if constexpr ((NF & 1) != 0) {
+        const int n = nw + (NF - 1) * 16 + g * 4;
+        if (m < a.M && n < a.N) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[NF - 1][mf][r];
+          epi_terms3(a, m, n, v);
+          epi_store3(a, a.act, m, n, a.N, v);
+        }
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t m = mw + mf * 16 + j;
+      const int n = nw + nf * 16 + g * 4;
+      if (m < a.M && n < a.N) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[nf][mf][r];
+        epi_terms3(a, m, n, v);
+        epi_store3(a, a.act, m, n, a.N, v);
+      }
+    }
+}
+
+}  // namespace

@@ -362,6 +362,89 @@ def test_gemm3_geglu_and_auto_plan():
     close("gemm3_atomic", acc, A.float() @ W.float().t(), tol_el=1e-4, tol_fro=1e-4)
 
 
+# ---- 256 x 320 tile kernel (gemm4: 2-slot ring, streamed W fragments) ---------------------------------
+T4 = (256 << 16) | 320
+
+
+@pytest.mark.parametrize("shape", [(256, 320, 64), (512, 640, 320), (1024, 320, 1280), (768, 1280, 192), (2048, 960, 2560)])
+def test_gemm4_row(shape):
+    ops = _ops()
+    M, N, K = shape
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    res = b16(rnd(M, N, seed=5))
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=T4)
+    close(f"gemm4_row{shape}", out, A.float() @ W.float().t() + bias + res.float())
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_SILU, force_tile=T4)
+    close(f"gemm4_row_silu{shape}", out, F.silu(A.float() @ W.float().t() + bias))
+    if K >= 320:
+        out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), force_tile=T4, splitk=3)
+        close(f"gemm4_row_splitk{shape}", out, A.float() @ W.float().t() + bias)
+        acc = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+        ops.gemm(A.cuda(), W.cuda(), out=acc, accum_atomic=True, splitk=2, force_tile=T4)
+        close(f"gemm4_atomic{shape}", acc, A.float() @ W.float().t(), tol_el=1e-4, tol_fro=1e-4)
+
+
+def test_gemm4_geglu():
+    ops = _ops()
+    M, K, Fh = 512, 192, 640
+    A = b16(rnd(M, K, seed=1))
+    W = b16(rnd(2 * Fh, K, seed=2, scale=K ** -0.5))
+    bias = rnd(2 * Fh, seed=3)
+    perm = ops.geglu_perm(Fh)
+    h = A.float() @ W.float().t() + bias
+    ref = h[:, :Fh] * F.gelu(h[:, Fh:])
+    pre = torch.empty(M, 2 * Fh, dtype=torch.bfloat16, device="cuda")
+    out = ops.gemm(A.cuda(), W[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), act=ops.ACT_GEGLU,
+                   preact=pre, force_tile=T4)
+    close("gemm4_geglu", out, ref)
+    close("gemm4_geglu_preact", pre, h[:, perm])
+
+
+def test_gemm4_many_items_per_block():
+    """more (tile, split) items than CUs: the persistent loop crosses item boundaries with tiles in flight"""
+    ops = _ops()
+    M, N, K = 256 * 150, 640, 128
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    out = ops.gemm(A.cuda(), W.cuda(), force_tile=T4)
+    close("gemm4_many", out, A.float() @ W.float().t())
+    out2 = ops.gemm(A.cuda(), W.cuda(), force_tile=T4)
+    assert torch.equal(out, out2)
+
+
+CONVS4 = [
+    (4, 8, 8, 320, 320, 3, 1, 1, 0), (2, 16, 16, 64, 640, 3, 1, 1, 0), (4, 16, 16, 128, 320, 3, 2, 1, 0),
+    (4, 8, 8, 64, 320, 3, 1, 1, 1), (2, 16, 16, 192, 320, 1, 1, 0, 0), (1, 32, 32, 640, 320, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS4)
+def test_gemm4_conv_fwd_and_dgrad(cfg):
+    ops = _ops()
+    B, H, W, Ci, Co, k, s, p, ups = cfg
+    x = b16(rnd(B, Ci, H, W, seed=1))
+    w = b16(rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5))
+    bias = rnd(Co, seed=3)
+    xin = x.float()
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    xin.requires_grad_()
+    ref = F.conv2d(xin, w.float(), bias, stride=s, padding=p)
+    xn = x.permute(0, 2, 3, 1).contiguous().cuda()
+    Mout = ref.shape[0] * ref.shape[2] * ref.shape[3]
+    if Mout % 256 == 0:
+        y = ops.conv2d_nhwc(xn, ops.pack_conv_weight(w.float()).cuda(), KH=k, KW=k, stride=s, pad=p, ups=ups,
+                            bias=bias.cuda(), force_tile=T4)
+        close(f"conv4_fwd{cfg}", y.permute(0, 3, 1, 2), ref)
+    if Co % 64 == 0 and Ci % 320 == 0 and (B * (H << ups) * (W << ups)) % 256 == 0:
+        dy = b16(rnd(*ref.shape, seed=4))
+        ref.backward(dy.float())
+        dyn = dy.permute(0, 2, 3, 1).contiguous().cuda()
+        dx = ops.conv2d_nhwc(dyn, ops.pack_conv_weight_dgrad(w.float()).cuda(), KH=k, KW=k, stride=s, pad=p, dgrad=1,
+                             out_hw=(H << ups, W << ups), force_tile=T4)
+        close(f"conv4_dgrad{cfg}", dx.permute(0, 3, 1, 2), xin.grad)
+
+
 CONVS3 = [
     (3, 8, 8, 320, 320, 3, 1, 1, 0), (2, 16, 16, 64, 640, 3, 1, 1, 0), (2, 16, 16, 128, 160, 3, 2, 1, 0),
     (2, 8, 8, 64, 128, 3, 1, 1, 1), (2, 16, 16, 192, 128, 1, 1, 0, 0), (4, 8, 8, 128, 256, 4, 2, 1, 0),
