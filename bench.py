@@ -23,7 +23,8 @@ PEAK_BF16 = 2.5e15  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.
 BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<64,128,row>", "gemm_kernel<64,64,row>",
            "gemm_kernel<128,128,conv>", "gemm_kernel<128,64,conv>", "gemm_kernel<64,128,conv>", "gemm_kernel<64,64,conv>",
            "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
-           "gemm3_kernel<256x160,row>", "gemm3_kernel<256x128,row>", "gemm3_kernel<256x160,conv>", "gemm3_kernel<256x128,conv>"]
+           "gemm3_kernel<256x160,row>", "gemm3_kernel<256x128,row>", "gemm3_kernel<256x160,conv>", "gemm3_kernel<256x128,conv>",
+           "gemm4_kernel<256x320,row>", "gemm4_kernel<256x320,conv>"]
 
 
 def cpu_baseline(n_teacher_steps):
@@ -137,7 +138,7 @@ def main():
         run(1)
         pipe.finish()
         L.fdmi_prof_enable(0)
-        nb = 16
+        nb = 24
         ms = (C.c_double * nb)()
         fl = (C.c_double * nb)()
         ln = (C.c_int64 * nb)()

@@ -109,15 +109,24 @@ __device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
   t.u = make_uint4(pack2bf(a[0], a[1]), pack2bf(a[2], a[3]), pack2bf(b[0], b[1]), pack2bf(b[2], b[3]));
   return t.v;
 }
+// reductions over the four 16-lane groups of a wave (lanes l, l^16, l^32, l^48) with the gfx950 lane-swap
+// VALU ops instead of two dependent ds_bpermute round trips through the LDS
+__device__ __forceinline__ float other16(float v) {  // value of lane l ^ 16
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  // after the swap r[0] = {row0, row0, row2, row2}, r[1] = {row1, row1, row3, row3}
+  return (threadIdx.x & 16) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
 __device__ __forceinline__ float xor_sum(float v) {
-  v += __shfl_xor(v, 16, 64);
-  v += __shfl_xor(v, 32, 64);
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 __device__ __forceinline__ float xor_max(float v) {
-  v = fmaxf(v, __shfl_xor(v, 16, 64));
-  v = fmaxf(v, __shfl_xor(v, 32, 64));
-  return v;
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
 }
 
 #define MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
@@ -135,6 +144,7 @@ __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_ex
 template <int DK, int DV, int QF, bool ONES>
 __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int STAGEB = RowTile<DK>::BYTES + TrTile<DV>::BYTES;  // one K tile + one V^T tile; two stages
   char* sK = smem;
   char* sV = smem + RowTile<DK>::BYTES;
   constexpr int KS = DK / 32, DF = DV / 16;
@@ -146,11 +156,19 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
   const int SP = attn_spad(a.Skv);
   const float sc = a.scale * 1.4426950408889634f;
 
+  // Q is multiplied by scale*log2(e) once, here, so the MFMA output is already the exp2 argument
   bf16x8 qf[QF][KS];
 #pragma unroll
   for (int f = 0; f < QF; ++f)
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[f][ks] = own_frag(a.Q, a.ldq, b, a.Sq, q0 + 16 * f + j, hoff, a.d, ks, g);
+    for (int ks = 0; ks < KS; ++ks) {
+      union { bf16x8 v; uint32_t u[4]; } t;
+      t.v = own_frag(a.Q, a.ldq, b, a.Sq, q0 + 16 * f + j, hoff, a.d, ks, g);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        t.u[e] = pack2bf(__uint_as_float(t.u[e] << 16) * sc, __uint_as_float(t.u[e] & 0xffff0000u) * sc);
+      qf[f][ks] = t.v;
+    }
 
   f32x4 acc_o[DF][QF];
   float m[QF], l[QF];
@@ -163,13 +181,20 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
   }
 
   // one KV tile for query fragments [f0, f0+QP); TAIL masks keys >= Skv (last tile only)
+  // Lazy running maximum: the accumulators of K Q^T start at -m (the row's reference maximum so far), so
+  // the MFMA result is directly the exp2 argument.  m only moves when a tile exceeds it by more than TAU
+  // (P then stays <= 2^TAU, harmless in bf16/fp32); moving it rescales O and re-bases this tile's scores.
+  constexpr float TAU = 8.f;
   auto tile_pair = [&](auto tail_tag, int f0, int t) {
     constexpr bool TAIL = decltype(tail_tag)::value;
+    const bool first = t == 0;
     f32x4 s[4][QP];
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
+    for (int f = 0; f < QP; ++f) {
+      const float c0 = first ? 0.f : -m[f0 + f];
 #pragma unroll
-      for (int f = 0; f < QP; ++f) s[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int kf = 0; kf < 4; ++kf) s[kf][f] = (f32x4){c0, c0, c0, c0};
+    }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 kfr[4];
@@ -197,23 +222,28 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kf][f][r]);
       mx = xor_max(mx);
-      const float mn = fmaxf(m[f0 + f], mx * sc);
-      const bool grew = __any(mn > m[f0 + f]);   // wave-uniform: no row max moved -> nothing to rescale
       float alpha = 1.f;
-      if (grew) {
-        alpha = fast_exp2(m[f0 + f] - mn);
-        m[f0 + f] = mn;
+      if (first || __any(mx > TAU)) {  // wave-uniform, rare after the first tiles
+        const float up = first ? mx : fmaxf(mx, 0.f);  // the reference only ever rises
+        if (!first) {
+          alpha = fast_exp2(-up);
 #pragma unroll
-        for (int df = 0; df < DF; ++df)
+          for (int df = 0; df < DF; ++df)
 #pragma unroll
-          for (int r = 0; r < 4; ++r) acc_o[df][f0 + f][r] *= alpha;
+            for (int r = 0; r < 4; ++r) acc_o[df][f0 + f][r] *= alpha;
+        }
+        m[f0 + f] = first ? up : m[f0 + f] + up;
+#pragma unroll
+        for (int kf = 0; kf < 4; ++kf)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) s[kf][f][r] -= up;
       }
       float ps = 0.f;
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(fmaf(s[kf][f][r], sc, -mn));
+          const float p = fast_exp2(s[kf][f][r]);
           s[kf][f][r] = p;
           if (!ONES) ps += p;
         }
@@ -231,19 +261,31 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
       }
   };
 
+  // Two LDS stages, ONE barrier per KV tile: iteration t stores tile t+1 (fetched into registers during
+  // iteration t-1) into the other stage, fetches tile t+2, then computes tile t.
   uint4 rk[RowTile<DK>::NREG], rv[TrTile<DV>::NREG];
   const int nt = (a.Skv + KVB - 1) / KVB;
   const bool ragged = (a.Skv % KVB) != 0;
   rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, 0, hoff, a.d, tid);
   tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, 0, tid);
+  rows_r2s<DK>(smem, rk, tid);
+  tr_r2s<DV>(smem + RowTile<DK>::BYTES, rv, tid);
+  if (nt > 1) {
+    rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, KVB, hoff, a.d, tid);
+    tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, KVB, tid);
+  }
   for (int t = 0; t < nt; ++t) {
-    __syncthreads();
-    rows_r2s<DK>(sK, rk, tid);
-    tr_r2s<DV>(sV, rv, tid);
-    __syncthreads();
+    __syncthreads();  // stage t&1 is complete; every wave is done with stage (t+1)&1
+    sK = smem + (t & 1) * STAGEB;
+    sV = sK + RowTile<DK>::BYTES;
     if (t + 1 < nt) {
-      rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, (t + 1) * KVB, hoff, a.d, tid);
-      tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, (t + 1) * KVB, tid);
+      char* nK = smem + ((t + 1) & 1) * STAGEB;
+      rows_r2s<DK>(nK, rk, tid);
+      tr_r2s<DV>(nK + RowTile<DK>::BYTES, rv, tid);
+      if (t + 2 < nt) {
+        rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, (t + 2) * KVB, hoff, a.d, tid);
+        tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, (t + 2) * KVB, tid);
+      }
     }
     if (ragged && t == nt - 1) {
 #pragma unroll
@@ -601,7 +643,7 @@ int set_smem(KernelT k, int bytes) {
 
 template <int DK, int DV, int NF>
 int fwd_t(const AttnArgs& a, hipStream_t st) {
-  constexpr int smem = RowTile<DK>::BYTES + TrTile<DV>::BYTES;
+  constexpr int smem = 2 * (RowTile<DK>::BYTES + TrTile<DV>::BYTES);
   static bool once = false;
   if (!once) {
     if (set_smem(attn_fwd_kernel<DK, DV, NF, false>, smem)) return -2;

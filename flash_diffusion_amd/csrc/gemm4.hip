@@ -18,7 +18,7 @@
 
 namespace {
 
-template <int MODE>
+template <int MODE, bool GEGLU>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256, BN = 320;
@@ -241,17 +241,17 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       cslot ^= 1;
     }
     // the next item's first tile is landing meanwhile
-    tile_epilogue<NF, MF>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+    tile_epilogue<NF, MF, GEGLU ? 1 : 0>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
   }
   wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
 }
 
-template <int MODE>
+template <int MODE, bool GEGLU>
 int launch4_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   constexpr int smem = 2 * (256 + 320) * 128;
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int items = (a.M / 256) * (a.N / 320) * (a.splitk > 1 ? a.splitk : 1);
@@ -266,8 +266,8 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   }
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(stream, PROF_GEMM3 + MODE * 2, gemm_flops(a));
-  hipLaunchKernelGGL((gemm4_kernel<MODE>), grid, dim3(512), smem, stream, a);
+  if (prof) fdmi_prof_begin(stream, PROF_GEMM4 + MODE, gemm_flops(a));
+  hipLaunchKernelGGL((gemm4_kernel<MODE, GEGLU>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -278,9 +278,13 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
 bool gemm4_eligible(const GemmArgs& a) {
   if ((a.K & 63) != 0 || (a.M & 255) != 0 || (a.N % 320) != 0) return false;
   if (a.mode == GEMM_CONV && ((a.Cin & 63) != 0 || a.Hout > 2048 || a.Wout > 2048)) return false;
-  if (a.act == ACT_GEGLU && !fdmi_tune_get(9)) return false;  // epilogue-bound at the UNet's K
+  if (a.act == ACT_GEGLU && (a.mode != GEMM_ROW || a.accum_atomic || fdmi_tune_get(9))) return false;
   return true;
 }
 int launch_gemm4(const GemmArgs& a, hipStream_t stream) {
-  return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW>(a, stream) : launch4_t<GEMM_CONV>(a, stream);
+  if (a.act == ACT_GEGLU) {
+    FDMI_CHECK(a.mode == GEMM_ROW && a.splitk <= 1 && !a.accum_atomic, "gemm4: GEGLU needs a plain row GEMM");
+    return launch4_t<GEMM_ROW, true>(a, stream);
+  }
+  return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false>(a, stream) : launch4_t<GEMM_CONV, false>(a, stream);
 }

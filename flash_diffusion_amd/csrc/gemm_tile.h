@@ -144,9 +144,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 
 // epilogue of one wave: rows mw + mf*16 + j, columns nw + nf*16 + g*4 .. +3; z = split-K slab index
-template <int NF, int MF>
+// EPI selects the compiled paths: 0 = everything but GEGLU, 1 = GEGLU only, 2 = all
+template <int NF, int MF, int EPI = 2>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw, int z, f32x4 (&acc)[NF][MF], int g, int j) {
-  if (a.accum_atomic) {
+  if (EPI != 1 && a.accum_atomic) {
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
@@ -164,7 +165,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
   // wide (8 columns per lane) path needs 8-element alignment of every row pointer involved
   const bool wide = (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
                     (!a.rowvec || (a.rowvec_ld & 7) == 0) && (!a.preact || (a.ldp & 7) == 0);
-  if (a.splitk > 1) {  // raw partial sums -> this split's fp32 slab (plain stores, deterministic)
+  if (EPI != 1 && a.splitk > 1) {  // raw partial sums -> this split's fp32 slab (plain stores, deterministic)
     float* slab = a.ws + (int64_t)z * a.M * a.N;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
@@ -185,7 +186,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
       }
     return;
   }
-  if (a.act == ACT_GEGLU) {
+  if (EPI != 0 && (EPI == 1 || a.act == ACT_GEGLU)) {
     // fragment 2q holds 16 value columns, fragment 2q+1 the matching 16 gate columns
     const int Nout = a.N >> 1;
     constexpr int NQUAD = NF / 4;  // groups of two (value, gate) pairs that can take the 8-wide path
@@ -224,6 +225,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
             for (int r = 0; r < 8; ++r) o[r] = val[r] * gelu_f(gate[r]);
             epi_store8(a, ACT_NONE, m, (nw >> 1) + t * 32 + q * 16 + (g >> 1) * 8, o);
           }
+          __builtin_amdgcn_sched_barrier(0);  // keep the next block's address math / loads from piling up registers
         }
       }
     }
@@ -251,10 +253,12 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
           for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
           epi_store3(a, ACT_NONE, m, (nw >> 1) + q * 16 + g * 4, Nout, o);
         }
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
     return;
   }
+  if constexpr (EPI == 1) return;
   if (wide) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {

@@ -36,6 +36,7 @@ def conv(B, hw, ci, co, ft, ups=0):
 
 
 def main():
+    only = sys.argv[1] if len(sys.argv) > 1 else ''
     rows = []
     for B in (16, 32):
         for (hw, C) in [(64, 320), (32, 640), (16, 1280), (8, 1280)]:
@@ -49,6 +50,8 @@ def main():
     print(f"{'shape':40s} {'auto':>8s} {'t160':>8s} {'t128':>8s} {'t320':>8s}  auto TF/s")
     tot = [0, 0]
     for name, fn, fl in rows:
+        if only and only not in name:
+            continue
         ts = [fn(ft) for ft in (0, T160, T128, T320)]
         best = min(t for t in ts[1:] if t == t)
         tot[0] += ts[0]; tot[1] += min(best, ts[0])
