@@ -205,6 +205,27 @@ __global__ __launch_bounds__(256) void cast_transpose_kernel(const float* w, bf1
   }
 }
 
+// the same for EVERY LoRA matrix of a plan in one launch: one block per 64x64 tile of the job table
+__global__ __launch_bounds__(256) void cast_transpose_jobs_kernel(const CastJob* jobs) {
+  __shared__ bf16_t tile[64][66];
+  const CastJob jb = jobs[blockIdx.x];
+  const int r0 = jb.r0, c0 = jb.c0, rows = jb.rows, cols = jb.cols;
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int r = i >> 6, c = i & 63;
+    bf16_t v = 0;
+    if (r0 + r < rows && c0 + c < cols) {
+      v = f2bf(jb.src[(int64_t)(r0 + r) * cols + c0 + c]);
+      jb.dst[(int64_t)(r0 + r) * cols + c0 + c] = v;
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+    const int c = i >> 6, r = i & 63;
+    if (c0 + c < cols && r0 + r < rows) jb.dstT[(int64_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+  }
+}
+
 // fused AdamW (torch.optim.AdamW semantics, decoupled weight decay, bias correction)
 __global__ __launch_bounds__(256) void adamw_kernel(float* p, const float* g, float* m, float* v, int64_t n,
                                                     float lr, float b1, float b2, float eps, float wd,
@@ -294,6 +315,12 @@ int launch_transpose2d_pad(const bf16_t* in, int64_t ldi, bf16_t* out, int64_t l
 }
 int launch_pad_cols(const bf16_t* src, int cols, bf16_t* dst, int cols_pad, int64_t rows, hipStream_t st) {
   LAUNCH(pad_cols_kernel, rows * cols_pad, src, cols, dst, cols_pad, rows)
+}
+int launch_cast_transpose_jobs(const CastJob* jobs, int njobs, hipStream_t st) {
+  if (njobs <= 0) return 0;
+  hipLaunchKernelGGL(cast_transpose_jobs_kernel, dim3(njobs), dim3(256), 0, st, jobs);
+  FDMI_HIP(hipGetLastError());
+  return 0;
 }
 int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int cols, hipStream_t st) {
   hipLaunchKernelGGL(cast_transpose_kernel, dim3(cdiv(rows, 64), cdiv(cols, 64)), dim3(256), 0, st, w, wb, wtb,

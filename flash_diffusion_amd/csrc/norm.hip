@@ -174,10 +174,10 @@ static int gn_rows_per_block(int B, int HW) {
 
 int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta, float* stats,
                          bf16_t* y, int B, int HW, int C, int G, float eps, int silu,
-                         hipStream_t st) {
+                         hipStream_t st, bool stats_zeroed) {
   FDMI_CHECK(C % 8 == 0 && C % G == 0 && G <= 32 && C <= 4096, "groupnorm: unsupported C/G");
   GnArgs a{x, nullptr, gamma, beta, stats, nullptr, y, B, HW, C, G, eps, silu, 0};
-  FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
+  if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
   hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
@@ -187,10 +187,10 @@ int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
 
 int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta,
                          const float* stats, float* bstats, bf16_t* dx, int B, int HW, int C, int G,
-                         float eps, int silu, int accumulate, hipStream_t st) {
+                         float eps, int silu, int accumulate, hipStream_t st, bool stats_zeroed) {
   FDMI_CHECK(C % 8 == 0 && C % G == 0 && G <= 32 && C <= 4096, "groupnorm: unsupported C/G");
   GnArgs a{x, dy, gamma, beta, (float*)stats, bstats, dx, B, HW, C, G, eps, silu, accumulate};
-  FDMI_HIP(hipMemsetAsync(bstats, 0, (size_t)B * G * 2 * sizeof(float), st));
+  if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(bstats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
   hipLaunchKernelGGL(gn_reduce_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);

@@ -111,6 +111,16 @@ struct Run {
   std::vector<std::function<int(Exec&)>> tape;
   bool save = false;
   hipStream_t st = nullptr;
+  // pool of fp32 accumulators (GroupNorm statistics, forward and backward) cleared by ONE memset per forward
+  char* zpool = nullptr;
+  size_t zoff = 0, zcap = 0;
+  float* zalloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    if (!zpool || zoff + bytes > zcap) return nullptr;
+    float* p = (float*)(zpool + zoff);
+    zoff += bytes;
+    return p;
+  }
   T* x0 = nullptr;   // NHWC input (grad wrt the sample)
   T* out = nullptr;  // output tensor
   int outC = 0;
@@ -138,11 +148,15 @@ struct fdmi_unet {
   std::map<std::string, LinearW*> lora_targets;
   std::vector<void*> owned;  // hipMalloc'ed packed weights
   std::vector<Lora*> loras;
+  CastJob* cast_jobs = nullptr;   // device table of the LoRA refresh (rebuilt when a master pointer changes)
+  int n_cast_jobs = 0;
+  bool cast_dirty = true;
   Run runs[8];
   double last_flops = 0;     // algorithmic MFMA flops of the last forward/backward call
 
   ~fdmi_unet() {
     for (void* p : owned) (void)hipFree(p);
+    if (cast_jobs) (void)hipFree(cast_jobs);
   }
 };
 
@@ -462,11 +476,24 @@ struct Exec {
 
   int lora_refresh() {
     if (R.dry()) return 0;
-    for (Lora* l : U->loras) {
-      RET_IF(launch_cast_transpose(l->A_master, l->A, l->AT, l->r, l->in, st));
-      RET_IF(launch_cast_transpose(l->B_master, l->B, l->BT, l->out, l->r, st));
+    if (U->cast_dirty) {  // (re)build the tile table of the one-launch refresh
+      std::vector<CastJob> jobs;
+      auto add = [&](const float* src, bf16_t* dst, bf16_t* dstT, int rows, int cols) {
+        for (int r0 = 0; r0 < rows; r0 += 64)
+          for (int c0 = 0; c0 < cols; c0 += 64) jobs.push_back(CastJob{src, dst, dstT, rows, cols, r0, c0});
+      };
+      for (Lora* l : U->loras) {
+        add(l->A_master, l->A, l->AT, l->r, l->in);
+        add(l->B_master, l->B, l->BT, l->out, l->r);
+      }
+      if (U->cast_jobs) FDMI_HIP(hipFree(U->cast_jobs));
+      U->cast_jobs = nullptr;
+      FDMI_HIP(hipMalloc((void**)&U->cast_jobs, jobs.size() * sizeof(CastJob)));
+      FDMI_HIP(hipMemcpy(U->cast_jobs, jobs.data(), jobs.size() * sizeof(CastJob), hipMemcpyHostToDevice));
+      U->n_cast_jobs = (int)jobs.size();
+      U->cast_dirty = false;
     }
-    return 0;
+    return launch_cast_transpose_jobs(U->cast_jobs, U->n_cast_jobs, st);
   }
 
   // transposed copy [cols][rows_pad] of a token tensor (cached), zero padded
@@ -608,19 +635,24 @@ struct Exec {
 
   T* groupnorm(T* x, Norm& n, float eps, int silu) {
     T* y = R.mk(x->rows, x->cols, x->B, x->H, x->W);
-    float* stats = (float*)R.arena.alloc((size_t)x->B * U->cfg.groups * 2 * sizeof(float));
+    const size_t sbytes = (size_t)x->B * U->cfg.groups * 2 * sizeof(float);
+    float* stats = R.zalloc(sbytes);
+    const bool zeroed = stats != nullptr;
+    if (!stats) stats = (float*)R.arena.alloc(sbytes);
     if (!y || !stats) return nullptr;
     const int HW = x->H * x->W, G = U->cfg.groups;
-    if (!R.dry()) NULL_IF(launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st));
+    if (!R.dry()) NULL_IF(launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st, zeroed));
     if (R.save) {
       R.tape.push_back([x, y, &n, stats, HW, G, eps, silu](Exec& E) -> int {
         if (!y->g) return 0;
         bf16_t* dx = E.grad_of(x);
-        float* bst = (float*)E.R.arena.alloc((size_t)x->B * G * 2 * sizeof(float));
+        float* bst = E.R.zalloc((size_t)x->B * G * 2 * sizeof(float));
+        const bool bzeroed = bst != nullptr;
+        if (!bst) bst = (float*)E.R.arena.alloc((size_t)x->B * G * 2 * sizeof(float));
         FDMI_CHECK(dx && bst, "unet: workspace exhausted (grad)");
         if (!E.R.dry())
           RET_IF(launch_groupnorm_bwd(x->p, y->g, n.gamma, n.beta, stats, bst, dx, x->B, HW, x->cols, G, eps, silu,
-                                      x->ginit ? 1 : 0, E.st));
+                                      x->ginit ? 1 : 0, E.st, bzeroed));
         x->ginit = true;
         return 0;
       });
@@ -799,6 +831,14 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   const bool inter = (flags & FDMI_UNET_INTERMEDIATE) != 0;
   hipStream_t st = R.st;
   if (!U->loras.empty()) RET_IF(E.lora_refresh());
+  {  // accumulator pool: every GroupNorm of the plan, forward + backward, 2 * B * groups floats each
+    const size_t per = (((size_t)B * c.groups * 2 * sizeof(float)) + 255) & ~(size_t)255;
+    R.zcap = per * 2 * 96;
+    R.zoff = 0;
+    R.zpool = (char*)R.arena.alloc(R.zcap);
+    FAIL_IF_NULL(R.zpool);
+    if (!R.dry()) FDMI_HIP(hipMemsetAsync(R.zpool, 0, R.zcap, st));
+  }
   const int cin_pad = U->conv_in.Cin_pad;
   // ---- inputs ----
   T* x0 = R.mk((int64_t)B * H * W, cin_pad, B, H, W);
@@ -965,6 +1005,7 @@ int fdmi_unet_set_lora(fdmi_unet* U, const char* target, const float* A, const f
   FDMI_CHECK(rank > 0 && rank % 8 == 0, "unet: LoRA rank must be a positive multiple of 8");
   Lora& l = it->second->lora;
   const Weight& w = it->second->w;
+  if (l.A_master != A || l.B_master != B) U->cast_dirty = true;
   l.A_master = A; l.B_master = B; l.A_grad = A_grad; l.B_grad = B_grad;
   if (!l.on) {
     l.r = rank; l.in = w.K; l.out = w.N;
