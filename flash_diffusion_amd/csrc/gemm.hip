@@ -494,7 +494,11 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
       }
     }
   };
-  if (gemm3_eligible(a)) consider(1, 256, gemm3_pick_bn(a), 256, 3.4);
+  if (gemm3_eligible(a)) {
+    consider(1, 256, gemm3_pick_bn(a), 256, 3.4);
+    // the other column width may quantise better (e.g. M=4096, N=1280: 128 tiles of 256x160 vs 160 of 256x128)
+    if (a.act != ACT_GEGLU && gemm3_pick_bn(a) == 160 && (a.N % 128) == 0) consider(1, 256, 128, 256, 3.4);
+  }
   if (gemm4_eligible(a)) consider(2, 256, 320, 256, 4.8);
   const bool geglu = a.act == ACT_GEGLU;
   consider(0, 128, 128, 512, 1.05);

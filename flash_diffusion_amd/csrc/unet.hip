@@ -81,6 +81,10 @@ struct TBlockW {
   Norm ln1, ln2, ln3;
   AttnW a1, a2;
   Weight ff1, ff2;
+  // cross-attention K / V / V^T of a fixed context (FDMI_UNET_CTX_FILL / _REUSE), plan-owned
+  bf16_t *ck = nullptr, *cv = nullptr, *cvt = nullptr;
+  int64_t c_rows = 0, c_vt = 0;
+  bool c_valid = false;
 };
 struct TransformerW {
   Norm gn;
@@ -130,6 +134,13 @@ struct Run {
     t->rows = rows; t->cols = cols; t->B = B; t->H = H; t->W = W;
     t->p = (bf16_t*)arena.alloc((size_t)rows * cols * 2);
     return t->p ? t : nullptr;
+  }
+  // tensor header over caller-provided storage (no arena allocation)
+  T* wrap(bf16_t* p, int64_t rows, int cols) {
+    tensors.emplace_back();
+    T* t = &tensors.back();
+    t->rows = rows; t->cols = cols; t->p = p;
+    return t;
   }
   bool dry() const { return arena.dry; }
 };
@@ -445,6 +456,7 @@ struct Exec {
   Run& R;
   hipStream_t st;
   double flops = 0;
+  int ctx_mode = 0;  // 0: none, 1: fill the cross-attention K/V cache, 2: reuse it (FDMI_UNET_CTX_*)
 
   bf16_t* grad_of(T* t) {  // lazily allocate the gradient buffer
     if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * 2);
@@ -678,12 +690,13 @@ struct Exec {
     return y;
   }
 
-  T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv) {
+  // vt_ext: caller-owned V^T buffer; vt_ready: it already holds the transposed V (cached context)
+  T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, bf16_t* vt_ext = nullptr, bool vt_ready = false) {
     const int d = q->cols / H;
     T* o = R.mk(q->rows, q->cols, q->B, q->H, q->W);
     const int64_t tr_kv = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Skv);
     const int64_t tr_q = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Sq);
-    bf16_t* VT = (bf16_t*)R.arena.alloc((size_t)tr_kv * 2);
+    bf16_t* VT = vt_ext ? vt_ext : (bf16_t*)R.arena.alloc((size_t)tr_kv * 2);
     float* lse = R.save ? (float*)R.arena.alloc((size_t)Bn * H * Sq * 4) : nullptr;
     if (!o || !VT || (R.save && !lse)) return nullptr;
     AttnArgs a{};
@@ -692,7 +705,7 @@ struct Exec {
     a.B = Bn; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.f / sqrtf((float)d);
     flops += 4.0 * Bn * H * (double)Sq * Skv * d;
     if (!R.dry()) {
-      NULL_IF(launch_transpose_heads(v->p, v->cols, VT, Bn, H, Skv, d, st, 1));
+      if (!vt_ready) NULL_IF(launch_transpose_heads(v->p, v->cols, VT, Bn, H, Skv, d, st, 1));
       NULL_IF(launch_attn_fwd(a, st));
     }
     if (R.save) {
@@ -800,10 +813,32 @@ struct Exec {
       n = layernorm(h, b.ln2);
       if (!n) return nullptr;
       q = linear(n, b.a2.q);
-      k = linear_w(ctx, b.a2.k.w, nullptr, b.a2.k.lora.on ? &b.a2.k.lora : nullptr, false);
-      v = linear_w(ctx, b.a2.v.w, nullptr, b.a2.v.lora.on ? &b.a2.v.lora : nullptr, false);
-      if (!q || !k || !v) return nullptr;
-      o = attention(q, k, v, Bn, t.heads, S, L);
+      const bool cacheable = ctx_mode != 0 && !R.save && !b.a2.k.lora.on && !b.a2.v.lora.on;
+      if (cacheable) {
+        const int Cc = b.a2.k.w.N, dd = Cc / t.heads;
+        const int64_t rows = (int64_t)Bn * L, vt = (int64_t)Bn * t.heads * attn_dvpad(dd) * attn_spad(L);
+        if (!R.dry() && (b.c_rows != rows || b.c_vt != vt || !b.ck)) {  // (re)size the plan-owned buffers
+          NULL_IF(dmalloc(U, &b.ck, (size_t)rows * Cc));
+          NULL_IF(dmalloc(U, &b.cv, (size_t)rows * Cc));
+          NULL_IF(dmalloc(U, &b.cvt, (size_t)vt));
+          b.c_rows = rows; b.c_vt = vt; b.c_valid = false;
+        }
+        const bool reuse = ctx_mode == 2 && b.c_valid;
+        k = R.wrap(b.ck, rows, Cc);
+        v = R.wrap(b.cv, rows, Cc);
+        if (!q || !k || !v) return nullptr;
+        if (!reuse) {
+          NULL_IF(gemm_rows(ctx->p, ctx->cols, rows, b.a2.k.w.w, Cc, b.a2.k.w.K, b.a2.k.w.bias, k->p, Cc, nullptr, 0));
+          NULL_IF(gemm_rows(ctx->p, ctx->cols, rows, b.a2.v.w.w, Cc, b.a2.v.w.K, b.a2.v.w.bias, v->p, Cc, nullptr, 0));
+        }
+        o = attention(q, k, v, Bn, t.heads, S, L, R.dry() ? nullptr : b.cvt, reuse);
+        if (!R.dry()) b.c_valid = true;
+      } else {
+        k = linear_w(ctx, b.a2.k.w, nullptr, b.a2.k.lora.on ? &b.a2.k.lora : nullptr, false);
+        v = linear_w(ctx, b.a2.v.w, nullptr, b.a2.v.lora.on ? &b.a2.v.lora : nullptr, false);
+        if (!q || !k || !v) return nullptr;
+        o = attention(q, k, v, Bn, t.heads, S, L);
+      }
       if (!o) return nullptr;
       h = linear(o, b.a2.o, h);
       if (!h) return nullptr;
@@ -824,6 +859,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
                 float* out, int B, int H, int W, int L, int flags) {
   const fdmi_unet_config& c = U->cfg;
   Exec E{U, R, R.st};
+  E.ctx_mode = (flags & FDMI_UNET_CTX_REUSE) ? 2 : ((flags & FDMI_UNET_CTX_FILL) ? 1 : 0);
   R.tensors.clear();
   R.tape.clear();
   R.arena.off = 0;

@@ -18,6 +18,8 @@ from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -290,7 +292,7 @@ class FlashDiffusion(nn.Module):
             return None
         return {"cond": {k: torch.cat([cond["cond"][k], uncond["cond"][k]], dim=0) for k in cond["cond"]}}
 
-    def _teacher_cfg(self, x, tt, cond, uncond, cfg_cond, *args, **kwargs):
+    def _teacher_cfg(self, x, tt, cond, uncond, cfg_cond, *args, ctx_cache=None, **kwargs):
         """The reference evaluates the frozen teacher twice per step, once per conditioning (FD:297-313).
         Every layer of the UNet is per-sample (GroupNorm included), so ONE call on the 2B batch
         [x | x] with [cond | uncond] gives the same two predictions with half the launches and twice
@@ -301,6 +303,9 @@ class FlashDiffusion(nn.Module):
             e_u = self.teacher_denoiser(sample=x, timestep=tt, conditioning=uncond,
                                         down_intrablock_additional_residuals=None, *args, **kwargs)
             return e_c, e_u
+        if (ctx_cache is not None and getattr(self.teacher_denoiser, "supports_ctx_cache", False)
+                and not os.environ.get("FDMI_NO_CTX_CACHE")):
+            kwargs = dict(kwargs, ctx_cache=ctx_cache)  # same [cond | uncond] context at every step of this loop
         e = self.teacher_denoiser(sample=torch.cat([x, x], dim=0), timestep=torch.cat([tt, tt], dim=0),
                                   conditioning=cfg_cond, down_intrablock_additional_residuals=None, *args, **kwargs)
         e_c, e_u = e.chunk(2, dim=0)
@@ -360,10 +365,10 @@ class FlashDiffusion(nn.Module):
             x = x_init
             fused = hasattr(sch, "fused_cfg_step")
             cfg_cond = self._cat_cond(conditioning, uncond)
-            for t in sch.timesteps[si:]:
+            for it, t in enumerate(sch.timesteps[si:]):
                 x_ = sch.scale_model_input(x, t)
                 e_c, e_u = self._teacher_cfg(x_, torch.full((B,), float(t), device=z.device), conditioning, uncond,
-                                             cfg_cond, *args, **kwargs)
+                                             cfg_cond, *args, ctx_cache="fill" if it == 0 else "reuse", **kwargs)
                 if fused:
                     x = sch.fused_cfg_step(e_c, e_u, g, t, x)
                 else:

@@ -19,6 +19,7 @@ from . import _lib
 from ._lib import check, f32, i32, i64, ptr, stream_ptr, vp
 
 FDMI_UNET_SAVE, FDMI_UNET_INTERMEDIATE, FDMI_UNET_INPUT_GRAD = 1, 2, 4
+FDMI_UNET_CTX_FILL, FDMI_UNET_CTX_REUSE = 8, 16
 
 
 from ._lib import UNetCfg  # noqa: E402  (C struct fdmi_unet_config)
@@ -162,6 +163,7 @@ class _UNetFn(torch.autograd.Function):
 class MiUNet2DConditionModel(nn.Module):
     """See module docstring.  Unknown diffusers kwargs are accepted and ignored when they carry the
     reference's values (None / defaults); unsupported non-default values raise."""
+    supports_ctx_cache = True  # forward(..., ctx_cache="fill"|"reuse"): see FDMI_UNET_CTX_* in include/fdmi.h
 
     def __init__(self, in_channels=4, out_channels=4, down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
                  up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3, block_out_channels=(320, 640, 1280, 1280),
@@ -415,6 +417,11 @@ class MiUNet2DConditionModel(nn.Module):
             t = t.expand(B)
         t = t.contiguous()
         flags = FDMI_UNET_INTERMEDIATE if return_intermediate else 0
+        # frozen-teacher loops: the caller promises the context equals the one of the last ctx_cache="fill" call, so
+        # the cross-attention K/V projections are read back instead of recomputed (include/fdmi.h FDMI_UNET_CTX_*)
+        ctx_cache = kwargs.pop("ctx_cache", None)
+        if ctx_cache is not None and not self.lora_rank:
+            flags |= FDMI_UNET_CTX_FILL if ctx_cache == "fill" else FDMI_UNET_CTX_REUSE
         lora = self.lora_parameters() if self.lora_rank else []
         need_grad = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in lora))
         sample = sample.float().contiguous()

@@ -153,7 +153,12 @@ typedef struct fdmi_unet_config {
 } fdmi_unet_config;
 enum { FDMI_UNET_SAVE = 1,          /* record what backward needs (student / GAN backbone) */
        FDMI_UNET_INTERMEDIATE = 2,  /* return_intermediate=True: output the mid-block features */
-       FDMI_UNET_INPUT_GRAD = 4     /* (workspace query only) backward will also produce d/d sample */ };
+       FDMI_UNET_INPUT_GRAD = 4,    /* (workspace query only) backward will also produce d/d sample */
+       /* Frozen-teacher loops call the plan several times with the SAME context (text embeddings): the
+          cross-attention K/V projections (and their head-transposed copies) depend on nothing else.
+          CTX_FILL computes them into plan-owned buffers, CTX_REUSE (same B, L, ctx contents; no SAVE, no
+          LoRA on those projections) reads them back instead of recomputing. */
+       FDMI_UNET_CTX_FILL = 8, FDMI_UNET_CTX_REUSE = 16 };
 
 fdmi_unet* fdmi_unet_create(const fdmi_unet_config* cfg);   /* NULL on error */
 void fdmi_unet_destroy(fdmi_unet* u);
