@@ -79,10 +79,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU: the HIP path has no CPU fallback"
-    torch.cuda.set_device(local)
+    # one process per GPU; (dev aid) FDMI_BENCH_BACKEND=gloo lets several ranks share one GPU to exercise the
+    # multi-process path on a single-GPU box -- the driver's runs use nccl (= RCCL) with one GPU per rank
+    backend = os.environ.get("FDMI_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local % torch.cuda.device_count() if backend != "nccl" else local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from flash_diffusion_amd import _lib, unet as _unet
@@ -130,13 +133,16 @@ def main():
     value = B * world * args.steps / dt
     step_flops = flops[0] / args.steps
 
-    # ---- roofline leg: per-launch HIP events on the launch stream, one extra (untimed) step ----
+    # ---- roofline leg: per-launch HIP events on the launch stream, one extra (untimed) step.  EVERY rank runs the
+    # step (it contains the gradient all-reduce: a collective only rank 0 entered would hang the job); only rank 0
+    # records events ----
     roofline = None
+    L = _lib.lib()
     if rank == 0:
-        L = _lib.lib()
         L.fdmi_prof_enable(1)
-        run(1)
-        pipe.finish()
+    run(1)
+    pipe.finish()
+    if rank == 0:
         L.fdmi_prof_enable(0)
         nb = 24
         ms = (C.c_double * nb)()

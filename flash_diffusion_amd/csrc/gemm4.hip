@@ -209,6 +209,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       // hand-over: this wave's pieces of tile k have landed and its reads of the other slot are done
       wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");  // (compiler) no LDS read of the new tile may be scheduled above the barrier
       // fragments of k-step 0 and the head of the W ring
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) af[0][mf] = lds_a(0, mf, cslot);
