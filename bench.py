@@ -169,6 +169,25 @@ def main():
                     "whole_step": {"algorithmic_tflop_per_step_per_gpu": step_flops / 1e12,
                                    "achieved_tflops_per_gpu": step_flops / (ms_per_step * 1e-3) / 1e12,
                                    "frac_of_peak": step_flops / (ms_per_step * 1e-3) / PEAK_BF16}}
+    # ---- secondary: the student's 4-step LCM sampler, FlashDiffusion.sample, same UNet kernels ----
+    sampler = None
+    if rank == 0 and args.arch != "tiny":
+        from flash_diffusion_amd.schedulers import LCMScheduler
+        model.sampling_noise_scheduler = LCMScheduler()
+        zb = batches[0]
+        ci = {k: v for k, v in zb.items() if k != "image"}
+        zz = torch.randn_like(zb["image"])
+        for _ in range(2):
+            model.sample(zz, num_steps=4, guidance_scale=1.0, conditioner_inputs=dict(ci))
+        torch.cuda.synchronize()
+        ts0 = time.perf_counter()
+        nrep = 3
+        for _ in range(nrep):
+            model.sample(zz, num_steps=4, guidance_scale=1.0, conditioner_inputs=dict(ci))
+        torch.cuda.synchronize()
+        dts = (time.perf_counter() - ts0) / nrep
+        sampler = {"metric": "student few-step sampling, latents/s (4 LCM steps = 4 UNet evaluations, guidance 1.0, "
+                             f"B={B}, LoRA r{rank_r} unmerged)", "value": B / dts, "unit": "images/s", "ms_per_batch": dts * 1e3}
     if world > 1:
         dist.barrier()
     cpu = None
@@ -184,7 +203,7 @@ def main():
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world},
-            "roofline": roofline, "cpu_baseline": cpu,
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler},
         }
         print(json.dumps(line))
     if world > 1:

@@ -17,6 +17,8 @@ from copy import deepcopy
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
 
+import copy
+
 import numpy as np
 import os
 
@@ -197,6 +199,10 @@ def gaussian_mixture_pmf(K, locs, var, mode_probs):
     return p / torch.sum(p)
 
 
+def ss_name(s):
+    return s.__class__.__name__
+
+
 class FlashDiffusion(nn.Module):
     def __init__(self, config: FlashDiffusionConfig, student_denoiser, teacher_denoiser=None,
                  teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
@@ -291,6 +297,112 @@ class FlashDiffusion(nn.Module):
         if cond is None or uncond is None or set(cond["cond"]) != set(uncond["cond"]):
             return None
         return {"cond": {k: torch.cat([cond["cond"][k], uncond["cond"][k]], dim=0) for k in cond["cond"]}}
+
+    # ---- few-step sampler (FD:754-915) and its logging wrapper (FD:917-1019): SURVEY 8(f) "next" row 1 ----
+    def _cfg_pair(self, net, x, tt, cond, uncond, g, ctx_cache=None):
+        """g * eps(cond) + (1 - g) * eps(uncond).  The reference makes two calls per step (FD:838-858); every layer is
+        per-sample, so ONE call on [x | x] with [cond | uncond] gives the same two predictions.  g == 1 multiplies the
+        unconditional branch by zero: it is skipped."""
+        if float(g) == 1.0:
+            return net(sample=x, timestep=tt, conditioning=cond, down_intrablock_additional_residuals=None)
+        both = self._cat_cond(cond, uncond)
+        if both is None:  # conditionings with different keys cannot share a batch: two calls, as the reference does
+            e_c = net(sample=x, timestep=tt, conditioning=cond, down_intrablock_additional_residuals=None)
+            e_u = net(sample=x, timestep=tt, conditioning=uncond, down_intrablock_additional_residuals=None)
+            return ops.axpby(e_c.contiguous(), float(g), e_u.contiguous(), 1.0 - float(g))
+        kw = {}
+        if ctx_cache is not None and getattr(net, "supports_ctx_cache", False) and not getattr(net, "lora_rank", 0):
+            kw["ctx_cache"] = ctx_cache
+        e = net(sample=torch.cat([x, x], dim=0), timestep=torch.cat([tt, tt], dim=0),
+                conditioning=both, down_intrablock_additional_residuals=None, **kw)
+        e_c, e_u = e.chunk(2, dim=0)
+        return ops.axpby(e_c.contiguous(), float(g), e_u.contiguous(), 1.0 - float(g))
+
+    @torch.no_grad()
+    def sample(self, z, num_steps=20, guidance_scale=1.0, teacher_guidance_scale=5.0, conditioner_inputs=None,
+               uncond_conditioner_inputs=None, max_samples=None, verbose=False, log_teacher_samples=False,
+               adapter_conditioning_scale=1.0):
+        """Same contract as the reference (FD:755-915) with vae = adapter = None: returns (samples, teacher_samples or
+        None) as latents.  Student: `sampling_noise_scheduler` (LCM) on the teacher scheduler's schedule when it accepts
+        custom timesteps; teacher (optional): `teacher_sampling_noise_scheduler` with its own CFG scale."""
+        assert self.sampling_noise_scheduler is not None, "sample() needs a sampling_noise_scheduler (e.g. LCMScheduler)"
+        self.teacher_noise_scheduler.set_timesteps(num_steps)
+        ss = self.sampling_noise_scheduler
+        try:
+            ss.set_timesteps(timesteps=self.teacher_noise_scheduler.timesteps)
+        except Exception:
+            ss.set_timesteps(num_steps)
+        sample = z
+        cond = self._get_conditioning(conditioner_inputs, set_ucg_rate_zero=True, device=z.device)
+        if uncond_conditioner_inputs is not None:
+            uncond = self._get_conditioning(uncond_conditioner_inputs, set_ucg_rate_zero=True, device=z.device)
+        else:
+            uncond = self._get_conditioning(conditioner_inputs, ucg_keys=self.ucg_keys, device=z.device)
+        if max_samples is not None:
+            sample = sample[:max_samples]
+            if cond:
+                cond["cond"] = {k: v[:max_samples] for k, v in cond["cond"].items()}
+                uncond["cond"] = {k: v[:max_samples] for k, v in uncond["cond"].items()}
+        sample_init = sample
+        sample = (sample * ss.init_noise_sigma).float().contiguous()
+        for t in ss.timesteps:
+            x = ss.scale_model_input(sample, t)
+            tt = torch.full((x.shape[0],), float(t), device=z.device)
+            e = self._cfg_pair(self.student_denoiser, x, tt, cond, uncond, guidance_scale)
+            sample = ss.step(e, t, sample, return_dict=False)[0]
+        decoded_ref = None
+        if log_teacher_samples:
+            ts = self.teacher_sampling_noise_scheduler
+            assert ts is not None, "log_teacher_samples needs a teacher_sampling_noise_scheduler"
+            ts.set_timesteps(num_steps)
+            ref = (sample_init * ts.init_noise_sigma).float().contiguous()
+            for it, t in enumerate(ts.timesteps):
+                x = ts.scale_model_input(ref, t)
+                tt = torch.full((x.shape[0],), float(t), device=z.device)
+                e = self._cfg_pair(self.teacher_denoiser, x, tt, cond, uncond, teacher_guidance_scale,
+                                   ctx_cache="fill" if it == 0 else "reuse")
+                ref = ts.step(e, t, ref, return_dict=False)[0]
+                decoded_ref = ref
+        return sample, decoded_ref
+
+    def log_samples(self, batch, input_shape=None, guidance_scale=1.0, teacher_guidance_scale=5.0, max_samples=8,
+                    num_steps=20, device="cpu", log_teacher_samples=False, conditioner_inputs=None,
+                    conditioner_uncond_inputs=None, adapter_conditioning_scale=1.0):
+        """FD:917-1019 (no VAE: `input_shape` = latent shape is mandatory, as in the reference's ValueError branch)."""
+        if isinstance(num_steps, int):
+            num_steps = [num_steps]
+        logs = {}
+        N = max_samples
+        if batch is not None:
+            N = min(N, min(len(batch[k]) for k in batch))
+        if conditioner_inputs is not None:
+            m = min(len(conditioner_inputs[k]) for k in conditioner_inputs)
+            conditioner_inputs.update({k: v.to(device) for k, v in conditioner_inputs.items() if torch.is_tensor(v)})
+            batch.update(conditioner_inputs)
+            N = min(N, m)
+        if conditioner_uncond_inputs is not None:
+            m = min(len(conditioner_uncond_inputs[k]) for k in conditioner_uncond_inputs)
+            conditioner_uncond_inputs.update({k: v.to(device) for k, v in conditioner_uncond_inputs.items()
+                                              if torch.is_tensor(v)})
+            batch_uncond = copy.deepcopy(batch)
+            batch_uncond.update(conditioner_uncond_inputs)
+            N = min(N, m)
+        else:
+            batch_uncond = None
+        if input_shape is None:
+            raise ValueError("input_shape must be passed when no VAE is used in the model")
+        for n in num_steps:
+            z = torch.randn(N, *input_shape).to(device)
+            samples, samples_ref = self.sample(z, num_steps=n, conditioner_inputs=batch,
+                                               uncond_conditioner_inputs=batch_uncond, guidance_scale=guidance_scale,
+                                               teacher_guidance_scale=teacher_guidance_scale, max_samples=N,
+                                               log_teacher_samples=log_teacher_samples,
+                                               adapter_conditioning_scale=adapter_conditioning_scale)
+            logs[f"samples_{n}_steps/{ss_name(self.sampling_noise_scheduler)}_{guidance_scale}_cfg/student"] = samples
+            if samples_ref is not None:
+                logs[f"samples_{n}_steps/{ss_name(self.teacher_sampling_noise_scheduler)}"
+                     f"_{teacher_guidance_scale}_cfg/teacher"] = samples_ref
+        return logs
 
     def _teacher_cfg(self, x, tt, cond, uncond, cfg_cond, *args, ctx_cache=None, **kwargs):
         """The reference evaluates the frozen teacher twice per step, once per conditioning (FD:297-313).

@@ -224,3 +224,85 @@ class DDPMScheduler(_Base):
             std = float(torch.clamp((1 - a_prev) / (1 - a_t) * cur_beta, min=1e-20) ** 0.5)
             return (ops.axpby(x0, c0, sample, c1, noise, std),)
         return (ops.axpby(x0, c0, sample, c1),)
+
+
+class LCMScheduler(_Base):
+    """The sampling scheduler of the few-step student sampler (FlashDiffusion.sample, FD:754-915; shipped configs:
+    SAMPLING_SCHEDULER: LCMScheduler).  Upstream LCMScheduler semantics: epsilon prediction, boundary-condition scalings
+    c_skip / c_out on timestep * timestep_scaling, re-noising with fresh Gaussian noise on every step but the last;
+    `set_timesteps` takes either `num_inference_steps` (floor(linspace) picks out of the reversed 50-step training
+    schedule) or custom `timesteps=` -- the reference hands over the teacher scheduler's schedule (FD:783-788).
+    The latent update  prev = A x + B eps + C noise  is ONE fused HIP launch (fdmi_axpby4); coefficients in host fp32."""
+
+    def __init__(self, original_inference_steps=50, timestep_scaling=10.0, sigma_data=0.5, **kw):
+        super().__init__(**kw)
+        self.config.original_inference_steps = original_inference_steps
+        self.config.timestep_scaling = timestep_scaling
+        self.sigma_data = sigma_data
+        self.final_alpha_cumprod = self.alphas_cumprod[0]
+        self._step_index = None
+        self.noise_fn = None   # tests inject the reference's re-noising draws here
+
+    def set_timesteps(self, num_inference_steps=None, device=None, original_inference_steps=None, timesteps=None,
+                      strength=1.0):
+        if num_inference_steps is None and timesteps is None:
+            raise ValueError("Must pass exactly one of `num_inference_steps` or `custom_timesteps`.")
+        if num_inference_steps is not None and timesteps is not None:
+            raise ValueError("Can only pass one of `num_inference_steps` or `custom_timesteps`.")
+        T = self.config.num_train_timesteps
+        original_steps = original_inference_steps or self.config.original_inference_steps
+        if original_steps > T:
+            raise ValueError("original_inference_steps cannot exceed num_train_timesteps")
+        k = T // original_steps
+        origin = np.asarray(list(range(1, int(original_steps * strength) + 1))) * k - 1
+        if timesteps is not None:
+            ts = np.asarray(timesteps.cpu().numpy() if torch.is_tensor(timesteps) else timesteps, dtype=np.int64)
+            if any(ts[i] >= ts[i - 1] for i in range(1, len(ts))):
+                raise ValueError("`custom_timesteps` must be in descending order.")
+            if ts[0] >= T:
+                raise ValueError("`timesteps` must start before `num_train_timesteps`.")
+        else:
+            if num_inference_steps > T or num_inference_steps > len(origin):
+                raise ValueError("`num_inference_steps` is larger than the available schedule")
+            rev = origin[::-1].copy()
+            idx = np.floor(np.linspace(0, len(rev), num=num_inference_steps, endpoint=False)).astype(np.int64)
+            ts = rev[idx]
+        self.timesteps = torch.from_numpy(np.asarray(ts, dtype=np.int64))
+        self.num_inference_steps = len(ts)
+        self._step_index = None
+
+    def boundary_scalings(self, timestep):
+        st = float(timestep) * self.config.timestep_scaling
+        sd = self.sigma_data
+        return sd ** 2 / (st ** 2 + sd ** 2), st / (st ** 2 + sd ** 2) ** 0.5
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=False, **kw):
+        if self._step_index is None:
+            cand = (self.timesteps == int(timestep)).nonzero()
+            self._step_index = int(cand[0].item()) if len(cand) else len(self.timesteps) - 1
+        i = self._step_index
+        prev_t = int(self.timesteps[i + 1]) if i + 1 < len(self.timesteps) else int(timestep)
+        a_t = self.alphas_cumprod[int(timestep)]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t, b_prev = 1 - a_t, 1 - a_prev
+        c_skip, c_out = self.boundary_scalings(int(timestep))
+        # denoised = c_out (x - sqrt(b_t) eps) / sqrt(a_t) + c_skip x
+        dx = float(c_out / a_t.sqrt() + c_skip)
+        de = float(-c_out * b_t.sqrt() / a_t.sqrt())
+        x = sample.float().contiguous()
+        e = model_output.float().contiguous()
+        if i != self.num_inference_steps - 1:
+            if self.noise_fn is not None:
+                noise = self.noise_fn(model_output.shape).to(device=x.device, dtype=torch.float32)
+            else:
+                noise = torch.randn(model_output.shape, generator=generator, device=x.device, dtype=torch.float32)
+            sp = float(a_prev.sqrt())
+            prev = ops.axpby(x, sp * dx, e, sp * de, noise.contiguous(), float(b_prev.sqrt()))
+            denoised = None
+        else:
+            prev = ops.axpby(x, dx, e, de)
+            denoised = prev
+        self._step_index += 1
+        if denoised is None and kw.get("return_denoised", False):
+            denoised = ops.axpby(x, dx, e, de)
+        return (prev, denoised)

@@ -212,6 +212,9 @@ class FlashDiffusionRef(torch.nn.Module):
         self.student_denoiser = student_denoiser
         self.teacher_denoiser = teacher_denoiser
         self.teacher_noise_scheduler = teacher_noise_scheduler
+        self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
+        self.sampling_noise_scheduler = sampling_noise_scheduler
+        self.vae = None
         self.conditioner = conditioner
         self.discriminator = discriminator
         self.iter_steps = 0
@@ -348,3 +351,94 @@ class FlashDiffusionRef(torch.nn.Module):
         f_fake, f_real = feat.chunk(2, dim=0)
         return gan_losses(cfg.gan_loss_type, self.discriminator, f_fake, f_real, step, s.size(0),
                           noise.device)
+
+    # ---- FD:754-915: few-step sampler (student; optionally the teacher's own sampler next to it) ----
+    @torch.no_grad()
+    def sample(self, z, num_steps=20, guidance_scale=1.0, teacher_guidance_scale=5.0, conditioner_inputs=None,
+               uncond_conditioner_inputs=None, max_samples=None, verbose=False, log_teacher_samples=False,
+               adapter_conditioning_scale=1.0):
+        self.teacher_noise_scheduler.set_timesteps(num_steps)                      # FD:781
+        ss = self.sampling_noise_scheduler
+        try:                                                                       # FD:783-788
+            ss.set_timesteps(timesteps=self.teacher_noise_scheduler.timesteps)
+        except Exception:
+            ss.set_timesteps(num_steps)
+        sample = z
+        cond = self._cond(conditioner_inputs, set_ucg_rate_zero=True, device=z.device)        # FD:793-795
+        if uncond_conditioner_inputs is not None:                                              # FD:798-805
+            uncond = self._cond(uncond_conditioner_inputs, set_ucg_rate_zero=True, device=z.device)
+        else:
+            uncond = self._cond(conditioner_inputs, ucg_keys=self.config.ucg_keys, device=z.device)
+        if max_samples is not None:                                                            # FD:807-818
+            sample = sample[:max_samples]
+            if cond:
+                cond["cond"] = {k: v[:max_samples] for k, v in cond["cond"].items()}
+                uncond["cond"] = {k: v[:max_samples] for k, v in uncond["cond"].items()}
+        sample_init = sample
+        sample = sample * ss.init_noise_sigma                                                  # FD:833
+        for t in ss.timesteps:                                                                 # FD:834-867
+            x = ss.scale_model_input(sample, t)
+            tt = t.to(z.device).repeat(x.shape[0])
+            e_c = self.student_denoiser(sample=x, timestep=tt, conditioning=cond,
+                                        down_intrablock_additional_residuals=None)
+            e_u = self.student_denoiser(sample=x, timestep=tt, conditioning=uncond,
+                                        down_intrablock_additional_residuals=None)
+            e = guidance_scale * e_c + (1 - guidance_scale) * e_u
+            sample = ss.step(e, t, sample, return_dict=False)[0]
+        decoded = sample                                                                       # vae is None (FD:869-872)
+        decoded_ref = None
+        if log_teacher_samples:                                                                # FD:876-913
+            ts = self.teacher_sampling_noise_scheduler
+            ts.set_timesteps(num_steps)
+            ref = sample_init * ts.init_noise_sigma
+            for t in ts.timesteps:
+                x = ts.scale_model_input(ref, t)
+                tt = t.to(z.device).repeat(x.shape[0])
+                e_c = self.teacher_denoiser(sample=x, timestep=tt, conditioning=cond,
+                                            down_intrablock_additional_residuals=None)
+                e_u = self.teacher_denoiser(sample=x, timestep=tt, conditioning=uncond,
+                                            down_intrablock_additional_residuals=None)
+                e = teacher_guidance_scale * e_c + (1 - teacher_guidance_scale) * e_u
+                ref = ts.step(e, t, ref, return_dict=False)[0]
+                decoded_ref = ref
+        return decoded, decoded_ref
+
+    # ---- FD:917-1019 ----
+    def log_samples(self, batch, input_shape=None, guidance_scale=1.0, teacher_guidance_scale=5.0, max_samples=8,
+                    num_steps=20, device="cpu", log_teacher_samples=False, conditioner_inputs=None,
+                    conditioner_uncond_inputs=None, adapter_conditioning_scale=1.0):
+        import copy as _copy
+        if isinstance(num_steps, int):
+            num_steps = [num_steps]
+        logs = {}
+        N = max_samples
+        if batch is not None:
+            N = min(N, min(len(batch[k]) for k in batch))
+        if conditioner_inputs is not None:
+            m = min(len(conditioner_inputs[k]) for k in conditioner_inputs)
+            conditioner_inputs.update({k: v.to(device) for k, v in conditioner_inputs.items() if torch.is_tensor(v)})
+            batch.update(conditioner_inputs)
+            N = min(N, m)
+        if conditioner_uncond_inputs is not None:
+            m = min(len(conditioner_uncond_inputs[k]) for k in conditioner_uncond_inputs)
+            conditioner_uncond_inputs.update({k: v.to(device) for k, v in conditioner_uncond_inputs.items()
+                                              if torch.is_tensor(v)})
+            batch_uncond = _copy.deepcopy(batch)
+            batch_uncond.update(conditioner_uncond_inputs)
+            N = min(N, m)
+        else:
+            batch_uncond = None
+        if input_shape is None:
+            raise ValueError("input_shape must be passed when no VAE is used in the model")   # FD:985-988
+        for n in num_steps:
+            z = torch.randn(N, *input_shape).to(device)                                        # FD:992
+            samples, samples_ref = self.sample(z, num_steps=n, conditioner_inputs=batch,
+                                               uncond_conditioner_inputs=batch_uncond, guidance_scale=guidance_scale,
+                                               teacher_guidance_scale=teacher_guidance_scale, max_samples=N,
+                                               log_teacher_samples=log_teacher_samples,
+                                               adapter_conditioning_scale=adapter_conditioning_scale)
+            logs[f"samples_{n}_steps/{self.sampling_noise_scheduler.__class__.__name__}_{guidance_scale}_cfg/student"] = samples
+            if samples_ref is not None:
+                logs[f"samples_{n}_steps/{self.teacher_sampling_noise_scheduler.__class__.__name__}"
+                     f"_{teacher_guidance_scale}_cfg/teacher"] = samples_ref
+        return logs

@@ -71,5 +71,52 @@ def main():
               "start_t", out["start_timestep"], os.path.getsize(path) // 1024, "KiB")
 
 
+def make_sample_golden():
+    """FlashDiffusion.sample (FD:754-915) of the REAL reference: 4-step LCM student sampler with CFG and the teacher's own
+    4-step DPM-Solver++ sampler next to it; the LCM re-noising draws are recorded so the HIP path can replay them."""
+    from .sched_cpu import DPMSolverMultistepSchedulerRef, LCMSchedulerRef
+    FD, FDC = shim_import.import_reference()
+    teacher, student, disc = build_models()
+    g = torch.Generator().manual_seed(21)
+    for p_ in student.parameters():          # peft leaves LoRA B = 0: make the student differ from the teacher
+        if p_.requires_grad and p_.abs().max() == 0:
+            p_.data.copy_(torch.randn(p_.shape, generator=g) * 0.05)
+    ref = FD(FDC(K=[4], num_iterations_per_K=[10]), student_denoiser=student, teacher_denoiser=teacher,
+             teacher_noise_scheduler=DPMSolverMultistepSchedulerRef(), conditioner=TensorConditioner(),
+             discriminator=disc)
+    ref.sampling_noise_scheduler = LCMSchedulerRef()
+    ref.teacher_sampling_noise_scheduler = DPMSolverMultistepSchedulerRef()
+    noises = []
+
+    def noise_fn(shape):
+        n = torch.randn(shape, generator=g)
+        noises.append(n)
+        return n
+
+    ref.sampling_noise_scheduler.noise_fn = noise_fn
+    batch = make_batch()
+    z = torch.randn(2, 4, 32, 32, generator=g)
+    un = {"crossattn": torch.randn(2, 77, 64, generator=g), "text": ["", ""]}
+    s, sr = ref.sample(z, num_steps=4, guidance_scale=1.3, teacher_guidance_scale=5.0, conditioner_inputs=batch,
+                       uncond_conditioner_inputs=un, log_teacher_samples=True)
+    blob = {"z": z.numpy(), "crossattn": batch["crossattn"].numpy(), "uncond_crossattn": un["crossattn"].numpy(),
+            "student_sample": s.numpy(), "teacher_sample": sr.numpy(), "guidance_scale": np.float64(1.3),
+            "teacher_guidance_scale": np.float64(5.0), "num_steps": np.int64(4),
+            "lcm_timesteps": ref.sampling_noise_scheduler.timesteps.numpy()}
+    for i, n in enumerate(noises):
+        blob[f"lcm_noise:{i}"] = n.numpy()
+    for n_, p_ in student.named_parameters():
+        if "lora" in n_:
+            blob["lora:" + n_] = p_.detach().numpy()
+    path = os.path.join(OUT, "sample_lcm4.npz")
+    np.savez_compressed(path, **blob)
+    print("sample_lcm4", float(s.abs().mean()), float(sr.abs().mean()), len(noises), os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if len(sys.argv) > 1 and sys.argv[1] == "sample":
+        make_sample_golden()
+    else:
+        main()
+        make_sample_golden()

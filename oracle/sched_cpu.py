@@ -241,12 +241,38 @@ class LCMSchedulerRef(_SchedulerBase):
         self._step_index = None
         self.noise_fn = None
 
-    def set_timesteps(self, num_inference_steps, device=None, timesteps=None):
+    def set_timesteps(self, num_inference_steps=None, device=None, original_inference_steps=None, timesteps=None,
+                      strength=1.0):
+        """Upstream LCMScheduler.set_timesteps (restated): custom `timesteps=` (what FD:783-788 tries first, handing over
+        the teacher scheduler's trailing schedule) or `num_inference_steps` picked by floor(linspace) out of the reversed
+        original 50-step training schedule {k, 2k, ...} - 1 with k = num_train_timesteps // original_inference_steps."""
+        if num_inference_steps is None and timesteps is None:
+            raise ValueError("Must pass exactly one of `num_inference_steps` or `custom_timesteps`.")
+        if num_inference_steps is not None and timesteps is not None:
+            raise ValueError("Can only pass one of `num_inference_steps` or `custom_timesteps`.")
+        original_steps = original_inference_steps or self.config.original_inference_steps
+        T = self.config.num_train_timesteps
+        if original_steps > T:
+            raise ValueError("original_inference_steps cannot exceed num_train_timesteps")
+        k = T // original_steps
+        origin = np.asarray(list(range(1, int(original_steps * strength) + 1))) * k - 1
         if timesteps is not None:
-            ts = np.asarray(timesteps, dtype=np.int64)
+            ts = np.asarray(torch.as_tensor(timesteps).cpu().numpy() if torch.is_tensor(timesteps) else timesteps,
+                            dtype=np.int64)
+            for i in range(1, len(ts)):
+                if ts[i] >= ts[i - 1]:
+                    raise ValueError("`custom_timesteps` must be in descending order.")
+            if ts[0] >= T:
+                raise ValueError("`timesteps` must start before `num_train_timesteps`.")
         else:
-            ts = self._spaced_timesteps(num_inference_steps)
-        self.timesteps = torch.from_numpy(ts).to(device=device, dtype=torch.int64)
+            if num_inference_steps > T:
+                raise ValueError("`num_inference_steps` cannot be larger than `num_train_timesteps`")
+            if num_inference_steps > len(origin):
+                raise ValueError("`num_inference_steps` cannot be larger than the original schedule")
+            rev = origin[::-1].copy()
+            idx = np.floor(np.linspace(0, len(rev), num=num_inference_steps, endpoint=False)).astype(np.int64)
+            ts = rev[idx]
+        self.timesteps = torch.from_numpy(np.asarray(ts, dtype=np.int64)).to(device=device, dtype=torch.int64)
         self.num_inference_steps = len(ts)
         self._step_index = None
 

@@ -31,3 +31,29 @@ def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def load_sample_case(name="sample_lcm4"):
+    """the few-step sampler fixture (oracle/make_golden.py::make_sample_golden)"""
+    blob = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    g = {"lora": {}, "noises": []}
+    for k in blob.files:
+        v = blob[k]
+        if k.startswith("lora:"):
+            g["lora"][k[5:]] = torch.from_numpy(v)
+        elif k.startswith("lcm_noise:"):
+            g["noises"].append((int(k.split(":")[1]), torch.from_numpy(v)))
+        else:
+            g[k] = torch.from_numpy(v) if v.ndim else v.item()
+    g["noises"] = [n for _, n in sorted(g["noises"], key=lambda t: t[0])]
+    return g
+
+
+def sampler_models_from_golden(g):
+    """the seeded tiny teacher / student of the fixtures, with the fixture's LoRA values loaded into the student"""
+    from oracle.golden_cases import build_models
+    teacher, student, disc = build_models()
+    named = dict(student.named_parameters())
+    for n, v in g["lora"].items():
+        named[n].data.copy_(v)
+    return teacher, student, disc

@@ -49,3 +49,36 @@ def test_scheduler_trailing_timesteps():
     # last step of dpmsolver++ with final sigma 0 returns the x0 prediction
     order, cs, c0, c1 = s.step_coefficients(0, 0)
     assert order == 1 and abs(cs) < 1e-12 and abs(c0 - 1.0) < 1e-6
+
+
+def test_oracle_sampler_reproduces_golden():
+    """FlashDiffusion.sample (FD:754-915): 4-step LCM student sampler + the teacher's DPM sampler, fixture made by the real
+    reference; the LCM re-noising draws are replayed."""
+    from oracle.sched_cpu import DPMSolverMultistepSchedulerRef, LCMSchedulerRef
+    from tests.golden_util import load_sample_case, sampler_models_from_golden
+    g = load_sample_case()
+    teacher, student, disc = sampler_models_from_golden(g)
+    m = FlashDiffusionRef(FlashConfigRef(K=[4], num_iterations_per_K=[10]), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=DPMSolverMultistepSchedulerRef(), conditioner=TensorConditioner(),
+                          discriminator=disc, sampling_noise_scheduler=LCMSchedulerRef(),
+                          teacher_sampling_noise_scheduler=DPMSolverMultistepSchedulerRef())
+    it = iter(g["noises"])
+    m.sampling_noise_scheduler.noise_fn = lambda shape: next(it)
+    B = g["z"].shape[0]
+    s, sr = m.sample(g["z"], num_steps=int(g["num_steps"]), guidance_scale=float(g["guidance_scale"]),
+                     teacher_guidance_scale=float(g["teacher_guidance_scale"]),
+                     conditioner_inputs={"crossattn": g["crossattn"], "text": ["a"] * B},
+                     uncond_conditioner_inputs={"crossattn": g["uncond_crossattn"], "text": [""] * B},
+                     log_teacher_samples=True)
+    assert m.sampling_noise_scheduler.timesteps.tolist() == g["lcm_timesteps"].tolist() == [999, 749, 499, 249]
+    assert rel_err(s, g["student_sample"]) < 1e-5 and rel_err(sr, g["teacher_sample"]) < 1e-5
+    assert rel_err(s, g["teacher_sample"]) > 1e-2   # the LoRA student is a different sampler
+
+
+def test_lcm_default_schedule():
+    from oracle.sched_cpu import LCMSchedulerRef
+    s = LCMSchedulerRef()
+    s.set_timesteps(4)
+    assert s.timesteps.tolist() == [999, 759, 499, 259]   # the well-known 4-step LCM schedule
+    s.set_timesteps(timesteps=[999, 749, 499, 249])
+    assert s.timesteps.tolist() == [999, 749, 499, 249] and s.num_inference_steps == 4

@@ -74,3 +74,48 @@ def test_restatement_is_bit_identical(case, step, sched):
     assert set(g1) == set(g2) and len(g1) > 0
     for n in g1:
         assert torch.equal(g1[n], g2[n]), n
+
+
+# ---- FlashDiffusion.sample / log_samples (FD:754-1019): the few-step sampler ("next" row 1 of SURVEY 8f) ----
+def _build_sampler(cls, cfg_cls):
+    from oracle.sched_cpu import LCMSchedulerRef
+    m = _build(cls, cfg_cls, DPMSolverMultistepSchedulerRef, K=[4], num_iterations_per_K=[10])
+    m.sampling_noise_scheduler = LCMSchedulerRef()
+    m.teacher_sampling_noise_scheduler = DPMSolverMultistepSchedulerRef()
+    return m
+
+
+@pytest.mark.parametrize("kw", [dict(num_steps=4, guidance_scale=1.0), dict(num_steps=3, guidance_scale=1.7, max_samples=1),
+                                dict(num_steps=4, guidance_scale=1.3, log_teacher_samples=True, teacher_guidance_scale=5.0,
+                                     with_uncond=True)])
+def test_sample_restatement_is_bit_identical(kw):
+    FD, FDC = shim_import.import_reference()
+    kw = dict(kw)
+    with_uncond = kw.pop("with_uncond", False)
+    outs = []
+    for cls, ccls in ((FD, FDC), (FlashDiffusionRef, FlashConfigRef)):
+        m = _build_sampler(cls, ccls)
+        b = _batch()
+        g = torch.Generator().manual_seed(11)
+        z = torch.randn(2, 4, 32, 32, generator=g)
+        un = {"crossattn": torch.randn(2, 77, 64, generator=g), "text": ["", ""]} if with_uncond else None
+        torch.manual_seed(7)
+        outs.append(m.sample(z, conditioner_inputs=b, uncond_conditioner_inputs=un, **kw))
+    (a, ar), (o, orf) = outs
+    assert torch.equal(a, o)
+    assert (ar is None) == (orf is None)
+    if ar is not None:
+        assert torch.equal(ar, orf)
+
+
+def test_log_samples_restatement_is_bit_identical():
+    FD, FDC = shim_import.import_reference()
+    logs = []
+    for cls, ccls in ((FD, FDC), (FlashDiffusionRef, FlashConfigRef)):
+        m = _build_sampler(cls, ccls)
+        torch.manual_seed(3)
+        logs.append(m.log_samples(_batch(), input_shape=(4, 32, 32), guidance_scale=1.5, max_samples=8, num_steps=[2, 4],
+                                  log_teacher_samples=True))
+    assert list(logs[0].keys()) == list(logs[1].keys()) and len(logs[0]) == 4
+    for k in logs[0]:
+        assert torch.equal(logs[0][k], logs[1][k]), k
