@@ -188,6 +188,32 @@ def main():
         dts = (time.perf_counter() - ts0) / nrep
         sampler = {"metric": "student few-step sampling, latents/s (4 LCM steps = 4 UNet evaluations, guidance 1.0, "
                              f"B={B}, LoRA r{rank_r} unmerged)", "value": B / dts, "unit": "images/s", "ms_per_batch": dts * 1e3}
+    # ---- secondary: the reference's literal 2-optimizer training_step (TR:194-217): a generator iteration AND a
+    # discriminator iteration, i.e. two full FlashDiffusion.forward calls (teacher loop included) with the lsgan GAN term ----
+    two_opt = None
+    if world == 1 and args.arch == "sd15":
+        from flash_diffusion_amd.workloads import sd15_discriminator
+        del pipe
+        m2 = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0,
+                         discriminator=sd15_discriminator(), gan_loss_type="lsgan")
+        p2 = TrainingPipeline(m2, TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-5, 1e-5],
+                                                 trainable_params=[["student_denoiser"], ["discriminator."]]),
+                              overlap=not args.no_overlap)
+        p2.configure_optimizers()
+        for i in range(2):
+            p2.training_step(batches[i % len(batches)], i)
+        p2.finish()
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        nrep = 2
+        for i in range(nrep):
+            p2.training_step(batches[i % len(batches)], i)
+        p2.finish()
+        torch.cuda.synchronize()
+        dq = (time.perf_counter() - tq) / nrep
+        two_opt = {"metric": "literal 2-optimizer training_step (G + D iteration, lsgan, SD1.5 PatchGAN head on the "
+                             "teacher's mid-block features)", "ms_per_step": dq * 1e3, "value": B / dq, "unit": "images/s"}
+        del p2, m2
     if world > 1:
         dist.barrier()
     cpu = None
@@ -203,7 +229,7 @@ def main():
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world},
-            "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler},
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler, "two_optimizer_step": two_opt},
         }
         print(json.dumps(line))
     if world > 1:

@@ -21,6 +21,13 @@ TINY = dict(in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64), 
             cross_attention_dim=64, attention_head_dim=2, transformer_layers_per_block=1)
 
 
+def sd15_discriminator(color_dim=1280, feat=64):
+    """the PatchGAN head of examples/train_flash_sd.py:225-240 on the teacher's mid-block features [B,1280,8,8]"""
+    import torch.nn as nn
+    return nn.Sequential(nn.Conv2d(color_dim, feat, 3, 1, 1), nn.SiLU(True), nn.Conv2d(feat, feat * 2, 4, 2, 1, bias=False),
+                         nn.SiLU(True), nn.GroupNorm(4, feat * 2), nn.Conv2d(feat * 2, 1, 4, 1, 0, bias=False), nn.Flatten())
+
+
 def build_flash(arch=SD15, lora_rank=128, n_teacher_steps=4, device="cuda", seed=0, discriminator=None,
                 use_dmd_loss=False, gan_loss_type="lsgan", guidance=8.0):
     """teacher (frozen) + student = copy + LoRA (peft init: A gaussian, B = 0), DPM-Solver++ trailing schedule
