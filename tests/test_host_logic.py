@@ -136,3 +136,29 @@ def test_data_parallel_all_reduce_gloo_world2():
     opt.step()
     for k, v in m.student_denoiser.state_dict().items():
         assert torch.allclose(v, res[0][k], atol=1e-6), k
+
+
+def test_lcm_scheduler_host_side_matches_oracle():
+    """schedule selection and boundary scalings of the product LCMScheduler (host fp32 math) vs the oracle restatement"""
+    from flash_diffusion_amd.schedulers import LCMScheduler
+    from oracle.sched_cpu import LCMSchedulerRef
+    a, b = LCMScheduler(), LCMSchedulerRef()
+    for n in (1, 2, 4, 8, 50):
+        a.set_timesteps(n)
+        b.set_timesteps(n)
+        assert a.timesteps.tolist() == b.timesteps.tolist()
+    a.set_timesteps(timesteps=[999, 749, 499, 249])
+    b.set_timesteps(timesteps=torch.tensor([999, 749, 499, 249]))
+    assert a.timesteps.tolist() == b.timesteps.tolist() and a.num_inference_steps == 4
+    for t in (999, 500, 3, 0):
+        cs, co = a.boundary_scalings(t)
+        rs, ro = b.boundary_scalings(float(t))
+        assert abs(cs - rs) < 1e-12 and abs(co - ro) < 1e-12
+    import pytest as _pt
+    with _pt.raises(ValueError):
+        a.set_timesteps()
+    with _pt.raises(ValueError):
+        a.set_timesteps(4, timesteps=[9, 5])
+    with _pt.raises(ValueError):
+        a.set_timesteps(timesteps=[5, 9])
+    assert torch.equal(a.alphas_cumprod, b.alphas_cumprod) and a.init_noise_sigma == b.init_noise_sigma == 1.0
