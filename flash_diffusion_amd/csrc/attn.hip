@@ -131,6 +131,12 @@ __device__ __forceinline__ float xor_max(float v) {
 
 #define MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
 constexpr float NEG_BIG = -1.0e30f;
+// in-place accumulate (vdst = srcC) from inline asm: hipcc otherwise lets the P V MFMAs write a fresh register set and
+// copies the whole O accumulator back at every loop latch (12 v_mov_b64 per KV tile).  The operands come from VALU
+// (cvt_pk) results: the wait states the compiler would insert for a builtin are provided by the caller (s_nop).
+__device__ __forceinline__ void mfma_inplace(f32x4& acc, const bf16x8& a, const bf16x8& b) {
+  asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
+}
 
 // =============================================================================================
 // forward:  O = softmax(scale Q K^T) V ;  lse (log2 domain) optional
@@ -181,19 +187,25 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
   }
 
   // one KV tile for query fragments [f0, f0+QP); TAIL masks keys >= Skv (last tile only)
-  // Lazy running maximum: the accumulators of K Q^T start at -m (the row's reference maximum so far), so
-  // the MFMA result is directly the exp2 argument.  m only moves when a tile exceeds it by more than TAU
-  // (P then stays <= 2^TAU, harmless in bf16/fp32); moving it rescales O and re-bases this tile's scores.
-  constexpr float TAU = 8.f;
-  auto tile_pair = [&](auto tail_tag, int f0, int t) {
+  // Lazy running maximum.  The accumulators of K Q^T start at -m (the row's reference maximum so far), so the MFMA
+  // result is directly the exp2 argument.  Three bodies of one KV tile:
+  //   FIRST (tile 0): m := the tile's row maximum;
+  //   FAST: m does not move, P = exp2(S - m) may exceed 1 but stays <= 2^TAU (harmless in bf16 / fp32) -- no
+  //         rescale of O, no per-element subtraction; if some row exceeds m by more than TAU the tile is NOT
+  //         processed (returns true) and the caller continues with
+  //   SLOW: classic online softmax (m rises by max(rowmax - m, 0), O and the tile are re-based every tile).
+  // The loop body is FAST with the re-basing block of SLOW kept as a cold, conditional block in front of the exp2.
+  constexpr float TAU = 16.f;
+  constexpr int T_FIRST = 0, T_FAST = 1, T_SLOW = 2;
+  auto tile_pair = [&](auto tail_tag, auto mode_tag, int f0, int t) -> bool {
     constexpr bool TAIL = decltype(tail_tag)::value;
-    const bool first = t == 0;
+    constexpr int MODE = decltype(mode_tag)::value;
     f32x4 s[4][QP];
+    f32x4 cinit[QP];  // one read-only C operand per query fragment, shared by the four key fragments' first MFMA
 #pragma unroll
     for (int f = 0; f < QP; ++f) {
-      const float c0 = first ? 0.f : -m[f0 + f];
-#pragma unroll
-      for (int kf = 0; kf < 4; ++kf) s[kf][f] = (f32x4){c0, c0, c0, c0};
+      const float c0 = MODE == T_FIRST ? 0.f : -m[f0 + f];
+      cinit[f] = (f32x4){c0, c0, c0, c0};
     }
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -203,9 +215,9 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
-        for (int f = 0; f < QP; ++f) s[kf][f] = MFMA(kfr[kf], qf[f0 + f][ks], s[kf][f]);
+        for (int f = 0; f < QP; ++f) s[kf][f] = MFMA(kfr[kf], qf[f0 + f][ks], ks == 0 ? cinit[f] : s[kf][f]);
     }
-    bf16x8 pb[QP][2];
+    float mx[QP];
 #pragma unroll
     for (int f = 0; f < QP; ++f) {
       if (TAIL) {
@@ -216,23 +228,37 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
           for (int r = 0; r < 4; ++r)
             if (kvbase + 16 * kf + r >= a.Skv) s[kf][f][r] = NEG_BIG;
       }
-      float mx = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), fmaxf(s[0][f][2], s[0][f][3]));
+      float v = fmaxf(fmaxf(s[0][f][0], s[0][f][1]), fmaxf(s[0][f][2], s[0][f][3]));
 #pragma unroll
       for (int kf = 1; kf < 4; ++kf)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kf][f][r]);
-      mx = xor_max(mx);
+        for (int r = 0; r < 4; ++r) v = fmaxf(v, s[kf][f][r]);
+      mx[f] = xor_max(v);
+    }
+    bool rebase = MODE != T_FAST;
+    if (MODE == T_FAST) {
+      float worst = mx[0];
+#pragma unroll
+      for (int f = 1; f < QP; ++f) worst = fmaxf(worst, mx[f]);
+      rebase = __any(worst > TAU);  // wave-uniform, rare
+    }
+    bf16x8 pb[QP][2];
+#pragma unroll
+    for (int f = 0; f < QP; ++f) {
       float alpha = 1.f;
-      if (first || __any(mx > TAU)) {  // wave-uniform, rare after the first tiles
-        const float up = first ? mx : fmaxf(mx, 0.f);  // the reference only ever rises
-        if (!first) {
+      if (__builtin_expect(rebase, MODE != T_FAST)) {
+        if (MODE == T_FAST) asm volatile("" ::: "memory");  // keep the block conditional (no speculation into the common path)
+        const float up = MODE == T_FIRST ? mx[f] : fmaxf(mx[f], 0.f);  // the reference only ever rises
+        if (MODE != T_FIRST) {
           alpha = fast_exp2(-up);
 #pragma unroll
           for (int df = 0; df < DF; ++df)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc_o[df][f0 + f][r] *= alpha;
+          m[f0 + f] += up;
+        } else {
+          m[f0 + f] = up;
         }
-        m[f0 + f] = first ? up : m[f0 + f] + up;
 #pragma unroll
         for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
@@ -251,14 +277,26 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
       pb[f][0] = pack8(s[0][f], s[1][f]);
       pb[f][1] = pack8(s[2][f], s[3][f]);
     }
+    bf16x8 vfr[2][DF];
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int df = 0; df < DF; ++df) {
-        const bf16x8 vfr = tr_frag(sV, df, s2, g, j);
+      for (int df = 0; df < DF; ++df) vfr[s2][df] = tr_frag(sV, df, s2, g, j);
+    // VALU (cvt_pk) results feed the inline-asm MFMAs: the P fragments are tied through the wait-state statement so
+    // the compiler cannot schedule their producers after it (register-only VALU ops float past a plain asm)
+    if constexpr (QP == 2) {
+      asm volatile("s_nop 4" : "+v"(pb[0][0]), "+v"(pb[0][1]), "+v"(pb[1][0]), "+v"(pb[1][1]));
+    } else {
+      asm volatile("s_nop 4" : "+v"(pb[0][0]), "+v"(pb[0][1]));
+    }
 #pragma unroll
-        for (int f = 0; f < QP; ++f) acc_o[df][f0 + f] = MFMA(vfr, pb[f][s2], acc_o[df][f0 + f]);
-      }
+    for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+      for (int df = 0; df < DF; ++df)
+#pragma unroll
+        for (int f = 0; f < QP; ++f) mfma_inplace(acc_o[df][f0 + f], vfr[s2][df], pb[f][s2]);
+    asm volatile("s_nop 3");  // the last MFMAs have read their A/B operands before compiler code may reuse those registers
+    return false;
   };
 
   // Two LDS stages, ONE barrier per KV tile: iteration t stores tile t+1 (fetched into registers during
@@ -274,7 +312,7 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
     rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, KVB, hoff, a.d, tid);
     tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, KVB, tid);
   }
-  for (int t = 0; t < nt; ++t) {
+  auto stage = [&](int t) {
     __syncthreads();  // stage t&1 is complete; every wave is done with stage (t+1)&1
     sK = smem + (t & 1) * STAGEB;
     sV = sK + RowTile<DK>::BYTES;
@@ -287,15 +325,29 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
         tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, (t + 2) * KVB, tid);
       }
     }
-    if (ragged && t == nt - 1) {
-#pragma unroll
-      for (int f0 = 0; f0 < QF; f0 += QP) tile_pair(std::true_type{}, f0, t);
-    } else {
-#pragma unroll
-      for (int f0 = 0; f0 < QF; f0 += QP) tile_pair(std::false_type{}, f0, t);
+  };
+  using MFirst = std::integral_constant<int, T_FIRST>;
+  using MFast = std::integral_constant<int, T_FAST>;
+  using MSlow = std::integral_constant<int, T_SLOW>;
+  static_assert(QF == QP, "the FAST -> SLOW hand-over assumes one tile_pair per KV tile");
+  // complete tiles [0, nfull) take the unmasked bodies; a ragged last tile is handled after the loops with the masked
+  // body (keeping it out of the loops leaves each loop a single straight-line body)
+  const int nfull = ragged ? nt - 1 : nt;
+  if (nfull > 0) {
+    stage(0);
+    tile_pair(std::false_type{}, MFirst{}, 0, 0);
+    for (int t = 1; t < nfull; ++t) {
+      stage(t);
+      tile_pair(std::false_type{}, MFast{}, 0, t);
     }
   }
+  if (ragged) {
+    stage(nt - 1);
+    if (nt == 1) tile_pair(std::true_type{}, MFirst{}, 0, 0);
+    else tile_pair(std::true_type{}, MSlow{}, 0, nt - 1);
+  }
   // ---- epilogue ----
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // the last in-place MFMAs (inline asm) must have landed before VALU reads O
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
     const int q = q0 + 16 * f + j;
@@ -643,12 +695,14 @@ int set_smem(KernelT k, int bytes) {
 
 template <int DK, int DV, int NF>
 int fwd_t(const AttnArgs& a, hipStream_t st) {
-  constexpr int smem = 2 * (RowTile<DK>::BYTES + TrTile<DV>::BYTES);
-  static bool once = false;
-  if (!once) {
+  constexpr int smem0 = 2 * (RowTile<DK>::BYTES + TrTile<DV>::BYTES);
+  // developer knob 10: extra (unused) LDS bytes per block, to lower the occupancy for latency-vs-throughput experiments
+  const int smem = smem0 + (fdmi_tune_get(10) > 0 ? fdmi_tune_get(10) : 0);
+  static int once = -1;
+  if (once != smem) {
     if (set_smem(attn_fwd_kernel<DK, DV, NF, false>, smem)) return -2;
     if (set_smem(attn_fwd_kernel<DK, DV, NF, true>, smem)) return -2;
-    once = true;
+    once = smem;
   }
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
