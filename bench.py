@@ -71,6 +71,7 @@ def main():
     ap.add_argument("--lora-rank", type=int, default=128)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (sampler, 2-optimizer step)")
     args = ap.parse_args()
 
     import torch
@@ -171,7 +172,7 @@ def main():
                                    "frac_of_peak": step_flops / (ms_per_step * 1e-3) / PEAK_BF16}}
     # ---- secondary: the student's 4-step LCM sampler, FlashDiffusion.sample, same UNet kernels ----
     sampler = None
-    if rank == 0 and args.arch != "tiny":
+    if rank == 0 and args.arch != "tiny" and not args.no_secondary:
         from flash_diffusion_amd.schedulers import LCMScheduler
         model.sampling_noise_scheduler = LCMScheduler()
         zb = batches[0]
@@ -191,7 +192,7 @@ def main():
     # ---- secondary: the reference's literal 2-optimizer training_step (TR:194-217): a generator iteration AND a
     # discriminator iteration, i.e. two full FlashDiffusion.forward calls (teacher loop included) with the lsgan GAN term ----
     two_opt = None
-    if world == 1 and args.arch == "sd15":
+    if world == 1 and args.arch == "sd15" and not args.no_secondary:
         from flash_diffusion_amd.workloads import sd15_discriminator
         del pipe
         m2 = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0,
