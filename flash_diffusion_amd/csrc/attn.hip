@@ -130,6 +130,16 @@ __device__ __forceinline__ float xor_max(float v) {
 }
 
 #define MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x32_bf16(A, B, C, 0, 0, 0)
+// a bf16 fragment times a scalar (scale * log2 e folded into Q or K once per block: the MFMA output is then the
+// exp2 argument, and -lse / -max rides in as the C operand)
+__device__ __forceinline__ bf16x8 scaled_frag(bf16x8 v, float c) {
+  union { bf16x8 v; uint32_t u[4]; } t;
+  t.v = v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e)
+    t.u[e] = pack2bf(__uint_as_float(t.u[e] << 16) * c, __uint_as_float(t.u[e] & 0xffff0000u) * c);
+  return t.v;
+}
 constexpr float NEG_BIG = -1.0e30f;
 // in-place accumulate (vdst = srcC) from inline asm: hipcc otherwise lets the P V MFMAs write a fresh register set and
 // copies the whole O accumulator back at every loop latch (12 v_mov_b64 per KV tile).  The operands come from VALU
@@ -384,7 +394,7 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 //   P^T = exp2(sc K Q^T - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta) scale,  dQ^T += K^T dS^T
 // =============================================================================================
 template <int DK, int DV, int QF>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (DK <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sVr = sK + RowTile<DK>::BYTES;
@@ -404,7 +414,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
     const int q = q0 + 16 * f + j;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      qf[f][ks] = own_frag(a.Q, a.ldq, b, a.Sq, q, hoff, a.d, ks, g);
+      qf[f][ks] = scaled_frag(own_frag(a.Q, a.ldq, b, a.Sq, q, hoff, a.d, ks, g), sc);  // S comes out in exp2 units
       dof[f][ks] = own_frag(a.dO, a.lddo, b, a.Sq, q, hoff, a.d, ks, g);
     }
     const bool ok = q < a.Sq;
@@ -419,23 +429,16 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 
   uint4 rk[RowTile<DK>::NREG], rv[RowTile<DK>::NREG], rt[TrTile<DV>::NREG];
   const int nt = (a.Skv + KVB - 1) / KVB;
-  for (int t = 0; t < nt; ++t) {
-    rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, t * KVB, hoff, a.d, tid);
-    rows_g2r<DK>(rv, a.V, a.ldv, b, a.Skv, t * KVB, hoff, a.d, tid);
-    tr_g2r<DV>(rt, a.KT, b, a.H, h, SP, t * KVB, tid);
-    __syncthreads();
-    rows_r2s<DK>(sK, rk, tid);
-    rows_r2s<DK>(sVr, rv, tid);
-    tr_r2s<DV>(sKT, rt, tid);
-    __syncthreads();
+  const bool ragged = (a.Skv % KVB) != 0;
+  // one key tile; TAIL masks keys >= Skv (only the ragged last tile pays for it).  P^T = exp2(S - lse) with -lse as the
+  // MFMA C operand; dS^T = P^T (dP^T - delta) -- the softmax scale is applied once, to dQ, in the epilogue
+  auto tile = [&](auto tail_tag, int t) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
     f32x4 s[4][QF], dp[4][QF];
+    f32x4 cinit[QF];
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kf = 0; kf < 4; ++kf)
-#pragma unroll
-      for (int f = 0; f < QF; ++f) {
-        s[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dp[kf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+    for (int f = 0; f < QF; ++f) cinit[f] = (f32x4){-lse[f], -lse[f], -lse[f], -lse[f]};
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -444,8 +447,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
         const bf16x8 vfr = row_frag<DK>(sVr, kf, ks, g, j);
 #pragma unroll
         for (int f = 0; f < QF; ++f) {
-          s[kf][f] = MFMA(kfr, qf[f][ks], s[kf][f]);
-          dp[kf][f] = MFMA(vfr, dof[f][ks], dp[kf][f]);
+          s[kf][f] = MFMA(kfr, qf[f][ks], ks == 0 ? cinit[f] : s[kf][f]);
+          dp[kf][f] = MFMA(vfr, dof[f][ks], ks == 0 ? zero4 : dp[kf][f]);
         }
       }
     }
@@ -457,9 +460,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          float p = fast_exp2(fmaf(s[kf][f][r], sc, -lse[f]));
-          if (kvbase + 16 * kf + r >= a.Skv) p = 0.f;
-          s[kf][f][r] = p * (dp[kf][f][r] - dl[f]) * a.scale;
+          float p = fast_exp2(s[kf][f][r]);
+          if (TAIL && kvbase + 16 * kf + r >= a.Skv) p = 0.f;
+          s[kf][f][r] = p * (dp[kf][f][r] - dl[f]);
         }
       ds[f][0] = pack8(s[0][f], s[1][f]);
       ds[f][1] = pack8(s[2][f], s[3][f]);
@@ -472,7 +475,29 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 #pragma unroll
         for (int f = 0; f < QF; ++f) acc[df][f] = MFMA(ktf, ds[f][s2], acc[df][f]);
       }
+  };
+  auto fetch = [&](int t) {
+    rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, t * KVB, hoff, a.d, tid);
+    rows_g2r<DK>(rv, a.V, a.ldv, b, a.Skv, t * KVB, hoff, a.d, tid);
+    tr_g2r<DV>(rt, a.KT, b, a.H, h, SP, t * KVB, tid);
+  };
+  fetch(0);
+  for (int t = 0; t < nt; ++t) {
+    __syncthreads();
+    rows_r2s<DK>(sK, rk, tid);
+    rows_r2s<DK>(sVr, rv, tid);
+    tr_r2s<DV>(sKT, rt, tid);
+    __syncthreads();
+    if (t + 1 < nt) fetch(t + 1);  // the next tile's global loads fly during this tile's math
+    if (ragged && t == nt - 1) tile(std::true_type{}, t);
+    else tile(std::false_type{}, t);
   }
+#pragma unroll
+  for (int f = 0; f < QF; ++f)
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[df][f][r] *= a.scale;
 #pragma unroll
   for (int f = 0; f < QF; ++f) {
     const int q = q0 + 16 * f + j;
@@ -497,7 +522,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(const AttnArgs a) {
 //   dP = dO V^T,  dS = P (dP - delta[q]) scale,  dV^T += dO^T P,  dK^T += Q^T dS
 // =============================================================================================
 template <int DK, int DV, int KF>
-__global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, (DK <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQ = smem;
   char* sdO = sQ + RowTile<DK>::BYTES;
@@ -517,7 +542,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
   for (int f = 0; f < KF; ++f)
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      kf_[f][ks] = own_frag(a.K, a.ldk, b, a.Skv, kv0 + 16 * f + j, hoff, a.d, ks, g);
+      kf_[f][ks] = scaled_frag(own_frag(a.K, a.ldk, b, a.Skv, kv0 + 16 * f + j, hoff, a.d, ks, g), sc);  // S in exp2 units
       vf_[f][ks] = own_frag(a.V, a.ldv, b, a.Skv, kv0 + 16 * f + j, hoff, a.d, ks, g);
     }
   f32x4 adk[DF][KF], adv[DF][KF];
@@ -530,31 +555,37 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     }
   uint4 rq[RowTile<DK>::NREG], rdo[RowTile<DK>::NREG], rqt[TrTile<DV>::NREG], rdot[TrTile<DV>::NREG];
   const int nt = (a.Sq + KVB - 1) / KVB;
-  for (int t = 0; t < nt; ++t) {
+  float nl_r = 0.f, dl_r = 0.f;  // (threads < 64) -lse / delta of the staged query tile
+  auto fetch = [&](int t) {
     rows_g2r<DK>(rq, a.Q, a.ldq, b, a.Sq, t * KVB, hoff, a.d, tid);
     rows_g2r<DK>(rdo, a.dO, a.lddo, b, a.Sq, t * KVB, hoff, a.d, tid);
     tr_g2r<DV>(rqt, a.QT, b, a.H, h, SPq, t * KVB, tid);
     tr_g2r<DV>(rdot, a.dOT, b, a.H, h, SPq, t * KVB, tid);
+    if (tid < 64) {
+      const int q = t * KVB + tid;
+      const bool ok = q < a.Sq;
+      nl_r = ok ? -a.lse[((int64_t)b * a.H + h) * a.Sq + q] : -1.0e30f;  // negated: it is the MFMA C operand
+      dl_r = ok ? a.delta[((int64_t)b * a.H + h) * a.Sq + q] : 0.f;
+    }
+  };
+  fetch(0);
+  for (int t = 0; t < nt; ++t) {
     __syncthreads();
     rows_r2s<DK>(sQ, rq, tid);
     rows_r2s<DK>(sdO, rdo, tid);
     tr_r2s<DV>(sQT, rqt, tid);
     tr_r2s<DV>(sdOT, rdot, tid);
     if (tid < 64) {
-      const int q = t * KVB + tid;
-      const bool ok = q < a.Sq;
-      sL[tid] = ok ? a.lse[((int64_t)b * a.H + h) * a.Sq + q] : 1.0e30f;
-      sL[64 + tid] = ok ? a.delta[((int64_t)b * a.H + h) * a.Sq + q] : 0.f;
+      sL[tid] = nl_r;
+      sL[64 + tid] = dl_r;
     }
     __syncthreads();
+    if (t + 1 < nt) fetch(t + 1);  // the next tile's global loads fly during this tile's math
     f32x4 s[4][KF], dp[4][KF];
+    f32x4 nls[4];  // -lse of this lane's four query rows per query fragment: the C operand of the S MFMAs
+    const f32x4 zero4 = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int qf = 0; qf < 4; ++qf)
-#pragma unroll
-      for (int f = 0; f < KF; ++f) {
-        s[qf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        dp[qf][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      }
+    for (int qf = 0; qf < 4; ++qf) nls[qf] = *(const f32x4*)(sL + 16 * qf + 4 * g);
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -563,8 +594,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         const bf16x8 dofr = row_frag<DK>(sdO, qf, ks, g, j);
 #pragma unroll
         for (int f = 0; f < KF; ++f) {
-          s[qf][f] = MFMA(qfr, kf_[f][ks], s[qf][f]);
-          dp[qf][f] = MFMA(dofr, vf_[f][ks], dp[qf][f]);
+          s[qf][f] = MFMA(qfr, kf_[f][ks], ks == 0 ? nls[qf] : s[qf][f]);
+          dp[qf][f] = MFMA(dofr, vf_[f][ks], ks == 0 ? zero4 : dp[qf][f]);
         }
       }
     }
@@ -573,14 +604,13 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
     for (int f = 0; f < KF; ++f) {
 #pragma unroll
       for (int qf = 0; qf < 4; ++qf) {
-        const float4 ls = *(const float4*)(sL + 16 * qf + 4 * g);
         const float4 dl = *(const float4*)(sL + 64 + 16 * qf + 4 * g);
-        const float lsv[4] = {ls.x, ls.y, ls.z, ls.w}, dlv[4] = {dl.x, dl.y, dl.z, dl.w};
+        const float dlv[4] = {dl.x, dl.y, dl.z, dl.w};
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float p = fast_exp2(fmaf(s[qf][f][r], sc, -lsv[r]));
+          const float p = fast_exp2(s[qf][f][r]);
           s[qf][f][r] = p;
-          dp[qf][f][r] = p * (dp[qf][f][r] - dlv[r]) * a.scale;
+          dp[qf][f][r] = p * (dp[qf][f][r] - dlv[r]);  // the softmax scale is applied once, to dK, in the epilogue
         }
       }
       pb[f][0] = pack8(s[0][f], s[1][f]);
@@ -601,6 +631,12 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(const AttnArgs a) {
         }
       }
   }
+#pragma unroll
+  for (int f = 0; f < KF; ++f)
+#pragma unroll
+    for (int df = 0; df < DF; ++df)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) adk[df][f][r] *= a.scale;
 #pragma unroll
   for (int f = 0; f < KF; ++f) {
     const int kv = kv0 + 16 * f + j;

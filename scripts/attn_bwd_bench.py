@@ -1,0 +1,14 @@
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from flash_diffusion_amd import ops
+from kbench import timeit
+BF = torch.bfloat16
+for (B, S, Skv, H, d) in [(16, 4096, 4096, 8, 40), (16, 1024, 1024, 8, 80), (16, 256, 256, 8, 160)]:
+    q = torch.randn(B, S, H * d, device="cuda").to(BF)
+    k = torch.randn(B, Skv, H * d, device="cuda").to(BF)
+    v = torch.randn(B, Skv, H * d, device="cuda").to(BF)
+    do = torch.randn(B, S, H * d, device="cuda").to(BF)
+    o, lse = ops.attn_fwd(q, k, v, H, d ** -0.5, need_lse=True)
+    us = timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, H, d ** -0.5), 5)
+    print(f"attn bwd B={B} S={S} d={d}: {us:9.1f} us {2.5 * 4.0 * B * H * S * Skv * d / us / 1e6:8.1f} TF/s", flush=True)
