@@ -155,14 +155,43 @@ __device__ __forceinline__ void mfma_inplace(f32x4& acc, const bf16x8& a, const 
 // raw v_exp_f32 (2^x); inputs here are <= 0 or the NEG_BIG sentinel, denormal results flush harmlessly
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 
+// ---- LDS-DMA staging (DMA variant of the forward kernel, head dims <= 64) --------------------------------------
+// K tile [64 keys][64 dims] and V^T tile [64 dims][64 keys], both as dense 128-B rows of eight 16-B chunks; the chunk at
+// physical position pc of row r holds logical chunk pc ^ ((r >> 1) & 7) (the swizzle is applied on the SOURCE address:
+// global_load_lds writes lane-linear), which makes the ds_read_b128 (K fragments) and ds_read_b64 (V^T fragments)
+// patterns below bank-conflict free.  Chunks / rows that do not exist (dims >= d, keys >= Skv) are fetched from a zero page.
+static __device__ uint4 g_attn_zero[1] = {};
+#define ATTN_LDS_AS __attribute__((address_space(3)))
+__device__ __forceinline__ void attn_glds16(const void* gptr, unsigned lds_addr) {  // M0 saved / restored inside
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gptr), "s"(lds_addr));
+}
+__device__ __forceinline__ bf16x8 row_frag_sw(const char* lds, int f, int ks, int g, int j) {
+  return *(const bf16x8*)(lds + (16 * f + j) * 128 + (((4 * ks + g) ^ ((j >> 1) & 7)) * 16));
+}
+__device__ __forceinline__ bf16x8 tr_frag_sw(const char* lds, int df, int s2, int g, int j) {
+  const int sw = (j >> 1) & 7, c0 = 4 * s2 + (g >> 1);
+  const char* row = lds + (16 * df + j) * 128 + (g & 1) * 8;
+  const uint2 lo = *(const uint2*)(row + ((c0 ^ sw) * 16));
+  const uint2 hi = *(const uint2*)(row + (((c0 + 2) ^ sw) * 16));
+  union { uint4 u; bf16x8 v; } t;
+  t.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return t.v;
+}
+
 // ONES: the V^T copy carries a row of ones at dd = d (spare padded row), so the PV MFMA accumulates the
 // softmax denominator for free and the VALU row-sum disappears.
-template <int DK, int DV, int QF, bool ONES>
+template <int DK, int DV, int QF, bool ONES, bool DMA>
 __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int STAGEB = RowTile<DK>::BYTES + TrTile<DV>::BYTES;  // one K tile + one V^T tile; two stages
+  static_assert(!DMA || (DK == 64 && DV <= 64), "DMA staging is laid out for 64-wide tiles");
+  constexpr int KBYTES = DMA ? 64 * 128 : RowTile<DK>::BYTES;
+  constexpr int STAGEB = DMA ? 2 * 64 * 128 : RowTile<DK>::BYTES + TrTile<DV>::BYTES;  // K tile + V^T tile; two stages
   char* sK = smem;
-  char* sV = smem + RowTile<DK>::BYTES;
+  char* sV = smem + KBYTES;
   constexpr int KS = DK / 32, DF = DV / 16;
   constexpr int QP = QF >= 2 ? 2 : 1;  // query fragments processed together (bounds live registers)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, g = lane >> 4, j = lane & 15;
@@ -197,6 +226,19 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
   }
 
   // one KV tile for query fragments [f0, f0+QP); TAIL masks keys >= Skv (last tile only)
+  // DMA layout: this lane's swizzled fragment offsets inside a tile (loop invariant; fragments 16 rows = 2048 B apart)
+  int kofs[KS > 0 ? KS : 1], vofs[2][2];
+  {
+    const int sw = (j >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kofs[ks] = j * 128 + (((4 * ks + g) ^ sw) & 7) * 16;
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {
+      const int c0 = 4 * s2 + (g >> 1);
+      vofs[s2][0] = j * 128 + (g & 1) * 8 + ((c0 ^ sw) * 16);
+      vofs[s2][1] = j * 128 + (g & 1) * 8 + (((c0 + 2) ^ sw) * 16);
+    }
+  }
   // Lazy running maximum.  The accumulators of K Q^T start at -m (the row's reference maximum so far), so the MFMA
   // result is directly the exp2 argument.  Three bodies of one KV tile:
   //   FIRST (tile 0): m := the tile's row maximum;
@@ -221,7 +263,8 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
     for (int ks = 0; ks < KS; ++ks) {
       bf16x8 kfr[4];
 #pragma unroll
-      for (int kf = 0; kf < 4; ++kf) kfr[kf] = row_frag<DK>(sK, kf, ks, g, j);
+      for (int kf = 0; kf < 4; ++kf)
+        kfr[kf] = DMA ? *(const bf16x8*)(sK + kofs[ks] + kf * 2048) : row_frag<DK>(sK, kf, ks, g, j);
 #pragma unroll
       for (int kf = 0; kf < 4; ++kf)
 #pragma unroll
@@ -291,7 +334,16 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-      for (int df = 0; df < DF; ++df) vfr[s2][df] = tr_frag(sV, df, s2, g, j);
+      for (int df = 0; df < DF; ++df) {
+        if (DMA) {
+          const uint2 lo = *(const uint2*)(sV + vofs[s2][0] + df * 2048), hi = *(const uint2*)(sV + vofs[s2][1] + df * 2048);
+          union { uint4 u; bf16x8 v; } tt;
+          tt.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          vfr[s2][df] = tt.v;
+        } else {
+          vfr[s2][df] = tr_frag(sV, df, s2, g, j);
+        }
+      }
     // VALU (cvt_pk) results feed the inline-asm MFMAs: the P fragments are tied through the wait-state statement so
     // the compiler cannot schedule their producers after it (register-only VALU ops float past a plain asm)
     if constexpr (QP == 2) {
@@ -309,32 +361,75 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
     return false;
   };
 
-  // Two LDS stages, ONE barrier per KV tile: iteration t stores tile t+1 (fetched into registers during
-  // iteration t-1) into the other stage, fetches tile t+2, then computes tile t.
-  uint4 rk[RowTile<DK>::NREG], rv[TrTile<DV>::NREG];
   const int nt = (a.Skv + KVB - 1) / KVB;
   const bool ragged = (a.Skv % KVB) != 0;
-  rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, 0, hoff, a.d, tid);
-  tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, 0, tid);
-  rows_r2s<DK>(smem, rk, tid);
-  tr_r2s<DV>(smem + RowTile<DK>::BYTES, rv, tid);
-  if (nt > 1) {
-    rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, KVB, hoff, a.d, tid);
-    tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, KVB, tid);
+  // ---- staging.  Register path: two LDS stages, ONE barrier per KV tile: iteration t stores tile t+1 (fetched into
+  // registers during iteration t-1) into the other stage, fetches tile t+2, then computes tile t.
+  // DMA path: iteration t issues the LDS-DMA of tile t+1 into the other stage right after the barrier, computes tile t
+  // and then waits for its own pieces (vmcnt(0)); the next barrier publishes them.  No staging registers, no ds_write,
+  // per-lane source pointers advance by a constant per tile (4 pieces of 1 KiB per wave per tile). ----
+  uint4 rk[DMA ? 1 : RowTile<DK>::NREG], rv[DMA ? 1 : TrTile<DV>::NREG];
+  const bf16_t* dsrc[4];   // DMA: this lane's source of pieces K0, K1, V0, V1 for the tile to fetch next
+  int64_t dinc[4];
+  const unsigned lds0 = (unsigned)(uintptr_t)((ATTN_LDS_AS char*)smem);
+  auto dma_setup = [&](int t) {  // (re)derive the per-lane sources for tile t (also masks rows past Skv in a ragged tile)
+    const bf16_t* zero = (const bf16_t*)g_attn_zero;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int row = 8 * (wave + 4 * i) + (lane >> 3), pc = lane & 7, c = pc ^ ((row >> 1) & 7);
+      const bool kok = c * 8 < a.d && t * KVB + row < a.Skv;
+      dsrc[i] = kok ? a.K + ((int64_t)b * a.Skv + t * KVB + row) * a.ldk + hoff + c * 8 : zero;
+      dinc[i] = kok ? (int64_t)KVB * a.ldk : 0;
+      const bool vok = row < attn_dvpad(a.d);
+      dsrc[2 + i] = vok ? a.VT + (((int64_t)b * a.H + h) * attn_dvpad(a.d) + row) * SP + t * KVB + c * 8 : zero;
+      dinc[2 + i] = vok ? KVB : 0;
+    }
+  };
+  auto dma_issue = [&](int t) {  // tile t -> stage t&1; afterwards the sources point at tile t+1
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (t & 1) * STAGEB + wave * 1024);
+    if (ragged && t == nt - 1) dma_setup(t);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      attn_glds16(dsrc[i], base + i * 4096);
+      attn_glds16(dsrc[2 + i], base + KBYTES + i * 4096);
+      dsrc[i] += dinc[i];
+      dsrc[2 + i] += dinc[2 + i];
+    }
+  };
+  if constexpr (DMA) {
+    dma_setup(0);
+    dma_issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  } else {
+    rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, 0, hoff, a.d, tid);
+    tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, 0, tid);
+    rows_r2s<DK>(smem, rk, tid);
+    tr_r2s<DV>(smem + RowTile<DK>::BYTES, rv, tid);
+    if (nt > 1) {
+      rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, KVB, hoff, a.d, tid);
+      tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, KVB, tid);
+    }
   }
   auto stage = [&](int t) {
     __syncthreads();  // stage t&1 is complete; every wave is done with stage (t+1)&1
     sK = smem + (t & 1) * STAGEB;
-    sV = sK + RowTile<DK>::BYTES;
-    if (t + 1 < nt) {
-      char* nK = smem + ((t + 1) & 1) * STAGEB;
-      rows_r2s<DK>(nK, rk, tid);
-      tr_r2s<DV>(nK + RowTile<DK>::BYTES, rv, tid);
-      if (t + 2 < nt) {
-        rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, (t + 2) * KVB, hoff, a.d, tid);
-        tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, (t + 2) * KVB, tid);
+    sV = sK + KBYTES;
+    if constexpr (DMA) {
+      if (t + 1 < nt) dma_issue(t + 1);
+    } else {
+      if (t + 1 < nt) {
+        char* nK = smem + ((t + 1) & 1) * STAGEB;
+        rows_r2s<DK>(nK, rk, tid);
+        tr_r2s<DV>(nK + RowTile<DK>::BYTES, rv, tid);
+        if (t + 2 < nt) {
+          rows_g2r<DK>(rk, a.K, a.ldk, b, a.Skv, (t + 2) * KVB, hoff, a.d, tid);
+          tr_g2r<DV>(rv, a.VT, b, a.H, h, SP, (t + 2) * KVB, tid);
+        }
       }
     }
+  };
+  auto landed = [&]() {  // DMA: this wave's pieces of the next tile are in LDS (the next barrier publishes them)
+    if constexpr (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   };
   using MFirst = std::integral_constant<int, T_FIRST>;
   using MFast = std::integral_constant<int, T_FAST>;
@@ -346,9 +441,11 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
   if (nfull > 0) {
     stage(0);
     tile_pair(std::false_type{}, MFirst{}, 0, 0);
+    landed();
     for (int t = 1; t < nfull; ++t) {
       stage(t);
       tile_pair(std::false_type{}, MFast{}, 0, t);
+      landed();
     }
   }
   if (ragged) {
@@ -731,22 +828,37 @@ int set_smem(KernelT k, int bytes) {
 
 template <int DK, int DV, int NF>
 int fwd_t(const AttnArgs& a, hipStream_t st) {
-  constexpr int smem0 = 2 * (RowTile<DK>::BYTES + TrTile<DV>::BYTES);
+  // LDS-DMA staged variant for 64-wide tiles (developer knob 11 != 0 falls back to the register-staged kernel)
+  constexpr bool CAN_DMA = DK == 64 && DV <= 64;
+  const bool dma = CAN_DMA && fdmi_tune_get(11) == 0;
+  constexpr int smem_reg = 2 * (RowTile<DK>::BYTES + TrTile<DV>::BYTES);
+  constexpr int smem_dma = 2 * 2 * 64 * 128;
   // developer knob 10: extra (unused) LDS bytes per block, to lower the occupancy for latency-vs-throughput experiments
-  const int smem = smem0 + (fdmi_tune_get(10) > 0 ? fdmi_tune_get(10) : 0);
+  const int smem = (dma ? smem_dma : smem_reg) + (fdmi_tune_get(10) > 0 ? fdmi_tune_get(10) : 0);
   static int once = -1;
   if (once != smem) {
-    if (set_smem(attn_fwd_kernel<DK, DV, NF, false>, smem)) return -2;
-    if (set_smem(attn_fwd_kernel<DK, DV, NF, true>, smem)) return -2;
+    if (set_smem(attn_fwd_kernel<DK, DV, NF, false, false>, smem)) return -2;
+    if (set_smem(attn_fwd_kernel<DK, DV, NF, true, false>, smem)) return -2;
+    if constexpr (CAN_DMA) {
+      if (set_smem(attn_fwd_kernel<DK, DV, NF, false, true>, smem)) return -2;
+      if (set_smem(attn_fwd_kernel<DK, DV, NF, true, true>, smem)) return -2;
+    }
     once = smem;
   }
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
-  if (a.vt_ones && a.d < DV)
-    hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, true>), grid, dim3(256), smem, st, a);
-  else
-    hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, false>), grid, dim3(256), smem, st, a);
+  const bool ones = a.vt_ones && a.d < DV;
+  if constexpr (CAN_DMA) {
+    if (dma) {
+      if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, true, true>), grid, dim3(256), smem, st, a);
+      else hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, false, true>), grid, dim3(256), smem, st, a);
+    }
+  }
+  if (!dma) {
+    if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, true, false>), grid, dim3(256), smem, st, a);
+    else hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, false, false>), grid, dim3(256), smem, st, a);
+  }
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;
