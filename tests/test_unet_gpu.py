@@ -180,7 +180,7 @@ def test_ctx_cache_reuse_matches_recompute():
     t1, t2 = torch.full((B,), 900.0, device="cuda"), torch.full((B,), 300.0, device="cuda")
     with torch.no_grad():
         ref1 = net(x1, t1, ctx).clone()
-        ref1b = net(x1, t1, ctx).clone()
+        reps = [net(x1, t1, ctx).clone() for _ in range(5)]
         ref2 = net(x2, t2, ctx).clone()
         a = net(x1, t1, ctx, ctx_cache="fill").clone()
         b = net(x2, t2, ctx, ctx_cache="reuse").clone()
@@ -188,6 +188,8 @@ def test_ctx_cache_reuse_matches_recompute():
         ctx2 = {"cond": {"crossattn": torch.randn(B, L, D, device="cuda")}}
         ref3 = net(x2, t2, ctx2).clone()
         c = net(x2, t2, ctx2, ctx_cache="fill").clone()
-    noise = max(rel_err(ref1b, ref1), 1e-3)
-    assert rel_err(a, ref1) <= 4 * noise and rel_err(b, ref2) <= 4 * noise and rel_err(c, ref3) <= 4 * noise
-    assert rel_err(b, ref1) > 20 * noise  # (a different sample really gives a different output)
+    # run-to-run spread of this tiny (32-channel, chaotic) UNet: float-atomic GroupNorm statistics flip bf16 roundings;
+    # measured 0 ... 1.2e-2 over repeated identical calls (scripts/ctxdbg.py)
+    noise = max([rel_err(r, ref1) for r in reps] + [5e-3])
+    assert rel_err(a, ref1) <= 3 * noise and rel_err(b, ref2) <= 3 * noise and rel_err(c, ref3) <= 3 * noise
+    assert rel_err(b, ref1) > 10 * noise  # (a different sample really gives a different output)
