@@ -15,8 +15,15 @@ Pinning status (see DESIGN.md "Oracle"):
     ``flash.models.flash.FlashDiffusion`` imported unmodified from
     /root/reference/src (``oracle/shim_import.py``), and the committed fixtures
     under ``tests/golden/`` were produced by that real reference class.
+  * the few-step sampler (FlashDiffusion.sample / log_samples, FD:754-1019): PINNED the same way
+    (``FlashDiffusionRef.sample``; fixture ``tests/golden/sample_lcm4.npz`` from the real class).
+  * the flow-matching step (FlashDiffusionSD3.forward, _dmd_loss, _gan_loss, get_sigmas;
+    flash_sd3/flash_diffusion_model.py): PINNED -- ``oracle/flash_sd3_ref.py`` is bit-identical to the
+    reference's own ``FlashDiffusionSD3`` (5 configurations x G/D step x 3 start indices), fixtures
+    ``tests/golden/sd3_*.npz`` from the real class.  (Oracle groundwork for SURVEY 8a row a18; the HIP
+    path of that row -- the SD3 transformer -- is not built yet.)
   * denoiser / scheduler arithmetic (diffusers UNet2DConditionModel,
-    DPMSolverMultistepScheduler, DDPMScheduler): PARITY UNPINNED by the
+    DPMSolverMultistepScheduler, DDPMScheduler, LCMScheduler, FlowMatchEulerDiscreteScheduler): PARITY UNPINNED by the
     reference -- it lives in an un-vendored fork of diffusers
     (requirements.txt:1, ``git+https://github.com/initml/diffusers.git@clement/feature/flash``,
     a branch ref, not installed, no network) and the reference's tests hold no

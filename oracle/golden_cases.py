@@ -51,3 +51,35 @@ def make_batch(B=2, hw=32, ctx_dim=64, seed=5):
     z = torch.from_numpy(rs.standard_normal((B, 4, hw, hw)).astype(np.float32))
     c = torch.from_numpy(rs.standard_normal((B, 77, ctx_dim)).astype(np.float32))
     return {"image": z, "crossattn": c, "text": ["a"] * B}
+
+
+# ---- FlashDiffusionSD3 (flow matching) fixtures: models and inputs are fully seeded ---------------------------------
+SD3_CASES = {
+    # name: (config kwargs, step, seed)
+    "sd3_g_dmd_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="lsgan",
+                             use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=7.0), 0, 11),
+    "sd3_d_hinge": (dict(K=[8], num_iterations_per_K=[10], timestep_distribution="mixture", gan_loss_type="hinge",
+                         mixture_num_components=4, mixture_var=0.5, mode_probs=[[0.1, 0.3, 0.3, 0.3]]), 1, 12),
+}
+
+
+def build_sd3_models():
+    """teacher / perturbed student test denoisers, PatchGAN-style head, text-embedding pipeline stub, batch"""
+    from .flash_sd3_ref import EmbeddingPipeline, TinyFlowDenoiser
+    teacher = TinyFlowDenoiser(seed=1)
+    student = copy.deepcopy(teacher)
+    g = torch.Generator().manual_seed(2)
+    for p in student.parameters():
+        p.data.add_(torch.randn(p.shape, generator=g) * 0.02)
+    teacher.freeze()
+    disc = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 4, 2, 1), torch.nn.SiLU(), torch.nn.Conv2d(8, 1, 8, 1, 0),
+                               torch.nn.Flatten())
+    g3 = torch.Generator().manual_seed(3)
+    for p in disc.parameters():
+        p.data.copy_(torch.randn(p.shape, generator=g3) * 0.1)
+    ge = torch.Generator().manual_seed(9)
+    pipe = EmbeddingPipeline(torch.randn(2, 5, 10, generator=ge), torch.randn(2, 12, generator=ge),
+                             torch.randn(2, 5, 10, generator=ge), torch.randn(2, 12, generator=ge))
+    gb = torch.Generator().manual_seed(5)
+    batch = {"image": torch.randn(2, 4, 16, 16, generator=gb), "text": ["a", "b"]}
+    return teacher, student, disc, pipe, batch

@@ -113,10 +113,51 @@ def make_sample_golden():
     print("sample_lcm4", float(s.abs().mean()), float(sr.abs().mean()), len(noises), os.path.getsize(path) // 1024, "KiB")
 
 
+def make_sd3_golden():
+    """FlashDiffusionSD3.forward (+ backward) of the REAL reference on the seeded test denoisers; draws recorded through
+    the bit-identical restatement (oracle/flash_sd3_ref.py)."""
+    from .flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from .golden_cases import SD3_CASES, build_sd3_models
+    from .sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    FD3, FD3C = shim_import.import_reference_sd3()
+    for name, (kw, step, seed) in SD3_CASES.items():
+        teacher, student, disc, pipe, batch = build_sd3_models()
+        ref = FD3(FD3C(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                  teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc, pipeline=pipe)
+        torch.manual_seed(seed)
+        out = ref(batch, step=step)
+        out["loss"][step].backward()
+        grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+        teacher, student, disc, pipe, batch2 = build_sd3_models()
+        ora = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                                   teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc,
+                                   pipeline=pipe)
+        torch.manual_seed(seed)
+        out2 = ora(batch2, step=step)
+        for k in ("teacher_output", "student_output", "noisy_sample"):
+            assert torch.equal(out[k], out2[k]), (name, k)
+        blob = {"z": batch["image"].numpy(), "step": np.int64(step), "start_timestep": np.float64(out["start_timestep"])}
+        for k, v in ora.last_draws.values.items():
+            blob["draw:" + k] = v.numpy()
+        for k in ("teacher_output", "student_output", "noisy_sample"):
+            blob["out:" + k] = out[k].detach().numpy()
+        for i in (0, 1):
+            blob[f"loss:{i}"] = np.float64(float(out["loss"][i]))
+        for n, g in grads.items():
+            blob["grad:" + n] = g.numpy()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, "loss", blob["loss:0"], blob["loss:1"], "ngrads", len(grads), "start_t", out["start_timestep"],
+              os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "sample":
         make_sample_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sd3":
+        make_sd3_golden()
     else:
         main()
         make_sample_golden()
+        make_sd3_golden()

@@ -307,3 +307,48 @@ class LCMSchedulerRef(_SchedulerBase):
             prev = denoised
         self._step_index += 1
         return (prev, denoised)
+
+
+class FlowMatchEulerDiscreteSchedulerRef:
+    """Upstream FlowMatchEulerDiscreteScheduler (rectified flow, SD3) restated: sigma-shifted linear schedule, Euler step
+    x <- x + (sigma_next - sigma) * v.  The surface FlashDiffusionSD3 uses (FD3:150, 262-270, 281-314, 431-447, 520-536,
+    947-958): set_timesteps, .timesteps (float), .sigmas (with a trailing 0), step, .config.num_train_timesteps.
+    (diffusers is absent offline: parity of these internals is unpinned, like the other schedulers; the orchestration
+    around them is pinned against the real FlashDiffusionSD3 in tests/test_oracle_vs_reference.py.)"""
+
+    def __init__(self, num_train_timesteps=1000, shift=3.0):
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, shift=shift)
+        ts = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+        sig = torch.from_numpy(ts) / num_train_timesteps
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = sig * num_train_timesteps
+        self.sigmas = sig
+        self.sigma_min = float(sig[-1])
+        self.sigma_max = float(sig[0])
+        self._step_index = None
+        self.num_inference_steps = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        N, shift = self.config.num_train_timesteps, self.config.shift
+        ts = np.linspace(self.sigma_max * N, self.sigma_min * N, num_inference_steps)
+        sig = ts / N
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        sig = torch.from_numpy(sig).to(dtype=torch.float32, device=device)
+        self.timesteps = sig * N
+        self.sigmas = torch.cat([sig, torch.zeros(1, device=sig.device)])
+        self.num_inference_steps = num_inference_steps
+        self._step_index = None
+
+    def index_for_timestep(self, timestep):
+        cand = (self.timesteps == timestep).nonzero()
+        pos = 1 if len(cand) > 1 else 0
+        return int(cand[pos].item())
+
+    def step(self, model_output, timestep, sample, return_dict=False, **kw):
+        if self._step_index is None:
+            t = timestep if torch.is_tensor(timestep) else torch.tensor(timestep)
+            self._step_index = self.index_for_timestep(t.to(self.timesteps.device))
+        sigma, sigma_next = self.sigmas[self._step_index], self.sigmas[self._step_index + 1]
+        prev = sample.to(torch.float32) + (sigma_next - sigma) * model_output
+        self._step_index += 1
+        return (prev.to(model_output.dtype),)

@@ -63,3 +63,11 @@ def import_reference():
         sys.path.insert(0, REFERENCE_SRC)
     from flash.models.flash import FlashDiffusion, FlashDiffusionConfig  # noqa: E402
     return FlashDiffusion, FlashDiffusionConfig
+
+
+def import_reference_sd3():
+    """Returns (FlashDiffusionSD3, FlashDiffusionSD3Config) -- the reference's own flow-matching (SD3) model classes
+    (/root/reference/src/flash/models/flash_sd3/flash_diffusion_model.py:42), same stubs as above."""
+    import_reference()
+    from flash.models.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config  # noqa: E402
+    return FlashDiffusionSD3, FlashDiffusionSD3Config

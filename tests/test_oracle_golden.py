@@ -82,3 +82,31 @@ def test_lcm_default_schedule():
     assert s.timesteps.tolist() == [999, 759, 499, 259]   # the well-known 4-step LCM schedule
     s.set_timesteps(timesteps=[999, 749, 499, 249])
     assert s.timesteps.tolist() == [999, 749, 499, 249] and s.num_inference_steps == 4
+
+
+@pytest.mark.parametrize("name", ["sd3_g_dmd_lsgan", "sd3_d_hinge"])
+def test_oracle_sd3_reproduces_golden(name):
+    """FlashDiffusionSD3.forward (flow matching): fixtures made by the real reference class"""
+    from oracle.flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.golden_cases import SD3_CASES, build_sd3_models
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    kw, step, _seed = SD3_CASES[name]
+    g = load_case(name)
+    teacher, student, disc, pipe, batch = build_sd3_models()
+    m = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                             teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc, pipeline=pipe)
+    m.draws = Draws(g["draws"])
+    assert torch.equal(batch["image"], g["z"])
+    out = m(batch, step=step)
+    assert abs(out["start_timestep"] - g["start_timestep"]) < 1e-4
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert rel_err(out[k], g["out"][k]) < 1e-5, k
+    for i in (0, 1):
+        assert abs(float(out["loss"][i]) - g["loss"][i]) <= 1e-5 * max(1.0, abs(g["loss"][i]))
+    out["loss"][step].backward()
+    n = 0
+    for pn, p in m.named_parameters():
+        if p.grad is not None:
+            assert rel_err(p.grad, g["grads"][pn]) < 1e-4, pn
+            n += 1
+    assert n == len(g["grads"]) and n > 0

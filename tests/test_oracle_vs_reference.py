@@ -119,3 +119,89 @@ def test_log_samples_restatement_is_bit_identical():
     assert list(logs[0].keys()) == list(logs[1].keys()) and len(logs[0]) == 4
     for k in logs[0]:
         assert torch.equal(logs[0][k], logs[1][k]), k
+
+
+# ---- FlashDiffusionSD3.forward (flow matching): oracle/flash_sd3_ref.py vs the real class ----
+def _build_sd3(cls, cfg_cls, with_disc=True, **cfg_kw):
+    from oracle.flash_sd3_ref import EmbeddingPipeline, TinyFlowDenoiser
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    teacher = TinyFlowDenoiser(seed=1)
+    student = copy.deepcopy(teacher)
+    g = torch.Generator().manual_seed(2)
+    for p in student.parameters():
+        p.data.add_(torch.randn(p.shape, generator=g) * 0.02)
+    teacher.freeze()
+    disc = None
+    if with_disc:
+        disc = torch.nn.Sequential(torch.nn.Conv2d(4, 8, 4, 2, 1), torch.nn.SiLU(), torch.nn.Conv2d(8, 1, 8, 1, 0),
+                                   torch.nn.Flatten())   # [B,4,16,16] -> [B,1]
+        g3 = torch.Generator().manual_seed(3)
+        for p in disc.parameters():
+            p.data.copy_(torch.randn(p.shape, generator=g3) * 0.1)
+    ge = torch.Generator().manual_seed(9)
+    pipe = EmbeddingPipeline(torch.randn(2, 5, 10, generator=ge), torch.randn(2, 12, generator=ge),
+                             torch.randn(2, 5, 10, generator=ge), torch.randn(2, 12, generator=ge))
+    m = cls(cfg_cls(**cfg_kw), student_denoiser=student, teacher_denoiser=teacher,
+            teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc, pipeline=pipe)
+    return m
+
+
+SD3_CASES = [
+    dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="lsgan", use_dmd_loss=True),
+    dict(K=[8], num_iterations_per_K=[10], timestep_distribution="mixture", gan_loss_type="hinge", distill_loss_type="l2",
+         mixture_num_components=4, mixture_var=0.5, mode_probs=[[0.1, 0.3, 0.3, 0.3]]),
+    dict(K=[6], num_iterations_per_K=[10], timestep_distribution="gaussian", gan_loss_type="non-saturating",
+         use_dmd_loss=True, use_teacher_as_real=True),
+    dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="wgan"),
+    dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="vanilla"),
+]
+
+
+@pytest.mark.parametrize("case", range(len(SD3_CASES)))
+@pytest.mark.parametrize("step", [0, 1])
+def test_sd3_restatement_is_bit_identical(case, step):
+    from oracle.flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    FD3, FD3C = shim_import.import_reference_sd3()
+    kw = SD3_CASES[case]
+    outs = []
+    for cls, ccls in ((FD3, FD3C), (FlashDiffusionSD3Ref, FlashSD3ConfigRef)):
+        for seed in (0, 1, 2):   # several start indices (incl. start_idx == 0: the pure-noise branch FD3:264-268)
+            m = _build_sd3(cls, ccls, **kw)
+            g = torch.Generator().manual_seed(5)
+            batch = {"image": torch.randn(2, 4, 16, 16, generator=g), "text": ["a", "b"]}
+            torch.manual_seed(100 + seed)
+            out = m(batch, step=step)
+            loss = out["loss"][step]
+            grads = None
+            if torch.is_tensor(loss) and loss.requires_grad:
+                loss.backward()
+                grads = {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}
+            outs.append((cls.__name__, seed, out, grads))
+    ref, ora = outs[:3], outs[3:]
+    for (_, seed, a, ga), (_, _, b, gb) in zip(ref, ora):
+        assert a["start_timestep"] == b["start_timestep"]
+        for k in ("teacher_output", "student_output", "noisy_sample"):
+            assert torch.equal(a[k], b[k]), (seed, k)
+        for i in (0, 1):
+            la, lb = a["loss"][i], b["loss"][i]
+            assert (torch.is_tensor(la) == torch.is_tensor(lb)) and float(la) == float(lb), (seed, i)
+        assert (ga is None) == (gb is None)
+        if ga is not None:
+            assert set(ga) == set(gb) and len(ga) > 0
+            for n in ga:
+                assert torch.equal(ga[n], gb[n]), (seed, n)
+
+
+def test_sd3_without_discriminator_returns_scalar_loss():
+    from oracle.flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    FD3, FD3C = shim_import.import_reference_sd3()
+    vals = []
+    for cls, ccls in ((FD3, FD3C), (FlashDiffusionSD3Ref, FlashSD3ConfigRef)):
+        m = _build_sd3(cls, ccls, with_disc=False, K=[4], num_iterations_per_K=[10], timestep_distribution="uniform",
+                       use_dmd_loss=True)
+        g = torch.Generator().manual_seed(5)
+        torch.manual_seed(7)
+        out = m({"image": torch.randn(2, 4, 16, 16, generator=g), "text": ["a", "b"]})
+        assert torch.is_tensor(out["loss"]) and out["loss"].dim() == 0     # FD3:357-364: a scalar, not a list
+        vals.append(out)
+    assert float(vals[0]["loss"]) == float(vals[1]["loss"]) and torch.equal(vals[0]["student_output"], vals[1]["student_output"])
