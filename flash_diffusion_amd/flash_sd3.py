@@ -1,0 +1,320 @@
+"""Host-side mirror of the reference's flow-matching distillation step ``FlashDiffusionSD3.forward``
+(/root/reference/src/flash/models/flash_sd3/flash_diffusion_model.py -- "FD3"), on device tensors,
+with the latent algebra on the HIP element-wise kernels of libfdmi.so:
+
+* noising  x_t = sigma eps + (1 - sigma) z  (FD3:262-270, 447, 535-536)          -> ``ops.add_noise`` (one launch)
+* teacher Euler step with CFG folded in  x <- x + (s' - s) (g e_c + (1-g) e_u)    -> ``ops.axpby`` (one launch, FD3:304-314)
+* student output  x0_hat = x_t - sigma v  (FD3:325)                               -> fused per-sample affine (autograd)
+* distillation loss (FD3:368-382) and the DMD term (FD3:416-499, restated as written: its "x0" is the real velocity,
+  no alpha-bar weighting)                                                          -> the fused loss kernels of flash.py
+
+The denoisers are whatever honours the reference's wrapper contract (``sample, timestep, conditioning, **kwargs``): the SD3
+transformer itself (TW:113-155) is NOT part of this module -- its HIP plan is the next build.
+Same constructor and return contract as the reference class, including the scalar ``loss`` when no discriminator is given
+(FD3:357-364) and ``return_post_mid_blocks=True`` on the discriminator backbone call (FD3:563).  ``vae`` must be None.
+"""
+from __future__ import annotations
+
+import copy
+from dataclasses import dataclass, field
+from types import SimpleNamespace
+from typing import Any, Dict, List, Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from .flash import Draws, _DistillLoss, _DmdLoss, _PerSampleAffine, gaussian_mixture_pmf
+
+
+@dataclass
+class FlashDiffusionSD3Config:
+    """flash_sd3/flash_diffusion_config.py, with its __post_init__ list expansion"""
+    K: List[int] = field(default_factory=lambda: [32, 32, 32, 32, 32])
+    num_iterations_per_K: List[int] = field(default_factory=lambda: [5000, 10000, 15000, 20000, 25000])
+    guidance_scale_min: Any = 3.0
+    guidance_scale_max: Any = 7.0
+    distill_loss_type: str = "l2"
+    ucg_keys: List[str] = field(default_factory=lambda: ["text"])
+    timestep_distribution: str = "mixture"
+    mixture_num_components: Any = 4
+    mixture_var: Any = 0.5
+    use_dmd_loss: bool = False
+    dmd_loss_scale: Any = 1.0
+    distill_loss_scale: Any = 1.0
+    adversarial_loss_scale: Any = 1.0
+    gan_loss_type: str = "hinge"
+    mode_probs: Optional[List[List[float]]] = None
+    use_teacher_as_real: bool = False
+    input_key: str = "image"
+
+    def __post_init__(self):
+        assert self.distill_loss_type in ("l2", "l1"), "lpips needs the VAE decoder + VGG (DESIGN.md section 8)"
+        assert self.timestep_distribution in ("gaussian", "uniform", "mixture")
+        assert self.gan_loss_type in ("hinge", "vanilla", "non-saturating", "wgan", "lsgan")
+        n = len(self.K)
+        for k in ("mixture_num_components", "guidance_scale_min", "guidance_scale_max", "mixture_var",
+                  "distill_loss_scale", "dmd_loss_scale", "adversarial_loss_scale"):
+            v = getattr(self, k)
+            if isinstance(v, (int, float)) and not isinstance(v, bool):
+                setattr(self, k, [v] * n)
+
+    def to_dict(self):
+        return dict(self.__dict__)
+
+
+class FlowMatchEulerDiscreteScheduler:
+    """The surface FlashDiffusionSD3 uses of diffusers' FlowMatchEulerDiscreteScheduler (upstream semantics, shift 3.0 for
+    SD3): ``set_timesteps``, float ``timesteps``, ``sigmas`` with a trailing 0, ``config.num_train_timesteps`` and an Euler
+    ``step`` -- the latent update is one fused HIP launch."""
+
+    def __init__(self, num_train_timesteps=1000, shift=3.0):
+        self.config = SimpleNamespace(num_train_timesteps=num_train_timesteps, shift=shift)
+        ts = np.linspace(1, num_train_timesteps, num_train_timesteps, dtype=np.float32)[::-1].copy()
+        sig = torch.from_numpy(ts) / num_train_timesteps
+        sig = shift * sig / (1 + (shift - 1) * sig)
+        self.timesteps = sig * num_train_timesteps
+        self.sigmas = sig
+        self.sigma_min, self.sigma_max = float(sig[-1]), float(sig[0])
+        self._step_index = None
+        self.num_inference_steps = None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        N, shift = self.config.num_train_timesteps, self.config.shift
+        sig = np.linspace(self.sigma_max * N, self.sigma_min * N, num_inference_steps) / N
+        sig = torch.from_numpy(shift * sig / (1 + (shift - 1) * sig)).to(dtype=torch.float32)
+        self.timesteps = sig * N
+        self.sigmas = torch.cat([sig, torch.zeros(1)])
+        self.num_inference_steps = num_inference_steps
+        self._step_index = None
+
+    def index_for_timestep(self, timestep):
+        cand = (self.timesteps == float(timestep)).nonzero()
+        return int(cand[1 if len(cand) > 1 else 0].item())
+
+    def step_delta(self, timestep):
+        """sigma_next - sigma of the step that starts at `timestep` (advances the internal step index)"""
+        if self._step_index is None:
+            self._step_index = self.index_for_timestep(timestep)
+        d = float(self.sigmas[self._step_index + 1] - self.sigmas[self._step_index])
+        self._step_index += 1
+        return d
+
+    def step(self, model_output, timestep, sample, return_dict=False, **kw):
+        return (ops.axpby(sample.float().contiguous(), 1.0, model_output.float().contiguous(), self.step_delta(timestep)),)
+
+
+def get_sigmas(scheduler, timesteps):
+    """FD3:947-958: per-sample sigma [B] (host lookup on the scheduler's own float timesteps)"""
+    st = scheduler.timesteps
+    idx = [int((st == float(t)).nonzero().item()) for t in timesteps.detach().cpu()]
+    return scheduler.sigmas[idx].to(dtype=torch.float32).flatten()
+
+
+class FlashDiffusionSD3(nn.Module):
+    def __init__(self, config: FlashDiffusionSD3Config, student_denoiser, teacher_denoiser=None,
+                 teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
+                 vae=None, conditioner=None, discriminator=None, pipeline=None, cpu_offload: bool = False):
+        super().__init__()
+        if vae is not None:
+            raise NotImplementedError("VAE encode/decode is out of the hot-path scope: feed latents")
+        self.config = config
+        self.input_key = config.input_key
+        self.student_denoiser = student_denoiser
+        self.teacher_denoiser = teacher_denoiser
+        self.teacher_noise_scheduler = teacher_noise_scheduler
+        self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
+        self.sampling_noise_scheduler = sampling_noise_scheduler
+        self.teacher_noise_scheduler_copy = copy.deepcopy(teacher_noise_scheduler)   # FD3:116 (1000-step copy)
+        self.vae = None
+        self.conditioner = conditioner
+        self.pipeline = pipeline
+        self.cpu_offload = cpu_offload
+        for k in ("guidance_scale_min", "guidance_scale_max", "K", "num_iterations_per_K", "distill_loss_type",
+                  "timestep_distribution", "mixture_num_components", "mixture_var", "use_dmd_loss", "dmd_loss_scale",
+                  "distill_loss_scale", "adversarial_loss_scale", "gan_loss_type", "mode_probs", "use_teacher_as_real"):
+            setattr(self, k, getattr(config, k))
+        if discriminator is not None and isinstance(discriminator, nn.Sequential):
+            from .discriminator import MiDiscriminator
+            try:
+                discriminator = MiDiscriminator.convert(discriminator)
+            except Exception:
+                pass   # not the conv / GroupNorm / SiLU PatchGAN shape: keep the module as given (boundary item 3)
+        self.discriminator = discriminator
+        self.use_adversarial_loss = discriminator is not None
+        self.disc_backbone = self.teacher_denoiser
+        self.iter_steps = 0
+        self.disc_update_counter = 0
+        self.K_steps = np.cumsum(self.num_iterations_per_K)
+        self.K_prev = self.K[0]
+        self.draws: Optional[Draws] = None      # tests inject the reference's random draws here
+        self.last_draws: Optional[Draws] = None
+        self.terms: Dict[str, Any] = {}
+
+    def freeze(self):
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def on_train_batch_end(self, batch, *a, **k):
+        pass
+
+    # FD3:135-177
+    def _timestep_pmf(self, K, K_step):
+        if self.timestep_distribution == "uniform":
+            return torch.ones(K) / K
+        if self.timestep_distribution == "gaussian":
+            p = torch.tensor([torch.exp(-torch.tensor([(i - K / 2) ** 2 / K])) for i in range(K)])
+            return p / torch.sum(p)
+        M = self.mixture_num_components[K_step]
+        mp = self.mode_probs[K_step] if self.mode_probs is not None else None
+        locs = [i * (K // M) for i in range(M)]
+        return gaussian_mixture_pmf(K, locs, self.mixture_var[K_step], mp if mp is not None else [1 / M] * M)
+
+    def _embeddings(self, batch, device):
+        """FD3:196-229: (cond, uncond) from ``pipeline.encode_prompt``"""
+        self.pipeline.to(device)
+        with torch.no_grad():
+            pe, npe, ppe, nppe = self.pipeline.encode_prompt(prompt=batch["text"], prompt_2=batch["text"],
+                                                             prompt_3=batch["text"], do_classifier_free_guidance=True,
+                                                             device=device)
+        if self.cpu_offload:
+            self.pipeline.to("cpu")
+        return ({"cond": {"vector": ppe, "crossattn": pe}}, {"cond": {"vector": nppe, "crossattn": npe}})
+
+    def forward(self, batch: Dict[str, Any], batch_idx=0, step=0, *args, **kwargs):
+        sch = self.teacher_noise_scheduler
+        d = self.draws if self.draws is not None else Draws()
+        self.last_draws = d
+        self.iter_steps += 1
+        z = batch[self.input_key].float().contiguous()
+        B = z.shape[0]
+        cond, uncond = self._embeddings(batch, z.device)
+        if self.iter_steps > self.K_steps[-1]:
+            K_step = len(self.K) - 1
+        else:
+            K_step = int(np.argmax(self.iter_steps < self.K_steps))
+        K = self.K[K_step]
+        g_min, g_max = self.guidance_scale_min[K_step], self.guidance_scale_max[K_step]
+        if K != self.K_prev:
+            raise NotImplementedError("K switching replaces the teacher by a copy of the student (FD3:244-249)")
+        noise = d.randn_like("noise", z)
+        sch.set_timesteps(K)
+        start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
+        si = int(start_idx)
+        start_t = sch.timesteps[si].to(z.device).repeat(B)
+        sig = get_sigmas(sch, start_t).to(z.device)                      # [B]
+        if si == 0:                                                      # FD3:264-268: start from pure noise
+            x_init = noise
+            if hasattr(sch, "init_noise_sigma"):
+                x_init = x_init * sch.init_noise_sigma
+        else:
+            with torch.no_grad():
+                x_init = ops.add_noise(z, noise.contiguous(), (1.0 - sig).contiguous(), sig.contiguous())
+        g = float(d.rand1("guidance")) * (g_max - g_min) + g_min
+        with torch.no_grad():                                            # FD3:282-314: Euler steps with CFG
+            x = x_init
+            for t in sch.timesteps[si:]:
+                tt = torch.full((B,), float(t), device=z.device)
+                e_c = self.teacher_denoiser(sample=x, timestep=tt, conditioning=cond, *args, **kwargs)
+                e_u = self.teacher_denoiser(sample=x, timestep=tt, conditioning=uncond, *args, **kwargs)
+                if hasattr(sch, "step_delta"):   # CFG combine + Euler update in one launch
+                    dl = sch.step_delta(t)
+                    x = ops.axpby(x.contiguous(), 1.0, e_c.float().contiguous(), g * dl, e_u.float().contiguous(),
+                                  (1.0 - g) * dl)
+                else:                            # any other scheduler duck type (FD3:304-314 literally)
+                    e = ops.axpby(e_c.float().contiguous(), g, e_u.float().contiguous(), 1.0 - g)
+                    x = sch.step(e, t, x, return_dict=False)[0]
+            teacher_output = x
+        v_s = self.student_denoiser(sample=x_init, timestep=start_t, conditioning=cond)
+        student_output = _PerSampleAffine.apply(v_s.float(), x_init, torch.ones_like(sig), (-sig).contiguous())   # FD3:325
+        l_distill = _DistillLoss.apply(student_output, teacher_output.detach(), self.distill_loss_type == "l1")
+        loss = l_distill * self.distill_loss_scale[K_step]
+        self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": g}
+        if self.use_dmd_loss:
+            l_dmd = self._dmd_loss(d, student_output, cond, cond, uncond, K_step)
+            self.terms["dmd"] = l_dmd.detach()
+            loss = loss + l_dmd * self.dmd_loss_scale[K_step]
+        if self.use_adversarial_loss:
+            gan = self._gan_loss(d, z, student_output, teacher_output, cond, step)
+            loss = loss + self.adversarial_loss_scale[K_step] * gan[0]
+            return {"loss": [loss, gan[1]], "teacher_output": teacher_output, "student_output": student_output,
+                    "noisy_sample": x_init, "start_timestep": float(start_t[0].item())}
+        return {"loss": loss.mean(), "teacher_output": teacher_output, "student_output": student_output,
+                "noisy_sample": x_init, "start_timestep": float(start_t[0].item())}
+
+    def _noised(self, x, noise, sig):
+        """sigma eps + (1 - sigma) x, differentiable w.r.t. x (gradient (1 - sigma) g)"""
+        return _PerSampleAffine.apply(x, noise, sig.contiguous(), (1.0 - sig).contiguous())
+
+    def _dmd_loss(self, d, s, student_cond, cond, uncond, K_step):
+        """FD3:416-499"""
+        sc = self.teacher_noise_scheduler_copy
+        B = s.shape[0]
+        noise = d.randn_like("dmd_noise", s)
+        ti = d.randint("dmd_t", 0, self.teacher_noise_scheduler.config.num_train_timesteps, (B,), "cpu")
+        t = sc.timesteps[ti.cpu()].to(s.device)
+        sig = get_sigmas(sc, t).to(s.device)
+        noisy = self._noised(s, noise.contiguous(), sig)
+        with torch.no_grad():
+            r_c = self.teacher_denoiser(sample=noisy.detach(), timestep=t, conditioning=cond)
+            r_u = self.teacher_denoiser(sample=noisy.detach(), timestep=t, conditioning=uncond)
+            f_c = self.student_denoiser(sample=noisy.detach(), timestep=t, conditioning=student_cond)
+            g = (float(d.rand1("dmd_guidance")) * (self.guidance_scale_max[K_step] - self.guidance_scale_min[K_step])
+                 + self.guidance_scale_min[K_step])
+            real = ops.axpby(r_c.float().contiguous(), g, r_u.float().contiguous(), 1.0 - g)
+            zero, one = torch.zeros(B, device=s.device), torch.ones(B, device=s.device)
+        # the fused DMD kernel with x0 := 0 * noisy + 1 * real (FD3:483) and coefficient (real - fake) * 1 (FD3:476-481)
+        return _DmdLoss.apply(s, noisy.detach(), real, f_c.float().contiguous(), zero, one, one)
+
+    def _gan_loss(self, d, z, s, teacher_output, conditioning, step):
+        """FD3:501-667"""
+        sc = self.teacher_noise_scheduler_copy
+        self.disc_update_counter += 1
+        B = s.shape[0]
+        noise = d.randn_like("gan_noise", s)
+        real = teacher_output if self.use_teacher_as_real else z
+        sel = [float(sc.timesteps[-10]), float(sc.timesteps[-250]), float(sc.timesteps[-500]), float(sc.timesteps[-750])]
+        idx = d.multinomial("gan_t", torch.tensor([0.25, 0.25, 0.25, 0.25]), B, replacement=True)
+        ts = torch.tensor(sel)[idx.cpu()].to(s.device)
+        sig = get_sigmas(sc, ts).to(s.device)
+        gen = step % 2 == 0
+        noisy_fake = self._noised(s if gen else s.detach(), noise.contiguous(), sig)
+        with torch.no_grad():
+            noisy_real = ops.add_noise(real.float().contiguous(), noise.contiguous(), (1.0 - sig).contiguous(), sig.contiguous())
+        x = torch.cat([noisy_fake, noisy_real], dim=0)
+        if conditioning is not None:
+            conditioning = {"cond": {k: torch.cat([v, v], dim=0) for k, v in conditioning["cond"].items()}}
+        feat = self.disc_backbone(sample=x, timestep=torch.cat([ts, ts], dim=0), conditioning=conditioning,
+                                  return_post_mid_blocks=True)
+        f_fake, f_real = feat.chunk(2, dim=0)
+        disc, kind, dev = self.discriminator, self.gan_loss_type, s.device
+        if kind == "wgan":
+            for p in disc.parameters():
+                p.data.clamp_(-0.01, 0.01)
+            if gen:
+                return [-disc(f_fake).mean(), 0]
+            return [0, -disc(f_real).mean() + disc(f_fake.detach()).mean()]
+        if kind == "lsgan":
+            valid, fake = torch.ones(B, 1, device=dev), torch.zeros(B, 1, device=dev)
+            if gen:
+                return [F.mse_loss(torch.sigmoid(disc(f_fake)), valid), 0]
+            return [0, 0.5 * (F.mse_loss(torch.sigmoid(disc(f_real)), valid)
+                              + F.mse_loss(torch.sigmoid(disc(f_fake.detach())), fake))]
+        if kind == "hinge":
+            if gen:
+                return [-disc(f_fake).mean(), 0]
+            return [0, F.relu(1.0 - disc(f_real)).mean() + F.relu(1.0 + disc(f_fake.detach())).mean()]
+        if kind == "non-saturating":
+            if gen:
+                return [-torch.mean(torch.log(torch.sigmoid(disc(f_fake)) + 1e-8)), 0]
+            return [0, -torch.mean(torch.log(torch.sigmoid(disc(f_real)) + 1e-8)
+                                   + torch.log(1 - torch.sigmoid(disc(f_fake.detach())) + 1e-8))]
+        valid = torch.ones(B, 1, device=dev)
+        if gen:
+            return [F.binary_cross_entropy_with_logits(disc(f_fake), valid), 0]
+        fake = torch.zeros(B, 1, device=dev)
+        return [0, F.binary_cross_entropy_with_logits(disc(f_real), valid)
+                + F.binary_cross_entropy_with_logits(disc(f_fake.detach()), fake)]
