@@ -162,3 +162,23 @@ def test_lcm_scheduler_host_side_matches_oracle():
     with _pt.raises(ValueError):
         a.set_timesteps(timesteps=[5, 9])
     assert torch.equal(a.alphas_cumprod, b.alphas_cumprod) and a.init_noise_sigma == b.init_noise_sigma == 1.0
+
+
+def test_flow_match_scheduler_host_side_matches_oracle():
+    """sigma-shifted schedule of the product FlowMatchEulerDiscreteScheduler (host fp32 math) vs the oracle restatement"""
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler, get_sigmas
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    a, b = FlowMatchEulerDiscreteScheduler(), FlowMatchEulerDiscreteSchedulerRef()
+    assert torch.equal(a.timesteps, b.timesteps) and torch.equal(a.sigmas, b.sigmas)       # the 1000-step training schedule
+    for n in (1, 4, 8, 32):
+        a.set_timesteps(n)
+        b.set_timesteps(n)
+        assert torch.equal(a.timesteps, b.timesteps) and torch.equal(a.sigmas, b.sigmas) and float(a.sigmas[-1]) == 0.0
+    a.set_timesteps(4)
+    sig = get_sigmas(a, a.timesteps[[0, 2, 3]])
+    assert torch.equal(sig, a.sigmas[[0, 2, 3]])
+    d0 = a.step_delta(a.timesteps[0])
+    d1 = a.step_delta(a.timesteps[1])
+    assert abs(d0 - float(a.sigmas[1] - a.sigmas[0])) < 1e-12 and abs(d1 - float(a.sigmas[2] - a.sigmas[1])) < 1e-12
+    c = FlashDiffusionSD3Config(K=[4, 2], num_iterations_per_K=[10, 20], guidance_scale_min=2.0)
+    assert c.guidance_scale_min == [2.0, 2.0] and c.mixture_num_components == [4, 4] and c.distill_loss_scale == [1.0, 1.0]
