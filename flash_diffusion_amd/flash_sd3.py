@@ -184,6 +184,50 @@ class FlashDiffusionSD3(nn.Module):
             self.pipeline.to("cpu")
         return ({"cond": {"vector": ppe, "crossattn": pe}}, {"cond": {"vector": nppe, "crossattn": npe}})
 
+    def _euler_cfg(self, net, sch, timesteps, x, cond, uncond, g, *args, **kwargs):
+        """FD3:282-314 / 767-795 / 812-841: Euler steps over `timesteps` with classifier-free guidance; the CFG combine and
+        the latent update are one fused launch per step when the scheduler exposes ``step_delta``"""
+        B = x.shape[0]
+        for t in timesteps:
+            tt = torch.full((B,), float(t), device=x.device)
+            e_c = net(sample=x, timestep=tt, conditioning=cond, *args, **kwargs)
+            e_u = net(sample=x, timestep=tt, conditioning=uncond, *args, **kwargs)
+            if hasattr(sch, "step_delta"):
+                dl = sch.step_delta(t)
+                x = ops.axpby(x.float().contiguous(), 1.0, e_c.float().contiguous(), g * dl, e_u.float().contiguous(),
+                              (1.0 - g) * dl)
+            else:                                # any other scheduler duck type (FD3:304-314 literally)
+                e = ops.axpby(e_c.float().contiguous(), g, e_u.float().contiguous(), 1.0 - g)
+                x = sch.step(e, t, x, return_dict=False)[0]
+        return x
+
+    @torch.no_grad()
+    def sample(self, z, num_steps=20, guidance_scale=1.0, teacher_guidance_scale=5.0, conditioner_inputs=None,
+               uncond_conditioner_inputs=None, max_samples=None, verbose=False, log_teacher_samples=False):
+        """FD3:682-843: few-step Euler sampling of the student from latent noise `z` (and, with ``log_teacher_samples``,
+        the teacher's samples from the same noise).  Returns latents: the VAE decode is out of scope."""
+        self.teacher_noise_scheduler.set_timesteps(num_steps)
+        ss = self.sampling_noise_scheduler
+        ss.set_timesteps(num_steps)
+        cond, uncond = self._embeddings(conditioner_inputs, z.device)
+        x = z.float()
+        if max_samples is not None:
+            x = x[:max_samples]
+            cond = {"cond": {k: v[:max_samples] for k, v in cond["cond"].items()}}
+            uncond = {"cond": {k: v[:max_samples] for k, v in uncond["cond"].items()}}
+        x = x.contiguous()
+        x0 = x
+        if hasattr(ss, "init_noise_sigma"):
+            x = x * ss.init_noise_sigma
+        out = self._euler_cfg(self.student_denoiser, ss, ss.timesteps, x, cond, uncond, float(guidance_scale))
+        ref = None
+        if log_teacher_samples:
+            ts = self.teacher_sampling_noise_scheduler
+            ts.set_timesteps(num_steps)
+            ref = x0 * ts.init_noise_sigma if hasattr(ts, "init_noise_sigma") else x0
+            ref = self._euler_cfg(self.teacher_denoiser, ts, ts.timesteps, ref, cond, uncond, float(teacher_guidance_scale))
+        return out, ref
+
     def forward(self, batch: Dict[str, Any], batch_idx=0, step=0, *args, **kwargs):
         sch = self.teacher_noise_scheduler
         d = self.draws if self.draws is not None else Draws()
@@ -215,18 +259,7 @@ class FlashDiffusionSD3(nn.Module):
                 x_init = ops.add_noise(z, noise.contiguous(), (1.0 - sig).contiguous(), sig.contiguous())
         g = float(d.rand1("guidance")) * (g_max - g_min) + g_min
         with torch.no_grad():                                            # FD3:282-314: Euler steps with CFG
-            x = x_init
-            for t in sch.timesteps[si:]:
-                tt = torch.full((B,), float(t), device=z.device)
-                e_c = self.teacher_denoiser(sample=x, timestep=tt, conditioning=cond, *args, **kwargs)
-                e_u = self.teacher_denoiser(sample=x, timestep=tt, conditioning=uncond, *args, **kwargs)
-                if hasattr(sch, "step_delta"):   # CFG combine + Euler update in one launch
-                    dl = sch.step_delta(t)
-                    x = ops.axpby(x.contiguous(), 1.0, e_c.float().contiguous(), g * dl, e_u.float().contiguous(),
-                                  (1.0 - g) * dl)
-                else:                            # any other scheduler duck type (FD3:304-314 literally)
-                    e = ops.axpby(e_c.float().contiguous(), g, e_u.float().contiguous(), 1.0 - g)
-                    x = sch.step(e, t, x, return_dict=False)[0]
+            x = self._euler_cfg(self.teacher_denoiser, sch, sch.timesteps[si:], x_init, cond, uncond, g, *args, **kwargs)
             teacher_output = x
         v_s = self.student_denoiser(sample=x_init, timestep=start_t, conditioning=cond)
         student_output = _PerSampleAffine.apply(v_s.float(), x_init, torch.ones_like(sig), (-sig).contiguous())   # FD3:325

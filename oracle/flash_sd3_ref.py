@@ -92,6 +92,8 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
         self.teacher_denoiser = teacher_denoiser
         self.teacher_noise_scheduler = teacher_noise_scheduler
         self.teacher_noise_scheduler_copy = copy.deepcopy(teacher_noise_scheduler)      # FD3:116
+        self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
+        self.sampling_noise_scheduler = sampling_noise_scheduler
         self.discriminator = discriminator
         self.use_adversarial_loss = discriminator is not None                            # FD3:120-128
         self.pipeline = pipeline
@@ -198,6 +200,44 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
                                      return_post_mid_blocks=True)
         ff, fr = feat.chunk(2, dim=0)
         return gan_losses(cfg.gan_loss_type, self.discriminator, ff, fr, step, s.size(0), noise.device)
+
+
+    # ---- FD3:682-843: Euler sampler of the student (and, optionally, of the teacher next to it) ----
+    @torch.no_grad()
+    def sample(self, z, num_steps=20, guidance_scale=1.0, teacher_guidance_scale=5.0, conditioner_inputs=None,
+               uncond_conditioner_inputs=None, max_samples=None, verbose=False, log_teacher_samples=False):
+        self.teacher_noise_scheduler.set_timesteps(num_steps)                                   # FD3:707
+        ss = self.sampling_noise_scheduler
+        ss.set_timesteps(num_steps)                                                             # FD3:709
+        sample = z
+        pe, npe, ppe, nppe = self.pipeline.encode_prompt(prompt=conditioner_inputs["text"], device=z.device)
+        cond = {"cond": {"vector": ppe, "crossattn": pe}}
+        uncond = {"cond": {"vector": nppe, "crossattn": npe}}
+        if max_samples is not None:                                                             # FD3:751-762
+            sample = sample[:max_samples]
+            cond["cond"] = {k: v[:max_samples] for k, v in cond["cond"].items()}
+            uncond["cond"] = {k: v[:max_samples] for k, v in uncond["cond"].items()}
+        sample_init = sample
+        if hasattr(ss, "init_noise_sigma"):
+            sample = sample * ss.init_noise_sigma
+        for t in ss.timesteps:                                                                  # FD3:767-795
+            tt = t.to(z.device).repeat(sample.shape[0])
+            e_c = self.student_denoiser(sample=sample, timestep=tt, conditioning=cond)
+            e_u = self.student_denoiser(sample=sample, timestep=tt, conditioning=uncond)
+            e = guidance_scale * e_c + (1 - guidance_scale) * e_u
+            sample = ss.step(e, t, sample, return_dict=False)[0]
+        ref = None
+        if log_teacher_samples:                                                                 # FD3:804-841
+            ts = self.teacher_sampling_noise_scheduler
+            ts.set_timesteps(num_steps)
+            ref = sample_init * ts.init_noise_sigma if hasattr(ts, "init_noise_sigma") else sample_init
+            for t in ts.timesteps:
+                tt = t.to(z.device).repeat(ref.shape[0])
+                e_c = self.teacher_denoiser(sample=ref, timestep=tt, conditioning=cond)
+                e_u = self.teacher_denoiser(sample=ref, timestep=tt, conditioning=uncond)
+                e = teacher_guidance_scale * e_c + (1 - teacher_guidance_scale) * e_u
+                ref = ts.step(e, t, ref, return_dict=False)[0]
+        return sample, ref
 
 
 class TinyFlowDenoiser(torch.nn.Module):

@@ -61,3 +61,33 @@ def test_sd3_step_matches_reference_golden(name):
         assert _cos(p.grad, ref) > 0.9999 and rel_err(p.grad, ref) < 2e-3, (pn, _cos(p.grad, ref), rel_err(p.grad, ref))
         n += 1
     assert n > 0
+
+
+@pytest.mark.parametrize("kw", [dict(num_steps=4, guidance_scale=1.0), dict(num_steps=3, guidance_scale=2.5, max_samples=1),
+                                dict(num_steps=4, guidance_scale=1.5, log_teacher_samples=True, teacher_guidance_scale=4.0)])
+def test_sd3_sampler_matches_oracle(kw):
+    """FlashDiffusionSD3.sample (FD3:682-843) against the oracle's restatement (itself pinned bit-identically to the real
+    class in tests/test_oracle_vs_reference.py); fp32 test-double denoisers on both sides, tolerance 2e-4 relative."""
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    from oracle.flash_sd3_ref import EmbeddingPipeline, FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    cfg = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform")
+    teacher, student, _, pipe, _ = build_sd3_models()
+    z = torch.randn(2, 4, 16, 16, generator=torch.Generator().manual_seed(13))
+    ci = {"text": ["a", "b"]}
+    ref_m = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**cfg), student_denoiser=student, teacher_denoiser=teacher,
+                                 teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(),
+                                 sampling_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(),
+                                 teacher_sampling_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), pipeline=pipe)
+    want, want_ref = ref_m.sample(z, conditioner_inputs=ci, **kw)
+    teacher, student, _, pipe, _ = build_sd3_models()
+    pipe = EmbeddingPipeline(pipe.e[0].cuda(), pipe.e[2].cuda(), pipe.e[1].cuda(), pipe.e[3].cuda())
+    m = FlashDiffusionSD3(FlashDiffusionSD3Config(**cfg), student_denoiser=student.cuda(), teacher_denoiser=teacher.cuda(),
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(),
+                          sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler(),
+                          teacher_sampling_noise_scheduler=FlowMatchEulerDiscreteScheduler(), pipeline=pipe)
+    got, got_ref = m.sample(z.cuda(), conditioner_inputs=ci, **kw)
+    assert got.shape == want.shape and rel_err(got, want) < 2e-4, rel_err(got, want)
+    assert (got_ref is None) == (want_ref is None)
+    if want_ref is not None:
+        assert rel_err(got_ref, want_ref) < 2e-4 and rel_err(got_ref, got) > 1e-3

@@ -205,3 +205,23 @@ def test_sd3_without_discriminator_returns_scalar_loss():
         assert torch.is_tensor(out["loss"]) and out["loss"].dim() == 0     # FD3:357-364: a scalar, not a list
         vals.append(out)
     assert float(vals[0]["loss"]) == float(vals[1]["loss"]) and torch.equal(vals[0]["student_output"], vals[1]["student_output"])
+
+
+@pytest.mark.parametrize("kw", [dict(num_steps=4, guidance_scale=1.0), dict(num_steps=3, guidance_scale=2.5, max_samples=1),
+                                dict(num_steps=4, guidance_scale=1.5, log_teacher_samples=True, teacher_guidance_scale=4.0)])
+def test_sd3_sample_restatement_is_bit_identical(kw):
+    from oracle.flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    FD3, FD3C = shim_import.import_reference_sd3()
+    outs = []
+    for cls, ccls in ((FD3, FD3C), (FlashDiffusionSD3Ref, FlashSD3ConfigRef)):
+        m = _build_sd3(cls, ccls, with_disc=False, K=[4], num_iterations_per_K=[10], timestep_distribution="uniform")
+        m.sampling_noise_scheduler = FlowMatchEulerDiscreteSchedulerRef()
+        m.teacher_sampling_noise_scheduler = FlowMatchEulerDiscreteSchedulerRef()
+        g = torch.Generator().manual_seed(13)
+        z = torch.randn(2, 4, 16, 16, generator=g)
+        outs.append(m.sample(z, conditioner_inputs={"text": ["a", "b"]}, **kw))
+    (a, ar), (o, orf) = outs
+    assert torch.equal(a, o) and (ar is None) == (orf is None)
+    if ar is not None:
+        assert torch.equal(ar, orf) and not torch.equal(ar, a)
