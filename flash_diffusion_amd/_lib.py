@@ -59,6 +59,12 @@ _SIGS = {
     "fdmi_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "fdmi_layernorm_fwd": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
     "fdmi_layernorm_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32, i32, vp]),
+    "fdmi_layernorm_mod_fwd": (i32, [vp, vp, vp, i64, i32, vp, vp, i64, i32, f32, vp]),
+    "fdmi_layernorm_mod_bwd": (i32, [vp, vp, vp, i64, i32, vp, i64, i32, f32, i32, vp]),
+    "fdmi_gate_residual": (i32, [vp, vp, i64, vp, vp, i64, i32, i32, vp]),
+    "fdmi_gelu_tanh": (i32, [vp, vp, i64, vp]),
+    "fdmi_gelu_tanh_bwd": (i32, [vp, vp, vp, i64, vp]),
+    "fdmi_batch_colsum": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "fdmi_attn_tr_elems": (i64, [i32, i32, i32, i32]),
     "fdmi_attn_bwd_ws_bytes": (i64, [i32, i32, i32, i32, i32]),
     "fdmi_attn_fwd": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, vp, i32, i32, i32, i32, i32, f32, vp]),

@@ -98,6 +98,34 @@ int fdmi_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* 
   return launch_layernorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, nullptr, 0, 1, (bf16_t*)dx, rows, C,
                               eps, accumulate, (hipStream_t)stream);
 }
+int fdmi_layernorm_mod_fwd(const void* x, const void* shift, const void* scale, int64_t mod_ld, int rows_per_batch,
+                           void* y, float* stats, int64_t rows, int C, float eps, void* stream) {
+  FDMI_CHECK(shift && scale, "layernorm_mod_fwd: shift and scale are required");
+  return launch_layernorm_fwd((const bf16_t*)x, nullptr, nullptr, (const bf16_t*)shift, (const bf16_t*)scale, mod_ld,
+                              rows_per_batch, (bf16_t*)y, rows, C, eps, (hipStream_t)stream, stats);
+}
+int fdmi_layernorm_mod_bwd(const void* x, const void* dy, const void* scale, int64_t mod_ld, int rows_per_batch, void* dx,
+                           int64_t rows, int C, float eps, int accumulate, void* stream) {
+  FDMI_CHECK(scale != nullptr, "layernorm_mod_bwd: scale is required");
+  return launch_layernorm_bwd((const bf16_t*)x, (const bf16_t*)dy, nullptr, (const bf16_t*)scale, mod_ld, rows_per_batch,
+                              (bf16_t*)dx, rows, C, eps, accumulate, (hipStream_t)stream);
+}
+int fdmi_gate_residual(const void* x, const void* gate, int64_t gate_ld, const void* res, void* y, int64_t rows, int C,
+                       int rows_per_batch, void* stream) {
+  return launch_gate_residual((const bf16_t*)x, (const bf16_t*)gate, gate_ld, (const bf16_t*)res, (bf16_t*)y, rows, C,
+                              rows_per_batch, (hipStream_t)stream);
+}
+int fdmi_gelu_tanh(const void* x, void* y, int64_t n, void* stream) {
+  return launch_gelu_tanh((const bf16_t*)x, (bf16_t*)y, n, (hipStream_t)stream);
+}
+int fdmi_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  return launch_gelu_tanh_bwd((const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n, (hipStream_t)stream);
+}
+int fdmi_batch_colsum(const void* dy, const void* x, const float* stats, float* out0, float* out1, int B,
+                      int rows_per_batch, int C, void* stream) {
+  return launch_batch_colsum((const bf16_t*)dy, (const bf16_t*)x, stats, out0, out1, B, rows_per_batch, C,
+                             (hipStream_t)stream);
+}
 
 int64_t fdmi_attn_tr_elems(int B, int H, int S, int d) {
   return (int64_t)B * H * attn_dvpad(d) * attn_spad(S);

@@ -1,0 +1,128 @@
+// HBM-bound kernels of the adaLN-single DiT path (Pixart-alpha) that the UNet path does not have:
+// the gated residual, tanh-GELU and its derivative, and the per-sample column sums that give the gradients of the
+// adaLN shift / scale / gate vectors.  All bf16 token-major [rows][C], 16-byte accesses, fp32 arithmetic.
+#include "ops.h"
+
+static inline int nblocks(int64_t total, int cap = 8192) {
+  int64_t b = (total + 255) / 256;
+  if (b > cap) b = cap;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+// y[m][c] = res[m][c] + gate[m / rows_per_batch][c] * x[m][c]   (res may be null: the backward's dy = gate * dout)
+__global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* x, const bf16_t* gate, int64_t gate_ld,
+                                                            const bf16_t* res, bf16_t* y, int64_t rows, int C,
+                                                            int rows_per_batch) {
+  const int CPR = C >> 3;
+  const int64_t total = rows * CPR;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t m = i / CPR;
+    const int c0 = (int)(i - m * CPR) * 8;
+    const u16x8 xv = *(const u16x8*)(x + m * C + c0);
+    const u16x8 gv = *(const u16x8*)(gate + (m / rows_per_batch) * gate_ld + c0);
+    u16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0}, o;
+    if (res) rv = *(const u16x8*)(res + m * C + c0);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(bf2f(gv[e]), bf2f(xv[e]), bf2f(rv[e])));
+    *(u16x8*)(y + m * C + c0) = o;
+  }
+}
+
+// tanh-approximated GELU (torch.nn.GELU(approximate="tanh")): 0.5 x (1 + tanh(k (x + 0.044715 x^3))), k = sqrt(2/pi)
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
+  return 0.5f * x * (1.f + tanhf(u));
+}
+__device__ __forceinline__ float dgelu_tanh_f(float x) {
+  const float x2 = x * x;
+  const float t = tanhf(0.7978845608028654f * fmaf(0.044715f * x2, x, x));
+  const float du = 0.7978845608028654f * fmaf(3.f * 0.044715f, x2, 1.f);
+  return 0.5f * (1.f + t) + 0.5f * x * (1.f - t * t) * du;
+}
+template <bool BWD>
+__global__ __launch_bounds__(256) void gelu_tanh_kernel(const bf16_t* x, const bf16_t* dy, bf16_t* out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (int64_t)gridDim.x * 256) {
+    const u16x8 xv = *(const u16x8*)(x + i * 8);
+    u16x8 o, dv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (BWD) dv = *(const u16x8*)(dy + i * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float v = bf2f(xv[e]);
+      o[e] = f2bf(BWD ? bf2f(dv[e]) * dgelu_tanh_f(v) : gelu_tanh_f(v));
+    }
+    *(u16x8*)(out + i * 8) = o;
+  }
+}
+
+// Per-sample column sums over the rows of each batch entry (outputs pre-zeroed, fp32 atomics):
+//   out1[b][c] += sum_r dy[r][c]                    (d shift)
+//   out0[b][c] += sum_r dy[r][c] * f(x[r][c])       (d scale with f = LayerNorm normalisation from stats[r] = (mean, rstd);
+//                                                    d gate with f = identity when stats is null)
+// grid (row chunks of RCH, B, ceil(C/8/256)); a thread owns one 8-channel chunk and walks the rows of its chunk.
+constexpr int BCS_RCH = 64;
+__global__ __launch_bounds__(256) void batch_colsum_kernel(const bf16_t* dy, const bf16_t* x, const float* stats,
+                                                           float* out0, float* out1, int rows_per_batch, int C) {
+  const int ch = blockIdx.z * 256 + threadIdx.x;
+  if (ch >= (C >> 3)) return;
+  const int b = blockIdx.y;
+  const int r0 = blockIdx.x * BCS_RCH;
+  const int r1 = min(r0 + BCS_RCH, rows_per_batch);
+  float s0[8], s1[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    const int64_t row = (int64_t)b * rows_per_batch + r;
+    const u16x8 dv = *(const u16x8*)(dy + row * C + ch * 8);
+    float mean = 0.f, rstd = 1.f;
+    if (stats) {
+      mean = stats[row * 2];
+      rstd = stats[row * 2 + 1];
+    }
+    if (x) {
+      const u16x8 xv = *(const u16x8*)(x + row * C + ch * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s0[e] = fmaf(bf2f(dv[e]), (bf2f(xv[e]) - mean) * rstd, s0[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] += bf2f(dv[e]);
+  }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    if (out0) atomicAdd(out0 + (int64_t)b * C + ch * 8 + e, s0[e]);
+    if (out1) atomicAdd(out1 + (int64_t)b * C + ch * 8 + e, s1[e]);
+  }
+}
+
+int launch_gate_residual(const bf16_t* x, const bf16_t* gate, int64_t gate_ld, const bf16_t* res, bf16_t* y,
+                         int64_t rows, int C, int rows_per_batch, hipStream_t st) {
+  FDMI_CHECK(C % 8 == 0 && gate_ld % 8 == 0 && rows_per_batch > 0, "gate_residual: C and gate_ld must be multiples of 8");
+  hipLaunchKernelGGL(gate_residual_kernel, dim3(nblocks(rows * (C >> 3))), dim3(256), 0, st, x, gate, gate_ld, res, y,
+                     rows, C, rows_per_batch);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_gelu_tanh(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t st) {
+  FDMI_CHECK(n % 8 == 0, "gelu_tanh: element count must be a multiple of 8");
+  hipLaunchKernelGGL(gelu_tanh_kernel<false>, dim3(nblocks(n >> 3)), dim3(256), 0, st, x, (const bf16_t*)nullptr, y,
+                     n >> 3);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_gelu_tanh_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t n, hipStream_t st) {
+  FDMI_CHECK(n % 8 == 0, "gelu_tanh_bwd: element count must be a multiple of 8");
+  hipLaunchKernelGGL(gelu_tanh_kernel<true>, dim3(nblocks(n >> 3)), dim3(256), 0, st, x, dy, dx, n >> 3);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_batch_colsum(const bf16_t* dy, const bf16_t* x, const float* stats, float* out0, float* out1, int B,
+                        int rows_per_batch, int C, hipStream_t st) {
+  FDMI_CHECK(C % 8 == 0 && B > 0 && rows_per_batch > 0, "batch_colsum: C must be a multiple of 8");
+  FDMI_CHECK(!out0 || x, "batch_colsum: out0 needs x");
+  if (out0) FDMI_HIP(hipMemsetAsync(out0, 0, (size_t)B * C * sizeof(float), st));
+  if (out1) FDMI_HIP(hipMemsetAsync(out1, 0, (size_t)B * C * sizeof(float), st));
+  hipLaunchKernelGGL(batch_colsum_kernel, dim3(cdiv(rows_per_batch, BCS_RCH), B, cdiv(C >> 3, 256)), dim3(256), 0, st, dy,
+                     x, stats, out0, out1, rows_per_batch, C);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}

@@ -208,6 +208,7 @@ struct LnArgs {
   const bf16_t* x; const bf16_t* dy; const float* gamma; const float* beta;
   const bf16_t* shift; const bf16_t* scale; int64_t mod_ld; int rows_per_batch;
   bf16_t* y; int64_t rows; int C; float eps; int accumulate;
+  float* stats;  // fwd, optional: [rows][2] = (mean, rstd) for the adaLN parameter gradients (dit.hip batch_colsum)
 };
 
 // LPR lanes cooperate on one row (LPR = 8..64, a power of two chosen so each lane holds <= 5 chunks of
@@ -259,6 +260,10 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
   const float rstd = rsqrtf(group_sum<LPR>(sq) * invC + a.eps);
   const int64_t mrow = a.scale ? (rrow / a.rows_per_batch) * a.mod_ld : 0;
   if (!BWD) {
+    if (a.stats && live && sub == 0) {
+      a.stats[row * 2] = mean;
+      a.stats[row * 2 + 1] = rstd;
+    }
 #pragma unroll
     for (int s = 0; s < MAXC; ++s) {
       const int ch = sub + LPR * s;
@@ -346,9 +351,10 @@ static int launch_ln(const LnArgs& a, hipStream_t st) {
 
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, const bf16_t* shift,
                          const bf16_t* scale, int64_t mod_ld, int rows_per_batch, bf16_t* y,
-                         int64_t rows, int C, float eps, hipStream_t st) {
+                         int64_t rows, int C, float eps, hipStream_t st, float* stats) {
   FDMI_CHECK(C % 8 == 0 && C <= 2560, "layernorm: C must be a multiple of 8 and <= 2560");
-  LnArgs a{x, nullptr, gamma, beta, shift, scale, mod_ld, rows_per_batch, y, rows, C, eps, 0};
+  FDMI_CHECK(!scale || (shift && rows_per_batch > 0 && mod_ld % 8 == 0), "layernorm: adaLN modulate needs shift, scale, rows_per_batch");
+  LnArgs a{x, nullptr, gamma, beta, shift, scale, mod_ld, rows_per_batch, y, rows, C, eps, 0, stats};
   return launch_ln<false>(a, st);
 }
 
@@ -356,6 +362,6 @@ int launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, 
                          int64_t mod_ld, int rows_per_batch, bf16_t* dx, int64_t rows, int C,
                          float eps, int accumulate, hipStream_t st) {
   FDMI_CHECK(C % 8 == 0 && C <= 2560, "layernorm: C must be a multiple of 8 and <= 2560");
-  LnArgs a{x, dy, gamma, nullptr, nullptr, scale, mod_ld, rows_per_batch, dx, rows, C, eps, accumulate};
+  LnArgs a{x, dy, gamma, nullptr, nullptr, scale, mod_ld, rows_per_batch, dx, rows, C, eps, accumulate, nullptr};
   return launch_ln<true>(a, st);
 }

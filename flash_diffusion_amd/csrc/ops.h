@@ -12,7 +12,7 @@ int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, 
                          float eps, int silu, int accumulate, hipStream_t st, bool stats_zeroed = false);
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, const bf16_t* shift,
                          const bf16_t* scale, int64_t mod_ld, int rows_per_batch, bf16_t* y,
-                         int64_t rows, int C, float eps, hipStream_t st);
+                         int64_t rows, int C, float eps, hipStream_t st, float* stats = nullptr);
 int launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const bf16_t* scale,
                          int64_t mod_ld, int rows_per_batch, bf16_t* dx, int64_t rows, int C,
                          float eps, int accumulate, hipStream_t st);
@@ -76,6 +76,16 @@ int launch_cast_transpose_jobs(const CastJob* jobs, int njobs, hipStream_t st);
 // fused AdamW on a flat f32 buffer
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,
                  float eps, float wd, int step, float grad_scale, hipStream_t st);
+
+// ---- dit.hip: adaLN-single DiT element-wise kernels ----
+// y = res + gate[m / rows_per_batch] * x  (res may be null)
+int launch_gate_residual(const bf16_t* x, const bf16_t* gate, int64_t gate_ld, const bf16_t* res, bf16_t* y,
+                         int64_t rows, int C, int rows_per_batch, hipStream_t st);
+int launch_gelu_tanh(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t st);
+int launch_gelu_tanh_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t n, hipStream_t st);
+// out1[b][c] = sum_r dy ; out0[b][c] = sum_r dy * f(x)  (f = LayerNorm normalisation from stats[rows][2], identity if null)
+int launch_batch_colsum(const bf16_t* dy, const bf16_t* x, const float* stats, float* out0, float* out1, int B,
+                        int rows_per_batch, int C, hipStream_t st);
 
 // ---- discriminator support + fused loss kernels (elem.hip) ----
 int launch_im2col(const bf16_t* x, bf16_t* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride,

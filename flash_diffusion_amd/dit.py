@@ -1,0 +1,517 @@
+"""MiTransformer2DModel -- drop-in for the reference's PixArt-alpha denoiser ``DiffusersTransformer2DWrapper``
+(/root/reference/src/flash/models/transformers/tranformers.py:9-100, with its ``AdaLayerNormSingle``,
+transformers/utils.py:8-102): same constructor keywords (examples/train_flash_pixart.py:63-86), same
+forward signature / conditioning dict / ``freeze()``, parameters named by their diffusers state_dict keys.
+
+Every operation on token-major activations ([B*T, C] bf16) is a hand-written HIP kernel of libfdmi.so reached through the
+op-level C-ABI (include/fdmi.h): bf16 MFMA GEMMs with fused bias / residual / SiLU epilogues, flash attention forward and
+backward (head dim 72), LayerNorm with the adaLN modulate fused (``fdmi_layernorm_mod_*``), the gated residual, tanh-GELU and
+the per-sample column sums that give the gradients of the modulation vectors (csrc/dit.hip).  torch supplies device
+memory, the stream, the autograd graph edges between those launches, the patch (un)folding of the 4-channel latent and
+the glue on per-sample vectors ([B, C]: adding the scale-shift tables, chunk / cat).  There is no torch compute path for
+the activations and no CPU fallback: without libfdmi.so every call raises.
+
+LoRA follows peft (examples/train_flash_pixart.py:237-256): y = W x + B(A x) on every module whose name ends in one of the
+target suffixes -- linears and the patch-embedding convolution alike (a k = stride convolution IS a linear map on the
+folded patches, so it runs as one)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence, Union
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+
+BF16 = torch.bfloat16
+PIXART_LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0", "proj_in", "proj_out", "ff.net.0.proj", "ff.net.2", "proj",
+                       "linear", "linear_1", "linear_2")      # examples/train_flash_pixart.py:240-253
+
+
+def _pad8(n):
+    return (n + 7) // 8 * 8
+
+
+# ---- autograd edges around the HIP launches -------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    """y = act(x W^T + b [+ (x A^T) B^T] [+ residual]); W frozen, A / B (LoRA, fp32 masters) trainable."""
+
+    @staticmethod
+    def forward(ctx, x, residual, lin, act, out_f32, need_bwd, A, B):
+        wb, wtb = lin.base16()
+        M = x.shape[0]
+        pre = torch.empty(M, lin.out_features, dtype=BF16, device=x.device) if (act and need_bwd) else None
+        t = None
+        if A is None:
+            y = ops.gemm(x, wb, bias=lin.bias, residual=residual, act=act, preact=pre, out_f32=out_f32)
+        else:
+            ab, _, bb, _ = lin.lora16()
+            t = ops.gemm(x, ab)
+            y0 = ops.gemm(x, wb, bias=lin.bias, residual=residual)
+            y = ops.gemm(t, bb, residual=y0, act=act, preact=pre, out_f32=out_f32)
+        lin.count(2.0 * M * lin.out_features * lin.in_features
+                  + (2.0 * M * lin.rank * (lin.in_features + lin.out_features) if A is not None else 0.0))
+        ctx.lin, ctx.act, ctx.out_f32, ctx.lora = lin, act, out_f32, A is not None
+        ctx.ashape = None if A is None else (A.shape, B.shape)
+        if need_bwd:
+            ctx.save_for_backward(x, pre, t)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lin = ctx.lin
+        x, pre, t = ctx.saved_tensors
+        dy = dy.contiguous()
+        if ctx.out_f32:
+            dy = ops.f32_to_bf16(dy)
+        if ctx.act:
+            dy = ops.silu_bwd(pre, dy)
+        M = x.shape[0]
+        Mp = _pad8(M)
+        dx = dA = dB = None
+        _, wtb = lin.base16()
+        flops = 0.0
+        if ctx.lora:
+            _, abt, _, bbt = lin.lora16()
+            u = ops.gemm(dy, bbt)                                       # dL/d(A x)            [M, r]
+            dB = ops.gemm(ops.transpose2d_pad(dy, Mp), ops.transpose2d_pad(t, Mp), out_f32=True, splitk=0)   # [N, r]
+            dA = ops.gemm(ops.transpose2d_pad(u, Mp), ops.transpose2d_pad(x, Mp), out_f32=True, splitk=0)    # [r, K]
+            dA, dB = dA.view(ctx.ashape[0]), dB.view(ctx.ashape[1])
+            flops += 6.0 * M * lin.rank * lin.out_features + 2.0 * M * lin.rank * lin.in_features
+        if ctx.needs_input_grad[0]:
+            dx = ops.gemm(dy, wtb)
+            flops += 2.0 * M * lin.out_features * lin.in_features
+            if ctx.lora:
+                dx = ops.gemm(u, abt, residual=dx)
+                flops += 2.0 * M * lin.rank * lin.in_features
+        lin.count(flops)
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None, None, dA, dB
+
+
+class _LnModFn(torch.autograd.Function):
+    """LayerNorm(x) * (1 + scale[b]) + shift[b] (non-affine LayerNorm: ada_norm_single)"""
+
+    @staticmethod
+    def forward(ctx, x, shift, scale, rpb, eps, need_bwd):
+        y, stats = ops.layernorm_mod_fwd(x, shift, scale, rpb, eps,
+                                         need_stats=need_bwd and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]))
+        ctx.rpb, ctx.eps = rpb, eps
+        if need_bwd:
+            ctx.save_for_backward(x, scale, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, stats = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.layernorm_mod_bwd(x, dy, scale, ctx.rpb, ctx.eps) if ctx.needs_input_grad[0] else None
+        dshift = dscale = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dscale, dshift = ops.batch_colsum(dy, x, stats, rows_per_batch=ctx.rpb)
+            dscale, dshift = dscale.to(BF16), dshift.to(BF16)
+        return dx, dshift, dscale, None, None, None
+
+
+class _GateResFn(torch.autograd.Function):
+    """res + gate[b] * x"""
+
+    @staticmethod
+    def forward(ctx, x, gate, res, rpb, need_bwd):
+        ctx.rpb = rpb
+        if need_bwd:
+            ctx.save_for_backward(x, gate)
+        return ops.gate_residual(x, gate, res, rpb)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gate = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = ops.gate_residual(dy, gate, None, ctx.rpb) if ctx.needs_input_grad[0] else None
+        dgate = None
+        if ctx.needs_input_grad[1]:
+            dgate = ops.batch_colsum(dy, x, None, rows_per_batch=ctx.rpb, want_sum=False)[0].to(BF16)
+        return dx, dgate, (dy if ctx.needs_input_grad[2] else None), None, None
+
+
+class _GeluTanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, need_bwd):
+        if need_bwd:
+            ctx.save_for_backward(x)
+        return ops.gelu_tanh(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.gelu_tanh_bwd(ctx.saved_tensors[0], dy.contiguous()), None
+
+
+class _AttnFn(torch.autograd.Function):
+    """softmax(scale Q K^T) V per head; `lens` (host ints or None): per-sample number of valid keys (prefix mask)"""
+
+    @staticmethod
+    def forward(ctx, q, k, v, H, scale, lens, need_bwd, owner):
+        B, Sq, Cc = q.shape
+        Skv = k.shape[1]
+        if lens is None:
+            r = ops.attn_fwd(q, k, v, H, scale, need_lse=need_bwd)
+            o, lse = r if need_bwd else (r, None)
+            owner.count(4.0 * B * Sq * Skv * Cc)
+        else:   # masked keys (T5 padding): one launch per sample on its valid prefix
+            o = torch.empty_like(q)
+            lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_bwd else None
+            for b, n in enumerate(lens):
+                ops.attn_fwd(q[b:b + 1], k[b:b + 1, :n], v[b:b + 1, :n], H, scale, need_lse=need_bwd, out=o[b:b + 1],
+                             lse_out=None if lse is None else lse[b:b + 1])
+                owner.count(4.0 * Sq * n * Cc)
+        ctx.H, ctx.scale, ctx.lens, ctx.owner = H, scale, lens, owner
+        if need_bwd:
+            ctx.save_for_backward(q, k, v, o, lse)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        do = do.contiguous()
+        B, Sq, Cc = q.shape
+        if ctx.lens is None:
+            dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, ctx.H, ctx.scale)
+            ctx.owner.count(8.0 * B * Sq * k.shape[1] * Cc)
+        else:
+            dq, dk, dv = torch.empty_like(q), torch.zeros_like(k), torch.zeros_like(v)
+            for b, n in enumerate(ctx.lens):
+                ops.attn_bwd(q[b:b + 1], k[b:b + 1, :n], v[b:b + 1, :n], o[b:b + 1], do[b:b + 1], lse[b:b + 1], ctx.H,
+                             ctx.scale, out=(dq[b:b + 1], dk[b:b + 1, :n], dv[b:b + 1, :n]))
+                ctx.owner.count(8.0 * Sq * n * Cc)
+        return dq, dk, dv, None, None, None, None, None
+
+
+# ---- modules ------------------------------------------------------------------------------------------------------------------
+class MiLinear(nn.Module):
+    """A frozen-or-plain linear map held as fp32 master weights + cached bf16 operand copies (W and W^T), with an optional
+    peft-style LoRA pair.  ``weight`` may be 4-D (the patch-embedding convolution): it is used as [out, in*kh*kw]."""
+
+    def __init__(self, out_features, in_features, bias=True, wshape=None):
+        super().__init__()
+        self.out_features, self.in_features = out_features, in_features
+        self.weight = nn.Parameter(torch.randn(wshape or (out_features, in_features)) * in_features ** -0.5)
+        self.bias = nn.Parameter(torch.zeros(out_features)) if bias else None
+        self.rank = 0
+        self._b16 = None
+        self._l16 = None
+        self._owner = [None]     # the model (list: not a sub-module) -- flop counter and LoRA epoch
+
+    def count(self, flops):
+        if self._owner[0] is not None:
+            self._owner[0].count(flops)
+
+    def base16(self):
+        w = self.weight
+        key = (w.data_ptr(), w._version)
+        if self._b16 is None or self._b16[0] != key:
+            assert ops._dev(w).dtype == torch.float32, "parameters must be fp32 on the GPU"
+            self._b16 = (key,) + tuple(ops.cast_transpose(w.detach().reshape(self.out_features, self.in_features)))
+        return self._b16[1], self._b16[2]
+
+    def lora16(self):
+        """bf16 (A, A^T, B, B^T); re-cast once per model forward (in-place optimizer kernels do not bump ._version)"""
+        epoch = self._owner[0]._lora_epoch if self._owner[0] is not None else -1
+        A, B = self.lora_A.default.weight, self.lora_B.default.weight
+        key = (epoch, A.data_ptr(), B.data_ptr(), A._version, B._version)
+        if self._l16 is None or self._l16[0] != key:
+            ab, abt = ops.cast_transpose(A.detach().reshape(self.rank, self.in_features))
+            bb, bbt = ops.cast_transpose(B.detach().reshape(self.out_features, self.rank))
+            self._l16 = (key, ab, abt, bb, bbt)
+        return self._l16[1:]
+
+    def add_lora(self, r, init_std_b=0.0, generator=None):
+        dev = self.weight.device
+        ashape = (r,) + tuple(self.weight.shape[1:])
+        bshape = (self.out_features, r) + (1,) * (self.weight.dim() - 2)
+        a = torch.randn(ashape, generator=generator).to(dev) / r                     # peft "gaussian" init: N(0, 1/r)
+        b = (torch.randn(bshape, generator=generator) * init_std_b).to(dev) if init_std_b else torch.zeros(bshape, device=dev)
+        self.lora_A = nn.ModuleDict({"default": _Leaf(a)})
+        self.lora_B = nn.ModuleDict({"default": _Leaf(b)})
+        self.rank = r
+
+    def forward(self, x, residual=None, act=ops.ACT_NONE, out_f32=False):
+        assert x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == self.in_features
+        assert not (act and residual is not None)
+        need_bwd = torch.is_grad_enabled() and (x.requires_grad or self.rank > 0
+                                                or (residual is not None and residual.requires_grad))
+        A = self.lora_A.default.weight if self.rank else None
+        B = self.lora_B.default.weight if self.rank else None
+        return _LinearFn.apply(x, residual, self, act, out_f32, need_bwd, A, B)
+
+
+class _Leaf(nn.Module):
+    def __init__(self, w):
+        super().__init__()
+        self.weight = nn.Parameter(w)
+
+
+class _Node(nn.Module):
+    """plain container so parameters get their dotted diffusers names"""
+
+
+class _TimestepEmbedding(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = MiLinear(dim, in_dim)
+        self.linear_2 = MiLinear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(self.linear_1(x, act=ops.ACT_SILU))
+
+
+class _Attention(nn.Module):
+    def __init__(self, dim, heads, dim_head, cross_dim, bias):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads, self.scale = heads, dim_head ** -0.5
+        kv = cross_dim if cross_dim is not None else dim
+        self.to_q = MiLinear(inner, dim, bias)
+        self.to_k = MiLinear(inner, kv, bias)
+        self.to_v = MiLinear(inner, kv, bias)
+        self.to_out = nn.ModuleList([MiLinear(dim, inner, True)])
+
+
+class _FF(nn.Module):
+    def __init__(self, dim):
+        super().__init__()
+        n0 = _Node()
+        n0.proj = MiLinear(4 * dim, dim)
+        self.net = nn.ModuleList([n0, nn.Identity(), MiLinear(dim, 4 * dim)])
+
+
+class _Block(nn.Module):
+    def __init__(self, dim, heads, dim_head, cross_dim, bias):
+        super().__init__()
+        self.attn1 = _Attention(dim, heads, dim_head, None, bias)
+        self.attn2 = _Attention(dim, heads, dim_head, cross_dim, bias)
+        self.ff = _FF(dim)
+        self.scale_shift_table = nn.Parameter(torch.randn(6, dim) / dim ** 0.5)
+
+
+def _sincos_1d(dim, pos):
+    omega = 1.0 / 10000 ** (np.arange(dim // 2, dtype=np.float64) / (dim / 2.0))
+    out = np.einsum("m,d->md", pos.reshape(-1), omega)
+    return np.concatenate([np.sin(out), np.cos(out)], axis=1)
+
+
+def sincos_pos_embed(dim, gh, gw, base_size, interpolation_scale):
+    """diffusers get_2d_sincos_pos_embed: first half of the channels from the column coordinate, second from the row"""
+    ys = np.arange(gh, dtype=np.float32) / (gh / base_size) / interpolation_scale
+    xs = np.arange(gw, dtype=np.float32) / (gw / base_size) / interpolation_scale
+    grid = np.stack(np.meshgrid(xs, ys), axis=0).reshape([2, 1, gw, gh])
+    return np.concatenate([_sincos_1d(dim // 2, grid[0]), _sincos_1d(dim // 2, grid[1])], axis=1)
+
+
+class MiTransformer2DModel(nn.Module):
+    """See module docstring.  diffusers keywords outside the PixArt-alpha configuration raise."""
+
+    def __init__(self, time_embed_dim=256, timesteps_embedding_num_channels=256, projection_class_embeddings_input_dim=None,
+                 use_concat_vector_conditioning=False, num_vector_conditionings=None, num_attention_heads=16,
+                 attention_head_dim=88, in_channels=None, out_channels=None, num_layers=1, cross_attention_dim=None,
+                 attention_bias=False, sample_size=None, patch_size=None, activation_fn="geglu", num_embeds_ada_norm=None,
+                 norm_type="layer_norm", norm_elementwise_affine=True, norm_eps=1e-5, caption_channels=None,
+                 interpolation_scale=None, **unused):
+        super().__init__()
+        if not (patch_size is not None and norm_type == "ada_norm_single" and activation_fn == "gelu-approximate"
+                and not norm_elementwise_affine):
+            raise NotImplementedError("only the PixArt-alpha configuration (patched input, ada_norm_single, gelu-approximate, "
+                                      "non-affine norms: examples/train_flash_pixart.py:63-86) is built")
+        for k, v in unused.items():
+            if v not in (None, False, 0, 0.0, "default"):
+                raise NotImplementedError(f"{k}={v!r} is outside the reference's configurations")
+        D = num_attention_heads * attention_head_dim
+        assert time_embed_dim == D, "adaLN-single feeds the blocks: time_embed_dim must equal heads * head_dim"
+        assert attention_head_dim % 8 == 0 and attention_head_dim <= 160 and D % 8 == 0
+        out_channels = in_channels if out_channels is None else out_channels
+        self.config_dict = dict(sample_size=sample_size, patch_size=patch_size, in_channels=in_channels,
+                                out_channels=out_channels, num_layers=num_layers, heads=num_attention_heads,
+                                head_dim=attention_head_dim, inner_dim=D, cross_attention_dim=cross_attention_dim,
+                                caption_channels=caption_channels, norm_eps=norm_eps, tdim=timesteps_embedding_num_channels,
+                                interpolation_scale=interpolation_scale if interpolation_scale is not None
+                                else max(sample_size // 64, 1))
+        p = patch_size
+        self.pos_embed = _Node()
+        self.pos_embed.proj = MiLinear(D, in_channels * p * p, True, wshape=(D, in_channels, p, p))
+        ada = _Node()
+        ada.timestep_embedder = _TimestepEmbedding(timesteps_embedding_num_channels, time_embed_dim)
+        self.vdim, self.n_vec = projection_class_embeddings_input_dim, num_vector_conditionings
+        if self.vdim is not None:                                                                 # TU:51-70
+            if not use_concat_vector_conditioning:
+                ada.add_embedding = _TimestepEmbedding(self.vdim, time_embed_dim)
+            else:
+                assert num_vector_conditionings is not None, \
+                    "num_vector_conditionings must be provided if use_concat_conditioning is True"
+                ada.add_embedding = nn.ModuleList([_TimestepEmbedding(self.vdim, time_embed_dim // num_vector_conditionings)
+                                                   for _ in range(num_vector_conditionings)])
+        ada.linear = MiLinear(6 * time_embed_dim, time_embed_dim)
+        self.adaln_single = ada
+        if caption_channels is not None:
+            self.caption_projection = _Node()
+            self.caption_projection.linear_1 = MiLinear(D, caption_channels)
+            self.caption_projection.linear_2 = MiLinear(D, D)
+        else:
+            self.caption_projection = None
+        self.transformer_blocks = nn.ModuleList([_Block(D, num_attention_heads, attention_head_dim, cross_attention_dim,
+                                                        attention_bias) for _ in range(num_layers)])
+        self.scale_shift_table = nn.Parameter(torch.randn(2, D) / D ** 0.5)
+        self.proj_out = MiLinear(p * p * out_channels, D)
+        self.lora_r = 0
+        self._lora_epoch = 0
+        self._pos_cache = {}
+        self._mask_cache = None
+        self.last_flops = 0.0
+        self.step_flops = 0.0
+        for m in self.modules():
+            if isinstance(m, MiLinear):
+                m._owner[0] = self
+
+    # ---- bookkeeping --------------------------------------------------------------------------------------------------
+    def count(self, flops):
+        self.last_flops += flops
+        self.step_flops += flops
+
+    def __deepcopy__(self, memo):      # student = deepcopy(teacher) (examples/train_flash_pixart.py:174): re-point owners
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        import copy
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_pos_cache" else copy.deepcopy(v, memo)
+        for m in new.modules():
+            if isinstance(m, MiLinear):
+                m._owner[0] = new
+                m._b16 = m._l16 = None
+        return new
+
+    def freeze(self):                                                                               # TW:94-100
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def add_adapter(self, r: int, target_modules: Sequence[str] = PIXART_LORA_TARGETS, init_std_b: float = 0.0,
+                    generator: Optional[torch.Generator] = None):
+        """peft ``get_peft_model(LoraConfig(r, target_modules))`` semantics: every base parameter frozen; A ~ N(0, 1/r),
+        B = 0 (init_std_b > 0 only for tests) on each module whose dotted name ends in a target suffix."""
+        assert self.lora_r == 0, "adapter already added"
+        for p in self.parameters():
+            p.requires_grad = False
+        n = 0
+        for name, m in self.named_modules():
+            if isinstance(m, MiLinear) and any(name == t or name.endswith("." + t) for t in target_modules):
+                m.add_lora(r, init_std_b, generator)
+                n += 1
+        assert n > 0, "no module matched target_modules"
+        self.lora_r = r
+        return self
+
+    def lora_parameters(self):
+        return [p for n, p in self.named_parameters() if ".lora_" in n]
+
+    # ---- forward ------------------------------------------------------------------------------------------------------
+    def _pos(self, h, w, B, device):
+        key = (h, w, B, str(device))
+        if key not in self._pos_cache:
+            c = self.config_dict
+            base = c["sample_size"] // c["patch_size"]
+            pe = sincos_pos_embed(c["inner_dim"], h, w, base, c["interpolation_scale"])
+            pe = torch.from_numpy(pe).float().to(device).to(BF16)
+            self._pos_cache[key] = pe.unsqueeze(0).expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
+        return self._pos_cache[key]
+
+    def _key_lens(self, mask, L) -> Optional[List[int]]:
+        if mask is None:
+            return None
+        key = (mask.data_ptr(), mask._version, tuple(mask.shape))
+        if self._mask_cache is None or self._mask_cache[0] != key:
+            m = (mask.detach().to("cpu") != 0)
+            lens = m.sum(dim=1).tolist()
+            for b, n in enumerate(lens):
+                if n == 0 or not bool(m[b, :n].all()):
+                    raise NotImplementedError("attention_mask must keep a non-empty prefix of the keys (tokenizer padding)")
+            self._mask_cache = (key, None if all(n == L for n in lens) else lens)
+        return self._mask_cache[1]
+
+    def _attn(self, a: _Attention, xq, xkv, B, Sq, Skv, lens, residual=None):
+        q = a.to_q(xq).view(B, Sq, -1)
+        k = a.to_k(xkv).view(B, Skv, -1)
+        v = a.to_v(xkv).view(B, Skv, -1)
+        nb = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+        o = _AttnFn.apply(q, k, v, a.heads, a.scale, lens, nb, self).view(B * Sq, -1)
+        return a.to_out[0](o, residual=residual)
+
+    def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
+                conditioning: Dict[str, Dict[str, torch.Tensor]], hidden_states_masks: Optional[torch.Tensor] = None,
+                *args, **kwargs):
+        assert isinstance(conditioning, dict), "conditionings must be a dictionary"                 # TW:69
+        cnd = conditioning["cond"]
+        vector, crossattn, concat = cnd.get("vector", None), cnd.get("crossattn", None), cnd.get("concat", None)
+        mask = cnd.get("attention_mask", None)
+        ops._dev(sample)      # device tensors only: there is no CPU fallback
+        c = self.config_dict
+        C_in = sample.shape[1]
+        if concat is not None:                                                                     # TW:79-80
+            sample = torch.cat([sample, concat], dim=1)
+        assert sample.shape[1] == c["in_channels"]
+        self.last_flops = 0.0
+        if self.lora_r:
+            self._lora_epoch += 1
+        grad = torch.is_grad_enabled()
+        B, _, Hh, Ww = sample.shape
+        p, D = c["patch_size"], c["inner_dim"]
+        h, w = Hh // p, Ww // p
+        T = h * w
+        dev = sample.device
+
+        # adaLN-single (TU:75-102): per-sample vectors [B, .]
+        if not torch.is_tensor(timestep):
+            timestep = torch.full((B,), float(timestep), device=dev)
+        ada = self.adaln_single
+        emb = ada.timestep_embedder(ops.timestep_embed(timestep.reshape(-1).to(dev), c["tdim"], True, 0.0))
+        if self.vdim is not None:
+            vb = vector.to(BF16)
+            if isinstance(ada.add_embedding, nn.ModuleList):
+                chunks = torch.chunk(vb, self.n_vec, dim=1)
+                emb = emb + torch.cat([ada.add_embedding[i](chunks[i].contiguous())
+                                       for i in range(len(ada.add_embedding))], dim=1)
+            else:
+                emb = emb + ada.add_embedding(vb.contiguous())
+        mod6 = ada.linear(torch.nn.functional.silu(emb)).float().view(B, 6, D)
+
+        # patch embedding: fold p x p patches (c, py, px order = the convolution weight's), one GEMM + positions
+        patches = sample.float().reshape(B, c["in_channels"], h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T, -1)
+        hid = self.pos_embed.proj(patches.to(BF16).contiguous(), residual=self._pos(h, w, B, dev))
+
+        # caption projection
+        L = crossattn.shape[1]
+        ctx = crossattn.to(BF16).reshape(B * L, -1).contiguous()
+        if self.caption_projection is not None:
+            t1 = self.caption_projection.linear_1(ctx)
+            ctx = self.caption_projection.linear_2(_GeluTanhFn.apply(t1, grad and t1.requires_grad))
+        lens = self._key_lens(mask, L)
+
+        eps = c["norm_eps"]
+        for blk in self.transformer_blocks:
+            mod = (blk.scale_shift_table[None] + mod6).to(BF16)        # shift_msa, scale_msa, gate_msa, shift_mlp, ...
+            nb = grad and (hid.requires_grad or mod.requires_grad)
+            n1 = _LnModFn.apply(hid, mod[:, 0], mod[:, 1], T, eps, nb)
+            a1 = self._attn(blk.attn1, n1, n1, B, T, T, None)
+            hid = _GateResFn.apply(a1, mod[:, 2], hid, T, grad and (a1.requires_grad or mod.requires_grad or hid.requires_grad))
+            hid = self._attn(blk.attn2, hid, ctx, B, T, L, lens, residual=hid)
+            nb = grad and (hid.requires_grad or mod.requires_grad)
+            n2 = _LnModFn.apply(hid, mod[:, 3], mod[:, 4], T, eps, nb)
+            f = blk.ff.net[0].proj(n2)
+            f = blk.ff.net[2](_GeluTanhFn.apply(f, grad and f.requires_grad))
+            hid = _GateResFn.apply(f, mod[:, 5], hid, T, grad and (f.requires_grad or mod.requires_grad or hid.requires_grad))
+
+        fin = (self.scale_shift_table[None] + emb.float()[:, None]).to(BF16)                       # shift, scale
+        n = _LnModFn.apply(hid, fin[:, 0], fin[:, 1], T, 1e-6, grad and (hid.requires_grad or fin.requires_grad))
+        y = self.proj_out(n, out_f32=True)                                                       # [B*T, p*p*out]
+        oc = c["out_channels"]
+        y = torch.einsum("nhwpqc->nchpwq", y.view(B, h, w, p, p, oc)).reshape(B, oc, h * p, w * p)
+        return y[:, :C_in]                                                                         # TW:91

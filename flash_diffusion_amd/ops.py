@@ -137,24 +137,25 @@ def layernorm_bwd(x, dy, gamma, eps, dx=None):
 
 
 # ---- attention ---------------------------------------------------------------------------------
-def attn_fwd(q, k, v, H, scale, need_lse=False):
-    """q [B,Sq,H*d], k/v [B,Skv,H*d] bf16 -> o [B,Sq,H*d] (, lse [B,H,Sq])"""
+def attn_fwd(q, k, v, H, scale, need_lse=False, out=None, lse_out=None):
+    """q [B,Sq,H*d], k/v [B,Skv,H*d] bf16 -> o [B,Sq,H*d] (, lse [B,H,Sq]); `out` / `lse_out`: preallocated results"""
     B, Sq, Cc = q.shape
     Skv = k.shape[1]
     d = Cc // H
-    o = torch.empty_like(q)
+    o = torch.empty_like(q) if out is None else out
     vt = torch.empty(lib().fdmi_attn_tr_elems(B, H, Skv, d), dtype=BF16, device=q.device)
-    lse = torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None
+    lse = lse_out if lse_out is not None else (
+        torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None)
     check(lib().fdmi_attn_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
                               ptr(vt), ptr(lse), B, H, Sq, Skv, d, scale, stream_ptr()))
     return (o, lse) if need_lse else o
 
 
-def attn_bwd(q, k, v, o, do, lse, H, scale):
+def attn_bwd(q, k, v, o, do, lse, H, scale, out=None):
     B, Sq, Cc = q.shape
     Skv = k.shape[1]
     d = Cc // H
-    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    dq, dk, dv = (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)) if out is None else out
     ws = torch.empty(lib().fdmi_attn_bwd_ws_bytes(B, H, Sq, Skv, d), dtype=torch.uint8, device=q.device)
     check(lib().fdmi_attn_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
                               ptr(do), do.stride(1), ptr(lse), ptr(dq), dq.stride(1), ptr(dk), dk.stride(1),
@@ -211,6 +212,85 @@ def transpose2d(x):
     out = torch.empty(cols, rows, dtype=BF16, device=x.device)
     check(lib().fdmi_transpose2d(ptr(x), x.stride(0), ptr(out), rows, rows, cols, stream_ptr()))
     return out
+
+
+def transpose2d_pad(x, rows_pad):
+    """[rows, cols] -> [cols, rows_pad] with the columns past `rows` zero (contraction dims must be multiples of 8)"""
+    rows, cols = x.shape
+    out = torch.empty(cols, rows_pad, dtype=BF16, device=x.device)
+    check(lib().fdmi_transpose2d_pad(ptr(x), x.stride(0), ptr(out), rows_pad, rows, cols, rows_pad, stream_ptr()))
+    return out
+
+
+def f32_to_bf16(x):
+    y = torch.empty(x.shape, dtype=BF16, device=x.device)
+    check(lib().fdmi_f32_to_bf16(ptr(x), ptr(y), x.numel(), stream_ptr()))
+    return y
+
+
+def silu_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().fdmi_silu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), stream_ptr()))
+    return dx
+
+
+# ---- adaLN-single DiT element-wise ops (csrc/dit.hip) --------------------------------------------------------------
+def _mod_ld(v, Cc):
+    """per-sample vector operand [B, C] bf16, possibly a column-slice view (e.g. mod[:, i] of a [B, n, C] table)"""
+    assert v.dtype == BF16 and v.dim() == 2 and v.shape[1] == Cc and v.stride(1) == 1
+    return v.stride(0)
+
+
+def layernorm_mod_fwd(x, shift, scale, rows_per_batch, eps, need_stats=False):
+    """y = LayerNorm(x) * (1 + scale[b]) + shift[b]; x [rows, C] bf16 -> (y, stats [rows, 2] = (mean, rstd) or None)"""
+    rows, Cc = x.shape
+    ld = _mod_ld(scale, Cc)
+    assert _mod_ld(shift, Cc) == ld
+    y = torch.empty_like(x)
+    stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if need_stats else None
+    check(lib().fdmi_layernorm_mod_fwd(ptr(x), ptr(shift), ptr(scale), ld, rows_per_batch, ptr(y), ptr(stats), rows, Cc,
+                                       eps, stream_ptr()))
+    return y, stats
+
+
+def layernorm_mod_bwd(x, dy, scale, rows_per_batch, eps):
+    rows, Cc = x.shape
+    dx = torch.empty_like(x)
+    check(lib().fdmi_layernorm_mod_bwd(ptr(x), ptr(dy), ptr(scale), _mod_ld(scale, Cc), rows_per_batch, ptr(dx), rows, Cc,
+                                       eps, 0, stream_ptr()))
+    return dx
+
+
+def gate_residual(x, gate, res, rows_per_batch):
+    """res + gate[b] * x (res None: gate[b] * x)"""
+    rows, Cc = x.shape
+    y = torch.empty_like(x)
+    check(lib().fdmi_gate_residual(ptr(x), ptr(gate), _mod_ld(gate, Cc), ptr(res), ptr(y), rows, Cc, rows_per_batch,
+                                   stream_ptr()))
+    return y
+
+
+def gelu_tanh(x):
+    y = torch.empty_like(x)
+    check(lib().fdmi_gelu_tanh(ptr(x), ptr(y), x.numel(), stream_ptr()))
+    return y
+
+
+def gelu_tanh_bwd(x, dy):
+    dx = torch.empty_like(x)
+    check(lib().fdmi_gelu_tanh_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), stream_ptr()))
+    return dx
+
+
+def batch_colsum(dy, x=None, stats=None, *, rows_per_batch, want_mul=True, want_sum=True):
+    """per-sample column sums over each sample's rows: (sum_r dy * f(x), sum_r dy), each [B, C] f32 or None;
+    f = LayerNorm normalisation with stats [rows, 2] = (mean, rstd), identity when stats is None"""
+    rows, Cc = dy.shape
+    B = rows // rows_per_batch
+    o0 = torch.empty(B, Cc, dtype=torch.float32, device=dy.device) if want_mul else None
+    o1 = torch.empty(B, Cc, dtype=torch.float32, device=dy.device) if want_sum else None
+    check(lib().fdmi_batch_colsum(ptr(dy), ptr(x), ptr(stats), ptr(o0), ptr(o1), B, rows_per_batch, Cc, stream_ptr()))
+    return o0, o1
 
 
 def adamw_(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=1, grad_scale=1.0):

@@ -72,6 +72,21 @@ int fdmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, voi
                        float eps, void* stream);
 int fdmi_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, int64_t rows, int C,
                        float eps, int accumulate, void* stream);
+/* adaLN modulate (DiT, reference transformers/utils.py:8-102 feeding diffusers' ada_norm_single blocks):
+ * y = LayerNorm(x) * (1 + scale[b]) + shift[b], b = row / rows_per_batch; shift / scale bf16 [B][mod_ld];
+ * stats (optional) receives (mean, rstd) per row for fdmi_batch_colsum.                          */
+int fdmi_layernorm_mod_fwd(const void* x, const void* shift, const void* scale, int64_t mod_ld, int rows_per_batch,
+                           void* y, float* stats /*[rows][2] or NULL*/, int64_t rows, int C, float eps, void* stream);
+int fdmi_layernorm_mod_bwd(const void* x, const void* dy, const void* scale, int64_t mod_ld, int rows_per_batch, void* dx,
+                           int64_t rows, int C, float eps, int accumulate, void* stream);
+/* y = res + gate[b] * x (res may be NULL); tanh-GELU and its backward; per-sample column sums
+ * out1[b][c] = sum_r dy, out0[b][c] = sum_r dy * f(x) (f: LayerNorm normalisation from stats, identity if NULL). */
+int fdmi_gate_residual(const void* x, const void* gate, int64_t gate_ld, const void* res, void* y, int64_t rows, int C,
+                       int rows_per_batch, void* stream);
+int fdmi_gelu_tanh(const void* x, void* y, int64_t n, void* stream);
+int fdmi_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+int fdmi_batch_colsum(const void* dy, const void* x, const float* stats, float* out0, float* out1, int B,
+                      int rows_per_batch, int C, void* stream);
 
 /* ---------------- fused attention (token-major [B,S,H*d] bf16) --------------------------------
  * fwd:  O = softmax(scale Q K^T) V.  `VT` is scratch of fdmi_attn_tr_elems(B,H,Skv,d) bf16 elements

@@ -83,3 +83,31 @@ def build_sd3_models():
     gb = torch.Generator().manual_seed(5)
     batch = {"image": torch.randn(2, 4, 16, 16, generator=gb), "text": ["a", "b"]}
     return teacher, student, disc, pipe, batch
+
+
+# ---- PixArt DiT denoiser: name -> (config overrides on dit_cpu.TINY_DIT, masked) -----------------------
+DIT_CASES = {
+    "dit_tiny": (dict(), False),
+    "dit_hd72_masked": (dict(attention_head_dim=72, num_attention_heads=4, cross_attention_dim=288, time_embed_dim=288,
+                             caption_channels=64, num_vector_conditionings=3), True),
+}
+
+
+def build_dit(name, lora_r=0):
+    """(oracle-restated PixArt denoiser with seeded weights [+ LoRA], inputs) for a DIT_CASES entry"""
+    from . import dit_cpu
+    over, masked = DIT_CASES[name]
+    cfg = {**dit_cpu.TINY_DIT, **over}
+    m = dit_cpu.seeded_init_(dit_cpu.PixartTransformerRef(**cfg), 3)
+    if lora_r:
+        dit_cpu.add_lora_(m, lora_r, seed=4, b_std=0.05)
+    g = torch.Generator().manual_seed(1)
+    nv = cfg["num_vector_conditionings"]
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    t = torch.tensor([999.0, 250.0])
+    cond = {"crossattn": torch.randn(2, 7, cfg["caption_channels"], generator=g),
+            "vector": torch.randn(2, nv * cfg["projection_class_embeddings_input_dim"], generator=g)}
+    if masked:
+        cond["attention_mask"] = torch.tensor([[1, 1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1]])
+    w = torch.randn(2, 4, 16, 16, generator=g)
+    return cfg, m, (x, t, {"cond": cond}), w

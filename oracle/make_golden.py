@@ -151,13 +151,45 @@ def make_sd3_golden():
               os.path.getsize(path) // 1024, "KiB")
 
 
+def make_dit_golden():
+    """PixArt denoiser fixtures: the reference's REAL wrapper class (on the restated diffusers base, oracle/shim_import.py)
+    with the seeded weights of golden_cases.build_dit -- frozen forward, LoRA forward and the LoRA gradients of sum(out * w)"""
+    from . import dit_cpu
+    from .golden_cases import DIT_CASES, build_dit
+    Wrapper, _ = shim_import.import_reference_dit()
+    for name in DIT_CASES:
+        blob = {}
+        for r in (0, 8):
+            cfg, ora, (x, t, cond), w = build_dit(name, lora_r=r)
+            real = Wrapper(**cfg)
+            if r:
+                dit_cpu.add_lora_(real, r, seed=4, b_std=0.05)
+            real.load_state_dict(ora.state_dict())
+            out = real(x, t, cond)
+            assert torch.equal(out, ora(x, t, cond)), name
+            if not r:
+                blob["out:frozen"] = out.detach().numpy()
+                continue
+            blob["out:lora"] = out.detach().numpy()
+            (out * w).sum().backward()
+            for n, p in real.named_parameters():
+                if p.grad is not None:
+                    blob["grad:" + n.replace(".base_layer.", ".")] = p.grad.numpy()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, "ngrads", sum(k.startswith("grad:") for k in blob), os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "sample":
         make_sample_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "sd3":
         make_sd3_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dit":
+        make_dit_golden()
     else:
         main()
         make_sample_golden()
         make_sd3_golden()
+        make_dit_golden()

@@ -55,10 +55,14 @@ def import_reference():
         d.schedulers = _stub("diffusers.schedulers", DDPMScheduler=_Dummy, LCMScheduler=_Dummy)
         d.models = _stub("diffusers.models", UNet2DConditionModel=_Dummy, UNet2DModel=_Dummy,
                          AutoencoderKL=_Dummy)
-        d.models.transformers = _stub("diffusers.models.transformers",
-                                      SD3Transformer2DModel=_Dummy, Transformer2DModel=_Dummy)
-        d.models.embeddings = _stub("diffusers.models.embeddings", TimestepEmbedding=_Dummy,
-                                    Timesteps=_Dummy)
+        # The DiT wrapper (transformers/tranformers.py:9) SUBCLASSES diffusers' Transformer2DModel and the reference's
+        # AdaLayerNormSingle (transformers/utils.py:8) builds diffusers' Timesteps / TimestepEmbedding: the stubs for those
+        # three are the oracle's restatements, so the reference's real wrapper runs on top of them (import_reference_dit).
+        from . import dit_cpu
+        d.models.transformers = _stub("diffusers.models.transformers", SD3Transformer2DModel=_Dummy,
+                                      Transformer2DModel=dit_cpu.Transformer2DModelRef)
+        d.models.embeddings = _stub("diffusers.models.embeddings", TimestepEmbedding=dit_cpu.TimestepEmbedding,
+                                    Timesteps=dit_cpu.Timesteps)
     if REFERENCE_SRC not in sys.path:
         sys.path.insert(0, REFERENCE_SRC)
     from flash.models.flash import FlashDiffusion, FlashDiffusionConfig  # noqa: E402
@@ -71,3 +75,14 @@ def import_reference_sd3():
     import_reference()
     from flash.models.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config  # noqa: E402
     return FlashDiffusionSD3, FlashDiffusionSD3Config
+
+
+def import_reference_dit():
+    """Returns (DiffusersTransformer2DWrapper, AdaLayerNormSingle) -- the reference's own PixArt wrapper
+    (/root/reference/src/flash/models/transformers/tranformers.py:9) and adaLN-single module (transformers/utils.py:8),
+    unmodified, with the oracle's restated ``Transformer2DModel`` / ``Timesteps`` / ``TimestepEmbedding`` standing in for the
+    absent diffusers classes they derive from."""
+    import_reference()
+    from flash.models.transformers import DiffusersTransformer2DWrapper  # noqa: E402
+    from flash.models.transformers.utils import AdaLayerNormSingle  # noqa: E402
+    return DiffusersTransformer2DWrapper, AdaLayerNormSingle

@@ -1,0 +1,160 @@
+"""TEST INFRASTRUCTURE -- torch-on-CPU stand-ins with the SIGNATURES of flash_diffusion_amd.ops, used only by
+tests/test_dit_host_logic.py (monkeypatched in place of the real module) to check the HOST composition of the DiT path --
+which launches, in which order, with which operands, and the hand-written backward formulas around them -- on a machine
+without a GPU.  bf16 storage is mimicked (fp32 arithmetic, results rounded to bf16).  The product never imports this file:
+flash_diffusion_amd.ops has no CPU path and raises without libfdmi.so; kernel numerics are covered by the -m gpu tests."""
+import math
+
+import torch
+
+BF16 = torch.bfloat16
+ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+
+
+def _dev(t):
+    return t
+
+
+def gemm(A, W, *, bias=None, residual=None, act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1, **kw):
+    assert A.dtype == BF16 and W.dtype == BF16 and A.shape[1] == W.shape[1] and A.shape[1] % 8 == 0, (A.shape, W.shape)
+    assert A.stride(1) == 1 and W.stride(1) == 1 and A.stride(0) % 8 == 0 and W.stride(0) % 8 == 0
+    v = alpha * (A.float() @ W.float().t())
+    if bias is not None:
+        assert bias.dtype == torch.float32
+        v = v + bias
+    if residual is not None:
+        assert residual.dtype == BF16 and residual.shape == v.shape
+        v = v + residual.float()
+    if preact is not None:
+        preact.copy_(v.to(BF16))
+    if act == ACT_SILU:
+        v = torch.nn.functional.silu(v)
+    else:
+        assert act == ACT_NONE
+    return v if out_f32 else v.to(BF16)
+
+
+def cast_transpose(w):
+    assert w.dtype == torch.float32 and w.dim() == 2
+    return w.to(BF16).contiguous(), w.t().to(BF16).contiguous()
+
+
+def transpose2d_pad(x, rows_pad):
+    rows, cols = x.shape
+    out = torch.zeros(cols, rows_pad, dtype=BF16)
+    out[:, :rows] = x.t()
+    return out
+
+
+def f32_to_bf16(x):
+    assert x.dtype == torch.float32
+    return x.to(BF16)
+
+
+def silu_bwd(x, dy):
+    xf = x.float()
+    s = torch.sigmoid(xf)
+    return (dy.float() * (s * (1 + xf * (1 - s)))).to(BF16)
+
+
+def timestep_embed(t, dim, flip=True, shift=0.0):
+    half = dim // 2
+    freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / (half - shift))
+    arg = t.float()[:, None] * freq[None]
+    sn, cs = torch.sin(arg), torch.cos(arg)
+    return (torch.cat([cs, sn], 1) if flip else torch.cat([sn, cs], 1)).to(BF16)
+
+
+def _heads(x, H):
+    B, S, Cc = x.shape
+    return x.float().reshape(B, S, H, Cc // H).transpose(1, 2)
+
+
+def attn_fwd(q, k, v, H, scale, need_lse=False, out=None, lse_out=None):
+    for t in (q, k, v):
+        assert t.dtype == BF16 and t.dim() == 3 and t.stride(2) == 1
+    s = (_heads(q, H) @ _heads(k, H).transpose(-1, -2)) * scale
+    lse = torch.logsumexp(s, dim=-1)
+    o = (torch.softmax(s, dim=-1) @ _heads(v, H)).transpose(1, 2).reshape(q.shape).to(BF16)
+    if out is not None:
+        out.copy_(o)
+        o = out
+    if lse_out is not None:
+        lse_out.copy_(lse)
+        lse = lse_out
+    return (o, lse) if need_lse else o
+
+
+def attn_bwd(q, k, v, o, do, lse, H, scale, out=None):
+    qh, kh, vh, doh, oh = (_heads(t, H) for t in (q, k, v, do, o))
+    p = torch.exp((qh @ kh.transpose(-1, -2)) * scale - lse[..., None])
+    dv = p.transpose(-1, -2) @ doh
+    dp = doh @ vh.transpose(-1, -2)
+    ds = p * (dp - (doh * oh).sum(-1, keepdim=True)) * scale
+    dq, dk = ds @ kh, ds.transpose(-1, -2) @ qh
+    back = lambda t, ref: t.transpose(1, 2).reshape(ref.shape).to(BF16)
+    res = back(dq, q), back(dk, k), back(dv, v)
+    if out is not None:
+        for dst, src in zip(out, res):
+            dst.copy_(src)
+        return out
+    return res
+
+
+def _mod(v, rows_per_batch):
+    assert v.dtype == BF16 and v.dim() == 2 and v.stride(1) == 1 and v.stride(0) % 8 == 0
+    return v.float().repeat_interleave(rows_per_batch, dim=0)
+
+
+def _ln(x, eps):
+    xf = x.float()
+    mean = xf.mean(-1, keepdim=True)
+    rstd = torch.rsqrt(((xf - mean) ** 2).mean(-1, keepdim=True) + eps)
+    return (xf - mean) * rstd, mean, rstd
+
+
+def layernorm_mod_fwd(x, shift, scale, rows_per_batch, eps, need_stats=False):
+    assert x.dtype == BF16 and x.dim() == 2 and x.is_contiguous()
+    xh, mean, rstd = _ln(x, eps)
+    y = xh * (1 + _mod(scale, rows_per_batch)) + _mod(shift, rows_per_batch)
+    return y.to(BF16), (torch.cat([mean, rstd], 1) if need_stats else None)
+
+
+def layernorm_mod_bwd(x, dy, scale, rows_per_batch, eps):
+    xh, _, rstd = _ln(x, eps)
+    dxh = dy.float() * (1 + _mod(scale, rows_per_batch))
+    dx = rstd * (dxh - dxh.mean(-1, keepdim=True) - xh * (dxh * xh).mean(-1, keepdim=True))
+    return dx.to(BF16)
+
+
+def gate_residual(x, gate, res, rows_per_batch):
+    y = _mod(gate, rows_per_batch) * x.float()
+    if res is not None:
+        y = y + res.float()
+    return y.to(BF16)
+
+
+def gelu_tanh(x):
+    return torch.nn.functional.gelu(x.float(), approximate="tanh").to(BF16)
+
+
+def gelu_tanh_bwd(x, dy):
+    xf = x.float().requires_grad_(True)
+    with torch.enable_grad():
+        y = torch.nn.functional.gelu(xf, approximate="tanh")
+    return torch.autograd.grad(y, xf, dy.float())[0].to(BF16)
+
+
+def batch_colsum(dy, x=None, stats=None, *, rows_per_batch, want_mul=True, want_sum=True):
+    rows, Cc = dy.shape
+    B = rows // rows_per_batch
+    d = dy.float()
+    o0 = o1 = None
+    if want_mul:
+        f = x.float()
+        if stats is not None:
+            f = (f - stats[:, :1]) * stats[:, 1:]
+        o0 = (d * f).view(B, rows_per_batch, Cc).sum(1)
+    if want_sum:
+        o1 = d.view(B, rows_per_batch, Cc).sum(1)
+    return o0, o1

@@ -110,3 +110,24 @@ def test_oracle_sd3_reproduces_golden(name):
             assert rel_err(p.grad, g["grads"][pn]) < 1e-4, pn
             n += 1
     assert n == len(g["grads"]) and n > 0
+
+
+@pytest.mark.parametrize("name", ["dit_tiny", "dit_hd72_masked"])
+def test_dit_oracle_reproduces_reference_fixture(name):
+    """oracle/dit_cpu.PixartTransformerRef vs the fixture written by the reference's real wrapper class (runs on any host:
+    tolerance 1e-5 relative for a different CPU's fp32 summation order)"""
+    from oracle.golden_cases import build_dit
+    from tests.golden_util import load_case, rel_err
+    g = load_case(name)
+    _, ora, (x, t, cond), w = build_dit(name)
+    assert rel_err(ora(x, t, cond), g["out"]["frozen"]) < 1e-5
+    _, ora, (x, t, cond), w = build_dit(name, lora_r=8)
+    out = ora(x, t, cond)
+    assert rel_err(out, g["out"]["lora"]) < 1e-5
+    (out * w).sum().backward()
+    n = 0
+    for k, p in ora.named_parameters():
+        if p.grad is not None:
+            assert rel_err(p.grad, g["grads"][k.replace(".base_layer.", ".")]) < 1e-4, k
+            n += 1
+    assert n == len(g["grads"])

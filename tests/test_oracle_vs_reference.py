@@ -225,3 +225,28 @@ def test_sd3_sample_restatement_is_bit_identical(kw):
     assert torch.equal(a, o) and (ar is None) == (orf is None)
     if ar is not None:
         assert torch.equal(ar, orf) and not torch.equal(ar, a)
+
+
+# ---- PixArt DiT wrapper: the reference's REAL wrapper + AdaLayerNormSingle on the restated base ----------
+@pytest.mark.parametrize("masked,concat_vec", [(False, True), (True, True), (False, False)])
+def test_dit_wrapper_restatement_is_bit_identical(masked, concat_vec):
+    from oracle import dit_cpu
+    Wrapper, AdaLN = shim_import.import_reference_dit()
+    cfg = dict(dit_cpu.TINY_DIT)
+    if not concat_vec:
+        cfg.update(use_concat_vector_conditioning=False, num_vector_conditionings=None, projection_class_embeddings_input_dim=32)
+    real, mine = Wrapper(**cfg), dit_cpu.PixartTransformerRef(**cfg)
+    assert isinstance(real.adaln_single, AdaLN) and issubclass(Wrapper, dit_cpu.Transformer2DModelRef)
+    assert {k: v.shape for k, v in real.state_dict().items()} == {k: v.shape for k, v in mine.state_dict().items()}
+    dit_cpu.seeded_init_(real, 3)
+    mine.load_state_dict(real.state_dict())
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 4, 16, 16, generator=g)
+    t = torch.tensor([999.0, 250.0])
+    cond = {"crossattn": torch.randn(2, 7, 48, generator=g), "vector": torch.randn(2, 32, generator=g)}
+    if masked:
+        cond["attention_mask"] = torch.tensor([[1, 1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1]])
+    a, b = real(x, t, {"cond": cond}), mine(x, t, {"cond": cond})
+    assert a.shape == (2, 4, 16, 16) and torch.equal(a, b)
+    real.freeze()
+    assert not any(p.requires_grad for p in real.parameters()) and not real.training
