@@ -64,11 +64,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--hw", type=int, default=64, help="latent height = width")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16 (8 for pixart: C4)")
+    ap.add_argument("--hw", type=int, default=None, help="latent height = width; default 64 (128 for pixart: C4)")
     ap.add_argument("--teacher-steps", type=int, default=4)
-    ap.add_argument("--arch", default="sd15", choices=["sd15", "sdxl", "tiny"])
-    ap.add_argument("--lora-rank", type=int, default=128)
+    ap.add_argument("--arch", default="sd15", choices=["sd15", "sdxl", "tiny", "pixart", "tiny_pixart"],
+                    help="sd15 = the headline workload C2; the others are developer legs (SURVEY 8a C3 / C4 shapes)")
+    ap.add_argument("--lora-rank", type=int, default=None, help="default 128 (sd15/sdxl), 64 (pixart), 8 (tiny*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (sampler, 2-optimizer step)")
@@ -91,17 +92,27 @@ def main():
 
     from flash_diffusion_amd import _lib, unet as _unet
     from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
-    from flash_diffusion_amd.workloads import SD15, SDXL, TINY, build_flash, synthetic_batch
-    arch = {"sd15": SD15, "sdxl": SDXL, "tiny": TINY}[args.arch]
-    rank_r = args.lora_rank if args.arch != "tiny" else 8
+    from flash_diffusion_amd.workloads import PIXART, SD15, SDXL, TINY, TINY_PIXART, build_flash, synthetic_batch
+    arch = {"sd15": SD15, "sdxl": SDXL, "tiny": TINY, "pixart": PIXART, "tiny_pixart": TINY_PIXART}[args.arch]
+    dit = args.arch.endswith("pixart")
+    if args.batch is None:
+        args.batch = 8 if args.arch == "pixart" else 16
+    if args.hw is None:
+        args.hw = 128 if args.arch == "pixart" else (16 if args.arch == "tiny_pixart" else 64)
+    rank_r = args.lora_rank or (8 if args.arch.startswith("tiny") else (64 if dit else 128))
     model = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0)
     pipe = TrainingPipeline(model, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-5],
                                                   trainable_params=[["student_denoiser"]]),
                             overlap=not args.no_overlap)
     pipe.configure_optimizers()
     B = args.batch
-    batches = [synthetic_batch(B, args.hw, arch["cross_attention_dim"], seed=1234 + rank + 1000 * i,
-                               vector_dim=arch.get("projection_class_embeddings_input_dim", 0) or 0) for i in range(4)]
+    if dit:   # T5 context [B, 120, caption_channels] + mask of ones, vector = num_vector_conditionings sinusoid blocks
+        batches = [synthetic_batch(B, args.hw, arch["caption_channels"], seed=1234 + rank + 1000 * i, L=120,
+                                   vector_dim=arch["projection_class_embeddings_input_dim"] * arch["num_vector_conditionings"],
+                                   attention_mask=True) for i in range(4)]
+    else:
+        batches = [synthetic_batch(B, args.hw, arch["cross_attention_dim"], seed=1234 + rank + 1000 * i,
+                                   vector_dim=arch.get("projection_class_embeddings_input_dim", 0) or 0) for i in range(4)]
 
     def run(n, counter=None):
         for i in range(n):
@@ -172,7 +183,7 @@ def main():
                                    "frac_of_peak": step_flops / (ms_per_step * 1e-3) / PEAK_BF16}}
     # ---- secondary: the student's 4-step LCM sampler, FlashDiffusion.sample, same UNet kernels ----
     sampler = None
-    if rank == 0 and args.arch != "tiny" and not args.no_secondary:
+    if rank == 0 and args.arch in ("sd15", "sdxl") and not args.no_secondary:
         from flash_diffusion_amd.schedulers import LCMScheduler
         model.sampling_noise_scheduler = LCMScheduler()
         zb = batches[0]
@@ -226,7 +237,8 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{'C2' if args.arch == 'sd15' else ('C3-single-GPU' if args.arch == 'sdxl' else 'dev')}: Flash-{args.arch.upper()} UNet teacher + LoRA r{rank_r} student, {B} images/GPU, "
+            "config": {"workload": f"{ {'sd15': 'C2', 'sdxl': 'C3-single-GPU', 'pixart': 'C4'}.get(args.arch, 'dev')}: Flash-{args.arch.upper()} "
+                                   f"{'DiT' if dit else 'UNet'} teacher + LoRA r{rank_r} student, {B} images/GPU, "
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world},

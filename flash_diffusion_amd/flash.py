@@ -127,6 +127,8 @@ class TensorConditioner(nn.Module):
         for k in ("crossattn", "vector", "concat"):
             if batch.get(k, None) is not None:
                 cond[k] = torch.zeros_like(batch[k]) if drop else batch[k]
+        if batch.get("attention_mask", None) is not None:   # T5 key mask of the PixArt path (TW:75): never dropped
+            cond["attention_mask"] = batch["attention_mask"]
         return {"cond": cond}
 
 

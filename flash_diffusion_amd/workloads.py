@@ -17,6 +17,15 @@ SDXL = dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280), 
             up_block_types=("CrossAttnUpBlock2D", "CrossAttnUpBlock2D", "UpBlock2D"), cross_attention_dim=2048,
             attention_head_dim=(5, 10, 20), transformer_layers_per_block=(1, 2, 10), class_embed_type="projection",
             projection_class_embeddings_input_dim=2816)   # examples/train_flash_sdxl.py:66-118
+PIXART = dict(sample_size=128, num_layers=28, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2,
+              attention_bias=True, num_attention_heads=16, cross_attention_dim=1152, activation_fn="gelu-approximate",
+              num_embeds_ada_norm=1000, norm_type="ada_norm_single", norm_elementwise_affine=False, norm_eps=1e-6,
+              caption_channels=4096, projection_class_embeddings_input_dim=256, time_embed_dim=1152,
+              timesteps_embedding_num_channels=256, use_concat_vector_conditioning=True,
+              num_vector_conditionings=3)                  # examples/train_flash_pixart.py:63-86 (PixArt-alpha XL/2)
+TINY_PIXART = dict(PIXART, sample_size=16, num_layers=2, attention_head_dim=8, num_attention_heads=4, cross_attention_dim=32,
+                   caption_channels=48, projection_class_embeddings_input_dim=16, time_embed_dim=32,
+                   timesteps_embedding_num_channels=16, num_vector_conditionings=2)
 TINY = dict(in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64), layers_per_block=2,
             cross_attention_dim=64, attention_head_dim=2, transformer_layers_per_block=1)
 
@@ -33,7 +42,11 @@ def build_flash(arch=SD15, lora_rank=128, n_teacher_steps=4, device="cuda", seed
     """teacher (frozen) + student = copy + LoRA (peft init: A gaussian, B = 0), DPM-Solver++ trailing schedule
     with K = n_teacher_steps and start index pinned to 0 (so every step runs exactly n teacher CFG steps)."""
     torch.manual_seed(seed)
-    teacher = MiUNet2DConditionModel(**arch)
+    if arch.get("norm_type") == "ada_norm_single":          # PixArt DiT denoiser (SURVEY 8a row a17)
+        from .dit import MiTransformer2DModel
+        teacher = MiTransformer2DModel(**arch)
+    else:
+        teacher = MiUNet2DConditionModel(**arch)
     student = copy.deepcopy(teacher)
     teacher = teacher.to(device)
     teacher.freeze()
@@ -51,10 +64,12 @@ def build_flash(arch=SD15, lora_rank=128, n_teacher_steps=4, device="cuda", seed
     return m
 
 
-def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77, vector_dim=0):
+def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77, vector_dim=0, attention_mask=False):
     g = torch.Generator(device="cpu").manual_seed(seed)
     b = {"image": torch.randn(B, 4, hw, hw, generator=g).to(device),
          "crossattn": torch.randn(B, L, ctx_dim, generator=g).to(device), "text": ["synthetic"] * B}
     if vector_dim:
         b["vector"] = torch.randn(B, vector_dim, generator=g).to(device)
+    if attention_mask:                                      # "mask of ones" for the PixArt T5 context
+        b["attention_mask"] = torch.ones(B, L, dtype=torch.long, device=device)
     return b
