@@ -308,7 +308,62 @@ def sincos_pos_embed(dim, gh, gw, base_size, interpolation_scale):
     return np.concatenate([_sincos_1d(dim // 2, grid[0]), _sincos_1d(dim // 2, grid[1])], axis=1)
 
 
-class MiTransformer2DModel(nn.Module):
+class _DenoiserBase(nn.Module):
+    """bookkeeping shared by the transformer denoisers: flop counter, LoRA (peft semantics), freeze, deepcopy"""
+
+    def _init_base(self):
+        self.lora_r = 0
+        self._lora_epoch = 0
+        self._pos_cache = {}
+        self.last_flops = 0.0
+        self.step_flops = 0.0   # running sum of algorithmic MFMA flops (bench.py resets it)
+        for m in self.modules():
+            if isinstance(m, MiLinear):
+                m._owner[0] = self
+
+    def count(self, flops):
+        self.last_flops += flops
+        self.step_flops += flops
+
+    def __deepcopy__(self, memo):      # student = deepcopy(teacher) (examples/train_flash_pixart.py:174): re-point owners
+        cls = self.__class__
+        new = cls.__new__(cls)
+        memo[id(self)] = new
+        import copy
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = {} if k == "_pos_cache" else copy.deepcopy(v, memo)
+        for m in new.modules():
+            if isinstance(m, MiLinear):
+                m._owner[0] = new
+                m._b16 = m._l16 = None
+        return new
+
+    def freeze(self):                                                                               # TW:94-100
+        self.eval()
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def add_adapter(self, r: int, target_modules: Sequence[str] = PIXART_LORA_TARGETS, init_std_b: float = 0.0,
+                    generator: Optional[torch.Generator] = None):
+        """peft ``get_peft_model(LoraConfig(r, target_modules))`` semantics: every base parameter frozen; A ~ N(0, 1/r),
+        B = 0 (init_std_b > 0 only for tests) on each module whose dotted name ends in a target suffix."""
+        assert self.lora_r == 0, "adapter already added"
+        for p in self.parameters():
+            p.requires_grad = False
+        n = 0
+        for name, m in self.named_modules():
+            if isinstance(m, MiLinear) and any(name == t or name.endswith("." + t) for t in target_modules):
+                m.add_lora(r, init_std_b, generator)
+                n += 1
+        assert n > 0, "no module matched target_modules"
+        self.lora_r = r
+        return self
+
+    def lora_parameters(self):
+        return [p for n, p in self.named_parameters() if ".lora_" in n]
+
+
+class MiTransformer2DModel(_DenoiserBase):
     """See module docstring.  diffusers keywords outside the PixArt-alpha configuration raise."""
 
     def __init__(self, time_embed_dim=256, timesteps_embedding_num_channels=256, projection_class_embeddings_input_dim=None,
@@ -361,57 +416,8 @@ class MiTransformer2DModel(nn.Module):
                                                         attention_bias) for _ in range(num_layers)])
         self.scale_shift_table = nn.Parameter(torch.randn(2, D) / D ** 0.5)
         self.proj_out = MiLinear(p * p * out_channels, D)
-        self.lora_r = 0
-        self._lora_epoch = 0
-        self._pos_cache = {}
         self._mask_cache = None
-        self.last_flops = 0.0
-        self.step_flops = 0.0
-        for m in self.modules():
-            if isinstance(m, MiLinear):
-                m._owner[0] = self
-
-    # ---- bookkeeping --------------------------------------------------------------------------------------------------
-    def count(self, flops):
-        self.last_flops += flops
-        self.step_flops += flops
-
-    def __deepcopy__(self, memo):      # student = deepcopy(teacher) (examples/train_flash_pixart.py:174): re-point owners
-        cls = self.__class__
-        new = cls.__new__(cls)
-        memo[id(self)] = new
-        import copy
-        for k, v in self.__dict__.items():
-            new.__dict__[k] = {} if k == "_pos_cache" else copy.deepcopy(v, memo)
-        for m in new.modules():
-            if isinstance(m, MiLinear):
-                m._owner[0] = new
-                m._b16 = m._l16 = None
-        return new
-
-    def freeze(self):                                                                               # TW:94-100
-        self.eval()
-        for p in self.parameters():
-            p.requires_grad = False
-
-    def add_adapter(self, r: int, target_modules: Sequence[str] = PIXART_LORA_TARGETS, init_std_b: float = 0.0,
-                    generator: Optional[torch.Generator] = None):
-        """peft ``get_peft_model(LoraConfig(r, target_modules))`` semantics: every base parameter frozen; A ~ N(0, 1/r),
-        B = 0 (init_std_b > 0 only for tests) on each module whose dotted name ends in a target suffix."""
-        assert self.lora_r == 0, "adapter already added"
-        for p in self.parameters():
-            p.requires_grad = False
-        n = 0
-        for name, m in self.named_modules():
-            if isinstance(m, MiLinear) and any(name == t or name.endswith("." + t) for t in target_modules):
-                m.add_lora(r, init_std_b, generator)
-                n += 1
-        assert n > 0, "no module matched target_modules"
-        self.lora_r = r
-        return self
-
-    def lora_parameters(self):
-        return [p for n, p in self.named_parameters() if ".lora_" in n]
+        self._init_base()
 
     # ---- forward ------------------------------------------------------------------------------------------------------
     def _pos(self, h, w, B, device):
@@ -515,3 +521,177 @@ class MiTransformer2DModel(nn.Module):
         oc = c["out_channels"]
         y = torch.einsum("nhwpqc->nchpwq", y.view(B, h, w, p, p, oc)).reshape(B, oc, h * p, w * p)
         return y[:, :C_in]                                                                         # TW:91
+
+
+# ======================================================================================================================
+# SD3 MMDiT: drop-in for DiffusersSD3Transformer2DWrapper (tranformers.py:103-163)
+# ======================================================================================================================
+class _AdaNorm(nn.Module):
+    """AdaLayerNormZero (6 vectors) / AdaLayerNormContinuous (2 vectors: scale, shift): only the projection has weights"""
+
+    def __init__(self, dim, n):
+        super().__init__()
+        self.linear = MiLinear(n * dim, dim)
+        self.n = n
+
+    def forward(self, silu_temb):
+        B = silu_temb.shape[0]
+        return self.linear(silu_temb).view(B, self.n, -1)
+
+
+class _JointAttention(nn.Module):
+    def __init__(self, dim, heads, context_pre_only):
+        super().__init__()
+        self.heads, self.scale = heads, (dim // heads) ** -0.5
+        self.to_q, self.to_k, self.to_v = MiLinear(dim, dim), MiLinear(dim, dim), MiLinear(dim, dim)
+        self.add_k_proj, self.add_v_proj, self.add_q_proj = MiLinear(dim, dim), MiLinear(dim, dim), MiLinear(dim, dim)
+        self.to_out = nn.ModuleList([MiLinear(dim, dim)])
+        if not context_pre_only:
+            self.to_add_out = MiLinear(dim, dim)
+
+
+class _JointBlock(nn.Module):
+    def __init__(self, dim, heads, context_pre_only):
+        super().__init__()
+        self.context_pre_only = context_pre_only
+        self.norm1 = _AdaNorm(dim, 6)
+        self.norm1_context = _AdaNorm(dim, 2 if context_pre_only else 6)
+        self.attn = _JointAttention(dim, heads, context_pre_only)
+        self.ff = _FF(dim)
+        if not context_pre_only:
+            self.ff_context = _FF(dim)
+
+
+class _TextProjection(nn.Module):
+    def __init__(self, in_dim, dim):
+        super().__init__()
+        self.linear_1 = MiLinear(dim, in_dim)
+        self.linear_2 = MiLinear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(self.linear_1(x, act=ops.ACT_SILU))
+
+
+class MiSD3Transformer2DModel(_DenoiserBase):
+    """Drop-in for the reference's SD3 denoiser ``DiffusersSD3Transformer2DWrapper`` (tranformers.py:103-163; constructor
+    keywords of examples/train_flash_sd3.py:65-77, SD3-medium: no qk-norm), parameters and the ``pos_embed.pos_embed``
+    buffer under diffusers' state_dict keys (``load_state_dict(pipe.transformer.state_dict(), strict=True)`` works).
+    Same construction as MiTransformer2DModel: token-major activations only ever touched by HIP launches (GEMM, flash
+    attention over the concatenated [latent | text] tokens, LayerNorm+modulate, gated residual, tanh-GELU); torch holds
+    the autograd edges, concatenates / splits the joint sequence and does the per-sample-vector glue."""
+
+    def __init__(self, sample_size=128, patch_size=2, in_channels=16, num_layers=18, attention_head_dim=64,
+                 num_attention_heads=18, joint_attention_dim=4096, caption_projection_dim=1152, pooled_projection_dim=2048,
+                 out_channels=16, pos_embed_max_size=96, **unused):
+        super().__init__()
+        for k, v in unused.items():
+            if v not in (None, False, 0, 0.0, "default"):
+                raise NotImplementedError(f"{k}={v!r} is outside the reference's configurations")
+        D = num_attention_heads * attention_head_dim
+        assert caption_projection_dim == D, "joint attention needs caption_projection_dim == heads * head_dim"
+        assert attention_head_dim % 8 == 0 and attention_head_dim <= 160
+        p = patch_size
+        self.config_dict = dict(sample_size=sample_size, patch_size=p, in_channels=in_channels, out_channels=out_channels,
+                                num_layers=num_layers, heads=num_attention_heads, head_dim=attention_head_dim, inner_dim=D,
+                                joint_attention_dim=joint_attention_dim, pooled_projection_dim=pooled_projection_dim,
+                                pos_embed_max_size=pos_embed_max_size)
+        self.pos_embed = _Node()
+        self.pos_embed.proj = MiLinear(D, in_channels * p * p, True, wshape=(D, in_channels, p, p))
+        pe = sincos_pos_embed(D, pos_embed_max_size, pos_embed_max_size, sample_size // p, 1)
+        self.pos_embed.register_buffer("pos_embed", torch.from_numpy(pe).float().unsqueeze(0), persistent=True)
+        tte = _Node()
+        tte.timestep_embedder = _TimestepEmbedding(256, D)
+        tte.text_embedder = _TextProjection(pooled_projection_dim, D)
+        self.time_text_embed = tte
+        self.context_embedder = MiLinear(D, joint_attention_dim)
+        self.transformer_blocks = nn.ModuleList([_JointBlock(D, num_attention_heads, i == num_layers - 1)
+                                                 for i in range(num_layers)])
+        self.norm_out = _AdaNorm(D, 2)
+        self.proj_out = MiLinear(p * p * out_channels, D)
+        self._init_base()
+
+    def _pos(self, h, w, B, device):
+        buf = self.pos_embed.pos_embed
+        key = (h, w, B, str(device), buf.data_ptr(), buf._version)
+        if key not in self._pos_cache:
+            self._pos_cache.clear()
+            m = self.config_dict["pos_embed_max_size"]
+            assert h <= m and w <= m, "input larger than pos_embed_max_size"
+            top, left = (m - h) // 2, (m - w) // 2
+            pe = buf.reshape(1, m, m, -1)[:, top:top + h, left:left + w, :].reshape(1, h * w, -1)
+            self._pos_cache[key] = pe.to(device).to(BF16).expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
+        return self._pos_cache[key]
+
+    def _ff(self, ff: _FF, n, grad):
+        f = ff.net[0].proj(n)
+        return ff.net[2](_GeluTanhFn.apply(f, grad and f.requires_grad))
+
+    def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
+                conditioning: Dict[str, Dict[str, torch.Tensor]], hidden_states_masks: Optional[torch.Tensor] = None,
+                *args, **kwargs):
+        assert isinstance(conditioning, dict), "conditionings must be a dictionary"                 # TW:131
+        cnd = conditioning["cond"]
+        vector, crossattn, concat = cnd.get("vector", None), cnd.get("crossattn", None), cnd.get("concat", None)
+        ops._dev(sample)      # device tensors only: there is no CPU fallback
+        c = self.config_dict
+        C_in = sample.shape[1]
+        if concat is not None:                                                                     # TW:141-142
+            sample = torch.cat([sample, concat], dim=1)
+        assert sample.shape[1] == c["in_channels"]
+        self.last_flops = 0.0
+        if self.lora_r:
+            self._lora_epoch += 1
+        grad = torch.is_grad_enabled()
+        B, _, Hh, Ww = sample.shape
+        p, D, H = c["patch_size"], c["inner_dim"], c["heads"]
+        h, w = Hh // p, Ww // p
+        T, L = h * w, crossattn.shape[1]
+        dev = sample.device
+        eps = 1e-6
+
+        # CombinedTimestepTextProjEmbeddings: per-sample vectors [B, D]
+        if not torch.is_tensor(timestep):
+            timestep = torch.full((B,), float(timestep), device=dev)
+        tte = self.time_text_embed
+        temb = tte.timestep_embedder(ops.timestep_embed(timestep.reshape(-1).to(dev), 256, True, 0.0)) \
+            + tte.text_embedder(vector.to(BF16).contiguous())
+        st = torch.nn.functional.silu(temb)
+
+        patches = sample.float().reshape(B, c["in_channels"], h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T, -1)
+        x = self.pos_embed.proj(patches.to(BF16).contiguous(), residual=self._pos(h, w, B, dev))
+        ctx = self.context_embedder(crossattn.to(BF16).reshape(B * L, -1).contiguous())
+
+        def need(*ts):
+            return grad and any(t.requires_grad for t in ts)
+
+        for blk in self.transformer_blocks:
+            a = blk.attn
+            m = blk.norm1(st)                                         # shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+            n = _LnModFn.apply(x, m[:, 0], m[:, 1], T, eps, need(x, m))
+            mc = blk.norm1_context(st)
+            if blk.context_pre_only:                                   # AdaLayerNormContinuous: (scale, shift)
+                nc = _LnModFn.apply(ctx, mc[:, 1], mc[:, 0], L, eps, need(ctx, mc))
+            else:
+                nc = _LnModFn.apply(ctx, mc[:, 0], mc[:, 1], L, eps, need(ctx, mc))
+            q = torch.cat([a.to_q(n).view(B, T, D), a.add_q_proj(nc).view(B, L, D)], dim=1)
+            k = torch.cat([a.to_k(n).view(B, T, D), a.add_k_proj(nc).view(B, L, D)], dim=1)
+            v = torch.cat([a.to_v(n).view(B, T, D), a.add_v_proj(nc).view(B, L, D)], dim=1)
+            o = _AttnFn.apply(q, k, v, H, a.scale, None, need(q, k, v), self)
+            ox = a.to_out[0](o[:, :T].reshape(B * T, D))
+            x = _GateResFn.apply(ox, m[:, 2], x, T, need(ox, m, x))
+            n2 = _LnModFn.apply(x, m[:, 3], m[:, 4], T, eps, need(x, m))
+            f = self._ff(blk.ff, n2, grad)
+            x = _GateResFn.apply(f, m[:, 5], x, T, need(f, m, x))
+            if not blk.context_pre_only:
+                oc = a.to_add_out(o[:, T:].reshape(B * L, D))
+                ctx = _GateResFn.apply(oc, mc[:, 2], ctx, L, need(oc, mc, ctx))
+                n2c = _LnModFn.apply(ctx, mc[:, 3], mc[:, 4], L, eps, need(ctx, mc))
+                fc = self._ff(blk.ff_context, n2c, grad)
+                ctx = _GateResFn.apply(fc, mc[:, 5], ctx, L, need(fc, mc, ctx))
+
+        mo = self.norm_out(st)                                        # (scale, shift)
+        n = _LnModFn.apply(x, mo[:, 1], mo[:, 0], T, eps, need(x, mo))
+        y = self.proj_out(n, out_f32=True)
+        oc_ = c["out_channels"]
+        y = torch.einsum("nhwpqc->nchpwq", y.view(B, h, w, p, p, oc_)).reshape(B, oc_, h * p, w * p)
+        return y[:, :C_in]                                                                         # TW:154

@@ -111,3 +111,27 @@ def build_dit(name, lora_r=0):
         cond["attention_mask"] = torch.tensor([[1, 1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1]])
     w = torch.randn(2, 4, 16, 16, generator=g)
     return cfg, m, (x, t, {"cond": cond}), w
+
+
+# ---- SD3 MMDiT denoiser: name -> config overrides on mmdit_cpu.TINY_MMDIT ------------------------------
+MMDIT_CASES = {
+    "mmdit_tiny": dict(),
+    "mmdit_hd64": dict(attention_head_dim=64, num_attention_heads=2, caption_projection_dim=128, num_layers=3,
+                       pos_embed_max_size=10),
+}
+
+
+def build_mmdit(name, lora_r=0):
+    """(oracle-restated SD3 denoiser with seeded weights [+ LoRA], inputs) for an MMDIT_CASES entry"""
+    from . import dit_cpu, mmdit_cpu
+    cfg = {**mmdit_cpu.TINY_MMDIT, **MMDIT_CASES[name]}
+    m = dit_cpu.seeded_init_(mmdit_cpu.SD3TransformerRef(**cfg), 3)
+    if lora_r:
+        dit_cpu.add_lora_(m, lora_r, seed=4, b_std=0.05)
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(2, 16, 16, 16, generator=g)
+    t = torch.tensor([999.0, 250.0])
+    cond = {"crossattn": torch.randn(2, 7, cfg["joint_attention_dim"], generator=g),
+            "vector": torch.randn(2, cfg["pooled_projection_dim"], generator=g)}
+    w = torch.randn(2, 16, 16, 16, generator=g)
+    return cfg, m, (x, t, {"cond": cond}), w

@@ -152,15 +152,18 @@ def make_sd3_golden():
 
 
 def make_dit_golden():
-    """PixArt denoiser fixtures: the reference's REAL wrapper class (on the restated diffusers base, oracle/shim_import.py)
-    with the seeded weights of golden_cases.build_dit -- frozen forward, LoRA forward and the LoRA gradients of sum(out * w)"""
+    """PixArt / SD3 denoiser fixtures: the reference's REAL wrapper classes (on the restated diffusers bases,
+    oracle/shim_import.py) with the seeded weights of golden_cases.build_dit / build_mmdit -- frozen forward, LoRA forward and
+    the LoRA gradients of sum(out * w)"""
     from . import dit_cpu
-    from .golden_cases import DIT_CASES, build_dit
-    Wrapper, _ = shim_import.import_reference_dit()
-    for name in DIT_CASES:
+    from .golden_cases import DIT_CASES, MMDIT_CASES, build_dit, build_mmdit
+    PixWrapper, _ = shim_import.import_reference_dit()
+    SD3Wrapper = shim_import.import_reference_sd3_wrapper()
+    for name in list(DIT_CASES) + list(MMDIT_CASES):
+        Wrapper, build = (PixWrapper, build_dit) if name in DIT_CASES else (SD3Wrapper, build_mmdit)
         blob = {}
         for r in (0, 8):
-            cfg, ora, (x, t, cond), w = build_dit(name, lora_r=r)
+            cfg, ora, (x, t, cond), w = build(name, lora_r=r)
             real = Wrapper(**cfg)
             if r:
                 dit_cpu.add_lora_(real, r, seed=4, b_std=0.05)

@@ -57,9 +57,10 @@ def import_reference():
                          AutoencoderKL=_Dummy)
         # The DiT wrapper (transformers/tranformers.py:9) SUBCLASSES diffusers' Transformer2DModel and the reference's
         # AdaLayerNormSingle (transformers/utils.py:8) builds diffusers' Timesteps / TimestepEmbedding: the stubs for those
-        # three are the oracle's restatements, so the reference's real wrapper runs on top of them (import_reference_dit).
-        from . import dit_cpu
-        d.models.transformers = _stub("diffusers.models.transformers", SD3Transformer2DModel=_Dummy,
+        # (and SD3Transformer2DModel, the base of the SD3 wrapper at tranformers.py:103) are the oracle's restatements, so the reference's real wrapper runs on top of them (import_reference_dit).
+        from . import dit_cpu, mmdit_cpu
+        d.models.transformers = _stub("diffusers.models.transformers",
+                                      SD3Transformer2DModel=mmdit_cpu.SD3Transformer2DModelRef,
                                       Transformer2DModel=dit_cpu.Transformer2DModelRef)
         d.models.embeddings = _stub("diffusers.models.embeddings", TimestepEmbedding=dit_cpu.TimestepEmbedding,
                                     Timesteps=dit_cpu.Timesteps)
@@ -86,3 +87,11 @@ def import_reference_dit():
     from flash.models.transformers import DiffusersTransformer2DWrapper  # noqa: E402
     from flash.models.transformers.utils import AdaLayerNormSingle  # noqa: E402
     return DiffusersTransformer2DWrapper, AdaLayerNormSingle
+
+
+def import_reference_sd3_wrapper():
+    """Returns DiffusersSD3Transformer2DWrapper (/root/reference/src/flash/models/transformers/tranformers.py:103),
+    unmodified, on top of the oracle's restated ``SD3Transformer2DModel`` (oracle/mmdit_cpu.py)."""
+    import_reference()
+    from flash.models.transformers import DiffusersSD3Transformer2DWrapper  # noqa: E402
+    return DiffusersSD3Transformer2DWrapper

@@ -160,3 +160,54 @@ def test_composition_against_the_reference_fixture(monkeypatch, name):
     for k, p in m.named_parameters():
         if ".lora_" in k:
             assert _cos(p.grad, g["grads"][k]) > 0.999 and rel_err(p.grad, g["grads"][k]) < 6e-2, k
+
+
+# ---- SD3 MMDiT (row a18) ------------------------------------------------------------------------------------------------------
+def test_mmdit_state_dict_keys_match_the_reference():
+    from flash_diffusion_amd import dit
+    from oracle import mmdit_cpu
+    ref = mmdit_cpu.SD3TransformerRef(**mmdit_cpu.TINY_MMDIT)
+    mine = dit.MiSD3Transformer2DModel(**mmdit_cpu.TINY_MMDIT)
+    a = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+    b = {k: tuple(v.shape) for k, v in mine.state_dict().items()}
+    assert a == b and "pos_embed.pos_embed" in b                      # strict=True load (examples/train_flash_sd3.py:79)
+    assert torch.equal(ref.pos_embed.pos_embed, mine.pos_embed.pos_embed)
+    names = dit_cpu.add_lora_(ref, 8)
+    mine.add_adapter(8)
+    a = {k.replace(".base_layer.", "."): tuple(v.shape) for k, v in ref.state_dict().items()}
+    assert a == {k: tuple(v.shape) for k, v in mine.state_dict().items()} and len(names) == len(mine.lora_parameters()) // 2
+
+
+@pytest.mark.parametrize("name", ["mmdit_tiny", "mmdit_hd64"])
+def test_mmdit_composition_against_the_reference_fixture(monkeypatch, name):
+    from flash_diffusion_amd import dit
+    from oracle.golden_cases import build_mmdit
+    from tests.golden_util import load_case, rel_err
+    monkeypatch.setattr(dit, "ops", fake_ops)
+    g = load_case(name)
+    cfg, ora, (x, t, cond), w = build_mmdit(name)
+    m = dit.MiSD3Transformer2DModel(**cfg)
+    m.load_state_dict(ora.state_dict(), strict=True)
+    m.freeze()
+    with torch.no_grad():
+        assert rel_err(m(x, t, cond), g["out"]["frozen"]) < 2e-2
+        assert rel_err(m(x, 999.0, cond), ora(x, torch.full((2,), 999.0), cond)) < 2e-2
+    xa = x.clone().requires_grad_(True)                               # input gradient through the frozen network
+    xb = x.clone().requires_grad_(True)
+    (ora(xa, t, cond) * w).sum().backward()
+    (m(xb, t, cond) * w).sum().backward()
+    assert _cos(xb.grad, xa.grad) > 0.995 and _rel(xb.grad, xa.grad) < 8e-2
+    cfg, ora, (x, t, cond), w = build_mmdit(name, lora_r=8)
+    m = dit.MiSD3Transformer2DModel(**cfg).add_adapter(8)
+    m.load_state_dict({k.replace(".base_layer.", "."): v for k, v in ora.state_dict().items()})
+    out = m(x, t, cond)
+    assert rel_err(out, g["out"]["lora"]) < 2e-2
+    (out * w).sum().backward()
+    n = 0
+    for k, p in m.named_parameters():
+        if ".lora_" in k:
+            assert _cos(p.grad, g["grads"][k]) > 0.999 and rel_err(p.grad, g["grads"][k]) < 6e-2, k
+            n += 1
+        else:
+            assert p.grad is None, k
+    assert n == len(g["grads"])

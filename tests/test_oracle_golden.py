@@ -131,3 +131,21 @@ def test_dit_oracle_reproduces_reference_fixture(name):
             assert rel_err(p.grad, g["grads"][k.replace(".base_layer.", ".")]) < 1e-4, k
             n += 1
     assert n == len(g["grads"])
+
+
+@pytest.mark.parametrize("name", ["mmdit_tiny", "mmdit_hd64"])
+def test_mmdit_oracle_reproduces_reference_fixture(name):
+    from oracle.golden_cases import build_mmdit
+    g = load_case(name)
+    _, ora, (x, t, cond), w = build_mmdit(name)
+    assert rel_err(ora(x, t, cond), g["out"]["frozen"]) < 1e-5
+    _, ora, (x, t, cond), w = build_mmdit(name, lora_r=8)
+    out = ora(x, t, cond)
+    assert rel_err(out, g["out"]["lora"]) < 1e-5
+    (out * w).sum().backward()
+    n = 0
+    for k, p in ora.named_parameters():
+        if p.grad is not None:
+            assert rel_err(p.grad, g["grads"][k.replace(".base_layer.", ".")]) < 1e-4, k
+            n += 1
+    assert n == len(g["grads"])

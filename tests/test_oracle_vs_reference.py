@@ -250,3 +250,22 @@ def test_dit_wrapper_restatement_is_bit_identical(masked, concat_vec):
     assert a.shape == (2, 4, 16, 16) and torch.equal(a, b)
     real.freeze()
     assert not any(p.requires_grad for p in real.parameters()) and not real.training
+
+
+# ---- SD3 MMDiT wrapper: the reference's REAL wrapper on the restated SD3Transformer2DModel --------------
+@pytest.mark.parametrize("name", ["mmdit_tiny", "mmdit_hd64"])
+def test_sd3_wrapper_restatement_is_bit_identical(name):
+    from oracle import dit_cpu, mmdit_cpu
+    from oracle.golden_cases import MMDIT_CASES, build_mmdit
+    Wrapper = shim_import.import_reference_sd3_wrapper()
+    cfg, mine, (x, t, cond), _ = build_mmdit(name)
+    real = Wrapper(**cfg)
+    assert issubclass(Wrapper, mmdit_cpu.SD3Transformer2DModelRef)
+    real.load_state_dict(mine.state_dict(), strict=True)
+    a, b = real(x, t, cond), mine(x, t, cond)
+    assert a.shape == x.shape and torch.equal(a, b)
+    # concat conditioning (TW:141-142): channels appended to the sample, output sliced back (TW:154)
+    cond2 = {"cond": dict(cond["cond"], concat=x[:, 8:])}
+    assert torch.equal(real(x[:, :8], t, cond2), mine(x[:, :8], t, cond2)) and real(x[:, :8], t, cond2).shape[1] == 8
+    real.freeze()
+    assert not any(p.requires_grad for p in real.parameters()) and not real.training

@@ -1,7 +1,7 @@
-"""GPU parity of the PixArt DiT path: (1) the adaLN-single kernels of csrc/dit.hip and the modulate
+"""GPU parity of the transformer denoisers -- PixArt DiT and SD3 MMDiT (row a18): (1) the adaLN-single kernels of csrc/dit.hip and the modulate
 path of the LayerNorm kernel against plain PyTorch fp32 references on the same bf16-rounded inputs (tolerances of
-tests/test_kernels_gpu.py); (2) flash_diffusion_amd.dit.MiTransformer2DModel -- forward, LoRA forward and LoRA gradients --
-against fixtures made by the reference's REAL wrapper class (tests/golden/dit_*.npz, oracle/make_golden.py dit).
+tests/test_kernels_gpu.py); (2) flash_diffusion_amd.dit.MiTransformer2DModel / MiSD3Transformer2DModel -- forward, LoRA forward and LoRA gradients --
+against fixtures made by the reference's REAL wrapper classes (tests/golden/dit_*.npz, mmdit_*.npz; oracle/make_golden.py dit).
 Tolerance for (2): bf16 activations through 2 blocks: outputs 2e-2 relative, LoRA gradients cosine > 0.999 and 6e-2 relative
 (what the same composition gives on CPU with bf16 storage mimicked, tests/test_dit_host_logic.py: 0.8e-2 / 2.5e-2).
 
@@ -12,7 +12,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from oracle.golden_cases import DIT_CASES, build_dit
+from oracle.golden_cases import DIT_CASES, MMDIT_CASES, build_dit, build_mmdit
 from tests.golden_util import load_case, rel_err
 from tests.test_kernels_gpu import b16, close, rnd
 
@@ -82,8 +82,8 @@ def _cos(a, b):
 
 
 def _product(cfg, ora, lora_r):
-    from flash_diffusion_amd.dit import MiTransformer2DModel
-    m = MiTransformer2DModel(**cfg)
+    from flash_diffusion_amd.dit import MiSD3Transformer2DModel, MiTransformer2DModel
+    m = (MiSD3Transformer2DModel if "pos_embed_max_size" in cfg else MiTransformer2DModel)(**cfg)
     if lora_r:
         m.add_adapter(lora_r)
     m.load_state_dict({k.replace(".base_layer.", "."): v for k, v in ora.state_dict().items()})
@@ -94,10 +94,14 @@ def _to_cuda(cond):
     return {"cond": {k: v.cuda() for k, v in cond["cond"].items()}}
 
 
-@pytest.mark.parametrize("name", list(DIT_CASES))
+def _build(name, **kw):
+    return build_dit(name, **kw) if name in DIT_CASES else build_mmdit(name, **kw)
+
+
+@pytest.mark.parametrize("name", list(DIT_CASES) + list(MMDIT_CASES))
 def test_dit_frozen_forward_matches_reference_golden(name):
     g = load_case(name)
-    cfg, ora, (x, t, cond), _ = build_dit(name)
+    cfg, ora, (x, t, cond), _ = _build(name)
     m = _product(cfg, ora, 0)
     m.freeze()
     with torch.no_grad():
@@ -106,10 +110,10 @@ def test_dit_frozen_forward_matches_reference_golden(name):
     assert rel_err(out, g["out"]["frozen"]) < 2e-2, rel_err(out, g["out"]["frozen"])
 
 
-@pytest.mark.parametrize("name", list(DIT_CASES))
+@pytest.mark.parametrize("name", list(DIT_CASES) + list(MMDIT_CASES))
 def test_dit_lora_step_matches_reference_golden(name):
     g = load_case(name)
-    cfg, ora, (x, t, cond), w = build_dit(name, lora_r=8)
+    cfg, ora, (x, t, cond), w = _build(name, lora_r=8)
     m = _product(cfg, ora, 8)
     out = m(x.cuda(), t.cuda(), _to_cuda(cond))
     assert rel_err(out, g["out"]["lora"]) < 2e-2, rel_err(out, g["out"]["lora"])
