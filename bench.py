@@ -67,7 +67,7 @@ def main():
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16 (8 for pixart: C4)")
     ap.add_argument("--hw", type=int, default=None, help="latent height = width; default 64 (128 for pixart: C4)")
     ap.add_argument("--teacher-steps", type=int, default=4)
-    ap.add_argument("--arch", default="sd15", choices=["sd15", "sdxl", "tiny", "pixart", "tiny_pixart"],
+    ap.add_argument("--arch", default="sd15", choices=["sd15", "sdxl", "tiny", "pixart", "tiny_pixart", "sd3", "tiny_sd3"],
                     help="sd15 = the headline workload C2; the others are developer legs (SURVEY 8a C3 / C4 shapes)")
     ap.add_argument("--lora-rank", type=int, default=None, help="default 128 (sd15/sdxl), 64 (pixart), 8 (tiny*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -92,21 +92,32 @@ def main():
 
     from flash_diffusion_amd import _lib, unet as _unet
     from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
-    from flash_diffusion_amd.workloads import PIXART, SD15, SDXL, TINY, TINY_PIXART, build_flash, synthetic_batch
-    arch = {"sd15": SD15, "sdxl": SDXL, "tiny": TINY, "pixart": PIXART, "tiny_pixart": TINY_PIXART}[args.arch]
+    from flash_diffusion_amd.workloads import (PIXART, SD3, SD15, SDXL, TINY, TINY_PIXART, TINY_SD3, build_flash,
+                                               build_flash_sd3, synthetic_batch)
+    arch = {"sd15": SD15, "sdxl": SDXL, "tiny": TINY, "pixart": PIXART, "tiny_pixart": TINY_PIXART, "sd3": SD3,
+            "tiny_sd3": TINY_SD3}[args.arch]
     dit = args.arch.endswith("pixart")
+    sd3 = args.arch.endswith("sd3")
     if args.batch is None:
-        args.batch = 8 if args.arch == "pixart" else 16
+        args.batch = {"pixart": 8, "sd3": 4}.get(args.arch, 16)
     if args.hw is None:
-        args.hw = 128 if args.arch == "pixart" else (16 if args.arch == "tiny_pixart" else 64)
-    rank_r = args.lora_rank or (8 if args.arch.startswith("tiny") else (64 if dit else 128))
-    model = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0)
+        args.hw = 128 if args.arch in ("pixart", "sd3") else (16 if args.arch.startswith("tiny_") else 64)
+    rank_r = args.lora_rank or (8 if args.arch.startswith("tiny") else (64 if (dit or sd3) else 128))
+    if sd3:
+        model = build_flash_sd3(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, B=args.batch,
+                                L=333 if args.arch == "sd3" else 7, device="cuda", seed=0)
+    else:
+        model = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0)
     pipe = TrainingPipeline(model, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-5],
                                                   trainable_params=[["student_denoiser"]]),
                             overlap=not args.no_overlap)
     pipe.configure_optimizers()
     B = args.batch
-    if dit:   # T5 context [B, 120, caption_channels] + mask of ones, vector = num_vector_conditionings sinusoid blocks
+    if sd3:   # 16-channel latents; the text embeddings come from the model's prompt-encoder stand-in
+        gs = [torch.Generator(device="cpu").manual_seed(1234 + rank + 1000 * i) for i in range(4)]
+        batches = [{"image": torch.randn(B, arch["in_channels"], args.hw, args.hw, generator=g).cuda(),
+                    "text": ["synthetic"] * B} for g in gs]
+    elif dit:   # T5 context [B, 120, caption_channels] + mask of ones, vector = num_vector_conditionings sinusoid blocks
         batches = [synthetic_batch(B, args.hw, arch["caption_channels"], seed=1234 + rank + 1000 * i, L=120,
                                    vector_dim=arch["projection_class_embeddings_input_dim"] * arch["num_vector_conditionings"],
                                    attention_mask=True) for i in range(4)]
@@ -237,8 +248,8 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{ {'sd15': 'C2', 'sdxl': 'C3-single-GPU', 'pixart': 'C4'}.get(args.arch, 'dev')}: Flash-{args.arch.upper()} "
-                                   f"{'DiT' if dit else 'UNet'} teacher + LoRA r{rank_r} student, {B} images/GPU, "
+            "config": {"workload": f"{ {'sd15': 'C2', 'sdxl': 'C3-single-GPU', 'pixart': 'C4', 'sd3': 'C5-single-GPU (distill only)'}.get(args.arch, 'dev')}: Flash-{args.arch.upper()} "
+                                   f"{'DiT' if dit else ('MMDiT' if sd3 else 'UNet')} teacher + LoRA r{rank_r} student, {B} images/GPU, "
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world},

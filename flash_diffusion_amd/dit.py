@@ -36,38 +36,35 @@ def _pad8(n):
 
 # ---- autograd edges around the HIP launches -------------------------------------------------------------------------------
 class _LinearFn(torch.autograd.Function):
-    """y = act(x W^T + b [+ (x A^T) B^T] [+ residual]); W frozen, A / B (LoRA, fp32 masters) trainable."""
+    """y = x W^T + b [+ (x A^T) B^T] [+ residual]; W frozen, A / B (LoRA, fp32 masters) trainable."""
 
     @staticmethod
-    def forward(ctx, x, residual, lin, act, out_f32, need_bwd, A, B):
+    def forward(ctx, x, residual, lin, out_f32, need_bwd, A, B):
         wb, wtb = lin.base16()
         M = x.shape[0]
-        pre = torch.empty(M, lin.out_features, dtype=BF16, device=x.device) if (act and need_bwd) else None
         t = None
         if A is None:
-            y = ops.gemm(x, wb, bias=lin.bias, residual=residual, act=act, preact=pre, out_f32=out_f32)
+            y = ops.gemm(x, wb, bias=lin.bias, residual=residual, out_f32=out_f32)
         else:
             ab, _, bb, _ = lin.lora16()
             t = ops.gemm(x, ab)
             y0 = ops.gemm(x, wb, bias=lin.bias, residual=residual)
-            y = ops.gemm(t, bb, residual=y0, act=act, preact=pre, out_f32=out_f32)
+            y = ops.gemm(t, bb, residual=y0, out_f32=out_f32)
         lin.count(2.0 * M * lin.out_features * lin.in_features
                   + (2.0 * M * lin.rank * (lin.in_features + lin.out_features) if A is not None else 0.0))
-        ctx.lin, ctx.act, ctx.out_f32, ctx.lora = lin, act, out_f32, A is not None
+        ctx.lin, ctx.out_f32, ctx.lora = lin, out_f32, A is not None
         ctx.ashape = None if A is None else (A.shape, B.shape)
         if need_bwd:
-            ctx.save_for_backward(x, pre, t)
+            ctx.save_for_backward(x, t)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         lin = ctx.lin
-        x, pre, t = ctx.saved_tensors
+        x, t = ctx.saved_tensors
         dy = dy.contiguous()
         if ctx.out_f32:
             dy = ops.f32_to_bf16(dy)
-        if ctx.act:
-            dy = ops.silu_bwd(pre, dy)
         M = x.shape[0]
         Mp = _pad8(M)
         dx = dA = dB = None
@@ -87,7 +84,7 @@ class _LinearFn(torch.autograd.Function):
                 dx = ops.gemm(u, abt, residual=dx)
                 flops += 2.0 * M * lin.rank * lin.in_features
         lin.count(flops)
-        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None, None, dA, dB
+        return dx, (dy if ctx.needs_input_grad[1] else None), None, None, None, dA, dB
 
 
 class _LnModFn(torch.autograd.Function):
@@ -133,6 +130,23 @@ class _GateResFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dgate = ops.batch_colsum(dy, x, None, rows_per_batch=ctx.rpb, want_sum=False)[0].to(BF16)
         return dx, dgate, (dy if ctx.needs_input_grad[2] else None), None, None
+
+
+class _SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, need_bwd):
+        if need_bwd:
+            ctx.save_for_backward(x)
+        return ops.silu(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.silu_bwd(ctx.saved_tensors[0], dy.contiguous()), None
+
+
+def _silu(x):
+    x = x.contiguous()
+    return _SiluFn.apply(x, torch.is_grad_enabled() and x.requires_grad)
 
 
 class _GeluTanhFn(torch.autograd.Function):
@@ -235,14 +249,13 @@ class MiLinear(nn.Module):
         self.lora_B = nn.ModuleDict({"default": _Leaf(b)})
         self.rank = r
 
-    def forward(self, x, residual=None, act=ops.ACT_NONE, out_f32=False):
+    def forward(self, x, residual=None, out_f32=False):
         assert x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == self.in_features
-        assert not (act and residual is not None)
         need_bwd = torch.is_grad_enabled() and (x.requires_grad or self.rank > 0
                                                 or (residual is not None and residual.requires_grad))
         A = self.lora_A.default.weight if self.rank else None
         B = self.lora_B.default.weight if self.rank else None
-        return _LinearFn.apply(x, residual, self, act, out_f32, need_bwd, A, B)
+        return _LinearFn.apply(x, residual, self, out_f32, need_bwd, A, B)
 
 
 class _Leaf(nn.Module):
@@ -262,7 +275,7 @@ class _TimestepEmbedding(nn.Module):
         self.linear_2 = MiLinear(dim, dim)
 
     def forward(self, x):
-        return self.linear_2(self.linear_1(x, act=ops.ACT_SILU))
+        return self.linear_2(_silu(self.linear_1(x)))
 
 
 class _Attention(nn.Module):
@@ -487,7 +500,7 @@ class MiTransformer2DModel(_DenoiserBase):
                                        for i in range(len(ada.add_embedding))], dim=1)
             else:
                 emb = emb + ada.add_embedding(vb.contiguous())
-        mod6 = ada.linear(torch.nn.functional.silu(emb)).float().view(B, 6, D)
+        mod6 = ada.linear(_silu(emb)).float().view(B, 6, D)
 
         # patch embedding: fold p x p patches (c, py, px order = the convolution weight's), one GEMM + positions
         patches = sample.float().reshape(B, c["in_channels"], h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T, -1)
@@ -569,7 +582,7 @@ class _TextProjection(nn.Module):
         self.linear_2 = MiLinear(dim, dim)
 
     def forward(self, x):
-        return self.linear_2(self.linear_1(x, act=ops.ACT_SILU))
+        return self.linear_2(_silu(self.linear_1(x)))
 
 
 class MiSD3Transformer2DModel(_DenoiserBase):
@@ -655,7 +668,7 @@ class MiSD3Transformer2DModel(_DenoiserBase):
         tte = self.time_text_embed
         temb = tte.timestep_embedder(ops.timestep_embed(timestep.reshape(-1).to(dev), 256, True, 0.0)) \
             + tte.text_embedder(vector.to(BF16).contiguous())
-        st = torch.nn.functional.silu(temb)
+        st = _silu(temb)
 
         patches = sample.float().reshape(B, c["in_channels"], h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T, -1)
         x = self.pos_embed.proj(patches.to(BF16).contiguous(), residual=self._pos(h, w, B, dev))

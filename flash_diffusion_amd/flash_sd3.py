@@ -151,6 +151,8 @@ class FlashDiffusionSD3(nn.Module):
         self.K_prev = self.K[0]
         self.draws: Optional[Draws] = None      # tests inject the reference's random draws here
         self.last_draws: Optional[Draws] = None
+        self.fixed_start_idx: Optional[int] = None     # benchmark / DDP: pin the teacher-step count (as FlashDiffusion)
+        self.fixed_guidance: Optional[float] = None
         self.terms: Dict[str, Any] = {}
 
     def freeze(self):
@@ -246,7 +248,10 @@ class FlashDiffusionSD3(nn.Module):
             raise NotImplementedError("K switching replaces the teacher by a copy of the student (FD3:244-249)")
         noise = d.randn_like("noise", z)
         sch.set_timesteps(K)
-        start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
+        if self.fixed_start_idx is not None:
+            start_idx = torch.tensor([self.fixed_start_idx])
+        else:
+            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
         si = int(start_idx)
         start_t = sch.timesteps[si].to(z.device).repeat(B)
         sig = get_sigmas(sch, start_t).to(z.device)                      # [B]
@@ -257,10 +262,16 @@ class FlashDiffusionSD3(nn.Module):
         else:
             with torch.no_grad():
                 x_init = ops.add_noise(z, noise.contiguous(), (1.0 - sig).contiguous(), sig.contiguous())
-        g = float(d.rand1("guidance")) * (g_max - g_min) + g_min
+        if self.fixed_guidance is not None:
+            g = float(self.fixed_guidance)
+        else:
+            g = float(d.rand1("guidance")) * (g_max - g_min) + g_min
         with torch.no_grad():                                            # FD3:282-314: Euler steps with CFG
             x = self._euler_cfg(self.teacher_denoiser, sch, sch.timesteps[si:], x_init, cond, uncond, g, *args, **kwargs)
             teacher_output = x
+        hook = getattr(self, "before_student", None)
+        if hook is not None:
+            hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
         v_s = self.student_denoiser(sample=x_init, timestep=start_t, conditioning=cond)
         student_output = _PerSampleAffine.apply(v_s.float(), x_init, torch.ones_like(sig), (-sig).contiguous())   # FD3:325
         l_distill = _DistillLoss.apply(student_output, teacher_output.detach(), self.distill_loss_type == "l1")

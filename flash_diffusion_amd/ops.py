@@ -228,6 +228,12 @@ def f32_to_bf16(x):
     return y
 
 
+def silu(x):
+    y = torch.empty_like(x)
+    check(lib().fdmi_silu(ptr(x), ptr(y), x.numel(), stream_ptr()))
+    return y
+
+
 def silu_bwd(x, dy):
     dx = torch.empty_like(x)
     check(lib().fdmi_silu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), stream_ptr()))

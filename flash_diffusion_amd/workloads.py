@@ -26,6 +26,11 @@ PIXART = dict(sample_size=128, num_layers=28, attention_head_dim=72, in_channels
 TINY_PIXART = dict(PIXART, sample_size=16, num_layers=2, attention_head_dim=8, num_attention_heads=4, cross_attention_dim=32,
                    caption_channels=48, projection_class_embeddings_input_dim=16, time_embed_dim=32,
                    timesteps_embedding_num_channels=16, num_vector_conditionings=2)
+SD3 = dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, attention_head_dim=64, num_attention_heads=24,
+           joint_attention_dim=4096, caption_projection_dim=1536, pooled_projection_dim=2048, out_channels=16,
+           pos_embed_max_size=192)                            # examples/train_flash_sd3.py:65-77 (SD3-medium)
+TINY_SD3 = dict(SD3, sample_size=16, num_layers=2, attention_head_dim=8, num_attention_heads=4, joint_attention_dim=48,
+                caption_projection_dim=32, pooled_projection_dim=24, pos_embed_max_size=12)
 TINY = dict(in_channels=4, out_channels=4, block_out_channels=(32, 64, 64, 64), layers_per_block=2,
             cross_attention_dim=64, attention_head_dim=2, transformer_layers_per_block=1)
 
@@ -73,3 +78,44 @@ def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77, vector_dim=0
     if attention_mask:                                      # "mask of ones" for the PixArt T5 context
         b["attention_mask"] = torch.ones(B, L, dtype=torch.long, device=device)
     return b
+
+
+class SyntheticPromptEncoder:
+    """Stands where ``StableDiffusion3Pipeline`` stands in FlashDiffusionSD3 (FD3:196-229): ``encode_prompt`` returns
+    (prompt_embeds, negative_prompt_embeds, pooled, negative_pooled) -- synthetic embeddings of the SD3 shapes
+    ([B, 333, 4096] = 77 CLIP + 256 T5 tokens, pooled [B, 2048]); the unconditional ones are zeros.  The text
+    encoders themselves are outside the hot path."""
+
+    def __init__(self, B, L, ctx_dim, pooled_dim, device="cuda", seed=4321):
+        g = torch.Generator(device="cpu").manual_seed(seed)
+        self.pe = torch.randn(B, L, ctx_dim, generator=g).to(device)
+        self.pp = torch.randn(B, pooled_dim, generator=g).to(device)
+
+    def to(self, *a, **k):
+        return self
+
+    def encode_prompt(self, *a, **k):
+        return self.pe, torch.zeros_like(self.pe), self.pp, torch.zeros_like(self.pp)
+
+
+def build_flash_sd3(arch=SD3, lora_rank=64, n_teacher_steps=4, B=4, L=333, device="cuda", seed=0, guidance=5.0):
+    """C5-shaped single-GPU leg: frozen MMDiT teacher + LoRA student (examples/train_flash_sd3.py:100-121), flow-matching
+    Euler teacher loop with K = n_teacher_steps and the start index pinned to 0, l2 distillation."""
+    from .dit import MiSD3Transformer2DModel
+    from .flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    torch.manual_seed(seed)
+    teacher = MiSD3Transformer2DModel(**arch)
+    student = copy.deepcopy(teacher)
+    teacher = teacher.to(device)
+    teacher.freeze()
+    student = student.to(device)
+    student.add_adapter(lora_rank)
+    cfg = FlashDiffusionSD3Config(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform",
+                                  distill_loss_type="l2", guidance_scale_min=3.0, guidance_scale_max=7.0)
+    m = FlashDiffusionSD3(cfg, student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(),
+                          pipeline=SyntheticPromptEncoder(B, L, arch["joint_attention_dim"], arch["pooled_projection_dim"],
+                                                          device))
+    m.fixed_start_idx = 0
+    m.fixed_guidance = guidance
+    return m
