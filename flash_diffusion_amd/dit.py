@@ -73,9 +73,15 @@ class _LinearFn(torch.autograd.Function):
         if ctx.lora:
             _, abt, _, bbt = lin.lora16()
             u = ops.gemm(dy, bbt)                                       # dL/d(A x)            [M, r]
-            dB = ops.gemm(ops.transpose2d_pad(dy, Mp), ops.transpose2d_pad(t, Mp), out_f32=True, splitk=0)   # [N, r]
-            dA = ops.gemm(ops.transpose2d_pad(u, Mp), ops.transpose2d_pad(x, Mp), out_f32=True, splitk=0)    # [r, K]
-            dA, dB = dA.view(ctx.ashape[0]), dB.view(ctx.ashape[1])
+            gv = lin._gviews           # views into the model's flat LoRA gradient (set by _reflatten_lora) or None
+            dB = ops.gemm(ops.transpose2d_pad(dy, Mp), ops.transpose2d_pad(t, Mp), out_f32=True, splitk=0,    # [N, r]
+                          out=None if gv is None else gv[1], accum_atomic=gv is not None)
+            dA = ops.gemm(ops.transpose2d_pad(u, Mp), ops.transpose2d_pad(x, Mp), out_f32=True, splitk=0,     # [r, K]
+                          out=None if gv is None else gv[0], accum_atomic=gv is not None)
+            if gv is None:
+                dA, dB = dA.view(ctx.ashape[0]), dB.view(ctx.ashape[1])
+            else:              # accumulated in place (fp32 atomics) where .grad already points: nothing for autograd to add
+                dA = dB = None
             flops += 6.0 * M * lin.rank * lin.out_features + 2.0 * M * lin.rank * lin.in_features
         if ctx.needs_input_grad[0]:
             dx = ops.gemm(dy, wtb)
@@ -214,6 +220,7 @@ class MiLinear(nn.Module):
         self.rank = 0
         self._b16 = None
         self._l16 = None
+        self._gviews = None
         self._owner = [None]     # the model (list: not a sub-module) -- flop counter and LoRA epoch
 
     def count(self, flops):
@@ -323,9 +330,11 @@ def sincos_pos_embed(dim, gh, gw, base_size, interpolation_scale):
 
 class _DenoiserBase(nn.Module):
     """bookkeeping shared by the transformer denoisers: flop counter, LoRA (peft semantics), freeze, deepcopy"""
+    per_sample = True   # no layer mixes samples: callers may batch [cond | uncond] into one call (flash_sd3._euler_cfg)
 
     def _init_base(self):
         self.lora_r = 0
+        self._lora_flat = self._lora_grad = None
         self._lora_epoch = 0
         self._pos_cache = {}
         self.last_flops = 0.0
@@ -348,7 +357,8 @@ class _DenoiserBase(nn.Module):
         for m in new.modules():
             if isinstance(m, MiLinear):
                 m._owner[0] = new
-                m._b16 = m._l16 = None
+                m._b16 = m._l16 = m._gviews = None
+        new._lora_flat = new._lora_grad = None
         return new
 
     def freeze(self):                                                                               # TW:94-100
@@ -374,6 +384,58 @@ class _DenoiserBase(nn.Module):
 
     def lora_parameters(self):
         return [p for n, p in self.named_parameters() if ".lora_" in n]
+
+    # ---- flat LoRA storage: ONE fused AdamW launch and ONE all-reduce per step (trainer.py) -----------------------
+    @property
+    def lora_rank(self):
+        return self.lora_r
+
+    def _reflatten_lora(self, device):
+        """(Re)establish the invariant that every LoRA tensor is a view into one flat fp32 buffer and every LoRA ``.grad`` a
+        view into one flat gradient buffer which the backward GEMMs accumulate into directly (after .to(device) / deepcopy /
+        load_state_dict).  Returns True when nothing had to move."""
+        named = [(n, p) for n, p in self.named_parameters() if ".lora_" in n]
+        total = sum(p.numel() for _, p in named)
+        flat = self._lora_flat
+        ok = flat is not None and flat.device == device and flat.numel() == total
+        if ok:
+            off = 0
+            for _, p in named:
+                if p.data_ptr() != flat.data_ptr() + off * 4:
+                    ok = False
+                    break
+                off += p.numel()
+        if not ok:
+            flat = torch.empty(total, dtype=torch.float32, device=device)
+            off = 0
+            for _, p in named:
+                flat[off:off + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = flat[off:off + p.numel()].view(p.shape)
+                off += p.numel()
+            self._lora_flat = flat
+            self._lora_grad = None
+        g = self._lora_grad
+        if g is None or g.device != device:
+            g = self._lora_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        off = 0
+        views = {}
+        for n, p in named:
+            v = g[off:off + p.numel()]
+            p.grad = v.view(p.shape)
+            mod, which = n.split(".lora_")[0], n.split(".lora_")[1][0]
+            lin = self.get_submodule(mod)
+            views.setdefault(mod, [None, None])[0 if which == "A" else 1] = \
+                v.view(lin.rank, lin.in_features) if which == "A" else v.view(lin.out_features, lin.rank)
+            off += p.numel()
+        for mod, (ga, gb) in views.items():
+            self.get_submodule(mod)._gviews = (ga, gb)
+        return ok
+
+    def lora_flat(self):
+        return self._lora_flat
+
+    def lora_flat_grad(self):
+        return self._lora_grad
 
 
 class MiTransformer2DModel(_DenoiserBase):

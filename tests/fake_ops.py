@@ -15,7 +15,8 @@ def _dev(t):
     return t
 
 
-def gemm(A, W, *, bias=None, residual=None, act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1, **kw):
+def gemm(A, W, *, bias=None, residual=None, act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1,
+         accum_atomic=False, **kw):
     assert A.dtype == BF16 and W.dtype == BF16 and A.shape[1] == W.shape[1] and A.shape[1] % 8 == 0, (A.shape, W.shape)
     assert A.stride(1) == 1 and W.stride(1) == 1 and A.stride(0) % 8 == 0 and W.stride(0) % 8 == 0
     v = alpha * (A.float() @ W.float().t())
@@ -30,6 +31,15 @@ def gemm(A, W, *, bias=None, residual=None, act=ACT_NONE, preact=None, out=None,
         v = torch.nn.functional.silu(v)
     else:
         assert act == ACT_NONE
+    if out is not None:
+        assert out.shape == v.shape and out.stride(1) == 1 and (out.dtype == torch.float32) == bool(out_f32)
+        if accum_atomic:
+            assert out_f32, "accum_atomic needs f32 C"
+            out.add_(v)
+        else:
+            out.copy_(v)
+        return out
+    assert not accum_atomic
     return v if out_f32 else v.to(BF16)
 
 
@@ -161,3 +171,27 @@ def batch_colsum(dy, x=None, stats=None, *, rows_per_batch, want_mul=True, want_
     if want_sum:
         o1 = d.view(B, rows_per_batch, Cc).sum(1)
     return o0, o1
+
+
+def axpby(x0, c0, x1=None, c1=0.0, x2=None, c2=0.0, x3=None, c3=0.0, out=None):
+    assert x0.dtype == torch.float32 and x0.is_contiguous()
+    r = x0 * c0
+    for x, c in ((x1, c1), (x2, c2), (x3, c3)):
+        if x is not None:
+            assert x.dtype == torch.float32 and x.is_contiguous() and x.shape == x0.shape
+            r = r + x * c
+    return r
+
+
+def add_noise(z, noise, sa, sb):
+    shape = (-1,) + (1,) * (z.dim() - 1)
+    return sa.view(shape) * z + sb.view(shape) * noise
+
+
+def adamw_(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, step=1, grad_scale=1.0):
+    """torch.optim.AdamW update (decoupled weight decay, bias correction), in place on fp32 buffers"""
+    gg = g * grad_scale
+    m.mul_(beta1).add_(gg, alpha=1 - beta1)
+    v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
+    p.mul_(1 - lr * weight_decay)
+    p.addcdiv_(m / (1 - beta1 ** step), (v / (1 - beta2 ** step)).sqrt() + eps, value=-lr)

@@ -211,3 +211,100 @@ def test_mmdit_composition_against_the_reference_fixture(monkeypatch, name):
         else:
             assert p.grad is None, k
     assert n == len(g["grads"])
+
+
+@pytest.mark.parametrize("kw", [dict(num_steps=3, guidance_scale=2.5), dict(num_steps=2, guidance_scale=1.5, max_samples=1,
+                                                                            log_teacher_samples=True)])
+def test_sd3_sampler_over_the_mmdit_batches_cfg(monkeypatch, kw):
+    """FlashDiffusionSD3.sample over MiSD3Transformer2DModel: the per-sample denoiser is called ONCE per step on [x | x] with
+    [cond | uncond] (the reference makes two calls, FD3:767-795) -- result against the oracle sampler over the oracle MMDiT"""
+    from flash_diffusion_amd import dit, flash_sd3
+    from oracle.flash_sd3_ref import EmbeddingPipeline, FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.golden_cases import build_mmdit
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    monkeypatch.setattr(dit, "ops", fake_ops)
+    monkeypatch.setattr(flash_sd3, "ops", fake_ops)
+    cfg, ora, (x, t, cond), _ = build_mmdit("mmdit_tiny")
+    _, ora_s, _, _ = build_mmdit("mmdit_tiny", lora_r=8)
+    g = torch.Generator().manual_seed(3)
+    c = cond["cond"]
+    pipe = EmbeddingPipeline(c["crossattn"], c["vector"], torch.randn(c["crossattn"].shape, generator=g),
+                             torch.randn(c["vector"].shape, generator=g))
+    kcfg = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform")
+    ref = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**kcfg), student_denoiser=ora_s, teacher_denoiser=ora,
+                               teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(),
+                               sampling_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(),
+                               teacher_sampling_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), pipeline=pipe)
+    teacher = dit.MiSD3Transformer2DModel(**cfg)
+    teacher.load_state_dict(ora.state_dict())
+    teacher.freeze()
+    student = dit.MiSD3Transformer2DModel(**cfg).add_adapter(8)
+    student.load_state_dict({k.replace(".base_layer.", "."): v for k, v in ora_s.state_dict().items()})
+    calls = []
+    orig = dit.MiSD3Transformer2DModel.forward
+    monkeypatch.setattr(dit.MiSD3Transformer2DModel, "forward",
+                        lambda self, *a, **k: (calls.append(k["sample"].shape[0]), orig(self, *a, **k))[1])
+    mine = flash_sd3.FlashDiffusionSD3(flash_sd3.FlashDiffusionSD3Config(**kcfg), student_denoiser=student,
+                                       teacher_denoiser=teacher,
+                                       teacher_noise_scheduler=flash_sd3.FlowMatchEulerDiscreteScheduler(),
+                                       sampling_noise_scheduler=flash_sd3.FlowMatchEulerDiscreteScheduler(),
+                                       teacher_sampling_noise_scheduler=flash_sd3.FlowMatchEulerDiscreteScheduler(),
+                                       pipeline=pipe)
+    z = torch.randn(2, 16, 16, 16, generator=g)
+    want, want_ref = ref.sample(z, conditioner_inputs={"text": ["a", "b"]}, **kw)
+    got, got_ref = mine.sample(z, conditioner_inputs={"text": ["a", "b"]}, **kw)
+    n = kw.get("max_samples") or 2
+    steps = kw["num_steps"] * (2 if kw.get("log_teacher_samples") else 1)
+    assert calls == [2 * n] * steps, calls                       # one 2B call per step
+    assert got.shape == want.shape and _rel(got, want) < 3e-2, _rel(got, want)
+    if want_ref is not None:
+        assert _rel(got_ref, want_ref) < 3e-2
+
+
+@pytest.mark.parametrize("kind", ["pixart", "sd3"])
+def test_flat_lora_buffer_and_fused_adamw(monkeypatch, kind):
+    """trainer.py's data-parallel path wants the LoRA tensors of the student in ONE flat fp32 buffer with ONE flat gradient
+    (one all-reduce, one AdamW launch): _reflatten_lora re-homes them; the backward GEMMs then accumulate straight into the
+    gradient views"""
+    from flash_diffusion_amd import dit, trainer
+    from oracle.golden_cases import build_dit, build_mmdit
+    monkeypatch.setattr(dit, "ops", fake_ops)
+    monkeypatch.setattr(trainer, "ops", fake_ops)
+    name, build, cls = (("dit_tiny", build_dit, dit.MiTransformer2DModel) if kind == "pixart"
+                        else ("mmdit_tiny", build_mmdit, dit.MiSD3Transformer2DModel))
+    cfg, ora, (x, t, cond), w = build(name, lora_r=8)
+    sd = {k.replace(".base_layer.", "."): v for k, v in ora.state_dict().items()}
+    plain = cls(**cfg).add_adapter(8)
+    plain.load_state_dict(sd)
+    flat = cls(**cfg).add_adapter(8)
+    flat.load_state_dict(sd)
+    assert flat.lora_rank == 8 and not flat._reflatten_lora(torch.device("cpu")) and flat._reflatten_lora(torch.device("cpu"))
+    buf, gbuf = flat.lora_flat(), flat.lora_flat_grad()
+    assert buf.numel() == sum(p.numel() for p in flat.lora_parameters()) == gbuf.numel()
+    off = 0
+    for p in flat.lora_parameters():                                   # views, in named_parameters order
+        assert p.data_ptr() == buf.data_ptr() + 4 * off and p.grad.data_ptr() == gbuf.data_ptr() + 4 * off
+        off += p.numel()
+    (plain(x, t, cond) * w).sum().backward()
+    (flat(x, t, cond) * w).sum().backward()
+    for (k, a), b in zip(plain.named_parameters(), flat.parameters()):
+        if ".lora_" in k:
+            assert torch.equal(a.grad, b.grad), k
+    g1 = gbuf.clone()
+    assert float(g1.abs().sum()) > 0
+    (flat(x, t, cond) * w).sum().backward()                            # a second backward accumulates
+    assert torch.allclose(gbuf, 2 * g1, rtol=1e-5, atol=1e-7)
+    gbuf.zero_()                                                       # what TrainingPipeline._zero_grad does
+    (flat(x, t, cond) * w).sum().backward()
+    assert torch.allclose(gbuf, g1, rtol=1e-5, atol=1e-7)
+    # one fused AdamW launch on the flat buffer == torch.optim.AdamW on the separate tensors
+    opt = trainer.FusedAdamW(flat.lora_parameters(), lr=1e-2, flat=buf, flat_grad=gbuf)
+    ref_opt = torch.optim.AdamW(plain.lora_parameters(), lr=1e-2)
+    opt.step()
+    ref_opt.step()
+    for a, b in zip(plain.lora_parameters(), flat.lora_parameters()):
+        assert torch.allclose(a, b, rtol=1e-5, atol=1e-7)
+    with torch.no_grad():                                              # the next forward sees the updated weights
+        assert _rel(flat(x, t, cond), plain(x, t, cond)) < 1e-3
+    student = copy.deepcopy(flat)                                      # a copy must not share the buffers
+    assert student.lora_flat() is None and all(m._gviews is None for m in student.modules() if hasattr(m, "_gviews"))
