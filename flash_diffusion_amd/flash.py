@@ -479,7 +479,15 @@ class FlashDiffusion(nn.Module):
             x = x_init
             fused = hasattr(sch, "fused_cfg_step")
             cfg_cond = self._cat_cond(conditioning, uncond)
-            for it, t in enumerate(sch.timesteps[si:]):
+            one_call = (os.environ.get("FDMI_TEACHER_LOOP") == "1" and cfg_cond is not None
+                        and getattr(self, "batch_cfg", True) and hasattr(sch, "loop_coefficients")
+                        and hasattr(self.teacher_denoiser, "teacher_loop") and not args and set(kwargs) <= {"device"}
+                        and set(cfg_cond["cond"]) <= {"crossattn", "vector"})
+            if one_call:   # the whole loop inside the library (fdmi_teacher_loop): opt-in until confirmed on the GPU
+                x = self.teacher_denoiser.teacher_loop(x, [float(t) for t in sch.timesteps[si:]],
+                                                       cfg_cond["cond"]["crossattn"], cfg_cond["cond"].get("vector"),
+                                                       sch.loop_coefficients(si, g))
+            for it, t in enumerate(sch.timesteps[si:] if not one_call else []):
                 x_ = sch.scale_model_input(x, t)
                 e_c, e_u = self._teacher_cfg(x_, torch.full((B,), float(t), device=z.device), conditioning, uncond,
                                              cfg_cond, *args, ctx_cache="fill" if it == 0 else "reuse", **kwargs)

@@ -162,6 +162,23 @@ class DPMSolverMultistepScheduler(_Base):
         self._step_index += 1
         return (prev,)
 
+    def loop_coefficients(self, start_index, guidance):
+        """[n][6] host coefficients of the whole CFG loop from step `start_index` of a fresh schedule (right after
+        set_timesteps): x0 = a0 x + a1 eps_c + a2 eps_u ; x = a3 x + a4 x0 + a5 x0_prev -- the numbers fused_cfg_step
+        would use step by step, for the C-ABI's fdmi_teacher_loop (no host round trip between steps)."""
+        rows, lower = [], 0
+        for i in range(start_index, len(self.timesteps)):
+            alpha_t, sigma_t = self._alpha_sigma(self.sigmas[i])
+            k = float(-sigma_t / alpha_t)
+            order, c_s, c_d0, c_d1 = self.step_coefficients(i, lower)
+            if order == 1:
+                upd = (c_s, c_d0, 0.0)
+            else:
+                upd = (c_s, c_d0 + c_d1, -c_d1)
+            rows.append((float(1.0 / alpha_t), k * guidance, k * (1.0 - guidance)) + upd)
+            lower = min(lower + 1, self.solver_order)
+        return rows
+
     def fused_cfg_step(self, eps_c, eps_u, guidance, timestep, sample):
         """CFG combine (FD:316-319) + step (FD:322-324) with the guidance folded into the x0 prediction:
         x0 = x/alpha - (sigma/alpha)(g eps_c + (1-g) eps_u)  -- one kernel instead of two."""

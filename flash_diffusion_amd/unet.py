@@ -466,6 +466,42 @@ class MiUNet2DConditionModel(nn.Module):
         self.step_flops += self.last_flops
         return out, slot
 
+    @torch.no_grad()
+    def teacher_loop(self, x, timesteps, crossattn2, vector2, coeffs):
+        """The frozen teacher's whole CFG loop in ONE C-ABI call (include/fdmi.h: fdmi_teacher_loop): x [B,C,H,W] f32 is
+        advanced through the steps `timesteps` (host floats) with the host coefficient rows `coeffs` ([n][6], see
+        schedulers.DPMSolverMultistepScheduler.loop_coefficients); crossattn2 [2B,L,D] / vector2 [2B,V] hold the conditional
+        rows first, then the unconditional ones.  Returns the new latent."""
+        assert x.is_cuda and not self.lora_rank, "teacher_loop is for a frozen denoiser on the GPU"
+        plan = self._ensure_packed(x.device)
+        L = _lib.lib()
+        B, _, H, W = x.shape
+        n = len(timesteps)
+        assert crossattn2.shape[0] == 2 * B and len(coeffs) == n and all(len(r) == 6 for r in coeffs)
+        Lc = crossattn2.shape[1]
+        x = x.float().contiguous().clone()
+        enc = crossattn2.float().contiguous()
+        vec = vector2.float().contiguous() if vector2 is not None else None
+        need = L.fdmi_unet_workspace_bytes(plan.handle, 2 * B, H, W, Lc, FDMI_UNET_CTX_FILL)
+        sneed = L.fdmi_teacher_loop_scratch_bytes(plan.handle, B, H, W)
+        if need < 0 or sneed < 0:
+            raise RuntimeError("fdmi: " + L.fdmi_last_error().decode())
+        ws = plan.workspaces.get(0)
+        if ws is None or ws.numel() < need or ws.device != x.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            plan.workspaces[0] = ws
+        sc = plan.workspaces.get("teacher_loop")
+        if sc is None or sc.numel() < sneed or sc.device != x.device:
+            sc = torch.empty(sneed, dtype=torch.uint8, device=x.device)
+            plan.workspaces["teacher_loop"] = sc
+        ts = (C.c_float * n)(*[float(t) for t in timesteps])
+        cf = (C.c_float * (6 * n))(*[float(v) for r in coeffs for v in r])
+        check(L.fdmi_teacher_loop(plan.handle, 0, ptr(x), ts, n, ptr(enc), ptr(vec), cf, B, H, W, Lc, ptr(ws), ws.numel(),
+                                  ptr(sc), sc.numel(), stream_ptr()))
+        self.last_flops = L.fdmi_unet_last_flops(plan.handle)
+        self.step_flops += self.last_flops
+        return x
+
     def _run_backward(self, slot, grad_out, needs_x, xshape):
         plan = self._plan()
         L = _lib.lib()

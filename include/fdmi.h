@@ -196,6 +196,21 @@ int fdmi_unet_forward(fdmi_unet* u, int slot, const float* sample, const float* 
 int fdmi_unet_backward(fdmi_unet* u, int slot, const float* grad_out, float* grad_sample, void* stream);
 double fdmi_unet_last_flops(fdmi_unet* u);  /* algorithmic MFMA flops of the last forward/backward */
 
+/* The frozen teacher's classifier-free-guidance loop (flash_diffusion_model.py:288-324) as ONE call: for each of the n
+ * steps  eps = unet([x | x], t_i, [ctx_cond | ctx_uncond])  (one forward on the 2B batch; the cross-attention K/V of the
+ * constant context are computed at step 0 and reused),
+ *        x0 = a0 x + a1 eps_cond + a2 eps_uncond   (guidance folded into the x0 prediction, FD:316-319)
+ *        x  = a3 x + a4 x0 + a5 x0_prev            (the scheduler's update, FD:322-324; x0_prev = previous step's x0),
+ * with a = coeffs[i][0..5], HOST arrays `timesteps` [n] and `coeffs` [n][6] computed by the caller in fp32 exactly as the
+ * scheduler does (DPM-Solver++ 2M, DDPM, Euler all have this form).  x [B,C,H,W] f32 is updated in place; ctx2 [2B,L,cross_dim]
+ * and class_labels2 [2B,class_embed_dim] (or NULL) hold the cond rows first, then the uncond rows.  `workspace` as for a
+ * forward at batch 2B (fdmi_unet_workspace_bytes(u, 2B, H, W, L, FDMI_UNET_CTX_FILL)), `scratch` of
+ * fdmi_teacher_loop_scratch_bytes bytes; nothing is retained after the call.                                              */
+int64_t fdmi_teacher_loop_scratch_bytes(fdmi_unet* u, int B, int H, int W);
+int fdmi_teacher_loop(fdmi_unet* u, int slot, float* x, const float* timesteps, int n, const float* ctx2,
+                      const float* class_labels2, const float* coeffs, int B, int H, int W, int L, void* workspace,
+                      int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

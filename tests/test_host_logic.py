@@ -182,3 +182,31 @@ def test_flow_match_scheduler_host_side_matches_oracle():
     assert abs(d0 - float(a.sigmas[1] - a.sigmas[0])) < 1e-12 and abs(d1 - float(a.sigmas[2] - a.sigmas[1])) < 1e-12
     c = FlashDiffusionSD3Config(K=[4, 2], num_iterations_per_K=[10, 20], guidance_scale_min=2.0)
     assert c.guidance_scale_min == [2.0, 2.0] and c.mixture_num_components == [4, 4] and c.distill_loss_scale == [1.0, 1.0]
+
+
+@pytest.mark.parametrize("K,si,g", [(4, 0, 8.0), (4, 1, 3.5), (8, 3, 5.0), (1, 0, 7.0)])
+def test_dpm_loop_coefficients_reproduce_the_stepwise_scheduler(monkeypatch, K, si, g):
+    """schedulers.DPMSolverMultistepScheduler.loop_coefficients -- the [n][6] host table handed to the C-ABI's
+    fdmi_teacher_loop (x0 = a0 x + a1 e_c + a2 e_u ; x = a3 x + a4 x0 + a5 x0_prev) -- against the step-by-step
+    fused_cfg_step it replaces, both evaluated on CPU with the stand-in axpby of tests/fake_ops.py"""
+    from flash_diffusion_amd import schedulers
+    from tests import fake_ops
+    monkeypatch.setattr(schedulers, "ops", fake_ops)
+    gen = torch.Generator().manual_seed(K * 10 + si)
+    x = torch.randn(2, 4, 8, 8, generator=gen)
+    eps = [(torch.randn(2, 4, 8, 8, generator=gen), torch.randn(2, 4, 8, 8, generator=gen)) for _ in range(K - si)]
+    sch = schedulers.DPMSolverMultistepScheduler()
+    sch.set_timesteps(K)
+    want = x
+    for (e_c, e_u), t in zip(eps, sch.timesteps[si:]):
+        want = sch.fused_cfg_step(e_c, e_u, g, t, want)
+    sch.set_timesteps(K)
+    rows = sch.loop_coefficients(si, g)
+    assert len(rows) == K - si and all(len(r) == 6 for r in rows)
+    got, prev = x, None
+    for (e_c, e_u), a in zip(eps, rows):
+        x0 = a[0] * got + a[1] * e_c + a[2] * e_u
+        got = a[3] * got + a[4] * x0 + (a[5] * prev if prev is not None else 0.0)
+        assert prev is not None or a[5] == 0.0
+        prev = x0
+    assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())

@@ -129,3 +129,39 @@ def test_dit_lora_step_matches_reference_golden(name):
         assert _cos(p.grad, ref) > 0.999 and rel_err(p.grad, ref) < 6e-2, (k, _cos(p.grad, ref), rel_err(p.grad, ref))
         n += 1
     assert n == len(g["grads"]) and n > 0
+
+
+def test_teacher_loop_single_call_matches_the_stepwise_loop():
+    """fdmi_teacher_loop (the frozen teacher's CFG loop as ONE C-ABI call: 2B-batched forwards with the context K/V cached,
+    guidance folded into the x0 prediction, DPM-Solver++ update from a host coefficient table) against the step-by-step
+    loop of flash.py (one forward + one fused scheduler step per iteration).  Tolerance: the tiny UNet's run-to-run
+    GroupNorm-atomics noise, as in tests/test_unet_gpu.py::test_ctx_cache_reuse_matches_recompute."""
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from flash_diffusion_amd.unet import MiUNet2DConditionModel
+    from flash_diffusion_amd.workloads import TINY
+    torch.manual_seed(0)
+    net = MiUNet2DConditionModel(**TINY).cuda()
+    net.freeze()
+    B, hw, L, D, K, si, g = 2, 16, 7, TINY["cross_attention_dim"], 4, 1, 6.0
+    ctx2 = torch.randn(2 * B, L, D, device="cuda")
+    x = torch.randn(B, 4, hw, hw, device="cuda")
+
+    def stepwise():
+        sch = DPMSolverMultistepScheduler()
+        sch.set_timesteps(K)
+        cur = x
+        with torch.no_grad():
+            for t in sch.timesteps[si:]:
+                tt = torch.full((2 * B,), float(t), device="cuda")
+                e = net(torch.cat([cur, cur]), tt, {"cond": {"crossattn": ctx2}})
+                e_c, e_u = e.chunk(2)
+                cur = sch.fused_cfg_step(e_c.contiguous(), e_u.contiguous(), g, t, cur)
+        return cur
+
+    want = stepwise()
+    noise = max([rel_err(stepwise(), want) for _ in range(3)] + [5e-3])
+    sch = DPMSolverMultistepScheduler()
+    sch.set_timesteps(K)
+    got = net.teacher_loop(x, [float(t) for t in sch.timesteps[si:]], ctx2, None, sch.loop_coefficients(si, g))
+    assert got.shape == x.shape and rel_err(got, want) <= 3 * noise, (rel_err(got, want), noise)
+    assert rel_err(got, x) > 10 * noise and rel_err(x, x.clone()) == 0   # the input is left untouched, the output moved
