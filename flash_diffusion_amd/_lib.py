@@ -53,6 +53,11 @@ _SIGS = {
     "fdmi_teacher_loop_scratch_bytes": (i64, [vp, i32, i32, i32]),
     "fdmi_teacher_loop": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, vp]),
     "fdmi_version": (i32, []),
+    "fdmi_comm_unique_id": (i32, [vp]),
+    "fdmi_allreduce_init": (i32, [i32, i32, vp]),
+    "fdmi_allreduce": (i32, [vp, i64, i32, vp]),
+    "fdmi_allreduce_world": (i32, []),
+    "fdmi_allreduce_destroy": (i32, []),
     "fdmi_tune_set": (i32, [i32, i32]),
     "fdmi_prof_enable": (i32, [i32]),
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),

@@ -211,6 +211,20 @@ int fdmi_teacher_loop(fdmi_unet* u, int slot, float* x, const float* timesteps, 
                       const float* class_labels2, const float* coeffs, int B, int H, int W, int L, void* workspace,
                       int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream);
 
+/* ---------------- data-parallel gradient exchange (RCCL over xGMI) --------------------------------
+ * One process per GPU.  Rank 0 calls fdmi_comm_unique_id and hands the 128 bytes to the other ranks out of band (env,
+ * file, socket); every rank then calls fdmi_allreduce_init once.  fdmi_allreduce is the ONE collective of a training
+ * step: the in-place SUM of the flat LoRA gradient (fold 1/world into fdmi_adamw's grad_scale), enqueued on `stream`.
+ * librccl.so is bound at run time, on first use.  (A PyTorch host uses torch.distributed's "nccl" backend -- the same
+ * RCCL -- instead: flash_diffusion_amd/trainer.py.)  Replaces Lightning DDP's gradient all-reduce,
+ * examples/train_flash_sd.py:383-386.                                                             */
+enum { FDMI_F32 = 0, FDMI_BF16 = 1 };
+int fdmi_comm_unique_id(void* out128);
+int fdmi_allreduce_init(int rank, int world, const void* uid128);
+int fdmi_allreduce(void* buf, int64_t count, int dtype, void* stream);
+int fdmi_allreduce_world(void);      /* 0 before init */
+int fdmi_allreduce_destroy(void);
+
 #ifdef __cplusplus
 }
 #endif

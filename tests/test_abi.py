@@ -42,3 +42,17 @@ def test_missing_library_fails_loudly(monkeypatch):
     monkeypatch.setattr(_lib, "_lib", None)
     with pytest.raises(RuntimeError, match="no fallback"):
         _lib.lib()
+
+
+def test_allreduce_entry_points_fail_cleanly_without_a_communicator():
+    """fdmi_allreduce* (RCCL bound at run time): before fdmi_allreduce_init the collective returns an error code with a
+    message, the library has no load-time dependency on librccl, and world size reads 0"""
+    import subprocess
+    from flash_diffusion_amd import _lib
+    L = _lib.lib()
+    assert L.fdmi_allreduce_world() == 0
+    assert L.fdmi_allreduce(None, 0, 0, None) != 0 and b"fdmi_allreduce_init" in L.fdmi_last_error()
+    assert L.fdmi_allreduce_init(3, 2, None) != 0 and b"bad rank" in L.fdmi_last_error()
+    assert L.fdmi_allreduce_destroy() == 0
+    needed = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    assert "rccl" not in needed.lower()

@@ -165,3 +165,26 @@ def test_teacher_loop_single_call_matches_the_stepwise_loop():
     got = net.teacher_loop(x, [float(t) for t in sch.timesteps[si:]], ctx2, None, sch.loop_coefficients(si, g))
     assert got.shape == x.shape and rel_err(got, want) <= 3 * noise, (rel_err(got, want), noise)
     assert rel_err(got, x) > 10 * noise and rel_err(x, x.clone()) == 0   # the input is left untouched, the output moved
+
+
+def test_rccl_allreduce_entry_points_world_1():
+    """fdmi_comm_unique_id / fdmi_allreduce_init / fdmi_allreduce / fdmi_allreduce_destroy on a single-rank communicator:
+    the in-place sum over one rank is the identity (f32 and bf16); the multi-rank path is the driver's 8-GPU run"""
+    import ctypes as C
+    from flash_diffusion_amd import _lib
+    from flash_diffusion_amd._lib import check, ptr, stream_ptr
+    L = _lib.lib()
+    uid = C.create_string_buffer(128)
+    check(L.fdmi_comm_unique_id(uid))
+    check(L.fdmi_allreduce_init(0, 1, uid))
+    try:
+        assert L.fdmi_allreduce_world() == 1
+        for dt, code in ((torch.float32, 0), (torch.bfloat16, 1)):
+            x = torch.randn(100003, device="cuda").to(dt)
+            y = x.clone()
+            check(L.fdmi_allreduce(ptr(y), y.numel(), code, stream_ptr()))
+            torch.cuda.synchronize()
+            assert torch.equal(x, y)
+    finally:
+        check(L.fdmi_allreduce_destroy())
+    assert L.fdmi_allreduce_world() == 0
