@@ -308,3 +308,58 @@ def test_flat_lora_buffer_and_fused_adamw(monkeypatch, kind):
         assert _rel(flat(x, t, cond), plain(x, t, cond)) < 1e-3
     student = copy.deepcopy(flat)                                      # a copy must not share the buffers
     assert student.lora_flat() is None and all(m._gviews is None for m in student.modules() if hasattr(m, "_gviews"))
+
+
+# ---- conditioner plumbing against the reference's REAL classes ---------------------------------------------
+def test_conditioner_wrapper_matches_the_reference(monkeypatch):
+    from oracle import shim_import
+    if not shim_import.reference_available():
+        pytest.skip("reference sources not present")
+    shim_import.import_reference()
+    import flash.models.embedders as R
+    from flash_diffusion_amd import conditioners as M
+    monkeypatch.setattr(M, "ops", fake_ops)
+    lin = dict(nn_modules=["torch.nn.Linear", "torch.nn.SiLU"], nn_modules_kwargs=[dict(in_features=6, out_features=5), {}])
+
+    class RefTensor(R.BaseConditioner):
+        def forward(self, batch, force_zero_embedding=False, *a, **k):
+            x = batch[self.input_key]
+            return {self.dim2outputkey[x.dim()]: 0 * x if force_zero_embedding else x}
+
+    def build(ns, tensor_cls):
+        cfgk = (lambda cls, **kw: cls(**kw)) if ns is M else None
+        if ns is M:
+            cs = [M.TensorEmbedder("text", 0.5), M.TimestepsEmbedder(16, input_key="size", unconditional_conditioning_rate=0.3),
+                  M.TimestepsEmbedder(16, input_key="crop"), M.TorchNNEmbedder(input_key="pooled", **lin),
+                  M.TensorEmbedder("text2", 0.0), M.TensorEmbedder("mask_image", 0.2)]
+        else:
+            cs = [tensor_cls(R.BaseConditionerConfig(input_key="text", unconditional_conditioning_rate=0.5)),
+                  R.TimestepsEmbedder(R.TimestepsEmbedderConfig(num_channels=16, input_key="size",
+                                                                unconditional_conditioning_rate=0.3)),
+                  R.TimestepsEmbedder(R.TimestepsEmbedderConfig(num_channels=16, input_key="crop")),
+                  R.TorchNNEmbedder(R.TorchNNEmbedderConfig(input_key="pooled", **lin)),
+                  tensor_cls(R.BaseConditionerConfig(input_key="text2")),
+                  tensor_cls(R.BaseConditionerConfig(input_key="mask_image", unconditional_conditioning_rate=0.2))]
+        return ns.ConditionerWrapper(cs)
+
+    real, mine = build(R, RefTensor), build(M, None)
+    mine.conditioners[3].load_state_dict(real.conditioners[3].state_dict())
+    g = torch.Generator().manual_seed(0)
+    batch = {"text": torch.randn(3, 7, 12, generator=g), "text2": torch.randn(3, 7, 4, generator=g),
+             "size": torch.tensor([[512.0, 512.0], [256.0, 128.0], [1024.0, 768.0]]),
+             "crop": torch.tensor([[0.0, 0.0], [16.0, 32.0], [8.0, 0.0]]), "pooled": torch.randn(3, 6, generator=g),
+             "mask_image": torch.randn(3, 1, 8, 8, generator=g)}
+    for kw in (dict(), dict(set_ucg_rate_zero=True), dict(ucg_keys=["text"]), dict(ucg_keys=["text", "size"], set_ucg_rate_zero=True)):
+        for seed in range(6):                                          # same host RNG stream => same dropout decisions
+            torch.manual_seed(seed)
+            a = real(batch, **kw)
+            torch.manual_seed(seed)
+            b = mine(batch, **kw)
+            assert set(a["cond"]) == set(b["cond"]) == {"crossattn", "vector", "concat"}
+            assert a["cond"]["crossattn"].shape == (3, 7, 16) and a["cond"]["vector"].shape == (3, 2 * 32 + 5)
+            for k in a["cond"]:
+                tol = 8e-3 if k == "vector" else 0.0                    # sinusoids come back from the kernel in bf16
+                assert a["cond"][k].shape == b["cond"][k].shape
+                assert float((a["cond"][k] - b["cond"][k]).abs().max()) <= tol, (kw, seed, k)
+    with pytest.raises(AssertionError):
+        M.BaseConditioner("text", 1.5)
