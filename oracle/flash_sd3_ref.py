@@ -240,6 +240,45 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
         return sample, ref
 
 
+    def log_samples(self, batch, input_shape=None, guidance_scale=1.0, teacher_guidance_scale=5.0, max_samples=8,
+                    num_steps=20, device="cpu", log_teacher_samples=False, conditioner_inputs=None,
+                    conditioner_uncond_inputs=None):
+        """FD3:845-945 (no VAE: `input_shape` = latent shape is mandatory, the reference's ValueError branch)"""
+        if isinstance(num_steps, int):
+            num_steps = [num_steps]
+        logs = {}
+        N = max_samples
+        if batch is not None:
+            N = min(N, min(len(batch[k]) for k in batch))
+        if conditioner_inputs is not None:
+            m = min(len(conditioner_inputs[k]) for k in conditioner_inputs)
+            conditioner_inputs.update({k: v.to(device) for k, v in conditioner_inputs.items() if torch.is_tensor(v)})
+            batch.update(conditioner_inputs)
+            N = min(N, m)
+        if conditioner_uncond_inputs is not None:
+            m = min(len(conditioner_uncond_inputs[k]) for k in conditioner_uncond_inputs)
+            conditioner_uncond_inputs.update({k: v.to(device) for k, v in conditioner_uncond_inputs.items()
+                                              if torch.is_tensor(v)})
+            batch_uncond = copy.deepcopy(batch)
+            batch_uncond.update(conditioner_uncond_inputs)
+            N = min(N, m)
+        else:
+            batch_uncond = None
+        if input_shape is None:
+            raise ValueError("input_shape must be passed when no VAE is used in the model")       # FD3:904-907
+        for n in num_steps:
+            z = torch.randn(N, *input_shape).to(device)                                            # FD3:911
+            samples, samples_ref = self.sample(z, num_steps=n, conditioner_inputs=batch,
+                                               uncond_conditioner_inputs=batch_uncond, guidance_scale=guidance_scale,
+                                               teacher_guidance_scale=teacher_guidance_scale, max_samples=N,
+                                               log_teacher_samples=log_teacher_samples)
+            logs[f"samples_{n}_steps/{self.sampling_noise_scheduler.__class__.__name__}_{guidance_scale}_cfg/student"] = samples
+            if samples_ref is not None:
+                logs[f"samples_{n}_steps/{self.teacher_sampling_noise_scheduler.__class__.__name__}"
+                     f"_{teacher_guidance_scale}_cfg/teacher"] = samples_ref
+        return logs
+
+
 class TinyFlowDenoiser(torch.nn.Module):
     """A small velocity model honouring the reference's transformer-wrapper contract (TW:113-155: sample [B,C,H,W],
     timestep [B], conditioning {"cond": {"vector", "crossattn"}}, unknown kwargs swallowed -- e.g. the

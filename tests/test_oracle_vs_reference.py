@@ -269,3 +269,23 @@ def test_sd3_wrapper_restatement_is_bit_identical(name):
     assert torch.equal(real(x[:, :8], t, cond2), mine(x[:, :8], t, cond2)) and real(x[:, :8], t, cond2).shape[1] == 8
     real.freeze()
     assert not any(p.requires_grad for p in real.parameters()) and not real.training
+
+
+def test_sd3_log_samples_restatement_is_bit_identical():
+    from oracle.flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    FD3, FD3C = shim_import.import_reference_sd3()
+    logs = []
+    for cls, ccls in ((FD3, FD3C), (FlashDiffusionSD3Ref, FlashSD3ConfigRef)):
+        m = _build_sd3(cls, ccls, with_disc=False, K=[4], num_iterations_per_K=[10], timestep_distribution="uniform")
+        m.sampling_noise_scheduler = FlowMatchEulerDiscreteSchedulerRef()
+        m.teacher_sampling_noise_scheduler = FlowMatchEulerDiscreteSchedulerRef()
+        torch.manual_seed(21)
+        logs.append(m.log_samples({"text": ["a", "b"]}, input_shape=(4, 16, 16), guidance_scale=1.5, max_samples=8,
+                                  num_steps=[2, 3], log_teacher_samples=True))
+        with pytest.raises(ValueError):
+            m.log_samples({"text": ["a", "b"]})
+    a, b = logs
+    assert list(a) == list(b) and len(a) == 4
+    for k in a:
+        assert a[k].shape[0] == 2 and torch.equal(a[k], b[k]), k
