@@ -62,6 +62,7 @@ _SIGS = {
     "fdmi_prof_enable": (i32, [i32]),
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),
+    "fdmi_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
     "fdmi_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "fdmi_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "fdmi_layernorm_fwd": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),

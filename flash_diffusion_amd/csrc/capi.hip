@@ -54,8 +54,7 @@ int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches
 const char* fdmi_last_error(void) { return g_err.c_str(); }
 int fdmi_version(void) { return 1; }
 
-int fdmi_gemm(const fdmi_gemm_desc* d, void* stream) {
-  FDMI_CHECK(d != nullptr, "null descriptor");
+static GemmArgs gemm_args_from(const fdmi_gemm_desc* d) {
   GemmArgs a;
   a.M = d->M; a.N = d->N; a.K = d->K;
   a.A = (const bf16_t*)d->A; a.lda = d->lda;
@@ -74,7 +73,19 @@ int fdmi_gemm(const fdmi_gemm_desc* d, void* stream) {
   a.accum_atomic = d->accum_atomic;
   a.force_tile = d->force_tile;
   a.use_glds = d->use_glds;
-  return launch_gemm(a, (hipStream_t)stream);
+  return a;
+}
+int fdmi_gemm(const fdmi_gemm_desc* d, void* stream) {
+  FDMI_CHECK(d != nullptr, "null descriptor");
+  return launch_gemm(gemm_args_from(d), (hipStream_t)stream);
+}
+// host-only: which kernel / tile / split the planner would launch for this problem (no device work)
+int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_t* BN, int32_t* splitk) {
+  FDMI_CHECK(d != nullptr && kernel && BM && BN && splitk, "gemm_plan: null argument");
+  const GemmArgs a = gemm_args_from(d);
+  const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic || a.splitk <= 0);
+  *kernel = p.big; *BM = p.big ? 256 : p.BM; *BN = p.BN; *splitk = p.splitk;
+  return 0;
 }
 
 int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, float* stats, void* y, int B,

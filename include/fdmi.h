@@ -61,6 +61,10 @@ typedef struct fdmi_gemm_desc {
   int32_t use_glds;
 } fdmi_gemm_desc;
 int fdmi_gemm(const fdmi_gemm_desc* d, void* stream);
+/* host-only planner query: kernel 0 = 128/64-row tiles (gemm.hip), 1 = 256 x {128,160} LDS-DMA ring (gemm3.hip),
+ * 2 = 256 x 320 (gemm4.hip); the tile and the split-K factor that fdmi_gemm would use (splitk <= 0 in the descriptor
+ * = let the planner split).  No device work, no GPU needed.                                       */
+int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_t* BN, int32_t* splitk);
 
 /* ---------------- normalisation (NHWC / token-major bf16, fp32 statistics) -------------------- */
 int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, float* stats /*[B][G][2]*/,
