@@ -32,14 +32,14 @@ struct GemmArgs {
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 // kernel / tile / split-K selection (shared by the launcher and by callers that must size `ws`)
-struct GemmPlan { int big = 0;  /* 0: gemm.hip tiles, 1: gemm3 (256 x BN), 2: gemm4 (256 x 320) */ int BM = 128, BN = 128, splitk = 1; };
+struct GemmPlan { int big = 0;  /* 0: gemm.hip tiles, 1: gemm3 (256 x BN), 2: gemm4 (256 x BN, BN = 320 | 192) */ int BM = 128, BN = 128, splitk = 1; };
 GemmPlan plan_gemm(const GemmArgs& a, bool ws_available);
 // bytes of fp32 workspace the auto split-K plan wants for this problem (0 = no split)
 size_t gemm_ws_bytes(const GemmArgs& a);
 bool gemm3_eligible(const GemmArgs& a);
 int gemm3_pick_bn(const GemmArgs& a);
 int launch_gemm3(const GemmArgs& a, int BN, hipStream_t stream);
-bool gemm4_eligible(const GemmArgs& a);   // 256 x 320 tile (gemm4.hip)
-int launch_gemm4(const GemmArgs& a, hipStream_t stream);
+bool gemm4_eligible(const GemmArgs& a, int BN = 320);   // 256 x {320, 192} tile (gemm4.hip)
+int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN = 320);
 // algorithmic flops of one launch (2*M*N*K)
 static inline double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }

@@ -476,7 +476,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   if (a.force_tile) {
     p.BM = a.force_tile >> 16;
     p.BN = a.force_tile & 0xffff;
-    p.big = p.BM == 256 ? (p.BN == 320 ? 2 : 1) : 0;
+    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : 0;
     p.splitk = a.splitk > 0 ? a.splitk : 1;
     return p;
   }
@@ -500,6 +500,8 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
     if (a.act != ACT_GEGLU && gemm3_pick_bn(a) == 160 && (a.N % 128) == 0) consider(1, 256, 128, 256, 3.4);
   }
   if (gemm4_eligible(a)) consider(2, 256, 320, 256, 4.8);
+  // 256 x 192 (widths of the transformer denoisers): developer knob 12 until its rate has been measured (est. 110 flop/B)
+  if (fdmi_tune_get(12) && gemm4_eligible(a, 192)) consider(2, 256, 192, 256, 3.9);
   const bool geglu = a.act == ACT_GEGLU;
   consider(0, 128, 128, 512, 1.05);
   consider(0, 128, 64, 768, 0.60);
@@ -552,7 +554,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic);
   if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
-  if (p.big == 2) FDMI_CHECK(gemm4_eligible(a), "gemm: 256x320 tile not applicable to this problem");
+  if (p.big == 2) FDMI_CHECK(gemm4_eligible(a, p.BN), "gemm: 256x320 / 256x192 tile not applicable to this problem");
   a.splitk = p.splitk;
   {  // every split must own at least one K tile (slabs of empty splits would stay uninitialised)
     const int kt = cdiv(a.K, 64);
@@ -566,7 +568,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
                                    p.big ? p.big * 1000 + p.BN : p.BM * 1000 + p.BN, a.splitk)];
   int rc;
   if (p.big == 2)
-    rc = launch_gemm4(a, stream);
+    rc = launch_gemm4(a, stream, p.BN);
   else if (p.big)
     rc = launch_gemm3(a, p.BN, stream);
   else if (a.mode == GEMM_ROW)

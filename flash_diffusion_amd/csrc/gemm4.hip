@@ -18,13 +18,17 @@
 
 namespace {
 
-template <int MODE, bool GEGLU>
+// BN = 320 is the tile described above.  BN = 192 is the same pipeline for widths that 320 does not divide but 192 does --
+// the transformer denoisers' 1152 / 1536 / 4608 / 6144 (PixArt, SD3): 56 KB per tile, 110 flop/B, wave tile 64 x 96.
+template <int MODE, bool GEGLU, int BN>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int BM = 256, BN = 320;
+  constexpr int BM = 256;
+  static_assert(BN % 64 == 0 && BN >= 128, "two waves along N, 16-wide fragments in pairs, 64-row LDS-DMA pieces");
   constexpr int STAGE = (BM + BN) * 128;
-  constexpr int AR = 4, WR = 5, NP = AR + WR;  // LDS-DMA pieces (1 KiB per wave) per thread per tile
-  constexpr int MF = 4, NF = 10, NQ = 2 * NF;  // NQ MFMA groups (k-step, W fragment) per tile
+  constexpr int AR = 4, WR = BN / 64, NP = AR + WR;  // LDS-DMA pieces (1 KiB per wave) per thread per tile
+  constexpr int MF = 4, NF = BN / 32, NQ = 2 * NF;   // NQ MFMA groups (k-step, W fragment) per tile
+  static_assert(NP <= NQ && NQ >= 8, "one piece per MFMA group; the W ring runs 3 groups ahead");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -247,15 +251,15 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
 }
 
-template <int MODE, bool GEGLU>
+template <int MODE, bool GEGLU, int BN>
 int launch4_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
-  constexpr int smem = 2 * (256 + 320) * 128;
+  constexpr int smem = 2 * (256 + BN) * 128;
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  const int items = (a.M / 256) * (a.N / 320) * (a.splitk > 1 ? a.splitk : 1);
+  const int items = (a.M / 256) * (a.N / BN) * (a.splitk > 1 ? a.splitk : 1);
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -268,7 +272,7 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, PROF_GEMM4 + MODE, gemm_flops(a));
-  hipLaunchKernelGGL((gemm4_kernel<MODE, GEGLU>), grid, dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((gemm4_kernel<MODE, GEGLU, BN>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -276,16 +280,22 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
 
 }  // namespace
 
-bool gemm4_eligible(const GemmArgs& a) {
-  if ((a.K & 63) != 0 || (a.M & 255) != 0 || (a.N % 320) != 0) return false;
+bool gemm4_eligible(const GemmArgs& a, int BN) {
+  if (BN != 320 && BN != 192) return false;
+  if ((a.K & 63) != 0 || (a.M & 255) != 0 || (a.N % BN) != 0) return false;
+  if (BN == 192 && a.act == ACT_GEGLU) return false;
   if (a.mode == GEMM_CONV && ((a.Cin & 63) != 0 || a.Hout > 2048 || a.Wout > 2048)) return false;
   if (a.act == ACT_GEGLU && (a.mode != GEMM_ROW || a.accum_atomic || fdmi_tune_get(9))) return false;
   return true;
 }
-int launch_gemm4(const GemmArgs& a, hipStream_t stream) {
+int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
+  if (BN == 192) {
+    FDMI_CHECK(a.act != ACT_GEGLU, "gemm4: the 256 x 192 tile has no GEGLU epilogue");
+    return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 192>(a, stream) : launch4_t<GEMM_CONV, false, 192>(a, stream);
+  }
   if (a.act == ACT_GEGLU) {
     FDMI_CHECK(a.mode == GEMM_ROW && a.splitk <= 1 && !a.accum_atomic, "gemm4: GEGLU needs a plain row GEMM");
-    return launch4_t<GEMM_ROW, true>(a, stream);
+    return launch4_t<GEMM_ROW, true, 320>(a, stream);
   }
-  return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false>(a, stream) : launch4_t<GEMM_CONV, false>(a, stream);
+  return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 320>(a, stream) : launch4_t<GEMM_CONV, false, 320>(a, stream);
 }

@@ -82,3 +82,15 @@ def test_gemm_planner_choices_for_the_benchmark_shapes():
     assert _plan(8, 6912, 1152)[0] == 0 and _plan(32768, 32, 1152)[0] == 0
     k, bm, bn, sk = _plan(1152, 64, 32768, splitk=0, accum_atomic=1, out_f32=1)
     assert sk == 16 and k == 0
+
+
+def test_planner_offers_the_256x192_tile_only_behind_its_knob():
+    from flash_diffusion_amd import _lib
+    L = _lib.lib()
+    assert _plan(32768, 1152, 1152)[:3] == (1, 256, 128)
+    L.fdmi_tune_set(12, 1)
+    try:
+        assert _plan(32768, 1152, 1152)[:3] == (2, 256, 192) and _plan(16384, 6144, 1536)[:3] == (2, 256, 192)
+        assert _plan(65536, 320, 320)[:3] == (2, 256, 320)            # widths that 320 divides keep the larger tile
+    finally:
+        L.fdmi_tune_set(12, 0)

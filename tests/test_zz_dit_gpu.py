@@ -131,6 +131,53 @@ def test_dit_lora_step_matches_reference_golden(name):
     assert n == len(g["grads"]) and n > 0
 
 
+# ---- 256 x 192 variant of the 2-slot ring kernel (gemm4<BN=192>): the tile for N = 1152 / 1536 / 4608 / 6144 -----------------
+T192 = (256 << 16) | 192
+
+
+@pytest.mark.parametrize("shape", [(256, 192, 64), (512, 1152, 1152), (1024, 384, 4608), (768, 1536, 192), (2048, 576, 1536)])
+def test_gemm4_bn192_row(shape):
+    ops = _ops()
+    M, N, K = shape
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    res = b16(rnd(M, N, seed=5))
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=T192)
+    close(f"gemm4_192_row{shape}", out, A.float() @ W.float().t() + bias + res.float())
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), out_f32=True, force_tile=T192)
+    close(f"gemm4_192_f32{shape}", out, A.float() @ W.float().t() + bias, tol_el=1e-4, tol_fro=1e-4)
+    if K >= 320:
+        out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), force_tile=T192, splitk=3)
+        close(f"gemm4_192_splitk{shape}", out, A.float() @ W.float().t() + bias)
+        acc = torch.zeros(M, N, dtype=torch.float32, device="cuda")
+        ops.gemm(A.cuda(), W.cuda(), out=acc, accum_atomic=True, splitk=2, force_tile=T192)
+        close(f"gemm4_192_atomic{shape}", acc, A.float() @ W.float().t(), tol_el=1e-4, tol_fro=1e-4)
+
+
+def test_gemm4_bn192_many_items_and_planner_knob():
+    """more (tile, split) items than CUs; and with developer knob 12 the planner itself picks the tile for a DiT shape"""
+    import ctypes as C
+    from flash_diffusion_amd import _lib
+    ops = _ops()
+    M, N, K = 256 * 150, 384, 128
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    out = ops.gemm(A.cuda(), W.cuda(), force_tile=T192)
+    close("gemm4_192_many", out, A.float() @ W.float().t())
+    assert torch.equal(out, ops.gemm(A.cuda(), W.cuda(), force_tile=T192))
+    M, N, K = 8192, 1152, 1152
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    L = _lib.lib()
+    L.fdmi_tune_set(12, 1)
+    try:
+        d = _lib.GemmDesc()
+        d.M, d.N, d.K, d.lda, d.ldw, d.splitk, d.use_glds, d.alpha = M, N, K, K, K, 1, 1, 1.0
+        o = [C.c_int32() for _ in range(4)]
+        assert L.fdmi_gemm_plan(C.byref(d), *[C.byref(x) for x in o]) == 0 and (o[0].value, o[2].value) == (2, 192)
+        close("gemm4_192_planned", ops.gemm(A.cuda(), W.cuda()), A.float() @ W.float().t())
+    finally:
+        L.fdmi_tune_set(12, 0)
+
+
 def test_teacher_loop_single_call_matches_the_stepwise_loop():
     """fdmi_teacher_loop (the frozen teacher's CFG loop as ONE C-ABI call: 2B-batched forwards with the context K/V cached,
     guidance folded into the x0 prediction, DPM-Solver++ update from a host coefficient table) against the step-by-step
