@@ -121,6 +121,9 @@ def lib():
             fn = getattr(l, name)
             fn.restype = res
             fn.argtypes = args
+        for kv in filter(None, os.environ.get("FDMI_TUNE", "").split(",")):   # developer knobs, e.g. FDMI_TUNE=12=1
+            k, v = kv.split("=")
+            l.fdmi_tune_set(int(k), int(v))
         _lib = l
     return _lib
 
