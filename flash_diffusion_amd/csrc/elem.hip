@@ -49,6 +49,17 @@ __global__ __launch_bounds__(256) void nchw_grad_to_nhwc_kernel(const float* g, 
     y[i] = c < C ? f2bf(g[((int64_t)b * C + c) * HW + s]) : (bf16_t)0;
   }
 }
+// y[NHWC bf16, width C] += scale * r[NCHW f32]   (T2I-adapter residuals, UW:100-106 / FD:208-218)
+__global__ __launch_bounds__(256) void add_nchw_to_nhwc_kernel(const float* r, float scale, bf16_t* y, int B, int C, int HW) {
+  const int64_t total = (int64_t)B * HW * C;
+  GRID_STRIDE(i, total) {
+    const int c = (int)(i % C);
+    const int64_t p = i / C;
+    const int b = (int)(p / HW);
+    const int s = (int)(p - (int64_t)b * HW);
+    y[i] = f2bf(fmaf(scale, r[((int64_t)b * C + c) * HW + s], bf2f(y[i])));
+  }
+}
 
 // sinusoidal timestep embedding (diffusers Timesteps: [sin | cos], flipped to [cos | sin])
 __global__ __launch_bounds__(256) void timestep_embed_kernel(const float* t, bf16_t* out, int B, int dim,
@@ -276,6 +287,9 @@ int launch_nchw_to_nhwc(const float* x, bf16_t* y, int B, int C, int HW, int Cpa
 int launch_nhwc_to_nchw(const bf16_t* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate,
                         hipStream_t st) {
   LAUNCH(nhwc_to_nchw_kernel, (int64_t)B * C * HW, x, ldx, y, B, C, HW, accumulate)
+}
+int launch_add_nchw_to_nhwc(const float* r, float scale, bf16_t* y, int B, int C, int HW, hipStream_t st) {
+  LAUNCH(add_nchw_to_nhwc_kernel, (int64_t)B * HW * C, r, scale, y, B, C, HW)
 }
 int launch_nchw_grad_to_nhwc(const float* g, bf16_t* y, int64_t ldy, int B, int C, int HW, hipStream_t st) {
   LAUNCH(nchw_grad_to_nhwc_kernel, (int64_t)B * HW * ldy, g, y, ldy, B, C, HW)

@@ -51,6 +51,8 @@ int launch_nchw_to_nhwc(const float* x, bf16_t* y, int B, int C, int HW, int Cpa
 int launch_nhwc_to_nchw(const bf16_t* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate,
                         hipStream_t st);
 int launch_nchw_grad_to_nhwc(const float* g, bf16_t* y, int64_t ldy, int B, int C, int HW, hipStream_t st);
+// y[NHWC bf16, width C] += scale * r[NCHW f32]
+int launch_add_nchw_to_nhwc(const float* r, float scale, bf16_t* y, int B, int C, int HW, hipStream_t st);
 int launch_timestep_embed(const float* t, bf16_t* out, int B, int dim, int flip, float shift, hipStream_t st);
 int launch_silu(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t st);
 // dst[m][dc0 + c] (=|+=) src[m][sc0 + c], c < cols

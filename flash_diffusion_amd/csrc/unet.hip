@@ -148,6 +148,9 @@ struct Run {
 }  // namespace
 
 struct fdmi_unet {
+  // T2I-adapter residuals for the NEXT forward (one f32 NCHW tensor per down block, consumed once): UW:100-106
+  std::vector<const float*> down_res;
+  float down_res_scale = 1.f;
   fdmi_unet_config cfg;
   int nl = 0, temb_ch = 0, temb_total = 0;
   Weight conv_in, conv_out, te1, te2, ce1, ce2, temb_proj;
@@ -913,6 +916,21 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   T* h = E.conv(x0, U->conv_in, 1, 0, nullptr, 0, nullptr);
   FAIL_IF_NULL(h);
   std::vector<T*> skips{h};
+  // T2I-adapter residuals (diffusers UNet2DConditionModel.forward, `down_intrablock_additional_residuals`): a block WITH
+  // cross-attention adds its residual to the hidden state after its last (resnet, attention) pair -- before that state is
+  // pushed as a skip and before the downsampler; a block WITHOUT attention adds it to the block's output, in place, i.e.
+  // also to the tensor already pushed as the block's last skip.  The residuals are constants of this forward (the adapter is
+  // frozen, examples/train_flash_canny_adapter.py:362), so they are added in place and need no tape entry.
+  std::vector<const float*> dres;
+  if (!R.dry()) dres.swap(U->down_res);  // (a workspace query leaves them for the real forward)
+  FDMI_CHECK(dres.empty() || dres.size() == U->down.size(), "unet: one adapter residual per down block expected");
+  size_t di = 0;
+  auto add_res = [&](T* t) -> int {
+    if (dres.empty()) return 0;
+    const float* r = dres[di++];
+    if (r && !R.dry()) RET_IF(launch_add_nchw_to_nhwc(r, U->down_res_scale, t->p, t->B, t->cols, t->H * t->W, st));
+    return 0;
+  };
   for (auto& sp : U->down) {
     StageW& s = *sp;
     for (size_t j = 0; j < s.res.size(); ++j) {
@@ -921,6 +939,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
       if (s.has_attn) {
         h = E.transformer(h, *s.attn[j], ctxb, L);
         FAIL_IF_NULL(h);
+        if (j + 1 == s.res.size()) RET_IF(add_res(h));
       }
       skips.push_back(h);
     }
@@ -929,6 +948,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
       FAIL_IF_NULL(h);
       skips.push_back(h);
     }
+    if (!s.has_attn) RET_IF(add_res(h));
   }
   // ---- mid ----
   h = E.resnet(h, *U->mid_r0, temb_all);
@@ -1093,6 +1113,14 @@ int fdmi_unet_backward(fdmi_unet* U, int slot, const float* grad_out, float* gra
 }
 
 double fdmi_unet_last_flops(fdmi_unet* U) { return U ? U->last_flops : 0.0; }
+
+int fdmi_unet_set_down_residuals(fdmi_unet* U, const float* const* residuals, int n, float scale) {
+  FDMI_CHECK(U != nullptr, "null plan");
+  FDMI_CHECK(n == 0 || (residuals && n == (int)U->down.size()), "unet: one adapter residual per down block expected");
+  U->down_res.assign(residuals, residuals + n);
+  U->down_res_scale = scale;
+  return 0;
+}
 
 // ---- the frozen teacher's CFG loop without a host round trip between steps (FD:288-324) ----------------------------
 static size_t tl_align(size_t x) { return (x + 255) & ~(size_t)255; }

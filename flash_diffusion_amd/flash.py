@@ -210,8 +210,8 @@ class FlashDiffusion(nn.Module):
                  teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
                  vae=None, conditioner=None, adapter=None, discriminator: nn.Module = None):
         super().__init__()
-        if vae is not None or adapter is not None:
-            raise NotImplementedError("VAE / T2I-adapter are outside the hot-path scope (SURVEY.md 2.1 rows 5-6)")
+        if vae is not None:
+            raise NotImplementedError("the VAE is outside the hot-path scope (SURVEY.md 2.1 row 6): pass latents")
         self.config = config
         self.input_key = config.input_key
         self.student_denoiser = student_denoiser
@@ -220,7 +220,12 @@ class FlashDiffusion(nn.Module):
         self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
         self.sampling_noise_scheduler = sampling_noise_scheduler
         self.vae = None
-        self.adapter = None
+        # T2I adapter (FD:91-94): any frozen module mapping batch[adapter_input_key] to one residual per UNet down block
+        # (the diffusers T2IAdapter network itself is outside the hot path); its features are threaded to every denoiser
+        # call exactly as the reference does (FD:207-218, 264, 301, 310, 436-450, 555-567, 820-899)
+        self.adapter = adapter
+        self.adapter_conditioning_scale = config.adapter_conditioning_scale
+        self.adapter_input_key = config.adapter_input_key
         self.conditioner = conditioner
         if isinstance(discriminator, nn.Sequential) and not hasattr(discriminator, "convert"):
             from .discriminator import MiDiscriminator
@@ -300,23 +305,35 @@ class FlashDiffusion(nn.Module):
             return None
         return {"cond": {k: torch.cat([cond["cond"][k], uncond["cond"][k]], dim=0) for k in cond["cond"]}}
 
+    def _adapter_residuals(self, inputs, scale):
+        """FD:207-218 / 820-829: list of residual tensors (scaled), or None without an adapter"""
+        if not self.adapter:
+            return None
+        with torch.no_grad():
+            return [v * scale for v in self.adapter(inputs[self.adapter_input_key])]
+
+    @staticmethod
+    def _dup(res):
+        """[v | v] per residual: the 2B-batched calls see the same control features in both halves (FD:555-557)"""
+        return None if res is None else [torch.cat([v, v], dim=0) for v in res]
+
     # ---- few-step sampler (FD:754-915) and its logging wrapper (FD:917-1019): SURVEY 8(f) "next" row 1 ----
-    def _cfg_pair(self, net, x, tt, cond, uncond, g, ctx_cache=None):
+    def _cfg_pair(self, net, x, tt, cond, uncond, g, ctx_cache=None, res=None):
         """g * eps(cond) + (1 - g) * eps(uncond).  The reference makes two calls per step (FD:838-858); every layer is
         per-sample, so ONE call on [x | x] with [cond | uncond] gives the same two predictions.  g == 1 multiplies the
         unconditional branch by zero: it is skipped."""
         if float(g) == 1.0:
-            return net(sample=x, timestep=tt, conditioning=cond, down_intrablock_additional_residuals=None)
+            return net(sample=x, timestep=tt, conditioning=cond, down_intrablock_additional_residuals=res)
         both = self._cat_cond(cond, uncond)
         if both is None:  # conditionings with different keys cannot share a batch: two calls, as the reference does
-            e_c = net(sample=x, timestep=tt, conditioning=cond, down_intrablock_additional_residuals=None)
-            e_u = net(sample=x, timestep=tt, conditioning=uncond, down_intrablock_additional_residuals=None)
+            e_c = net(sample=x, timestep=tt, conditioning=cond, down_intrablock_additional_residuals=res)
+            e_u = net(sample=x, timestep=tt, conditioning=uncond, down_intrablock_additional_residuals=res)
             return ops.axpby(e_c.contiguous(), float(g), e_u.contiguous(), 1.0 - float(g))
         kw = {}
         if ctx_cache is not None and getattr(net, "supports_ctx_cache", False) and not getattr(net, "lora_rank", 0):
             kw["ctx_cache"] = ctx_cache
         e = net(sample=torch.cat([x, x], dim=0), timestep=torch.cat([tt, tt], dim=0),
-                conditioning=both, down_intrablock_additional_residuals=None, **kw)
+                conditioning=both, down_intrablock_additional_residuals=self._dup(res), **kw)
         e_c, e_u = e.chunk(2, dim=0)
         return ops.axpby(e_c.contiguous(), float(g), e_u.contiguous(), 1.0 - float(g))
 
@@ -345,12 +362,13 @@ class FlashDiffusion(nn.Module):
             if cond:
                 cond["cond"] = {k: v[:max_samples] for k, v in cond["cond"].items()}
                 uncond["cond"] = {k: v[:max_samples] for k, v in uncond["cond"].items()}
+        res = self._adapter_residuals(conditioner_inputs, adapter_conditioning_scale)        # FD:820-829
         sample_init = sample
         sample = (sample * ss.init_noise_sigma).float().contiguous()
         for t in ss.timesteps:
             x = ss.scale_model_input(sample, t)
             tt = torch.full((x.shape[0],), float(t), device=z.device)
-            e = self._cfg_pair(self.student_denoiser, x, tt, cond, uncond, guidance_scale)
+            e = self._cfg_pair(self.student_denoiser, x, tt, cond, uncond, guidance_scale, res=res)
             sample = ss.step(e, t, sample, return_dict=False)[0]
         decoded_ref = None
         if log_teacher_samples:
@@ -362,7 +380,7 @@ class FlashDiffusion(nn.Module):
                 x = ts.scale_model_input(ref, t)
                 tt = torch.full((x.shape[0],), float(t), device=z.device)
                 e = self._cfg_pair(self.teacher_denoiser, x, tt, cond, uncond, teacher_guidance_scale,
-                                   ctx_cache="fill" if it == 0 else "reuse")
+                                   ctx_cache="fill" if it == 0 else "reuse", res=res)
                 ref = ts.step(e, t, ref, return_dict=False)[0]
                 decoded_ref = ref
         return sample, decoded_ref
@@ -406,22 +424,23 @@ class FlashDiffusion(nn.Module):
                      f"_{teacher_guidance_scale}_cfg/teacher"] = samples_ref
         return logs
 
-    def _teacher_cfg(self, x, tt, cond, uncond, cfg_cond, *args, ctx_cache=None, **kwargs):
+    def _teacher_cfg(self, x, tt, cond, uncond, cfg_cond, *args, ctx_cache=None, res=None, **kwargs):
         """The reference evaluates the frozen teacher twice per step, once per conditioning (FD:297-313).
         Every layer of the UNet is per-sample (GroupNorm included), so ONE call on the 2B batch
         [x | x] with [cond | uncond] gives the same two predictions with half the launches and twice
         the rows per GEMM."""
         if cfg_cond is None or not getattr(self, "batch_cfg", True):
             e_c = self.teacher_denoiser(sample=x, timestep=tt, conditioning=cond,
-                                        down_intrablock_additional_residuals=None, *args, **kwargs)
+                                        down_intrablock_additional_residuals=res, *args, **kwargs)
             e_u = self.teacher_denoiser(sample=x, timestep=tt, conditioning=uncond,
-                                        down_intrablock_additional_residuals=None, *args, **kwargs)
+                                        down_intrablock_additional_residuals=res, *args, **kwargs)
             return e_c, e_u
         if (ctx_cache is not None and getattr(self.teacher_denoiser, "supports_ctx_cache", False)
                 and not os.environ.get("FDMI_NO_CTX_CACHE")):
             kwargs = dict(kwargs, ctx_cache=ctx_cache)  # same [cond | uncond] context at every step of this loop
         e = self.teacher_denoiser(sample=torch.cat([x, x], dim=0), timestep=torch.cat([tt, tt], dim=0),
-                                  conditioning=cfg_cond, down_intrablock_additional_residuals=None, *args, **kwargs)
+                                  conditioning=cfg_cond, down_intrablock_additional_residuals=self._dup(res), *args,
+                                  **kwargs)
         e_c, e_u = e.chunk(2, dim=0)
         return e_c.contiguous(), e_u.contiguous()
 
@@ -448,6 +467,7 @@ class FlashDiffusion(nn.Module):
             uncond = self._get_conditioning(ub, set_ucg_rate_zero=True, *args, **kwargs)
         else:
             uncond = self._get_conditioning(batch, ucg_keys=self.ucg_keys, *args, **kwargs)
+        res = self._adapter_residuals(batch, self.adapter_conditioning_scale)          # FD:207-218
         if self.iter_steps > self.K_steps[-1]:
             K_step = len(self.K) - 1
         else:
@@ -482,7 +502,7 @@ class FlashDiffusion(nn.Module):
             one_call = (os.environ.get("FDMI_TEACHER_LOOP") == "1" and cfg_cond is not None
                         and getattr(self, "batch_cfg", True) and hasattr(sch, "loop_coefficients")
                         and hasattr(self.teacher_denoiser, "teacher_loop") and not args and set(kwargs) <= {"device"}
-                        and set(cfg_cond["cond"]) <= {"crossattn", "vector"})
+                        and set(cfg_cond["cond"]) <= {"crossattn", "vector"} and res is None)
             if one_call:   # the whole loop inside the library (fdmi_teacher_loop): opt-in until confirmed on the GPU
                 x = self.teacher_denoiser.teacher_loop(x, [float(t) for t in sch.timesteps[si:]],
                                                        cfg_cond["cond"]["crossattn"], cfg_cond["cond"].get("vector"),
@@ -490,7 +510,7 @@ class FlashDiffusion(nn.Module):
             for it, t in enumerate(sch.timesteps[si:] if not one_call else []):
                 x_ = sch.scale_model_input(x, t)
                 e_c, e_u = self._teacher_cfg(x_, torch.full((B,), float(t), device=z.device), conditioning, uncond,
-                                             cfg_cond, *args, ctx_cache="fill" if it == 0 else "reuse", **kwargs)
+                                             cfg_cond, *args, ctx_cache="fill" if it == 0 else "reuse", res=res, **kwargs)
                 if fused:
                     x = sch.fused_cfg_step(e_c, e_u, g, t, x)
                 else:
@@ -503,7 +523,7 @@ class FlashDiffusion(nn.Module):
         if hook is not None:
             hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
         eps_s = self.student_denoiser(sample=x_in, timestep=start_t, conditioning=student_conditioning,
-                                      down_intrablock_additional_residuals=None)
+                                      down_intrablock_additional_residuals=res)
         c_skip, c_out = self._scalings_for_boundary_conditions(start_t.float())
         inv_a, ms_a = self._x0_coeffs(start_t.long())
         # student_output = c_skip x + c_out (x - sigma eps)/alpha
@@ -515,11 +535,11 @@ class FlashDiffusion(nn.Module):
         loss = l_distill * self.distill_loss_scale[K_step]
         self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": g, "n_teacher_steps": K - si}
         if self.use_dmd_loss:
-            l_dmd = self._dmd_loss(d, student_output, student_conditioning, conditioning, uncond, K_step)
+            l_dmd = self._dmd_loss(d, student_output, student_conditioning, conditioning, uncond, K_step, res)
             self.terms["dmd"] = l_dmd.detach()
             loss = loss + l_dmd * self.dmd_loss_scale[K_step]
         if self.discriminator is not None:
-            gan = self._gan_loss(d, z, student_output, teacher_output, conditioning, step)
+            gan = self._gan_loss(d, z, student_output, teacher_output, conditioning, step, res)
         else:
             gan = [0, 0]  # the reference cannot run without a discriminator (FD:347); we degrade gracefully
         self.terms["gan_G"] = gan[0].detach() if torch.is_tensor(gan[0]) else gan[0]
@@ -533,7 +553,7 @@ class FlashDiffusion(nn.Module):
         """FD:368-382"""
         return _DistillLoss.apply(s, t.detach(), self.distill_loss_type == "l1")
 
-    def _dmd_loss(self, d, s, student_cond, cond, uncond, K_step):
+    def _dmd_loss(self, d, s, student_cond, cond, uncond, K_step, res=None):
         """FD:401-499"""
         sch = self.teacher_noise_scheduler
         B = s.shape[0]
@@ -542,9 +562,9 @@ class FlashDiffusion(nn.Module):
         noisy = sch.add_noise(s, noise, t)
         with torch.no_grad():
             tf = t.float()
-            e_c, e_u = self._teacher_cfg(noisy.detach(), tf, cond, uncond, self._cat_cond(cond, uncond))
+            e_c, e_u = self._teacher_cfg(noisy.detach(), tf, cond, uncond, self._cat_cond(cond, uncond), res=res)
             e_f = self.student_denoiser(sample=noisy, timestep=tf, conditioning=student_cond,
-                                        down_intrablock_additional_residuals=None)
+                                        down_intrablock_additional_residuals=res)
             g = (float(d.rand1("dmd_guidance")) * (self.guidance_scale_max[K_step] - self.guidance_scale_min[K_step])
                  + self.guidance_scale_min[K_step])
             real = ops.axpby(e_c, g, e_u, 1.0 - g)
@@ -553,7 +573,7 @@ class FlashDiffusion(nn.Module):
             inv_a, ms_a = self._x0_coeffs(t)
         return _DmdLoss.apply(s, noisy.detach(), real, e_f, inv_a.float().contiguous(), ms_a.float().contiguous(), kb)
 
-    def _gan_loss(self, d, z, s, teacher_output, conditioning, step):
+    def _gan_loss(self, d, z, s, teacher_output, conditioning, step, res=None):
         """FD:501-667"""
         sch = self.teacher_noise_scheduler
         self.disc_update_counter += 1
@@ -572,7 +592,7 @@ class FlashDiffusion(nn.Module):
             conditioning = {"cond": {k: torch.cat([v, v], dim=0) for k, v in conditioning["cond"].items()}}
         t2 = torch.cat([ts, ts], dim=0).float()
         feat = self.disc_backbone(sample=x, timestep=t2, conditioning=conditioning,
-                                  down_intrablock_additional_residuals=None, return_intermediate=True)
+                                  down_intrablock_additional_residuals=self._dup(res), return_intermediate=True)
         f_fake, f_real = feat.chunk(2, dim=0)
         disc = self.discriminator
         kind = self.gan_loss_type

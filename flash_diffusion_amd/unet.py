@@ -406,10 +406,16 @@ class MiUNet2DConditionModel(nn.Module):
         concat = conditioning["cond"].get("concat", None)
         if concat is not None:
             sample = torch.cat([sample, concat], dim=1)
-        if down_intrablock_additional_residuals is not None:
-            raise NotImplementedError("T2I-adapter residuals are out of scope (SURVEY.md 2.1 row 5)")
         assert crossattn is not None, "crossattn conditioning is required by UNet2DConditionModel"
         B = sample.shape[0]
+        # T2I-adapter residuals (UW:100-106): constants of this call (the adapter is frozen), handed to the plan right
+        # before the forward (include/fdmi.h: fdmi_unet_set_down_residuals)
+        self._pending_res = None
+        if down_intrablock_additional_residuals is not None:
+            want = self._down_residual_shapes(B, sample.shape[2], sample.shape[3])
+            res = [r.detach().float().contiguous() for r in down_intrablock_additional_residuals]
+            assert [tuple(r.shape) for r in res] == want, f"adapter residual shapes {[tuple(r.shape) for r in res]} != {want}"
+            self._pending_res = res
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([float(timestep)], device=sample.device)
         t = timestep.to(device=sample.device, dtype=torch.float32).reshape(-1)
@@ -430,6 +436,17 @@ class MiUNet2DConditionModel(nn.Module):
         if need_grad:
             return _UNetFn.apply(self, sample, t, enc, vec, flags | FDMI_UNET_SAVE, *lora)
         out, _ = self._run_forward(sample, t, enc, vec, flags)
+        return out
+
+    def _down_residual_shapes(self, B, H, W):
+        """shape of each down block's output where diffusers adds the adapter residual: a cross-attention block before
+        its downsampler, an attention-free block after it"""
+        c = self.config_dict
+        nl = len(c["block_out_channels"])
+        out = []
+        for i, ch in enumerate(c["block_out_channels"]):
+            sh = i + (1 if (not c["down_block_types"][i].startswith("CrossAttn") and i != nl - 1) else 0)
+            out.append((B, ch, H >> sh, W >> sh))
         return out
 
     # ---- C-ABI calls ---------------------------------------------------------------------------------
@@ -460,6 +477,11 @@ class MiUNet2DConditionModel(nn.Module):
             out = torch.empty(B, cfg["block_out_channels"][-1], H // f, W // f, dtype=torch.float32, device=sample.device)
         else:
             out = torch.empty(B, cfg["out_channels"], H, W, dtype=torch.float32, device=sample.device)
+        res = getattr(self, "_pending_res", None)
+        self._pending_res = None
+        if res is not None:
+            arr = (C.c_void_p * len(res))(*[r.data_ptr() for r in res])
+            check(L.fdmi_unet_set_down_residuals(plan.handle, arr, len(res), 1.0))
         check(L.fdmi_unet_forward(plan.handle, slot, ptr(sample), ptr(t), ptr(enc), ptr(vec), ptr(out), B, H, W, Lc,
                                   ptr(ws), ws.numel(), flags, stream_ptr()))
         self.last_flops = L.fdmi_unet_last_flops(plan.handle)

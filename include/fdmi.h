@@ -199,6 +199,12 @@ int fdmi_unet_forward(fdmi_unet* u, int slot, const float* sample, const float* 
 /* grad_out: f32 NCHW gradient of the forward's output; grad_sample: f32 NCHW or NULL */
 int fdmi_unet_backward(fdmi_unet* u, int slot, const float* grad_out, float* grad_sample, void* stream);
 double fdmi_unet_last_flops(fdmi_unet* u);  /* algorithmic MFMA flops of the last forward/backward */
+/* T2I-adapter residuals (`down_intrablock_additional_residuals`, unet.py:100-106 / flash_diffusion_model.py:208-218) for the
+ * NEXT fdmi_unet_forward on this plan, consumed by it: residuals[i] is an f32 NCHW tensor with the shape of down block i's
+ * output (NULL entries are skipped), added times `scale` where diffusers adds it: after the last (resnet, attention) pair of
+ * a cross-attention block (before its skip connection and downsampler), to the output of an attention-free block.  The
+ * adapter is frozen in the reference's recipes, so no gradient flows to the residuals.  n = 0 clears.              */
+int fdmi_unet_set_down_residuals(fdmi_unet* u, const float* const* residuals, int n, float scale);
 
 /* The frozen teacher's classifier-free-guidance loop (flash_diffusion_model.py:288-324) as ONE call: for each of the n
  * steps  eps = unet([x | x], t_i, [ctx_cond | ctx_uncond])  (one forward on the 2B batch; the cross-attention K/V of the

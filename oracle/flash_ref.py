@@ -206,7 +206,10 @@ class FlashDiffusionRef(torch.nn.Module):
                  teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None, vae=None,
                  conditioner=None, adapter=None, discriminator=None):
         super().__init__()
-        assert vae is None and adapter is None, "VAE / T2I adapter are out of scope (SURVEY.md 2.1 rows 5,6)"
+        assert vae is None, "VAE is out of scope (SURVEY.md 2.1 row 6)"
+        self.adapter = adapter                                               # FD:91-94 (T2I adapter: image -> residual list)
+        self.adapter_conditioning_scale = config.adapter_conditioning_scale
+        self.adapter_input_key = config.adapter_input_key
         self.config = config
         self.input_key = config.input_key
         self.student_denoiser = student_denoiser
@@ -249,6 +252,12 @@ class FlashDiffusionRef(torch.nn.Module):
             uncond = self._cond(ub, set_ucg_rate_zero=True, *args, **kwargs)
         else:
             uncond = self._cond(batch, ucg_keys=cfg.ucg_keys, *args, **kwargs)      # FD:203
+        if self.adapter:                                                      # FD:207-218
+            res = self.adapter(batch[self.adapter_input_key])
+            for k, v in enumerate(res):
+                res[k] = v * self.adapter_conditioning_scale
+        else:
+            res = None
         if self.iter_steps > self.K_steps[-1]:                                # FD:221-227
             K_step = len(cfg.K) - 1
         else:
@@ -268,7 +277,7 @@ class FlashDiffusionRef(torch.nn.Module):
             x_init = sch.add_noise(z, noise, start_t)                         # FD:250
         x_in = sch.scale_model_input(x_init, start_t)
         eps_s = self.student_denoiser(sample=x_in, timestep=start_t, conditioning=student_conditioning,
-                                      down_intrablock_additional_residuals=None)   # FD:260
+                                      down_intrablock_additional_residuals=res)    # FD:260
         c_skip, c_out = boundary_scalings(start_t)                            # FD:267
         shp = (z.shape[0],) + (1,) * (z.ndim - 1)
         c_skip, c_out = c_skip.reshape(shp), c_out.reshape(shp)
@@ -281,9 +290,9 @@ class FlashDiffusionRef(torch.nn.Module):
                 tt = torch.tensor([t], device=z.device).repeat(z.shape[0])
                 x_ = sch.scale_model_input(x, t)
                 e_c = self.teacher_denoiser(sample=x_, timestep=tt, conditioning=conditioning,
-                                            down_intrablock_additional_residuals=None, *args, **kwargs)
+                                            down_intrablock_additional_residuals=res, *args, **kwargs)
                 e_u = self.teacher_denoiser(sample=x_, timestep=tt, conditioning=uncond,
-                                            down_intrablock_additional_residuals=None, *args, **kwargs)
+                                            down_intrablock_additional_residuals=res, *args, **kwargs)
                 e = g * e_c + (1 - g) * e_u
                 x = sch.step(e, t, x, return_dict=False)[0]
         teacher_output = x
@@ -292,11 +301,11 @@ class FlashDiffusionRef(torch.nn.Module):
         loss = l_distill * cfg.distill_loss_scale[K_step]
         self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": float(g)}
         if cfg.use_dmd_loss:                                                  # FD:335-345
-            l_dmd = self.dmd_loss(d, student_output, student_conditioning, conditioning, uncond, K_step)
+            l_dmd = self.dmd_loss(d, student_output, student_conditioning, conditioning, uncond, K_step, res)
             self.terms["dmd"] = l_dmd.detach()
             loss = loss + l_dmd * cfg.dmd_loss_scale[K_step]
         if self.discriminator is not None:
-            gan = self.gan_loss(d, z, student_output, teacher_output, conditioning, step)   # FD:347
+            gan = self.gan_loss(d, z, student_output, teacher_output, conditioning, step, res)   # FD:347
         else:
             gan = [0, 0]   # the reference crashes here without a discriminator; used by bench.py's cpu_baseline
         self.terms["gan_G"] = gan[0].detach() if torch.is_tensor(gan[0]) else gan[0]
@@ -306,7 +315,7 @@ class FlashDiffusionRef(torch.nn.Module):
                 "student_output": student_output, "noisy_sample": x_init,
                 "start_timestep": start_t[0].item()}
 
-    def dmd_loss(self, d, s, student_cond, cond, uncond, K_step):
+    def dmd_loss(self, d, s, student_cond, cond, uncond, K_step, res=None):
         """FD:401-499."""
         cfg, sch = self.config, self.teacher_noise_scheduler
         noise = d.randn_like("dmd_noise", s)
@@ -314,11 +323,11 @@ class FlashDiffusionRef(torch.nn.Module):
         noisy = sch.add_noise(s, noise, t)
         with torch.no_grad():
             e_c = self.teacher_denoiser(sample=noisy, timestep=t, conditioning=cond,
-                                        down_intrablock_additional_residuals=None)
+                                        down_intrablock_additional_residuals=res)
             e_u = self.teacher_denoiser(sample=noisy, timestep=t, conditioning=uncond,
-                                        down_intrablock_additional_residuals=None)
+                                        down_intrablock_additional_residuals=res)
             e_f = self.student_denoiser(sample=noisy, timestep=t, conditioning=student_cond,
-                                        down_intrablock_additional_residuals=None)
+                                        down_intrablock_additional_residuals=res)
             g = (d.rand1("dmd_guidance").to(s.device)
                  * (cfg.guidance_scale_max[K_step] - cfg.guidance_scale_min[K_step])
                  + cfg.guidance_scale_min[K_step])
@@ -331,7 +340,7 @@ class FlashDiffusionRef(torch.nn.Module):
         w = 1.0 / ((s - x0).abs().mean([1, 2, 3], keepdim=True) + 1e-5).detach()
         return F.mse_loss(s, (s - w * coeff).detach(), reduction="mean")
 
-    def gan_loss(self, d, z, s, teacher_output, conditioning, step):
+    def gan_loss(self, d, z, s, teacher_output, conditioning, step, res=None):
         """FD:501-667."""
         cfg, sch = self.config, self.teacher_noise_scheduler
         self.disc_update_counter += 1
@@ -346,8 +355,13 @@ class FlashDiffusionRef(torch.nn.Module):
         if conditioning is not None:
             conditioning = {"cond": {k: torch.cat([v, v], dim=0) for k, v in conditioning["cond"].items()}}
         t2 = torch.cat([ts, ts], dim=0)
+        if self.adapter:                                                      # FD:555-560 (mutates the caller's list)
+            for k, v in enumerate(res):
+                res[k] = torch.cat([v, v], dim=0)
+        else:
+            res = None
         feat = self.teacher_denoiser(sample=x, timestep=t2, conditioning=conditioning,
-                                     down_intrablock_additional_residuals=None, return_intermediate=True)
+                                     down_intrablock_additional_residuals=res, return_intermediate=True)
         f_fake, f_real = feat.chunk(2, dim=0)
         return gan_losses(cfg.gan_loss_type, self.discriminator, f_fake, f_real, step, s.size(0),
                           noise.device)
@@ -374,15 +388,21 @@ class FlashDiffusionRef(torch.nn.Module):
             if cond:
                 cond["cond"] = {k: v[:max_samples] for k, v in cond["cond"].items()}
                 uncond["cond"] = {k: v[:max_samples] for k, v in uncond["cond"].items()}
+        if self.adapter:                                                                       # FD:820-829
+            res = self.adapter(conditioner_inputs[self.adapter_input_key])
+            for k, v in enumerate(res):
+                res[k] = v * adapter_conditioning_scale
+        else:
+            res = None
         sample_init = sample
         sample = sample * ss.init_noise_sigma                                                  # FD:833
         for t in ss.timesteps:                                                                 # FD:834-867
             x = ss.scale_model_input(sample, t)
             tt = t.to(z.device).repeat(x.shape[0])
             e_c = self.student_denoiser(sample=x, timestep=tt, conditioning=cond,
-                                        down_intrablock_additional_residuals=None)
+                                        down_intrablock_additional_residuals=res)
             e_u = self.student_denoiser(sample=x, timestep=tt, conditioning=uncond,
-                                        down_intrablock_additional_residuals=None)
+                                        down_intrablock_additional_residuals=res)
             e = guidance_scale * e_c + (1 - guidance_scale) * e_u
             sample = ss.step(e, t, sample, return_dict=False)[0]
         decoded = sample                                                                       # vae is None (FD:869-872)
@@ -395,9 +415,9 @@ class FlashDiffusionRef(torch.nn.Module):
                 x = ts.scale_model_input(ref, t)
                 tt = t.to(z.device).repeat(x.shape[0])
                 e_c = self.teacher_denoiser(sample=x, timestep=tt, conditioning=cond,
-                                            down_intrablock_additional_residuals=None)
+                                            down_intrablock_additional_residuals=res)
                 e_u = self.teacher_denoiser(sample=x, timestep=tt, conditioning=uncond,
-                                            down_intrablock_additional_residuals=None)
+                                            down_intrablock_additional_residuals=res)
                 e = teacher_guidance_scale * e_c + (1 - teacher_guidance_scale) * e_u
                 ref = ts.step(e, t, ref, return_dict=False)[0]
                 decoded_ref = ref

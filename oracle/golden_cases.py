@@ -33,6 +33,19 @@ CASES = {
 }
 
 
+# T2I-adapter residuals threaded through every denoiser call (FD:207-218, 264-310, 436-450, 555-567): (config, sched, step, seed)
+ADAPTER_CASES = {
+    "g_adapter_dmd_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="l2",
+                                 gan_loss_type="lsgan", use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=13.0,
+                                 dmd_loss_scale=0.3, adversarial_loss_scale=0.1, adapter_input_key="edge",
+                                 adapter_conditioning_scale=0.7), "dpm", 0, 15),
+}
+
+
+def make_edge(B=2, hw=32, seed=8):
+    return torch.randn(B, 1, hw, hw, generator=torch.Generator().manual_seed(seed))
+
+
 def build_models(unet_cfg=None, lora_rank=LORA_RANK, disc_kw=None):
     unet_cfg = unet_cfg or tiny_config()
     teacher = seeded_init_(UNet2DConditionRef(unet_cfg), 1)

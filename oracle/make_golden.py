@@ -28,17 +28,26 @@ def _record_draws(seed, model_fn):
     return model_fn()
 
 
-def main():
+def main(cases=None):
     from .flash_ref import FlashConfigRef, FlashDiffusionRef
+    from .golden_cases import ADAPTER_CASES, make_edge
+    from .unet_cpu import TinyT2IAdapter, tiny_config
     FD, FDC = shim_import.import_reference()
     os.makedirs(OUT, exist_ok=True)
-    for name, (kw, sched, step, seed) in CASES.items():
+    for name, (kw, sched, step, seed) in (cases if cases is not None else CASES).items():
+        with_adapter = name in ADAPTER_CASES
+
+        def make_batch_():
+            b = make_batch()
+            if with_adapter:
+                b["edge"] = make_edge()
+            return b
         # 1) the real reference
         teacher, student, disc = build_models()
         ref = FD(FDC(**kw), student_denoiser=student, teacher_denoiser=teacher,
                  teacher_noise_scheduler=SCHEDS[sched](), conditioner=TensorConditioner(),
-                 discriminator=disc)
-        batch = make_batch()
+                 discriminator=disc, adapter=TinyT2IAdapter(tiny_config()) if with_adapter else None)
+        batch = make_batch_()
         torch.manual_seed(seed)
         out = ref(batch, step=step, device="cpu")
         loss = out["loss"][step]
@@ -48,9 +57,9 @@ def main():
         teacher, student, disc = build_models()
         ora = FlashDiffusionRef(FlashConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
                                 teacher_noise_scheduler=SCHEDS[sched](), conditioner=TensorConditioner(),
-                                discriminator=disc)
+                                discriminator=disc, adapter=TinyT2IAdapter(tiny_config()) if with_adapter else None)
         torch.manual_seed(seed)
-        out2 = ora(make_batch(), step=step, device="cpu")
+        out2 = ora(make_batch_(), step=step, device="cpu")
         for k in ("teacher_output", "student_output", "noisy_sample"):
             assert torch.equal(out[k], out2[k]), (name, k)
         blob = {"z": batch["image"].numpy(), "crossattn": batch["crossattn"].numpy(),
@@ -191,8 +200,13 @@ if __name__ == "__main__":
         make_sd3_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "dit":
         make_dit_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "adapter":
+        from .golden_cases import ADAPTER_CASES
+        main(ADAPTER_CASES)
     else:
         main()
+        from .golden_cases import ADAPTER_CASES
+        main(ADAPTER_CASES)
         make_sample_golden()
         make_sd3_golden()
         make_dit_golden()

@@ -251,12 +251,16 @@ class DownBlock(nn.Module):
             self.downsamplers = nn.ModuleList([Downsample2D(cout)])
         self.add_down = add_down
 
-    def forward(self, h, temb, ctx):
+    def forward(self, h, temb, ctx, additional_residuals=None):
+        """`additional_residuals` (T2I adapter): CrossAttnDownBlock2D adds it after its last (resnet, attention) pair, before
+        the state is recorded as a skip and before the downsampler (upstream diffusers)"""
         outs = []
         for i, r in enumerate(self.resnets):
             h = r(h, temb)
             if self.has_attn:
                 h = self.attentions[i](h, ctx)
+                if i == len(self.resnets) - 1 and additional_residuals is not None:
+                    h = h + additional_residuals
             outs.append(h)
         if self.add_down:
             h = self.downsamplers[0](h)
@@ -353,10 +357,12 @@ class UNet2DConditionRef(nn.Module):
         concat = conditioning["cond"].get("concat", None)
         if concat is not None:
             sample = torch.cat([sample, concat], dim=1)
-        assert down_intrablock_additional_residuals is None, "T2I adapter residuals: out of scope"
-        return self.unet_forward(sample, timestep, ctx, class_labels, return_intermediate)
+        res = None
+        if down_intrablock_additional_residuals is not None:       # UW:100-106: cloned, "since unet will modify it"
+            res = [r.clone() for r in down_intrablock_additional_residuals]
+        return self.unet_forward(sample, timestep, ctx, class_labels, return_intermediate, res)
 
-    def unet_forward(self, sample, timestep, ctx, class_labels=None, return_intermediate=False):
+    def unet_forward(self, sample, timestep, ctx, class_labels=None, return_intermediate=False, down_residuals=None):
         cfg = self.cfg
         if not torch.is_tensor(timestep):
             timestep = torch.tensor([timestep], dtype=torch.float32 if isinstance(timestep, float)
@@ -371,8 +377,18 @@ class UNet2DConditionRef(nn.Module):
             emb = emb + self.class_embedding(class_labels.to(sample.dtype))
         h = self.conv_in(sample)
         skips = [h]
+        # T2I-adapter residuals (upstream UNet2DConditionModel.forward, is_adapter branch): one per down block, popped in
+        # order; a block without attention gets it added IN PLACE to its output -- the same tensor object as the block's
+        # last skip, which therefore carries it too
+        down_residuals = list(down_residuals) if down_residuals is not None else []
         for blk in self.down_blocks:
-            h, outs = blk(h, emb, ctx)
+            if blk.has_attn:
+                extra = down_residuals.pop(0) if down_residuals else None
+                h, outs = blk(h, emb, ctx, extra)
+            else:
+                h, outs = blk(h, emb, ctx)
+                if down_residuals:
+                    h += down_residuals.pop(0)
             skips.extend(outs)
         h = self.mid_block(h, emb, ctx)
         if return_intermediate:
@@ -444,3 +460,27 @@ def make_discriminator(kind="sd15", color_dim=1280, feat=64, last_k=4):
             nn.Conv2d(color_dim, feat, 4, 2, 1, bias=False), nn.SiLU(True),
             nn.Conv2d(feat, 1, 4, 1, 0, bias=False), nn.Flatten())
     raise ValueError(kind)
+
+
+class TinyT2IAdapter(nn.Module):
+    """Test stand-in for DiffusersT2IAdapterWrapper (adapters/t2i_adapter.py:7-27; diffusers' T2IAdapter is absent): a
+    frozen conv pyramid mapping a control image [B, c, H, W] (H, W = latent size) to one residual per UNet down block, each
+    with the shape of that block's output at the point diffusers adds it -- level i at H >> i (every earlier block halves
+    the resolution; the last block has no downsampler)."""
+
+    def __init__(self, unet_cfg, in_channels=1, seed=7):
+        super().__init__()
+        n = len(unet_cfg.block_out_channels)
+        self.convs = nn.ModuleList([nn.Conv2d(in_channels, c, 3, 1, 1) for c in unet_cfg.block_out_channels])
+        self.n = n
+        g = torch.Generator().manual_seed(seed)
+        for p in self.parameters():
+            p.data.copy_(torch.randn(p.shape, generator=g) * 0.2)
+            p.requires_grad = False
+
+    def forward(self, cond):
+        out = []
+        for i, c in enumerate(self.convs):
+            x = F.avg_pool2d(cond, 1 << i) if i else cond
+            out.append(c(x))
+        return out

@@ -149,3 +149,24 @@ def test_mmdit_oracle_reproduces_reference_fixture(name):
             assert rel_err(p.grad, g["grads"][k.replace(".base_layer.", ".")]) < 1e-4, k
             n += 1
     assert n == len(g["grads"])
+
+
+def test_oracle_reproduces_adapter_golden():
+    """T2I-adapter residuals on every denoiser call (FD:207-218, 264-310, 436-450, 555-567): fixture by the real reference"""
+    from oracle.golden_cases import ADAPTER_CASES, make_edge
+    from oracle.unet_cpu import TinyT2IAdapter, tiny_config
+    (name, (kw, sched, step, _)), = ADAPTER_CASES.items()
+    g = load_case(name)
+    teacher, student, disc = build_models()
+    m = FlashDiffusionRef(FlashConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=SCHEDS[sched](), conditioner=TensorConditioner(), discriminator=disc,
+                          adapter=TinyT2IAdapter(tiny_config()))
+    m.draws = Draws(g["draws"])
+    batch = {"image": g["z"], "crossattn": g["crossattn"], "text": ["a"] * g["z"].shape[0], "edge": make_edge()}
+    out = m(batch, step=step)
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert rel_err(out[k], g["out"][k]) < 1e-5, k
+    assert abs(float(out["loss"][0]) - g["loss"][0]) <= 1e-5 * max(1.0, abs(g["loss"][0]))
+    out["loss"][step].backward()
+    n = sum(1 for pn, p in m.named_parameters() if p.grad is not None and rel_err(p.grad, g["grads"][pn]) < 1e-4)
+    assert n == len(g["grads"])

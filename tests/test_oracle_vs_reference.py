@@ -289,3 +289,54 @@ def test_sd3_log_samples_restatement_is_bit_identical():
     assert list(a) == list(b) and len(a) == 4
     for k in a:
         assert a[k].shape[0] == 2 and torch.equal(a[k], b[k]), k
+
+
+# ---- T2I-adapter residuals (FD:207-218, 555-560, 820-829) ------------------------------------------------
+@pytest.mark.parametrize("step", [0, 1])
+def test_adapter_residuals_restatement_is_bit_identical(step):
+    from oracle.unet_cpu import TinyT2IAdapter
+    FD, FDC = shim_import.import_reference()
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="l2", gan_loss_type="lsgan",
+              use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=13.0, adapter_input_key="edge",
+              adapter_conditioning_scale=0.7)
+    outs = []
+    for cls, ccls in ((FD, FDC), (FlashDiffusionRef, FlashConfigRef)):
+        m = _build(cls, ccls, DPMSolverMultistepSchedulerRef, **kw)
+        m.adapter = TinyT2IAdapter(tiny_config())
+        batch = _batch()
+        batch["edge"] = torch.randn(2, 1, 32, 32, generator=torch.Generator().manual_seed(8))
+        torch.manual_seed(77)
+        out = m(batch, step=step, device="cpu")
+        out["loss"][step].backward()
+        outs.append((out, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (o1, g1), (o2, g2) = outs
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert torch.equal(o1[k], o2[k]), k
+    assert float(o1["loss"][0]) == float(o2["loss"][0]) and float(o1["loss"][1]) == float(o2["loss"][1])
+    assert set(g1) == set(g2) and len(g1) > 0 and all(torch.equal(g1[n], g2[n]) for n in g1)
+    # the residuals really change the result
+    m = _build(FlashDiffusionRef, FlashConfigRef, DPMSolverMultistepSchedulerRef, **kw)
+    torch.manual_seed(77)
+    plain = m(_batch(), step=step, device="cpu")
+    assert not torch.equal(plain["teacher_output"], o2["teacher_output"])
+
+
+def test_adapter_residuals_in_the_sampler_are_bit_identical():
+    from oracle.sched_cpu import LCMSchedulerRef
+    from oracle.unet_cpu import TinyT2IAdapter
+    FD, FDC = shim_import.import_reference()
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", adapter_input_key="edge")
+    outs = []
+    for cls, ccls in ((FD, FDC), (FlashDiffusionRef, FlashConfigRef)):
+        m = _build(cls, ccls, DPMSolverMultistepSchedulerRef, **kw)
+        m.adapter = TinyT2IAdapter(tiny_config())
+        m.sampling_noise_scheduler = LCMSchedulerRef()
+        m.teacher_sampling_noise_scheduler = DPMSolverMultistepSchedulerRef()
+        ci = {k: v for k, v in _batch().items() if k != "image"}
+        ci["edge"] = torch.randn(2, 1, 32, 32, generator=torch.Generator().manual_seed(8))
+        z = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(9))
+        torch.manual_seed(3)
+        outs.append(m.sample(z, num_steps=3, guidance_scale=1.5, conditioner_inputs=ci, log_teacher_samples=True,
+                             adapter_conditioning_scale=0.5))
+    (a, ar), (b, br) = outs
+    assert torch.equal(a, b) and torch.equal(ar, br)

@@ -214,6 +214,67 @@ def test_teacher_loop_single_call_matches_the_stepwise_loop():
     assert rel_err(got, x) > 10 * noise and rel_err(x, x.clone()) == 0   # the input is left untouched, the output moved
 
 
+# ---- T2I-adapter residuals: fdmi_unet_set_down_residuals + the threading in FlashDiffusion -----------------
+def test_unet_adapter_residuals_match_the_oracle():
+    from oracle.unet_cpu import TinyT2IAdapter, UNet2DConditionRef, seeded_init_, tiny_config
+    from tests.unet_util import mi_from_oracle
+    ora = seeded_init_(UNet2DConditionRef(tiny_config()), 1)
+    ora.freeze()
+    net = mi_from_oracle(ora)
+    g = torch.Generator().manual_seed(0)
+    x, t = torch.randn(2, 4, 32, 32, generator=g), torch.tensor([700.0, 40.0])
+    ctx = torch.randn(2, 7, tiny_config().cross_attention_dim, generator=g)
+    res = TinyT2IAdapter(tiny_config())(torch.randn(2, 1, 32, 32, generator=g))
+    cond = {"cond": {"crossattn": ctx}}
+    with torch.no_grad():
+        want, plain = ora(x, t, cond, down_intrablock_additional_residuals=res), ora(x, t, cond)
+        got = net(x.cuda(), t.cuda(), {"cond": {"crossattn": ctx.cuda()}},
+                  down_intrablock_additional_residuals=[r.cuda() for r in res])
+        got_plain = net(x.cuda(), t.cuda(), {"cond": {"crossattn": ctx.cuda()}})       # the residuals were consumed
+        feat = net(x.cuda(), t.cuda(), {"cond": {"crossattn": ctx.cuda()}}, return_intermediate=True,
+                   down_intrablock_additional_residuals=[r.cuda() for r in res])
+        want_feat = ora(x, t, cond, down_intrablock_additional_residuals=res, return_intermediate=True)
+    assert rel_err(want, plain) > 5e-2                                              # they matter
+    assert rel_err(got, want) < 3e-2 and rel_err(got_plain, plain) < 3e-2 and rel_err(feat, want_feat) < 3e-2
+    with pytest.raises(AssertionError):
+        net(x.cuda(), t.cuda(), {"cond": {"crossattn": ctx.cuda()}}, down_intrablock_additional_residuals=[res[0].cuda()])
+
+
+def test_step_with_adapter_matches_reference_golden():
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import ADAPTER_CASES, LORA_RANK, build_models, make_edge
+    from oracle.unet_cpu import TinyT2IAdapter, tiny_config
+    from tests.unet_util import mi_from_oracle
+    import copy
+    (name, (kw, sched, step, _)), = ADAPTER_CASES.items()
+    g = load_case(name)
+    teacher_o, student_o, disc_o = build_models()
+    teacher = mi_from_oracle(teacher_o)
+    teacher.freeze()
+    student = mi_from_oracle(student_o, lora_rank=LORA_RANK)
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                       discriminator=copy.deepcopy(disc_o).cuda(), adapter=TinyT2IAdapter(tiny_config()).cuda()).cuda()
+    m.draws = Draws(g["draws"])
+    B = g["z"].shape[0]
+    out = m({"image": g["z"].cuda(), "crossattn": g["crossattn"].cuda(), "text": ["a"] * B, "edge": make_edge().cuda()},
+            step=step, device="cuda")
+    assert out["start_timestep"] == g["start_timestep"]
+    for k in ("teacher_output", "student_output"):
+        assert rel_err(out[k], g["out"][k]) < 4e-2, (k, rel_err(out[k], g["out"][k]))
+    assert abs(float(out["loss"][0]) - g["loss"][0]) < 6e-2 * abs(g["loss"][0])
+    out["loss"][step].backward()
+    torch.cuda.synchronize()
+    fa, fb = [], []
+    for pn, p in m.named_parameters():
+        if ".lora_" in pn and p.grad is not None:
+            ref = [v for k, v in g["grads"].items() if k.replace(".base_layer.", ".") == pn][0]
+            fa.append(p.grad.detach().float().cpu().flatten())
+            fb.append(ref.float().flatten())
+    assert len(fa) > 0 and _cos(torch.cat(fa), torch.cat(fb)) > 0.99
+
+
 def test_rccl_allreduce_entry_points_world_1():
     """fdmi_comm_unique_id / fdmi_allreduce_init / fdmi_allreduce / fdmi_allreduce_destroy on a single-rank communicator:
     the in-place sum over one rank is the identity (f32 and bf16); the multi-rank path is the driver's 8-GPU run"""
