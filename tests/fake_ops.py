@@ -195,3 +195,26 @@ def adamw_(p, g, m, v, lr, beta1=0.9, beta2=0.999, eps=1e-8, weight_decay=0.01, 
     v.mul_(beta2).addcmul_(gg, gg, value=1 - beta2)
     p.mul_(1 - lr * weight_decay)
     p.addcdiv_(m / (1 - beta1 ** step), (v / (1 - beta2 ** step)).sqrt() + eps, value=-lr)
+
+
+# ---- stand-ins for the fused loss launches of flash.py (autograd Functions that call libfdmi.so directly) ---------------------
+class FakeDistillLoss:
+    """flash._DistillLoss: mean over the batch of the per-sample mean (|s - t|^p), p = 2 (l2) / 1 (l1)  (FD:368-382)"""
+
+    @staticmethod
+    def apply(s, t, l1):
+        d = (s - t).abs() if l1 else (s - t) ** 2
+        return d.reshape(s.shape[0], -1).mean(1).mean()
+
+
+class FakeDmdLoss:
+    """flash._DmdLoss (FD:459-499): x0 = inv_a noisy + ms_a real; w = 1 / (mean|s - x0| + 1e-5) per sample;
+    loss = mse(s, (s - w (real - fake) kb).detach())"""
+
+    @staticmethod
+    def apply(s, noisy, real, fake, inv_a, ms_a, kb):
+        shp = (-1,) + (1,) * (s.dim() - 1)
+        x0 = inv_a.view(shp) * noisy + ms_a.view(shp) * real
+        w = 1.0 / ((s - x0).abs().mean(list(range(1, s.dim())), keepdim=True) + 1e-5)
+        coeff = (real - fake) * kb.view(shp)
+        return torch.nn.functional.mse_loss(s, (s - w * coeff).detach(), reduction="mean")

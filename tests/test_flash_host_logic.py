@@ -1,0 +1,174 @@
+"""Host logic of the step orchestration on CPU: the PRODUCT classes flash_diffusion_amd.flash.FlashDiffusion and
+flash_sd3.FlashDiffusionSD3 (with the product schedulers) are run with tests/fake_ops.py standing in for the HIP launches and
+with the oracle's fp32 denoisers in the denoiser slots (the classes are denoiser-agnostic: anything honouring the wrapper
+signature), every random draw injected, and compared with the fixtures the REAL reference produced (tests/golden/*.npz) --
+everything is fp32 here, so the bar is 1e-4 relative.  This pins the orchestration (draw order, timestep selection, CFG loop,
+scheduler coefficients, loss assembly, which call receives which conditioning / adapter residual, gradient flow to LoRA and
+discriminator) without a GPU; the kernels themselves and the HIP denoisers are covered by the -m gpu tests."""
+import copy
+
+import pytest
+import torch
+
+from oracle.golden_cases import ADAPTER_CASES, CASES, SD3_CASES, build_models, build_sd3_models, make_edge
+from tests import fake_ops
+from tests.golden_util import load_case, rel_err
+
+
+class _Head(torch.nn.Module):   # not an nn.Sequential: FlashDiffusion keeps it as a plain torch module
+    def __init__(self, seq):
+        super().__init__()
+        self.seq = seq
+
+    def forward(self, x):
+        return self.seq(x)
+
+
+def _patch(monkeypatch):
+    from flash_diffusion_amd import flash, flash_sd3, schedulers
+    for mod in (flash, flash_sd3, schedulers):
+        monkeypatch.setattr(mod, "ops", fake_ops)
+    for mod in (flash, flash_sd3):
+        monkeypatch.setattr(mod, "_DistillLoss", fake_ops.FakeDistillLoss)
+        monkeypatch.setattr(mod, "_DmdLoss", fake_ops.FakeDmdLoss)
+
+
+def _check_grads(m, g, rename=lambda k: k):
+    n = 0
+    for pn, p in m.named_parameters():
+        key = rename(pn)
+        if p.grad is None:
+            assert key not in g["grads"] or float(g["grads"][key].abs().max()) == 0.0, pn
+            continue
+        assert key in g["grads"], pn
+        ref = g["grads"][key]
+        if float(ref.norm()) > 1e-12:
+            assert rel_err(p.grad, ref) < 2e-3, (pn, rel_err(p.grad, ref))
+            n += 1
+    assert n == sum(1 for v in g["grads"].values() if float(v.norm()) > 1e-12) and n > 0
+
+
+@pytest.mark.parametrize("name", list(CASES) + list(ADAPTER_CASES))
+def test_flash_step_orchestration_matches_reference_golden(monkeypatch, name):
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DDPMScheduler, DPMSolverMultistepScheduler
+    from oracle.unet_cpu import TinyT2IAdapter, tiny_config
+    _patch(monkeypatch)
+    kw, sched, step, _ = (CASES.get(name) or ADAPTER_CASES[name])
+    g = load_case(name)
+    teacher, student, disc = build_models()
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler() if sched == "dpm" else DDPMScheduler(),
+                       conditioner=TensorConditioner(), discriminator=_Head(disc),
+                       adapter=TinyT2IAdapter(tiny_config()) if name in ADAPTER_CASES else None)
+    m.draws = Draws(g["draws"])
+    B = g["z"].shape[0]
+    batch = {"image": g["z"], "crossattn": g["crossattn"], "text": ["a"] * B}
+    if name in ADAPTER_CASES:
+        batch["edge"] = make_edge()
+    calls = []
+    orig = type(teacher).forward
+    monkeypatch.setattr(type(teacher), "forward", lambda self, *a, **k: (calls.append(k["sample"].shape[0]), orig(self, *a, **k))[1])
+    out = m(batch, step=step, device="cpu")
+    assert 2 * B in calls                                   # the teacher's CFG pair really went out as ONE 2B call
+    assert out["start_timestep"] == g["start_timestep"]
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert rel_err(out[k], g["out"][k]) < 1e-4, (k, rel_err(out[k], g["out"][k]))
+    for i in (0, 1):
+        assert abs(float(out["loss"][i]) - g["loss"][i]) <= 1e-4 * max(1.0, abs(g["loss"][i])), i
+    out["loss"][step].backward()
+    _check_grads(m, g, lambda k: k.replace("discriminator.seq.", "discriminator."))
+
+
+@pytest.mark.parametrize("name", list(SD3_CASES))
+def test_sd3_step_orchestration_matches_reference_golden(monkeypatch, name):
+    from flash_diffusion_amd.flash import Draws
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    _patch(monkeypatch)
+    kw, step, _ = SD3_CASES[name]
+    g = load_case(name)
+    teacher, student, disc, pipe, batch = build_sd3_models()
+    m = FlashDiffusionSD3(FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), discriminator=_Head(disc), pipeline=pipe)
+    m.draws = Draws(g["draws"])
+    out = m(batch, step=step)
+    assert abs(out["start_timestep"] - g["start_timestep"]) < 1e-3
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert rel_err(out[k], g["out"][k]) < 1e-4, (k, rel_err(out[k], g["out"][k]))
+    for i in (0, 1):
+        assert abs(float(out["loss"][i]) - g["loss"][i]) <= 1e-4 * max(1.0, abs(g["loss"][i])), i
+    out["loss"][step].backward()
+    _check_grads(m, g, lambda k: k.replace("discriminator.seq.", "discriminator."))
+    # pinned start index / guidance (what bench.py and the data-parallel trainer set) and the trainer's hook
+    m2 = FlashDiffusionSD3(FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                           teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), discriminator=_Head(disc), pipeline=pipe)
+    m2.fixed_start_idx, m2.fixed_guidance = 0, 4.0
+    seen = []
+    m2.before_student = lambda: seen.append(1)
+    o2 = m2(batch, step=0)
+    assert seen == [1] and m2.terms["guidance"] == 4.0 and abs(o2["start_timestep"] - float(m2.teacher_noise_scheduler.timesteps[0])) < 1e-3
+
+
+def test_sampler_orchestration_matches_reference_golden(monkeypatch):
+    """FlashDiffusion.sample (FD:754-915) with the product LCM / DPM-Solver++ schedulers on the stand-in ops: 4-step student
+    sampler + the teacher's own sampler, fixture by the real reference (LCM re-noising draws replayed)"""
+    from flash_diffusion_amd.flash import FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler, LCMScheduler
+    from tests.golden_util import load_sample_case, sampler_models_from_golden
+    _patch(monkeypatch)
+    g = load_sample_case()
+    teacher, student, _ = sampler_models_from_golden(g)
+    m = FlashDiffusion(FlashDiffusionConfig(K=[4], num_iterations_per_K=[10]), student_denoiser=student,
+                       teacher_denoiser=teacher, teacher_noise_scheduler=DPMSolverMultistepScheduler(),
+                       conditioner=TensorConditioner(), discriminator=None, sampling_noise_scheduler=LCMScheduler(),
+                       teacher_sampling_noise_scheduler=DPMSolverMultistepScheduler())
+    it = iter(g["noises"])
+    m.sampling_noise_scheduler.noise_fn = lambda shape: next(it)
+    B = g["z"].shape[0]
+    s, sr = m.sample(g["z"], num_steps=int(g["num_steps"]), guidance_scale=float(g["guidance_scale"]),
+                     teacher_guidance_scale=float(g["teacher_guidance_scale"]),
+                     conditioner_inputs={"crossattn": g["crossattn"], "text": ["a"] * B},
+                     uncond_conditioner_inputs={"crossattn": g["uncond_crossattn"], "text": [""] * B},
+                     log_teacher_samples=True)
+    assert m.sampling_noise_scheduler.timesteps.tolist() == g["lcm_timesteps"].tolist()
+    assert rel_err(s, g["student_sample"]) < 1e-4 and rel_err(sr, g["teacher_sample"]) < 1e-4
+
+
+def test_teacher_loop_route_is_taken_only_when_asked(monkeypatch):
+    """FDMI_TEACHER_LOOP=1 hands the whole CFG loop to the denoiser's `teacher_loop` (fdmi_teacher_loop) with the scheduler's
+    coefficient table; here a recording stand-in that replays the table on the oracle denoiser checks the hand-over (timesteps,
+    [cond | uncond] context, coefficients) gives the step-by-step result"""
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    _patch(monkeypatch)
+    name = "g_noreg_vanilla"
+    kw, sched, step, _ = CASES[name]
+    g = load_case(name)
+    outs = []
+    for route in ("0", "1"):
+        monkeypatch.setenv("FDMI_TEACHER_LOOP", route)
+        teacher, student, disc = build_models()
+        used = []
+
+        def teacher_loop(x, timesteps, ctx2, vec2, coeffs, _t=teacher, _used=used):
+            _used.append((list(timesteps), tuple(ctx2.shape), len(coeffs)))
+            B = x.shape[0]
+            prev = None
+            for t, a in zip(timesteps, coeffs):
+                e = _t(sample=torch.cat([x, x]), timestep=torch.full((2 * B,), t), conditioning={"cond": {"crossattn": ctx2}})
+                e_c, e_u = e.chunk(2)
+                x0 = a[0] * x + a[1] * e_c + a[2] * e_u
+                x = a[3] * x + a[4] * x0 + (a[5] * prev if prev is not None else 0.0)
+                prev = x0
+            return x
+        teacher.teacher_loop = teacher_loop
+        m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                           teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                           discriminator=_Head(disc))
+        m.draws = Draws(g["draws"])
+        B = g["z"].shape[0]
+        outs.append((m({"image": g["z"], "crossattn": g["crossattn"], "text": ["a"] * B}, step=step, device="cpu"), used))
+    (o0, u0), (o1, u1) = outs
+    assert u0 == [] and len(u1) == 1 and u1[0][1][0] == 2 * g["z"].shape[0] and u1[0][2] == len(u1[0][0])
+    assert rel_err(o1["teacher_output"], o0["teacher_output"]) < 1e-5
+    assert rel_err(o1["teacher_output"], g["out"]["teacher_output"]) < 1e-4
