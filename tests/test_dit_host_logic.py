@@ -363,3 +363,106 @@ def test_conditioner_wrapper_matches_the_reference(monkeypatch):
                 assert float((a["cond"][k] - b["cond"][k]).abs().max()) <= tol, (kw, seed, k)
     with pytest.raises(AssertionError):
         M.BaseConditioner("text", 1.5)
+
+
+# ---- whole steps over the transformer denoisers (C4 / C5 pipelines end to end, on CPU) ---------------------------------------
+def _patch_flash(monkeypatch):
+    from flash_diffusion_amd import dit, flash, flash_sd3, schedulers
+    for mod in (dit, flash, flash_sd3, schedulers):
+        monkeypatch.setattr(mod, "ops", fake_ops)
+    for mod in (flash, flash_sd3):
+        monkeypatch.setattr(mod, "_DistillLoss", fake_ops.FakeDistillLoss)
+        monkeypatch.setattr(mod, "_DmdLoss", fake_ops.FakeDmdLoss)
+
+
+def test_flash_step_over_the_pixart_dit(monkeypatch):
+    """C4 end to end: product FlashDiffusion + DPM-Solver++ + MiTransformer2DModel teacher / LoRA student (stand-in ops) against
+    the oracle FlashDiffusionRef over the oracle PixArt denoisers, same injected draws; T5-style key mask + vector conditioning
+    go through the [cond | uncond] batched teacher call.  bf16 storage is mimicked: 3e-2."""
+    from flash_diffusion_amd import dit
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle import flash_ref
+    from oracle.golden_cases import build_dit
+    from oracle.sched_cpu import DPMSolverMultistepSchedulerRef
+    _patch_flash(monkeypatch)
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="l2", use_dmd_loss=True,
+              guidance_scale_min=3.0, guidance_scale_max=7.0, dmd_loss_scale=0.3)
+    cfg, t_o, (x, t, cond), _ = build_dit("dit_hd72_masked")
+    _, s_o, _, _ = build_dit("dit_hd72_masked", lora_r=8)
+    t_o.freeze()
+    batch = {"image": x, "text": ["a", "b"], **cond["cond"]}
+
+    class OraCond(torch.nn.Module):                        # the oracle's TensorConditioner knows no attention_mask
+        def forward(self, b, ucg_keys=None, set_ucg_rate_zero=False, *a, **k):
+            drop = ucg_keys is not None and "text" in ucg_keys
+            c = {k2: (torch.zeros_like(b[k2]) if drop else b[k2]) for k2 in ("crossattn", "vector")}
+            c["attention_mask"] = b["attention_mask"]
+            return {"cond": c}
+    ref = flash_ref.FlashDiffusionRef(flash_ref.FlashConfigRef(**kw), student_denoiser=s_o, teacher_denoiser=t_o,
+                                      teacher_noise_scheduler=DPMSolverMultistepSchedulerRef(), conditioner=OraCond())
+    torch.manual_seed(5)
+    want = ref(dict(batch), step=0)
+    want["loss"][0].backward()
+    teacher = dit.MiTransformer2DModel(**cfg)
+    teacher.load_state_dict(t_o.state_dict())
+    teacher.freeze()
+    student = dit.MiTransformer2DModel(**cfg).add_adapter(8)
+    student.load_state_dict({k.replace(".base_layer.", "."): v for k, v in s_o.state_dict().items()})
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner())
+    m.draws = Draws(ref.last_draws.values)
+    got = m(dict(batch), step=0, device="cpu")
+    assert got["start_timestep"] == want["start_timestep"]
+    for k in ("teacher_output", "student_output"):
+        assert _rel(got[k], want[k]) < 3e-2, (k, _rel(got[k], want[k]))
+    assert abs(float(got["loss"][0]) - float(want["loss"][0])) < 5e-2 * abs(float(want["loss"][0]))
+    got["loss"][0].backward()
+    rg = {k.replace(".base_layer.", "."): p.grad for k, p in s_o.named_parameters() if p.grad is not None}
+    fa = torch.cat([p.grad.flatten() for k, p in student.named_parameters() if ".lora_" in k])
+    fb = torch.cat([rg[k].flatten() for k, p in student.named_parameters() if ".lora_" in k])
+    assert _cos(fa, fb) > 0.99, _cos(fa, fb)
+
+
+def test_sd3_step_over_the_mmdit(monkeypatch):
+    """C5 end to end (distillation + DMD): product FlashDiffusionSD3 + flow-match Euler + MiSD3Transformer2DModel teacher / LoRA
+    student against the oracle FlashDiffusionSD3Ref over the oracle MMDiT, same injected draws; the teacher loop goes out as
+    one 2B call per step"""
+    from flash_diffusion_amd import dit, flash_sd3
+    from flash_diffusion_amd.flash import Draws
+    from oracle.flash_sd3_ref import EmbeddingPipeline, FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.golden_cases import build_mmdit
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    _patch_flash(monkeypatch)
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", use_dmd_loss=True, guidance_scale_min=3.0,
+              guidance_scale_max=7.0)
+    cfg, t_o, (x, t, cond), _ = build_mmdit("mmdit_hd64")
+    _, s_o, _, _ = build_mmdit("mmdit_hd64", lora_r=8)
+    t_o.freeze()
+    c = cond["cond"]
+    pipe = EmbeddingPipeline(c["crossattn"], c["vector"], torch.zeros_like(c["crossattn"]), torch.zeros_like(c["vector"]))
+    batch = {"image": x, "text": ["a", "b"]}
+    ref = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**kw), student_denoiser=s_o, teacher_denoiser=t_o,
+                               teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), pipeline=pipe)
+    torch.manual_seed(6)
+    want = ref(dict(batch), step=0)
+    wl = want["loss"][0] if isinstance(want["loss"], (list, tuple)) else want["loss"]
+    wl.backward()
+    teacher = dit.MiSD3Transformer2DModel(**cfg)
+    teacher.load_state_dict(t_o.state_dict())
+    teacher.freeze()
+    student = dit.MiSD3Transformer2DModel(**cfg).add_adapter(8)
+    student.load_state_dict({k.replace(".base_layer.", "."): v for k, v in s_o.state_dict().items()})
+    m = flash_sd3.FlashDiffusionSD3(flash_sd3.FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                                    teacher_noise_scheduler=flash_sd3.FlowMatchEulerDiscreteScheduler(), pipeline=pipe)
+    m.draws = Draws(ref.last_draws.values)
+    got = m(dict(batch), step=0)
+    gl = got["loss"][0] if isinstance(got["loss"], (list, tuple)) else got["loss"]
+    for k in ("teacher_output", "student_output"):
+        assert _rel(got[k], want[k]) < 3e-2, (k, _rel(got[k], want[k]))
+    assert abs(float(gl) - float(wl)) < 5e-2 * abs(float(wl))
+    gl.backward()
+    rg = {k.replace(".base_layer.", "."): p.grad for k, p in s_o.named_parameters() if p.grad is not None}
+    fa = torch.cat([p.grad.flatten() for k, p in student.named_parameters() if ".lora_" in k])
+    fb = torch.cat([rg[k].flatten() for k, p in student.named_parameters() if ".lora_" in k])
+    assert _cos(fa, fb) > 0.99, _cos(fa, fb)
