@@ -466,3 +466,19 @@ def test_sd3_step_over_the_mmdit(monkeypatch):
     fa = torch.cat([p.grad.flatten() for k, p in student.named_parameters() if ".lora_" in k])
     fb = torch.cat([rg[k].flatten() for k, p in student.named_parameters() if ".lora_" in k])
     assert _cos(fa, fb) > 0.99, _cos(fa, fb)
+
+
+def test_full_size_parameter_counts_match_the_published_models():
+    """the reference's pinned hyper-parameters (examples/train_flash_pixart.py:63-86, train_flash_sd3.py:65-77) must give the
+    published model sizes: PixArt-alpha XL/2 = 0.61 B parameters, SD3-medium MMDiT = 2.03 B (built on the meta device)"""
+    from flash_diffusion_amd import dit
+    from flash_diffusion_amd.workloads import PIXART, SD3
+    with torch.device("meta"):
+        pix = dit.MiTransformer2DModel(**PIXART)
+        sd3 = dit.MiSD3Transformer2DModel(**SD3)
+    assert sum(p.numel() for p in pix.parameters()) == 611_595_680
+    assert sum(p.numel() for p in sd3.parameters()) == 2_028_328_000
+    assert tuple(sd3.pos_embed.pos_embed.shape) == (1, 192 * 192, 1536)
+    n_pix = sum(1 for n, m in pix.named_modules() if isinstance(m, dit.MiLinear)
+                and any(n == t or n.endswith("." + t) for t in dit.PIXART_LORA_TARGETS))
+    assert n_pix == 293      # 28 blocks x 10 linears + patch conv + 2 + 6 + 2 embedder linears + adaLN + proj_out
