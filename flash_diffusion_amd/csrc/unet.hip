@@ -780,6 +780,17 @@ struct Exec {
     return y;
   }
 
+  // [a ; a]: the point where the two halves of a classifier-free-guidance batch stop being identical (no-save runs only)
+  T* dup(T* a) {
+    T* y = R.mk(2 * a->rows, a->cols, 2 * a->B, a->H, a->W);
+    if (!y) return nullptr;
+    if (!R.dry()) {
+      NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0, st));
+      NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p + (int64_t)a->rows * a->cols, y->cols, 0, a->rows, a->cols, 0, st));
+    }
+    return y;
+  }
+
   // ---- blocks ----------------------------------------------------------------------------------
   T* resnet(T* x, ResnetW& r, T* temb_all) {
     const fdmi_unet_config& c = U->cfg;
@@ -797,8 +808,11 @@ struct Exec {
     return conv(a2, r.c2, 1, 0, nullptr, 0, sc);
   }
 
-  T* transformer(T* x, TransformerW& t, T* ctx, int L) {
-    const int Bn = x->B, S = x->H * x->W;
+  // dup_after_attn1: x holds ONE half of a [x | x] guidance batch whose halves are identical up to here; the first
+  // cross-attention (different context per half) is where they part: the state is duplicated right before it
+  T* transformer(T* x, TransformerW& t, T* ctx, int L, bool dup_after_attn1 = false) {
+    int Bn = x->B;
+    const int S = x->H * x->W;
     T* hn = groupnorm(x, t.gn, 1e-6f, 0);
     if (!hn) return nullptr;
     T* h = linear_w(hn, t.pin);
@@ -813,6 +827,13 @@ struct Exec {
       if (!o) return nullptr;
       h = linear(o, b.a1.o, h);
       if (!h) return nullptr;
+      if (dup_after_attn1) {
+        dup_after_attn1 = false;
+        h = dup(h);
+        x = dup(x);   // the residual of proj_out
+        if (!h || !x) return nullptr;
+        Bn *= 2;
+      }
       n = layernorm(h, b.ln2);
       if (!n) return nullptr;
       q = linear(n, b.a2.q);
@@ -879,14 +900,19 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
     if (!R.dry()) FDMI_HIP(hipMemsetAsync(R.zpool, 0, R.zcap, st));
   }
   const int cin_pad = U->conv_in.Cin_pad;
+  // FDMI_UNET_CFG_HALVES: sample and timestep rows B/2.. repeat rows 0..B/2-1 (a [x | x] guidance batch; only the context
+  // differs): conv_in, the first ResNet block and the first self-attention are computed once and duplicated
+  const bool halves = (flags & FDMI_UNET_CFG_HALVES) && !R.save && !inter && (B % 2) == 0 && !U->down.empty() &&
+                      U->down[0]->has_attn && U->down_res.empty();
+  const int Bx = halves ? B / 2 : B;
   // ---- inputs ----
-  T* x0 = R.mk((int64_t)B * H * W, cin_pad, B, H, W);
+  T* x0 = R.mk((int64_t)Bx * H * W, cin_pad, Bx, H, W);
   T* ctxb = R.mk((int64_t)B * L, c.cross_dim);
   float* tf = (float*)R.arena.alloc((size_t)B * 4);
   FAIL_IF_NULL(x0); FAIL_IF_NULL(ctxb); FAIL_IF_NULL(tf);
   R.x0 = x0;
   if (!R.dry()) {
-    RET_IF(launch_nchw_to_nhwc(x, x0->p, B, c.in_channels, H * W, cin_pad, st));
+    RET_IF(launch_nchw_to_nhwc(x, x0->p, Bx, c.in_channels, H * W, cin_pad, st));
     RET_IF(launch_f32_to_bf16(ctx, ctxb->p, (int64_t)B * L * c.cross_dim, st));
   }
   // ---- time embedding ----
@@ -915,7 +941,9 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   // ---- down ----
   T* h = E.conv(x0, U->conv_in, 1, 0, nullptr, 0, nullptr);
   FAIL_IF_NULL(h);
-  std::vector<T*> skips{h};
+  std::vector<T*> skips{halves ? E.dup(h) : h};
+  FAIL_IF_NULL(skips[0]);
+  bool dup_pending = halves;
   // T2I-adapter residuals (diffusers UNet2DConditionModel.forward, `down_intrablock_additional_residuals`): a block WITH
   // cross-attention adds its residual to the hidden state after its last (resnet, attention) pair -- before that state is
   // pushed as a skip and before the downsampler; a block WITHOUT attention adds it to the block's output, in place, i.e.
@@ -937,7 +965,8 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
       h = E.resnet(h, *s.res[j], temb_all);
       FAIL_IF_NULL(h);
       if (s.has_attn) {
-        h = E.transformer(h, *s.attn[j], ctxb, L);
+        h = E.transformer(h, *s.attn[j], ctxb, L, dup_pending);
+        dup_pending = false;
         FAIL_IF_NULL(h);
         if (j + 1 == s.res.size()) RET_IF(add_res(h));
       }
@@ -1161,7 +1190,8 @@ int fdmi_teacher_loop(fdmi_unet* U, int slot, float* x, const float* timesteps, 
     uint32_t tbits;
     memcpy(&tbits, &timesteps[i], 4);
     FDMI_HIP(hipMemsetD32Async((hipDeviceptr_t)tt, (int)tbits, 2 * (size_t)B, st));
-    int rc = run_forward(U, R, xx, tt, ctx2, cls2, eps, 2 * B, H, W, L, i == 0 ? FDMI_UNET_CTX_FILL : FDMI_UNET_CTX_REUSE);
+    int rc = run_forward(U, R, xx, tt, ctx2, cls2, eps, 2 * B, H, W, L,
+                         (i == 0 ? FDMI_UNET_CTX_FILL : FDMI_UNET_CTX_REUSE) | (fdmi_tune_get(13) ? FDMI_UNET_CFG_HALVES : 0));
     if (rc) return rc;
     flops += U->last_flops;
     float* cur = x0[i & 1];

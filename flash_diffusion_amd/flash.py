@@ -438,6 +438,9 @@ class FlashDiffusion(nn.Module):
         if (ctx_cache is not None and getattr(self.teacher_denoiser, "supports_ctx_cache", False)
                 and not os.environ.get("FDMI_NO_CTX_CACHE")):
             kwargs = dict(kwargs, ctx_cache=ctx_cache)  # same [cond | uncond] context at every step of this loop
+        if (os.environ.get("FDMI_CFG_DEDUP") == "1" and getattr(self.teacher_denoiser, "supports_cfg_halves", False)
+                and res is None):   # [x | x]: layers before the first cross-attention once (opt-in until its first GPU run)
+            kwargs = dict(kwargs, cfg_halves=True)
         e = self.teacher_denoiser(sample=torch.cat([x, x], dim=0), timestep=torch.cat([tt, tt], dim=0),
                                   conditioning=cfg_cond, down_intrablock_additional_residuals=self._dup(res), *args,
                                   **kwargs)

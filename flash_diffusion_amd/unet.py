@@ -19,7 +19,7 @@ from . import _lib
 from ._lib import check, f32, i32, i64, ptr, stream_ptr, vp
 
 FDMI_UNET_SAVE, FDMI_UNET_INTERMEDIATE, FDMI_UNET_INPUT_GRAD = 1, 2, 4
-FDMI_UNET_CTX_FILL, FDMI_UNET_CTX_REUSE = 8, 16
+FDMI_UNET_CTX_FILL, FDMI_UNET_CTX_REUSE, FDMI_UNET_CFG_HALVES = 8, 16, 32
 
 
 from ._lib import UNetCfg  # noqa: E402  (C struct fdmi_unet_config)
@@ -164,6 +164,7 @@ class MiUNet2DConditionModel(nn.Module):
     """See module docstring.  Unknown diffusers kwargs are accepted and ignored when they carry the
     reference's values (None / defaults); unsupported non-default values raise."""
     supports_ctx_cache = True  # forward(..., ctx_cache="fill"|"reuse"): see FDMI_UNET_CTX_* in include/fdmi.h
+    supports_cfg_halves = True  # forward(..., cfg_halves=True): [x | x] batch, see FDMI_UNET_CFG_HALVES
 
     def __init__(self, in_channels=4, out_channels=4, down_block_types=("CrossAttnDownBlock2D",) * 3 + ("DownBlock2D",),
                  up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3, block_out_channels=(320, 640, 1280, 1280),
@@ -428,6 +429,10 @@ class MiUNet2DConditionModel(nn.Module):
         ctx_cache = kwargs.pop("ctx_cache", None)
         if ctx_cache is not None and not self.lora_rank:
             flags |= FDMI_UNET_CTX_FILL if ctx_cache == "fill" else FDMI_UNET_CTX_REUSE
+        # classifier-free-guidance batch [x | x] (same sample and timestep in both halves, the caller's promise): the layers
+        # before the first cross-attention are computed once (FDMI_UNET_CFG_HALVES)
+        if kwargs.pop("cfg_halves", False) and not self.lora_rank and down_intrablock_additional_residuals is None:
+            flags |= FDMI_UNET_CFG_HALVES
         lora = self.lora_parameters() if self.lora_rank else []
         need_grad = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in lora))
         sample = sample.float().contiguous()

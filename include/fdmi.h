@@ -177,7 +177,11 @@ enum { FDMI_UNET_SAVE = 1,          /* record what backward needs (student / GAN
           cross-attention K/V projections (and their head-transposed copies) depend on nothing else.
           CTX_FILL computes them into plan-owned buffers, CTX_REUSE (same B, L, ctx contents; no SAVE, no
           LoRA on those projections) reads them back instead of recomputing. */
-       FDMI_UNET_CTX_FILL = 8, FDMI_UNET_CTX_REUSE = 16 };
+       FDMI_UNET_CTX_FILL = 8, FDMI_UNET_CTX_REUSE = 16,
+       /* The caller promises that sample / timestep rows B/2.. repeat rows 0..B/2-1 (a classifier-free-guidance batch
+          [x | x], only the context halves differ): everything up to the first cross-attention is computed once and
+          duplicated.  Ignored with SAVE / INTERMEDIATE / adapter residuals or when the first down block has no attention. */
+       FDMI_UNET_CFG_HALVES = 32 };
 
 fdmi_unet* fdmi_unet_create(const fdmi_unet_config* cfg);   /* NULL on error */
 void fdmi_unet_destroy(fdmi_unet* u);

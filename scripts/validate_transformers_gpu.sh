@@ -20,8 +20,10 @@ run 05_bench_pixart env FDMI_GEMM_LOG=1 timeout 1200 python bench.py --arch pixa
 run 06_bench_pixart_bn192 env FDMI_TUNE=12=1 timeout 1200 python bench.py --arch pixart --steps 3 --warmup 1 --no-cpu-baseline
 run 07_bench_sd3 timeout 1200 python bench.py --arch sd3 --steps 3 --warmup 1 --no-cpu-baseline
 run 08_bench_sd3_bn192 env FDMI_TUNE=12=1 timeout 1200 python bench.py --arch sd3 --steps 3 --warmup 1 --no-cpu-baseline
-# 5. C2 with the single-call teacher loop
-run 09_bench_c2_teacher_loop env FDMI_TEACHER_LOOP=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
+# 5. C2 with the [x | x] prefix dedupe, then with the single-call teacher loop (knob 13 = dedupe inside that loop)
+run 09a_bench_c2_cfg_dedup env FDMI_CFG_DEDUP=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
+run 09b_bench_c2_teacher_loop env FDMI_TEACHER_LOOP=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
+run 09c_bench_c2_teacher_loop_dedup env FDMI_TEACHER_LOOP=1 FDMI_TUNE=13=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
 grep -h '"metric"' "$out"/0[3-9]*.log | python -c "
 import sys, json
 for l in sys.stdin:

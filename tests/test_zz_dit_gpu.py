@@ -313,6 +313,34 @@ def _body_test_step_with_adapter_matches_reference_golden():
     assert len(fa) > 0 and _cos(torch.cat(fa), torch.cat(fb)) > 0.99
 
 
+def test_cfg_halves_prefix_dedupe_matches_the_plain_call():
+    run_isolated(__name__, "_body_test_cfg_halves_prefix_dedupe_matches_the_plain_call", ())
+
+
+def _body_test_cfg_halves_prefix_dedupe_matches_the_plain_call():
+    """FDMI_UNET_CFG_HALVES: on a [x | x] batch with [cond | uncond] contexts the layers before the first cross-attention are
+    computed once and duplicated -- same result as the plain 2B call up to the tiny UNet's run-to-run GroupNorm-atomics noise;
+    also together with the context K/V cache"""
+    from flash_diffusion_amd.unet import MiUNet2DConditionModel
+    from flash_diffusion_amd.workloads import TINY
+    torch.manual_seed(0)
+    net = MiUNet2DConditionModel(**TINY).cuda()
+    net.freeze()
+    B, hw, L, D = 2, 16, 7, TINY["cross_attention_dim"]
+    x = torch.randn(B, 4, hw, hw, device="cuda")
+    xx, tt = torch.cat([x, x]), torch.full((2 * B,), 600.0, device="cuda")
+    ctx = {"cond": {"crossattn": torch.randn(2 * B, L, D, device="cuda")}}
+    with torch.no_grad():
+        ref = net(xx, tt, ctx).clone()
+        noise = max([rel_err(net(xx, tt, ctx), ref) for _ in range(4)] + [5e-3])
+        a = net(xx, tt, ctx, cfg_halves=True).clone()
+        b = net(xx, tt, ctx, cfg_halves=True, ctx_cache="fill").clone()
+        c = net(xx, tt, ctx, cfg_halves=True, ctx_cache="reuse").clone()
+    assert rel_err(ref[:B], ref[B:]) > 10 * noise                 # the halves do differ (different contexts)
+    for got in (a, b, c):
+        assert rel_err(got, ref) <= 3 * noise, (rel_err(got, ref), noise)
+
+
 def test_rccl_allreduce_entry_points_world_1():
     run_isolated(__name__, "_body_test_rccl_allreduce_entry_points_world_1", ())
 
