@@ -9,7 +9,7 @@ mkdir -p "$out"
 run() { name=$1; shift; echo "== $name: $*"; ( "$@" ) > "$out/$name.log" 2>&1; echo "   exit $? ($(tail -1 "$out/$name.log" | cut -c1-160))"; }
 
 # 1. parity: new kernels, DiT / MMDiT vs the reference's fixtures, teacher loop, all-reduce entry points (xfail-marked file)
-run 01_pytest_zz timeout 900 python -m pytest tests/test_zz_dit_gpu.py -q -rxXs -p no:cacheprovider
+run 01_pytest_zz env FDMI_RUN_DEV_KNOBS=1 timeout 900 python -m pytest tests/test_zz_dit_gpu.py -q -rxXs -p no:cacheprovider
 # 2. the SD3 sampler test added without a GPU run
 run 02_pytest_sd3 timeout 600 python -m pytest tests/test_flash_sd3_gpu.py -q -p no:cacheprovider
 # 3. trainer integration of the transformer students (flat LoRA buffer, fused AdamW, deferred step) on tiny shapes

@@ -9,6 +9,8 @@ This file was written in a round whose GPU budget was already spent: its first r
 run, hence the non-strict xfail marker (an XPASS is the expected outcome; the marker goes once a GPU run has confirmed it).
 It sorts last so that nothing else depends on it, and every test body runs in its own interpreter (tests/isolate.py): a memory
 fault or a hang in a kernel that has never run costs that one test, not the pytest process holding the other results."""
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -151,8 +153,14 @@ def _body_test_dit_lora_step_matches_reference_golden(name):
 
 # ---- 256 x 192 variant of the 2-slot ring kernel (gemm4<BN=192>): the tile for N = 1152 / 1536 / 4608 / 6144 -----------------
 T192 = (256 << 16) | 192
+# a kernel template instantiation that has never been launched and that nothing selects by default (planner knob 12): its
+# first launch belongs to a developer's gpurun call (scripts/validate_transformers_gpu.sh sets the switch), not to the
+# round-end run whose box also has to produce the smoke and bench results afterwards
+dev_knob = pytest.mark.skipif(os.environ.get("FDMI_RUN_DEV_KNOBS") != "1",
+                              reason="developer-knob kernel variant: set FDMI_RUN_DEV_KNOBS=1 to run")
 
 
+@dev_knob
 @pytest.mark.parametrize("shape", [(256, 192, 64), (512, 1152, 1152), (1024, 384, 4608), (768, 1536, 192), (2048, 576, 1536)])
 def test_gemm4_bn192_row(shape):
     run_isolated(__name__, "_body_test_gemm4_bn192_row", (shape,))
@@ -176,6 +184,7 @@ def _body_test_gemm4_bn192_row(shape):
         close(f"gemm4_192_atomic{shape}", acc, A.float() @ W.float().t(), tol_el=1e-4, tol_fro=1e-4)
 
 
+@dev_knob
 def test_gemm4_bn192_many_items_and_planner_knob():
     run_isolated(__name__, "_body_test_gemm4_bn192_many_items_and_planner_knob", ())
 
