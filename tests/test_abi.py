@@ -94,3 +94,47 @@ def test_planner_offers_the_256x192_tile_only_behind_its_knob():
         assert _plan(65536, 320, 320)[:3] == (2, 256, 320)            # widths that 320 divides keep the larger tile
     finally:
         L.fdmi_tune_set(12, 0)
+
+
+def test_ctypes_argument_types_match_the_header_prototypes():
+    """every prototype of include/fdmi.h, parsed here, against the argtypes / restype _lib.py binds: a float bound as a double or
+    an int64 as an int32 is silent at call time and garbage in the kernel (capi.hip includes the same header under extern "C",
+    so a definition that disagrees with it does not compile)"""
+    import ctypes as C
+    from flash_diffusion_amd import _lib
+    import flash_diffusion_amd.unet  # noqa: F401
+    src = open(os.path.join(ROOT, "include", "fdmi.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    protos = re.findall(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(fdmi_[a-z0-9_]+)\s*\(([^)]*)\)\s*;", src)
+    scalars = {"int": "i32", "int32_t": "i32", "int64_t": "i64", "float": "f32", "double": "f64", "void": "void"}
+
+    def from_c(t):
+        t = re.sub(r"\bconst\b", "", t).strip()
+        if "*" in t:
+            return "char*" if t.replace("*", "").strip() == "char" else "ptr"
+        return scalars[t]
+
+    def from_ctypes(ct):
+        if ct is None:
+            return "void"
+        if ct is C.c_char_p:
+            return "char*"
+        if ct is C.c_void_p or (hasattr(ct, "_type_") and not isinstance(ct._type_, str)):
+            return "ptr"
+        return {C.c_int32: "i32", C.c_int64: "i64", C.c_float: "f32", C.c_double: "f64"}[ct]
+
+    sigs = dict(_lib._SIGS)
+    sigs.update(_lib.EXTRA_SIGS)
+    assert len(protos) >= 55
+    for ret, name, args in protos:
+        if name == "fdmi_last_error":
+            continue
+        hdr = []
+        for a in ([x.strip() for x in args.split(",")] if args.strip() not in ("", "void") else []):
+            arr = re.search(r"\[\d*\]$", a) is not None
+            typ = a if a.endswith("*") else re.sub(r"\b[A-Za-z_][A-Za-z0-9_]*\s*(\[\d*\])?$", "", a).strip()
+            hdr.append(from_c(typ + ("*" if arr else "")))
+        res, at = sigs[name]
+        assert [from_ctypes(x) for x in at] == hdr, (name, hdr, [from_ctypes(x) for x in at])
+        assert from_ctypes(res) == from_c(ret), (name, ret)

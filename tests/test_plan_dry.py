@@ -1,0 +1,88 @@
+"""CPU: the C++ UNet plan executor (csrc/unet.hip) walked in its workspace-query mode -- every op of the forward and of the
+taped backward is visited, buffers are bump-allocated and the algorithmic FLOPs counted, but no kernel is launched -- so the
+plan's topology, its flag handling and its FLOP accounting are pinned without a GPU against SURVEY.md appendix C
+(SD1.5 0.8033 TFLOP/image, SDXL 6.7612 at 128x128 latents, down+mid only 0.2614 / 2.933; backward = dgrad + 2x attention)."""
+import pytest
+import torch
+
+from flash_diffusion_amd import _lib
+from flash_diffusion_amd.unet import (FDMI_UNET_CFG_HALVES, FDMI_UNET_CTX_FILL, FDMI_UNET_CTX_REUSE, FDMI_UNET_INPUT_GRAD,
+                                      FDMI_UNET_INTERMEDIATE, FDMI_UNET_SAVE, MiUNet2DConditionModel)
+from flash_diffusion_amd.workloads import SD15, SDXL, TINY
+
+
+def _plan(arch):
+    with torch.device("meta"):
+        m = MiUNet2DConditionModel(**arch)
+    return m, m._plan()
+
+
+def _query(plan, B, HW, L, flags):
+    lib = _lib.lib()
+    need = lib.fdmi_unet_workspace_bytes(plan.handle, B, HW, HW, L, flags)
+    assert need > 0, lib.fdmi_last_error()
+    return need, lib.fdmi_unet_last_flops(plan.handle)
+
+
+@pytest.mark.parametrize("name,arch,B,HW,per_image,down_mid", [("sd15", SD15, 16, 64, 0.8033, 0.2614),
+                                                              ("sdxl", SDXL, 8, 128, 6.7612, 2.933)])
+def test_forward_flops_match_the_analytical_model(name, arch, B, HW, per_image, down_mid):
+    m, plan = _plan(arch)
+    _, fl = _query(plan, B, HW, 77, 0)
+    assert abs(fl / 1e12 / B - per_image) < 2e-4 * per_image + 1e-4, fl
+    _, fl2 = _query(plan, 2 * B, HW, 77, 0)
+    assert abs(fl2 - 2 * fl) < 1e-6 * fl                       # linear in the batch
+    _, fdm = _query(plan, B, HW, 77, FDMI_UNET_INTERMEDIATE)   # the GAN backbone: down + mid blocks only
+    assert abs(fdm / 1e12 / B - down_mid) < 1e-3 * down_mid + 1e-4, fdm
+
+
+def test_backward_flops_and_workspace_sd15():
+    """frozen base weights: backward = dgrad of every GEMM / conv + 2x the attention forward = 14.87 TFLOP at B=16
+    (+ the first conv's input gradient); a saved forward needs more workspace than an inference forward, and asking for the
+    input gradient costs no extra buffer"""
+    m, plan = _plan(SD15)
+    ws0, f = _query(plan, 16, 64, 77, 0)
+    ws1, b = _query(plan, 16, 64, 77, FDMI_UNET_SAVE)
+    ws2, b2 = _query(plan, 16, 64, 77, FDMI_UNET_SAVE | FDMI_UNET_INPUT_GRAD)
+    A = 16 * 0.1261e12
+    assert abs(b - (f + A)) < 0.02 * f, (b, f + A)
+    assert b2 == b and ws1 > ws0 and ws2 == ws1
+    assert ws1 < 64 * 2 ** 30      # far inside one MI355X's 288 GB together with the teacher's workspace
+
+
+def test_context_cache_flags_keep_the_topology():
+    """FDMI_UNET_CTX_FILL / _REUSE move the cross-attention K/V into plan-owned buffers: same algorithmic FLOPs (the plan counts
+    the projections it skips as not executed only on the real run), slightly less workspace"""
+    m, plan = _plan(SD15)
+    ws0, f0 = _query(plan, 32, 64, 77, 0)
+    ws1, f1 = _query(plan, 32, 64, 77, FDMI_UNET_CTX_FILL)
+    ws2, f2 = _query(plan, 32, 64, 77, FDMI_UNET_CTX_REUSE)
+    assert f0 == f1 == f2 and ws1 <= ws0 and ws2 == ws1
+
+
+@pytest.mark.parametrize("arch,B,HW", [(SD15, 32, 64), (TINY, 4, 32)])
+def test_cfg_halves_removes_exactly_the_shared_prefix(arch, B, HW):
+    """FDMI_UNET_CFG_HALVES on a [x | x] batch: conv_in, the first ResNet block, and the first transformer's GroupNorm / proj_in /
+    LayerNorm / q,k,v / self-attention / to_out run at B/2 -- the saving is half of those ops' FLOPs, computed here from the
+    architecture alone"""
+    m, plan = _plan(arch)
+    _, full = _query(plan, B, HW, 77, FDMI_UNET_CTX_FILL)
+    _, half = _query(plan, B, HW, 77, FDMI_UNET_CTX_FILL | FDMI_UNET_CFG_HALVES)
+    c = m.config_dict
+    C0, cin, heads = c["block_out_channels"][0], c["in_channels"], c["attention_head_dim"][0]
+    cin_pad = (cin + 7) // 8 * 8
+    M = B * HW * HW
+    conv_in = 2 * M * C0 * 9 * cin_pad
+    resnet = 2 * (2 * M * C0 * 9 * C0)
+    lin = 2 * M * C0 * C0
+    attn = 4 * B * heads * (HW * HW) ** 2 * (C0 // heads)
+    prefix = conv_in + resnet + 5 * lin + attn          # proj_in, q, k, v, to_out
+    assert abs((full - half) - prefix / 2) < 1e-6 * full, (full - half, prefix / 2)
+    # a plan whose first down block has no attention ignores the flag
+    m2, plan2 = _plan(SDXL)
+    assert _query(plan2, 4, 64, 77, FDMI_UNET_CFG_HALVES)[1] == _query(plan2, 4, 64, 77, 0)[1]
+
+
+def test_odd_batch_ignores_cfg_halves_and_bad_sizes_fail():
+    m, plan = _plan(TINY)
+    assert _query(plan, 3, 32, 77, FDMI_UNET_CFG_HALVES)[1] == _query(plan, 3, 32, 77, 0)[1]
