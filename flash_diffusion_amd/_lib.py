@@ -50,6 +50,7 @@ _SIGS = {
     "fdmi_unet_forward": (i32, [vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, i32, vp]),
     "fdmi_unet_backward": (i32, [vp, i32, vp, vp, vp]),
     "fdmi_unet_last_flops": (C.c_double, [vp]),
+    "fdmi_unet_last_gn_epilogue": (i32, [vp, C.POINTER(i32)]),
     "fdmi_unet_set_down_residuals": (i32, [vp, vp, i32, f32]),
     "fdmi_teacher_loop_scratch_bytes": (i64, [vp, i32, i32, i32]),
     "fdmi_teacher_loop": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, vp]),
@@ -64,6 +65,9 @@ _SIGS = {
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "fdmi_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
+    "fdmi_gemm_gn_ok": (i32, [C.POINTER(GemmDesc), i32, i32]),
+    "fdmi_gemm_gn": (i32, [C.POINTER(GemmDesc), vp, i32, i32, vp]),
+    "fdmi_groupnorm_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "fdmi_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "fdmi_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "fdmi_layernorm_fwd": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),

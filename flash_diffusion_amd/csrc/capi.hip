@@ -88,6 +88,26 @@ int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_
   return 0;
 }
 
+static GemmArgs gemm_gn_args_from(const fdmi_gemm_desc* d, float* gn_stats, int gn_rows, int gn_G) {
+  GemmArgs a = gemm_args_from(d);
+  a.gn_stats = gn_stats; a.gn_rows = gn_rows; a.gn_G = gn_G;
+  a.gn_cpg = gn_G > 0 ? a.N / gn_G : 0;
+  return a;
+}
+int fdmi_gemm_gn_ok(const fdmi_gemm_desc* d, int gn_rows, int gn_G) {
+  if (!d) return 0;
+  const GemmArgs a = gemm_gn_args_from(d, (float*)(uintptr_t)256, gn_rows, gn_G);   // (host-only query: any non-null pointer)
+  return gemm_gn_ok(a, a.ws != nullptr || a.accum_atomic) ? 1 : 0;
+}
+int fdmi_gemm_gn(const fdmi_gemm_desc* d, float* gn_stats, int gn_rows, int gn_G, void* stream) {
+  FDMI_CHECK(d != nullptr && gn_stats != nullptr, "gemm_gn: null argument");
+  return launch_gemm(gemm_gn_args_from(d, gn_stats, gn_rows, gn_G), (hipStream_t)stream);
+}
+int fdmi_groupnorm_apply(const void* x, const float* gamma, const float* beta, const float* stats, void* y, int B, int HW,
+                         int C, int G, float eps, int silu, void* stream) {
+  return launch_groupnorm_fwd((const bf16_t*)x, gamma, beta, (float*)stats, (bf16_t*)y, B, HW, C, G, eps, silu,
+                              (hipStream_t)stream, true, true);
+}
 int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, float* stats, void* y, int B,
                        int HW, int C, int G, float eps, int silu, void* stream) {
   return launch_groupnorm_fwd((const bf16_t*)x, gamma, beta, stats, (bf16_t*)y, B, HW, C, G, eps, silu,

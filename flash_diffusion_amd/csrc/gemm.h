@@ -28,6 +28,10 @@ struct GemmArgs {
   int accum_atomic = 0;           // C is f32 and receives atomicAdd(alpha*acc) (wgrad accumulation)
   int force_tile = 0;             // 0 auto; else (BM<<16 | BN)
   int use_glds = 1;               // LDS-DMA staging (1) or register staging (0)
+  // optional: GroupNorm statistics of the tensor this GEMM produces, accumulated by the epilogue into
+  // gn_stats[m / gn_rows][gn_G][2] += (sum, sum of squares) over the group's gn_cpg channels (pre-zeroed by the caller) so
+  // that the consuming GroupNorm skips its reduction pass.  Only honoured when gemm_gn_ok(args): ask first.
+  float* gn_stats = nullptr; int gn_rows = 0, gn_cpg = 0, gn_G = 0;
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
@@ -41,5 +45,8 @@ int gemm3_pick_bn(const GemmArgs& a);
 int launch_gemm3(const GemmArgs& a, int BN, hipStream_t stream);
 bool gemm4_eligible(const GemmArgs& a, int BN = 320);   // 256 x {320, 192} tile (gemm4.hip)
 int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN = 320);
+// true when launch_gemm will run this problem on a kernel whose epilogue accumulates GemmArgs::gn_stats (a 256-row tile
+// without split-K, full tiles inside one sample, 8-column-aligned operands); a.gn_* and a.ws-availability as at launch
+bool gemm_gn_ok(const GemmArgs& a, bool ws_available);
 // algorithmic flops of one launch (2*M*N*K)
 static inline double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }

@@ -511,6 +511,15 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   return p;
 }
 
+bool gemm_gn_ok(const GemmArgs& a, bool ws_available) {
+  if (!a.gn_stats || a.gn_cpg < 8 || a.gn_G < 1 || a.gn_G > 32 || a.N != a.gn_cpg * a.gn_G) return false;
+  if (a.gn_rows <= 0 || (a.gn_rows & 255) != 0 || (a.M & 255) != 0 || (a.M % a.gn_rows) != 0) return false;
+  if (a.out_f32 || a.accum_atomic || a.act == ACT_GEGLU || a.preact || a.force_tile || a.splitk > 1) return false;
+  if ((a.N & 7) || (a.ldc & 7) || (a.residual && (a.ldr & 7)) || (a.rowvec && (a.rowvec_ld & 7))) return false;
+  const GemmPlan p = plan_gemm(a, ws_available);
+  return p.big != 0 && p.splitk == 1 && (p.big != 2 || p.BN == 320) && (a.N % p.BN) == 0;
+}
+
 size_t gemm_ws_bytes(const GemmArgs& a) {
   GemmArgs b = a;
   b.splitk = 0;
@@ -563,6 +572,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.splitk > 1 && !a.accum_atomic) {
     FDMI_CHECK(a.ws != nullptr, "gemm: split-K needs a workspace of splitk*M*N floats");
   }
+  if (a.gn_stats) FDMI_CHECK(gemm_gn_ok(a_in, a_in.ws != nullptr || a_in.accum_atomic), "gemm: gn_stats requested for a problem whose kernel cannot accumulate them (ask gemm_gn_ok first)");
   if (g_gemm_log.on)
     ++g_gemm_log.n[std::make_tuple(a.mode, a.M, a.N, a.K, a.act, (a.residual ? 1 : 0) | (a.preact ? 2 : 0) | (a.accum_atomic ? 4 : 0) | (a.out_f32 ? 8 : 0) | (a.dgrad ? 16 : 0),
                                    p.big ? p.big * 1000 + p.BN : p.BM * 1000 + p.BN, a.splitk)];

@@ -30,7 +30,8 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BN, int MODE>
+// GN: the epilogue also accumulates the consumer's GroupNorm statistics (GemmArgs::gn_stats); separate instantiations
+template <int BN, int MODE, bool GN = false>
 __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256;
@@ -219,7 +220,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  auto epilogue = [&](const Item& it) { tile_epilogue<NF, MF>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j); };
+  auto epilogue = [&](const Item& it) { tile_epilogue<NF, MF, 2, GN>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j); };
 
   // ---- flattened 3-stage ring across items: counted vmcnt, one raw barrier per K tile ----
   int inflight = 0;
@@ -257,12 +258,12 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   }
 }
 
-template <int BN, int MODE>
+template <int BN, int MODE, bool GN = false>
 int launch3_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   constexpr int smem = 3 * (256 + BN) * 128;
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm3_kernel<BN, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm3_kernel<BN, MODE, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int items = cdiv(a.M, 256) * cdiv(a.N, BN) * (a.splitk > 1 ? a.splitk : 1);
@@ -278,7 +279,7 @@ int launch3_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);   // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, PROF_GEMM3 + MODE * 2 + (BN == 160 ? 0 : 1), gemm_flops(a));
-  hipLaunchKernelGGL((gemm3_kernel<BN, MODE>), grid, dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((gemm3_kernel<BN, MODE, GN>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -299,6 +300,10 @@ int gemm3_pick_bn(const GemmArgs& a) {
   return ((double)cdiv(a.N, 160) * 160 / a.N <= (double)cdiv(a.N, 128) * 128 / a.N) ? 160 : 128;
 }
 int launch_gemm3(const GemmArgs& a, int BN, hipStream_t stream) {
+  if (a.gn_stats) {
+    if (a.mode == GEMM_ROW) return BN == 160 ? launch3_t<160, GEMM_ROW, true>(a, stream) : launch3_t<128, GEMM_ROW, true>(a, stream);
+    return BN == 160 ? launch3_t<160, GEMM_CONV, true>(a, stream) : launch3_t<128, GEMM_CONV, true>(a, stream);
+  }
   if (a.mode == GEMM_ROW) return BN == 160 ? launch3_t<160, GEMM_ROW>(a, stream) : launch3_t<128, GEMM_ROW>(a, stream);
   return BN == 160 ? launch3_t<160, GEMM_CONV>(a, stream) : launch3_t<128, GEMM_CONV>(a, stream);
 }

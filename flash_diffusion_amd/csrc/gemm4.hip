@@ -20,7 +20,9 @@ namespace {
 
 // BN = 320 is the tile described above.  BN = 192 is the same pipeline for widths that 320 does not divide but 192 does --
 // the transformer denoisers' 1152 / 1536 / 4608 / 6144 (PixArt, SD3): 56 KB per tile, 110 flop/B, wave tile 64 x 96.
-template <int MODE, bool GEGLU, int BN>
+// GN: the epilogue also accumulates the consumer's GroupNorm statistics (GemmArgs::gn_stats); a separate instantiation, so the
+// default kernels are instruction-identical with and without the feature
+template <int MODE, bool GEGLU, int BN, bool GN = false>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256;
@@ -246,17 +248,17 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       cslot ^= 1;
     }
     // the next item's first tile is landing meanwhile
-    tile_epilogue<NF, MF, GEGLU ? 1 : 0>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+    tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
   }
   wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
 }
 
-template <int MODE, bool GEGLU, int BN>
+template <int MODE, bool GEGLU, int BN, bool GN = false>
 int launch4_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   constexpr int smem = 2 * (256 + BN) * 128;
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int items = (a.M / 256) * (a.N / BN) * (a.splitk > 1 ? a.splitk : 1);
@@ -272,7 +274,7 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, PROF_GEMM4 + MODE, gemm_flops(a));
-  hipLaunchKernelGGL((gemm4_kernel<MODE, GEGLU, BN>), grid, dim3(512), smem, stream, a);
+  hipLaunchKernelGGL((gemm4_kernel<MODE, GEGLU, BN, GN>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -297,5 +299,7 @@ int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
     FDMI_CHECK(a.mode == GEMM_ROW && a.splitk <= 1 && !a.accum_atomic, "gemm4: GEGLU needs a plain row GEMM");
     return launch4_t<GEMM_ROW, true, 320>(a, stream);
   }
+  if (a.gn_stats)
+    return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 320, true>(a, stream) : launch4_t<GEMM_CONV, false, 320, true>(a, stream);
   return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 320>(a, stream) : launch4_t<GEMM_CONV, false, 320>(a, stream);
 }

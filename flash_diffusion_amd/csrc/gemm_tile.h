@@ -124,6 +124,38 @@ __device__ __forceinline__ void epi_store8(const GemmArgs& a, int act, int64_t m
   }
 }
 
+// ---- GroupNorm statistics of the CONSUMER in the producing GEMM's epilogue (GemmArgs::gn_stats; opt-in, see gemm_gn_ok) ----
+// gn_stats[b][G][2] receives (sum, sum of squares) of the bf16-rounded values this wave stores -- what norm.hip's
+// gn_reduce_kernel would read back from HBM.  A lane owns NC (8 or 4) consecutive columns n.. of one row per row fragment;
+// cpg >= 8 >= NC, so its columns touch at most two groups: A = n / cpg (the first `split` columns) and B = A + 1.
+template <int NC>
+__device__ __forceinline__ void gn_lane_add(const float* v, int split, float (&s)[4]) {
+#pragma unroll
+  for (int e = 0; e < NC; ++e) {
+    const float r = bf2f(f2bf(v[e]));
+    if (e < split) { s[0] += r; s[1] = fmaf(r, r, s[1]); }
+    else           { s[2] += r; s[3] = fmaf(r, r, s[3]); }
+  }
+}
+// sum over the 16 lanes j of a lane group (the 16 rows of a fragment), then one lane adds the wave's partial sums
+__device__ __forceinline__ void gn_flush(const GemmArgs& a, int64_t mw, int n, int nc, int j, float (&s)[4]) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) s[q] += __shfl_xor(s[q], o, 64);
+  }
+  if (j == 0 && n < a.N) {
+    const int gA = n / a.gn_cpg;
+    float* d = a.gn_stats + ((mw / a.gn_rows) * a.gn_G + gA) * 2;
+    atomicAdd(d, s[0]);
+    atomicAdd(d + 1, s[1]);
+    if ((n + nc - 1) / a.gn_cpg != gA) {
+      atomicAdd(d + 2, s[2]);
+      atomicAdd(d + 3, s[3]);
+    }
+  }
+}
+
 // LDS-DMA issued from inline asm: hipcc then keeps no scoreboard entry for it, so the ONLY waits on
 // these loads are the counted ones placed by hand below (with the builtin, the waitcnt pass drained
 // the ring with vmcnt(0) at every loop back-edge of the persistent loop).  M0 (the LDS destination
@@ -145,7 +177,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // epilogue of one wave: rows mw + mf*16 + j, columns nw + nf*16 + g*4 .. +3; z = split-K slab index
 // EPI selects the compiled paths: 0 = everything but GEGLU, 1 = GEGLU only, 2 = all
-template <int NF, int MF, int EPI = 2>
+// GN: also accumulate the consumer's GroupNorm statistics (full tiles, `wide` layout, no split-K: gemm_gn_ok)
+template <int NF, int MF, int EPI = 2, bool GN = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw, int z, f32x4 (&acc)[NF][MF], int g, int j) {
   if (EPI != 1 && a.accum_atomic) {
 #pragma unroll
@@ -259,7 +292,57 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
     return;
   }
   if constexpr (EPI == 1) return;
-  if (wide) {
+  if constexpr (GN) {
+    if (wide) {   // (launch_gemm only picks a GN instantiation when gemm_gn_ok: gn_stats set, wide operands)
+      // column-pair outer, row fragment inner: the per-lane partial sums of a column chunk run over the wave's 16 * MF rows
+      // (all of one sample: gn_rows % 256 == 0) before ONE cross-lane reduction per chunk
+#pragma unroll
+      for (int pr = 0; pr < NF / 2; ++pr) {
+        const int nf = 2 * pr;
+        const int n = nw + (nf + (g & 1)) * 16 + (g >> 1) * 8;
+        const int split = (n / a.gn_cpg + 1) * a.gn_cpg - n;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int64_t m = mw + mf * 16 + j;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
+          if (m < a.M && n < a.N) {
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              v[r] = acc[nf][mf][r];
+              v[4 + r] = acc[nf + 1][mf][r];
+            }
+            epi_terms8(a, m, n, v);
+            epi_store8(a, a.act, m, n, v);   // leaves the stored (pre-rounding) values in v
+            gn_lane_add<8>(v, split, s);
+          }
+        }
+        gn_flush(a, mw, n, 8, j, s);
+      }
+      if constexpr ((NF & 1) != 0) {
+        const int n = nw + (NF - 1) * 16 + g * 4;
+        const int split = (n / a.gn_cpg + 1) * a.gn_cpg - n;
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int64_t m = mw + mf * 16 + j;
+          if (m < a.M && n < a.N) {
+            float v[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = acc[NF - 1][mf][r];
+            epi_terms3(a, m, n, v);
+            epi_store3(a, a.act, m, n, a.N, v);
+            gn_lane_add<4>(v, split, s);
+          }
+        }
+        gn_flush(a, mw, n, 4, j, s);
+      }
+      return;
+    }
+  }
+  if (!GN && wide) {
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       const int64_t m = mw + mf * 16 + j;

@@ -174,12 +174,14 @@ static int gn_rows_per_block(int B, int HW) {
 
 int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta, float* stats,
                          bf16_t* y, int B, int HW, int C, int G, float eps, int silu,
-                         hipStream_t st, bool stats_zeroed) {
+                         hipStream_t st, bool stats_zeroed, bool stats_ready) {
   FDMI_CHECK(C % 8 == 0 && C % G == 0 && G <= 32 && C <= 4096, "groupnorm: unsupported C/G");
   GnArgs a{x, nullptr, gamma, beta, stats, nullptr, y, B, HW, C, G, eps, silu, 0};
-  if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
-  hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+  if (!stats_ready) {
+    if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
+    hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+  }
   hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
   return 0;

@@ -6,7 +6,8 @@
 // ---- norm.hip ----
 int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta, float* stats,
                          bf16_t* y, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
-                         bool stats_zeroed = false);  // stats_zeroed: caller already cleared the accumulators
+                         bool stats_zeroed = false,   // stats_zeroed: caller already cleared the accumulators
+                         bool stats_ready = false);   // stats_ready: they already hold the sums (producer's GEMM epilogue)
 int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta,
                          const float* stats, float* bstats, bf16_t* dx, int B, int HW, int C, int G,
                          float eps, int silu, int accumulate, hipStream_t st, bool stats_zeroed = false);

@@ -42,6 +42,7 @@ struct T {  // NHWC / token-major bf16 activation [rows][cols] (+ lazily allocat
   int cols = 0;
   int B = 0, H = 0, W = 0;
   bool ginit = false;
+  float* gn = nullptr;   // GroupNorm sums [B][G][2] of this tensor, left by the producing GEMM's epilogue (knob 14)
 };
 
 struct Weight {
@@ -167,6 +168,7 @@ struct fdmi_unet {
   bool cast_dirty = true;
   Run runs[8];
   double last_flops = 0;     // algorithmic MFMA flops of the last forward/backward call
+  int last_gn = 0, last_gn_epi = 0;  // GroupNorms of the last forward / how many took their sums from a GEMM epilogue
 
   ~fdmi_unet() {
     for (void* p : owned) (void)hipFree(p);
@@ -460,6 +462,7 @@ struct Exec {
   hipStream_t st;
   double flops = 0;
   int ctx_mode = 0;  // 0: none, 1: fill the cross-attention K/V cache, 2: reuse it (FDMI_UNET_CTX_*)
+  bool gn_epi = false;  // developer knob 14: GroupNorm statistics in the producing GEMM's epilogue (see want_gn)
 
   bf16_t* grad_of(T* t) {  // lazily allocate the gradient buffer
     if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * 2);
@@ -478,14 +481,31 @@ struct Exec {
     if (R.dry()) return 0;
     return launch_gemm(a, st);
   }
+  // The consumer of this GEMM's output is a GroupNorm: let the epilogue accumulate its (sum, sum of squares) per (sample, group)
+  // into an accumulator of the pre-zeroed pool, so that groupnorm() skips the reduction pass over the tensor.  Only problems the
+  // 256-row kernels run without split-K qualify (gemm_gn_ok); everything else keeps the reduce kernel.  Call right before gemm(a).
+  void want_gn(GemmArgs& a, int rows_per_sample) {
+    const int G = U->cfg.groups;
+    if (!gn_epi || rows_per_sample <= 0 || a.N % G || a.accum_atomic || a.splitk != 1 || gemm_ws_bytes(a)) return;
+    a.gn_stats = (float*)(uintptr_t)256;  // (placeholder for the host-side query)
+    a.gn_rows = rows_per_sample; a.gn_G = G; a.gn_cpg = a.N / G;
+    float* s = gemm_gn_ok(a, false) ? R.zalloc((size_t)(a.M / rows_per_sample) * G * 2 * sizeof(float)) : nullptr;
+    a.gn_stats = s;
+  }
   // ---- C = A W^T style helper; accumulate=true adds into C (residual = C) ----
-  int gemm_rows(const bf16_t* A, int64_t lda, int64_t M, const bf16_t* W, int N, int K, const float* bias,
-                bf16_t* C, int64_t ldc, const bf16_t* residual, int64_t ldr, int act = ACT_NONE,
-                bf16_t* preact = nullptr) {
+  static GemmArgs rows_args(const bf16_t* A, int64_t lda, int64_t M, const bf16_t* W, int N, int K, const float* bias,
+                            bf16_t* C, int64_t ldc, const bf16_t* residual, int64_t ldr, int act = ACT_NONE,
+                            bf16_t* preact = nullptr) {
     GemmArgs a;
     a.M = (int)M; a.N = N; a.K = K; a.A = A; a.lda = lda; a.W = W; a.ldw = K; a.bias = bias;
     a.C = C; a.ldc = ldc; a.residual = residual; a.ldr = ldr; a.act = act;
     a.preact = preact; a.ldp = N;
+    return a;
+  }
+  int gemm_rows(const bf16_t* A, int64_t lda, int64_t M, const bf16_t* W, int N, int K, const float* bias,
+                bf16_t* C, int64_t ldc, const bf16_t* residual, int64_t ldr, int act = ACT_NONE,
+                bf16_t* preact = nullptr) {
+    GemmArgs a = rows_args(A, lda, M, W, N, K, bias, C, ldc, residual, ldr, act, preact);
     return gemm(a);
   }
 
@@ -523,11 +543,17 @@ struct Exec {
 
   // y = x W^T + b (+ residual) (+ LoRA)
   T* linear(T* x, LinearW& L, T* residual = nullptr) { return linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr); }
-  T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true) {
+  // gn_rows > 0: the output feeds a GroupNorm over samples of gn_rows rows (want_gn)
+  T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true, int gn_rows = 0) {
     T* y = R.mk(x->rows, w.N, x->B, x->H, x->W);
     if (!y) return nullptr;
-    NULL_IF(gemm_rows(x->p, x->cols, x->rows, w.w, w.N, w.K, w.bias, y->p, w.N, residual ? residual->p : nullptr,
-                      residual ? residual->cols : 0));
+    {
+      GemmArgs a = rows_args(x->p, x->cols, x->rows, w.w, w.N, w.K, w.bias, y->p, w.N, residual ? residual->p : nullptr,
+                             residual ? residual->cols : 0);
+      if (gn_rows > 0 && !lo) want_gn(a, gn_rows);   // (a LoRA delta is added to y afterwards: the sums would be stale)
+      NULL_IF(gemm(a));
+      y->gn = a.gn_stats;
+    }
     T* t = nullptr;
     if (lo) {
       t = R.mk(x->rows, lo->r);
@@ -592,7 +618,7 @@ struct Exec {
   }
 
   // 3x3 (or kxk) convolution on NHWC; stride 1|2, optional fused nearest-2x upsample of the input
-  T* conv(T* x, Weight& w, int stride, int ups, const bf16_t* rowvec, int64_t rowvec_ld, T* residual) {
+  T* conv(T* x, Weight& w, int stride, int ups, const bf16_t* rowvec, int64_t rowvec_ld, T* residual, bool gn_next = false) {
     const int pad = w.KH / 2;
     const int Hv = x->H << ups, Wv = x->W << ups;
     const int Ho = (Hv + 2 * pad - w.KH) / stride + 1, Wo = (Wv + 2 * pad - w.KW) / stride + 1;
@@ -606,7 +632,9 @@ struct Exec {
     a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = Ho * Wo;
     a.residual = residual ? residual->p : nullptr; a.ldr = residual ? residual->cols : 0;
     a.C = y->p; a.ldc = w.N;
+    if (gn_next) want_gn(a, Ho * Wo);
     NULL_IF(gemm(a));
+    y->gn = a.gn_stats;
     if (R.save) {
       R.tape.push_back([x, y, residual, &w, stride, ups, pad, Hv, Wv, Ho, Wo](Exec& E) -> int {
         if (!y->g) return 0;
@@ -651,12 +679,16 @@ struct Exec {
   T* groupnorm(T* x, Norm& n, float eps, int silu) {
     T* y = R.mk(x->rows, x->cols, x->B, x->H, x->W);
     const size_t sbytes = (size_t)x->B * U->cfg.groups * 2 * sizeof(float);
-    float* stats = R.zalloc(sbytes);
+    const bool ready = x->gn != nullptr;   // the producing GEMM's epilogue already left the sums (want_gn)
+    ++U->last_gn;
+    if (ready) ++U->last_gn_epi;
+    float* stats = ready ? x->gn : R.zalloc(sbytes);
     const bool zeroed = stats != nullptr;
     if (!stats) stats = (float*)R.arena.alloc(sbytes);
     if (!y || !stats) return nullptr;
     const int HW = x->H * x->W, G = U->cfg.groups;
-    if (!R.dry()) NULL_IF(launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st, zeroed));
+    if (!R.dry())
+      NULL_IF(launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st, zeroed, ready));
     if (R.save) {
       R.tape.push_back([x, y, &n, stats, HW, G, eps, silu](Exec& E) -> int {
         if (!y->g) return 0;
@@ -792,11 +824,12 @@ struct Exec {
   }
 
   // ---- blocks ----------------------------------------------------------------------------------
-  T* resnet(T* x, ResnetW& r, T* temb_all) {
+  // gn_next: the block's output goes straight into a GroupNorm (the next ResNet block's or a transformer's)
+  T* resnet(T* x, ResnetW& r, T* temb_all, bool gn_next = false) {
     const fdmi_unet_config& c = U->cfg;
     T* a = groupnorm(x, r.n1, c.eps, 1);
     if (!a) return nullptr;
-    T* h = conv(a, r.c1, 1, 0, temb_all->p + r.temb_off, temb_all->cols, nullptr);
+    T* h = conv(a, r.c1, 1, 0, temb_all->p + r.temb_off, temb_all->cols, nullptr, true);
     if (!h) return nullptr;
     T* a2 = groupnorm(h, r.n2, c.eps, 1);
     if (!a2) return nullptr;
@@ -805,12 +838,12 @@ struct Exec {
       sc = linear_w(x, r.sc);
       if (!sc) return nullptr;
     }
-    return conv(a2, r.c2, 1, 0, nullptr, 0, sc);
+    return conv(a2, r.c2, 1, 0, nullptr, 0, sc, gn_next);
   }
 
   // dup_after_attn1: x holds ONE half of a [x | x] guidance batch whose halves are identical up to here; the first
   // cross-attention (different context per half) is where they part: the state is duplicated right before it
-  T* transformer(T* x, TransformerW& t, T* ctx, int L, bool dup_after_attn1 = false) {
+  T* transformer(T* x, TransformerW& t, T* ctx, int L, bool dup_after_attn1 = false, bool gn_next = false) {
     int Bn = x->B;
     const int S = x->H * x->W;
     T* hn = groupnorm(x, t.gn, 1e-6f, 0);
@@ -873,7 +906,7 @@ struct Exec {
       h = linear_w(f, b.ff2, h);
       if (!h) return nullptr;
     }
-    return linear_w(h, t.pout, x);
+    return linear_w(h, t.pout, x, nullptr, true, gn_next ? S : 0);
   }
 };
 
@@ -884,6 +917,10 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   const fdmi_unet_config& c = U->cfg;
   Exec E{U, R, R.st};
   E.ctx_mode = (flags & FDMI_UNET_CTX_REUSE) ? 2 : ((flags & FDMI_UNET_CTX_FILL) ? 1 : 0);
+  // developer knob 14 (FDMI_TUNE=14=1): GroupNorm statistics from the producing GEMM's epilogue.  Adapter residuals are added
+  // in place AFTER their tensor was produced, so a forward that carries them keeps the reduce kernel everywhere.
+  E.gn_epi = fdmi_tune_get(14) != 0 && U->down_res.empty();
+  U->last_gn = U->last_gn_epi = 0;
   R.tensors.clear();
   R.tape.clear();
   R.arena.off = 0;
@@ -939,7 +976,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   RET_IF(E.gemm_rows(semb->p, semb->cols, B, U->temb_proj.w, U->temb_proj.N, U->temb_proj.K, U->temb_proj.bias,
                      temb_all->p, temb_all->cols, nullptr, 0));
   // ---- down ----
-  T* h = E.conv(x0, U->conv_in, 1, 0, nullptr, 0, nullptr);
+  T* h = E.conv(x0, U->conv_in, 1, 0, nullptr, 0, nullptr, true);   // -> the first ResNet block's norm1
   FAIL_IF_NULL(h);
   std::vector<T*> skips{halves ? E.dup(h) : h};
   FAIL_IF_NULL(skips[0]);
@@ -962,10 +999,13 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   for (auto& sp : U->down) {
     StageW& s = *sp;
     for (size_t j = 0; j < s.res.size(); ++j) {
-      h = E.resnet(h, *s.res[j], temb_all);
+      // what reads the block's output next: a transformer's GroupNorm / the next ResNet block's norm1 / (last block of a
+      // stage without downsampler) the mid block's norm1 -- or a downsampling conv, which has no norm in front of it
+      const bool more = j + 1 < s.res.size() || !s.has_resample;
+      h = E.resnet(h, *s.res[j], temb_all, s.has_attn || more);
       FAIL_IF_NULL(h);
       if (s.has_attn) {
-        h = E.transformer(h, *s.attn[j], ctxb, L, dup_pending);
+        h = E.transformer(h, *s.attn[j], ctxb, L, dup_pending, more);
         dup_pending = false;
         FAIL_IF_NULL(h);
         if (j + 1 == s.res.size()) RET_IF(add_res(h));
@@ -973,16 +1013,16 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
       skips.push_back(h);
     }
     if (s.has_resample) {
-      h = E.conv(h, s.resample, 2, 0, nullptr, 0, nullptr);
+      h = E.conv(h, s.resample, 2, 0, nullptr, 0, nullptr, true);   // -> the next stage's first norm1
       FAIL_IF_NULL(h);
       skips.push_back(h);
     }
     if (!s.has_attn) RET_IF(add_res(h));
   }
   // ---- mid ----
-  h = E.resnet(h, *U->mid_r0, temb_all);
+  h = E.resnet(h, *U->mid_r0, temb_all, true);
   FAIL_IF_NULL(h);
-  h = E.transformer(h, *U->mid_attn, ctxb, L);
+  h = E.transformer(h, *U->mid_attn, ctxb, L, false, true);
   FAIL_IF_NULL(h);
   h = E.resnet(h, *U->mid_r1, temb_all);
   FAIL_IF_NULL(h);
@@ -994,10 +1034,13 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
         skips.pop_back();
         T* hc = E.cat(h, sk);
         FAIL_IF_NULL(hc);
-        h = E.resnet(hc, *s.res[j], temb_all);
+        // the up path's block outputs are concatenated with a skip before the next norm (no statistics to pass on), except
+        // the very last one, which conv_norm_out reads
+        const bool last = &sp == &U->up.back() && j + 1 == s.res.size() && !s.has_resample;
+        h = E.resnet(hc, *s.res[j], temb_all, s.has_attn || last);
         FAIL_IF_NULL(h);
         if (s.has_attn) {
-          h = E.transformer(h, *s.attn[j], ctxb, L);
+          h = E.transformer(h, *s.attn[j], ctxb, L, false, last);
           FAIL_IF_NULL(h);
         }
       }
@@ -1142,6 +1185,10 @@ int fdmi_unet_backward(fdmi_unet* U, int slot, const float* grad_out, float* gra
 }
 
 double fdmi_unet_last_flops(fdmi_unet* U) { return U ? U->last_flops : 0.0; }
+int fdmi_unet_last_gn_epilogue(fdmi_unet* U, int* total) {
+  if (total) *total = U ? U->last_gn : 0;
+  return U ? U->last_gn_epi : 0;
+}
 
 int fdmi_unet_set_down_residuals(fdmi_unet* U, const float* const* residuals, int n, float scale) {
   FDMI_CHECK(U != nullptr, "null plan");

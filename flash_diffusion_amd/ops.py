@@ -46,9 +46,10 @@ def geglu_perm(n_half, device=None):
 # ---- GEMM / conv -------------------------------------------------------------------------------
 def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows_per_batch=1, residual=None,
          act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1, ws=None, accum_atomic=False,
-         force_tile=0, use_glds=True, conv=None):
+         force_tile=0, use_glds=True, conv=None, gn=None):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue).  conv: dict(Hin,Win,Cin,Hout,Wout,KH,KW,stride,pad,ups,dgrad)
-    with A the NHWC activation."""
+    with A the NHWC activation.  gn=(stats [B,G,2] f32 zeroed, rows_per_sample): the epilogue also accumulates the GroupNorm
+    sums of the output (fdmi_gemm_gn; raises when the problem's kernel cannot -- ask gemm_gn_ok first)."""
     _dev(A)
     d = GemmDesc()
     N = W.shape[0] if N is None else N
@@ -78,8 +79,26 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
         ws = torch.empty((splitk if splitk > 1 else 16) * M * N, dtype=torch.float32, device=A.device)
     d.splitk, d.ws = splitk, ptr(ws)
     d.accum_atomic, d.force_tile, d.use_glds = int(accum_atomic), force_tile, int(use_glds)
-    check(lib().fdmi_gemm(C.byref(d), stream_ptr()))
+    if gn is not None:
+        stats, rows = gn
+        assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[2] == 2
+        check(lib().fdmi_gemm_gn(C.byref(d), ptr(stats), rows, stats.shape[1], stream_ptr()))
+    else:
+        check(lib().fdmi_gemm(C.byref(d), stream_ptr()))
     return out
+
+
+def gemm_gn_ok(M, N, K, rows_per_sample, G, conv=None, ldc=None, **fields):
+    """host-only: would fdmi_gemm_gn accept this problem (a 256-row kernel, no split-K, full tiles inside one sample)?"""
+    d = GemmDesc()
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.splitk, d.use_glds, d.alpha = M, N, K, K, K, (N if ldc is None else ldc), 1, 1, 1.0
+    if conv is not None:
+        d.mode = 1
+        for k, v in conv.items():
+            setattr(d, k, int(v))
+    for k, v in fields.items():
+        setattr(d, k, v)
+    return bool(lib().fdmi_gemm_gn_ok(C.byref(d), rows_per_sample, G))
 
 
 def conv2d_nhwc(x, w_packed, *, KH, KW, stride=1, pad=0, ups=0, dgrad=0, out_hw=None, **kw):
@@ -106,6 +125,15 @@ def groupnorm_fwd(x, gamma, beta, G, eps, silu):
     check(lib().fdmi_groupnorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(y), B, HW, Cc, G, eps,
                                    int(silu), stream_ptr()))
     return y, stats
+
+
+def groupnorm_apply(x, gamma, beta, stats, eps, silu):
+    """groupnorm_fwd without its reduction pass: stats [B,G,2] already hold (sum, sum of squares) per (sample, group)"""
+    B, HW, Cc = x.shape
+    y = torch.empty_like(x)
+    check(lib().fdmi_groupnorm_apply(ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(y), B, HW, Cc, stats.shape[1], eps,
+                                     int(silu), stream_ptr()))
+    return y
 
 
 def groupnorm_bwd(x, dy, gamma, beta, stats, G, eps, silu, dx=None):

@@ -65,6 +65,15 @@ int fdmi_gemm(const fdmi_gemm_desc* d, void* stream);
  * 2 = 256 x 320 (gemm4.hip); the tile and the split-K factor that fdmi_gemm would use (splitk <= 0 in the descriptor
  * = let the planner split).  No device work, no GPU needed.                                       */
 int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_t* BN, int32_t* splitk);
+/* The GEMM / conv above whose epilogue ALSO accumulates the GroupNorm statistics of its output for the consumer:
+ * gn_stats[m / gn_rows][gn_G][2] += (sum, sum of squares) of the stored bf16 values over each group of N / gn_G channels
+ * (caller pre-zeroes gn_stats; gn_rows = rows per sample = H*W).  Only the 256-row kernels without split-K own this epilogue:
+ * fdmi_gemm_gn_ok (host only, no GPU needed) returns 1 when fdmi_gemm_gn will accept the problem, 0 otherwise (then run
+ * fdmi_gemm and fdmi_groupnorm_fwd).  fdmi_groupnorm_apply is fdmi_groupnorm_fwd without its reduction pass.        */
+int fdmi_gemm_gn_ok(const fdmi_gemm_desc* d, int gn_rows, int gn_G);
+int fdmi_gemm_gn(const fdmi_gemm_desc* d, float* gn_stats, int gn_rows, int gn_G, void* stream);
+int fdmi_groupnorm_apply(const void* x, const float* gamma, const float* beta, const float* stats /*[B][G][2] sums*/,
+                         void* y, int B, int HW, int C, int G, float eps, int silu, void* stream);
 
 /* ---------------- normalisation (NHWC / token-major bf16, fp32 statistics) -------------------- */
 int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, float* stats /*[B][G][2]*/,
@@ -203,6 +212,9 @@ int fdmi_unet_forward(fdmi_unet* u, int slot, const float* sample, const float* 
 /* grad_out: f32 NCHW gradient of the forward's output; grad_sample: f32 NCHW or NULL */
 int fdmi_unet_backward(fdmi_unet* u, int slot, const float* grad_out, float* grad_sample, void* stream);
 double fdmi_unet_last_flops(fdmi_unet* u);  /* algorithmic MFMA flops of the last forward/backward */
+/* GroupNorms of the last forward (or workspace query) whose statistics were accumulated by the producing GEMM's epilogue
+ * (developer knob 14, see fdmi_gemm_gn); *total = all GroupNorms of that forward.                                      */
+int fdmi_unet_last_gn_epilogue(fdmi_unet* u, int* total);
 /* T2I-adapter residuals (`down_intrablock_additional_residuals`, unet.py:100-106 / flash_diffusion_model.py:208-218) for the
  * NEXT fdmi_unet_forward on this plan, consumed by it: residuals[i] is an f32 NCHW tensor with the shape of down block i's
  * output (NULL entries are skipped), added times `scale` where diffusers adds it: after the last (resnet, attention) pair of

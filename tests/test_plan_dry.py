@@ -86,3 +86,83 @@ def test_cfg_halves_removes_exactly_the_shared_prefix(arch, B, HW):
 def test_odd_batch_ignores_cfg_halves_and_bad_sizes_fail():
     m, plan = _plan(TINY)
     assert _query(plan, 3, 32, 77, FDMI_UNET_CFG_HALVES)[1] == _query(plan, 3, 32, 77, 0)[1]
+
+
+# ---- GroupNorm statistics in the producing GEMM's epilogue (developer knob 14; GPU numerics in tests/test_zz_dit_gpu.py) ----
+def _gn_plan(B, H, Ci, Co, kind):
+    import ctypes as C
+    from flash_diffusion_amd import ops
+    HW = H * H
+    d = _lib.GemmDesc()
+    d.M, d.N, d.K = B * HW, Co, (9 * Ci if kind == "conv" else Ci)
+    conv = None
+    if kind == "conv":
+        conv = dict(Hin=H, Win=H, Cin=Ci, Hout=H, Wout=H, KH=3, KW=3, stride=1, pad=1)
+        d.mode = 1
+        for k, v in conv.items():
+            setattr(d, k, v)
+    d.lda = d.ldw = d.K
+    d.splitk, d.use_glds, d.alpha, d.ldc = 1, 1, 1.0, Co
+    out = [C.c_int32() for _ in range(4)]
+    assert _lib.lib().fdmi_gemm_plan(C.byref(d), *[C.byref(x) for x in out]) == 0
+    return ops.gemm_gn_ok(B * HW, Co, d.K, HW, 32, conv=conv), out[0].value, out[2].value
+
+
+def test_gn_epilogue_test_problems_cover_all_three_kernels():
+    """the op-level GPU test's problems are eligible and reach the 256x320, 256x160 and 256x128 instantiations"""
+    from tests.test_zz_dit_gpu import GN_EPI
+    seen = set()
+    for cfg in GN_EPI:
+        ok, kernel, bn = _gn_plan(*cfg)
+        assert ok, cfg
+        seen.add((kernel, bn))
+    assert seen == {(2, 320), (1, 160), (1, 128)}, seen
+
+
+def test_gn_epilogue_eligibility():
+    from flash_diffusion_amd import ops
+    cv = lambda H, C: dict(Hin=H, Win=H, Cin=C, Hout=H, Wout=H, KH=3, KW=3, stride=1, pad=1)
+    assert ops.gemm_gn_ok(16 * 4096, 320, 2880, 4096, 32, conv=cv(64, 320))         # SD1.5 level 0 conv
+    assert ops.gemm_gn_ok(65536, 320, 320, 4096, 32)                                # proj_out (+ residual) at level 0
+    assert not ops.gemm_gn_ok(16 * 64, 1280, 11520, 64, 32, conv=cv(8, 1280))       # 8x8 level: a 256-row tile spans 4 samples
+    assert not ops.gemm_gn_ok(65536, 128, 320, 4096, 32)                            # 4 channels per group < the 8-column chunk
+    assert not ops.gemm_gn_ok(65536, 320, 320, 4096, 32, out_f32=1)                 # sums are defined on the stored bf16 values
+    assert not ops.gemm_gn_ok(65536, 320, 320, 4096, 32, splitk=4)                  # split-K slabs: no single owner of a value
+    assert not ops.gemm_gn_ok(65536 + 128, 320, 320, 4096, 32)                      # ragged M
+    assert not ops.gemm_gn_ok(65536, 320, 320, 4096, 32, ldc=324)                   # output rows not 16-byte aligned
+    assert not ops.gemm_gn_ok(200, 320, 320, 100, 32)                               # too small for a 256-row kernel
+
+
+def test_plan_takes_groupnorm_sums_from_the_epilogue_only_behind_knob_14():
+    """workspace-query walk of the SD1.5 plan: with the knob, the GroupNorms fed by an eligible conv / linear (64x64 and 32x32
+    levels; the up path's concatenated inputs and the small levels keep the reduce kernel) skip their reduction; FLOPs and
+    workspace are unchanged; a forward carrying T2I-adapter residuals (added in place after production) never uses it"""
+    import ctypes as C
+    lib = _lib.lib()
+    m, plan = _plan(SD15)
+
+    def counts(B, flags):
+        ws, fl = _query(plan, B, 64, 77, flags)
+        tot = C.c_int32()
+        n = lib.fdmi_unet_last_gn_epilogue(plan.handle, C.byref(tot))
+        return ws, fl, n, tot.value
+
+    base = counts(16, 0)
+    assert base[2] == 0 and base[3] == 61
+    lib.fdmi_tune_set(14, 1)
+    try:
+        on = counts(16, 0)
+        assert on[:2] == base[:2] and on[3] == 61 and 20 <= on[2] <= 25, on
+        on2 = counts(32, FDMI_UNET_CTX_FILL | FDMI_UNET_CFG_HALVES)
+        assert on2[2] >= on[2]                     # the 2B teacher batch fills the 256x320 grid at the 32x32 level too
+        sv = counts(16, FDMI_UNET_SAVE)
+        assert sv[2] == on[2]                      # same forward when the tape is recorded
+        null = (C.c_void_p * 4)()
+        assert lib.fdmi_unet_set_down_residuals(plan.handle, null, 4, C.c_float(1.0)) == 0
+        assert counts(16, 0)[2] == 0
+        assert lib.fdmi_unet_set_down_residuals(plan.handle, None, 0, C.c_float(1.0)) == 0
+        mt, pt = _plan(TINY)
+        _query(pt, 2, 32, 77, 0)
+        assert lib.fdmi_unet_last_gn_epilogue(pt.handle, None) == 0     # nothing in the tiny plan reaches a 256-row kernel
+    finally:
+        lib.fdmi_tune_set(14, 0)

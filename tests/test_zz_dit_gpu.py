@@ -375,3 +375,109 @@ def _body_test_rccl_allreduce_entry_points_world_1():
     finally:
         check(L.fdmi_allreduce_destroy())
     assert L.fdmi_allreduce_world() == 0
+
+
+# ---- GroupNorm statistics in the producing GEMM's epilogue (fdmi_gemm_gn, developer knob 14) ------------------------------
+# (B, H = W, Cin, Cout, kind): conv3x3 / 1x1-as-row-GEMM problems.  The planner (fdmi_gemm_plan, checked on CPU in
+# tests/test_plan_dry.py) sends the first three to the 256 x 320 kernel (M = 65536 / 32768 rows), the next ones to the
+# 256 x 160 ring kernel (5 fragments per wave: pairs + the 4-column tail path; group widths 10 and 15 straddle the 8-column
+# chunks) and to the 256 x 128 one (group width 8 and 20)
+GN_EPI = [(16, 64, 64, 320, "conv"), (16, 64, 320, 320, "row"), (8, 64, 128, 640, "conv"),
+          (2, 32, 64, 320, "conv"), (4, 16, 320, 320, "row"), (2, 16, 64, 480, "conv"), (2, 16, 192, 480, "row"),
+          (1, 32, 128, 640, "conv"), (2, 32, 128, 256, "row")]
+
+
+@pytest.mark.parametrize("cfg", GN_EPI)
+def test_gemm_epilogue_groupnorm_statistics(cfg):
+    run_isolated(__name__, "_body_test_gemm_epilogue_groupnorm_statistics", (cfg,))
+
+
+def _body_test_gemm_epilogue_groupnorm_statistics(cfg):
+    """the GN instantiation of the 256-row kernels: (a) its output is bit-identical to the plain launch, (b) the accumulated
+    (sum, sum of squares) equal the sums over the stored bf16 tensor, (c) groupnorm_apply on them equals groupnorm_fwd"""
+    ops = _ops()
+    B, H, Ci, Co, kind = cfg
+    G, HW = 32, H * H
+    x = b16(rnd(B, H, H, Ci, seed=1)).cuda()
+    bias = rnd(Co, seed=3).cuda()
+    res = b16(rnd(B * HW, Co, seed=4)).cuda()
+    rowvec = b16(rnd(B, Co, seed=5)).cuda()
+    if kind == "conv":
+        w = ops.pack_conv_weight(b16(rnd(Co, Ci, 3, 3, seed=2, scale=(Ci * 9) ** -0.5)).float()).cuda()
+        conv = dict(Hin=H, Win=H, Cin=Ci, Hout=H, Wout=H, KH=3, KW=3, stride=1, pad=1)
+        kw = dict(M=B * HW, conv=conv, bias=bias, rowvec=rowvec, rows_per_batch=HW, residual=res)
+        assert ops.gemm_gn_ok(B * HW, Co, 9 * Ci, HW, G, conv=conv), "test problem must be eligible"
+        A = x
+    else:
+        w = b16(rnd(Co, Ci, seed=2, scale=Ci ** -0.5)).cuda()
+        kw = dict(bias=bias, residual=res)
+        assert ops.gemm_gn_ok(B * HW, Co, Ci, HW, G), "test problem must be eligible"
+        A = x.view(B * HW, Ci)
+    plain = ops.gemm(A, w, **kw)
+    stats = torch.zeros(B, G, 2, dtype=torch.float32, device="cuda")
+    y = ops.gemm(A, w, gn=(stats, HW), **kw)
+    torch.cuda.synchronize()
+    assert torch.equal(y, plain), "the GN instantiation must store exactly what the plain kernel stores"
+    yf = y.float().view(B, HW, G, Co // G)
+    ref = torch.stack([yf.sum((1, 3)), (yf * yf).sum((1, 3))], -1)
+    close(f"gn_epi_sums{cfg}", stats, ref, tol_el=2e-4, tol_fro=1e-4)
+    gamma, beta = (rnd(Co, seed=6) * 0.2 + 1).cuda(), rnd(Co, seed=7).cuda()
+    want, st2 = ops.groupnorm_fwd(y.view(B, HW, Co), gamma, beta, G, 1e-5, 1)
+    close(f"gn_epi_reduce{cfg}", st2, ref, tol_el=2e-4, tol_fro=1e-4)
+    got = ops.groupnorm_apply(y.view(B, HW, Co), gamma, beta, stats, 1e-5, 1)
+    close(f"gn_epi_apply{cfg}", got, want.float(), tol_el=2 ** -6, tol_fro=2e-3)
+
+
+def test_gemm_gn_refuses_ineligible_problems():
+    run_isolated(__name__, "_body_test_gemm_gn_refuses_ineligible_problems", ())
+
+
+def _body_test_gemm_gn_refuses_ineligible_problems():
+    ops = _ops()
+    A, w = b16(rnd(128, 64, seed=1)).cuda(), b16(rnd(64, 64, seed=2)).cuda()     # M < 256: no 256-row kernel
+    stats = torch.zeros(1, 32, 2, device="cuda")
+    with pytest.raises(RuntimeError, match="gn_stats"):
+        ops.gemm(A, w, gn=(stats, 128))
+
+
+def test_unet_forward_with_epilogue_groupnorm_statistics():
+    run_isolated(__name__, "_body_test_unet_forward_with_epilogue_groupnorm_statistics", (), timeout=900)
+
+
+def _body_test_unet_forward_with_epilogue_groupnorm_statistics():
+    """developer knob 14 on the full-width SD1.5 plan (B = 2, 64x64 latents): a third of the GroupNorms take their sums from the
+    producing conv / linear, the forward and the input gradient agree with the reduce-kernel path up to bf16 rounding noise"""
+    import ctypes as C
+    from flash_diffusion_amd import _lib
+    from flash_diffusion_amd.unet import MiUNet2DConditionModel
+    from flash_diffusion_amd.workloads import SD15
+    L = _lib.lib()
+    torch.manual_seed(0)
+    net = MiUNet2DConditionModel(**SD15).cuda()
+    net.freeze()
+    g = torch.Generator(device="cpu").manual_seed(1)
+    x = torch.randn(2, 4, 64, 64, generator=g).cuda()
+    t = torch.tensor([801.0, 301.0]).cuda()
+    ctx = {"cond": {"crossattn": torch.randn(2, 77, 768, generator=g).cuda()}}
+    w = torch.randn(2, 4, 64, 64, generator=g).cuda()
+
+    def run():
+        xr = x.clone().requires_grad_()
+        out = net(xr, t, ctx)
+        (out * w).sum().backward()
+        torch.cuda.synchronize()
+        tot = C.c_int32()
+        return out.detach().clone(), xr.grad.clone(), L.fdmi_unet_last_gn_epilogue(net._plan().handle, C.byref(tot)), tot.value
+
+    ref, gref, n0, tot0 = run()
+    again, gagain, _, _ = run()
+    noise = max(rel_err(again, ref), 2e-3)          # float-atomic GroupNorm sums differ from run to run
+    gnoise = max(rel_err(gagain, gref), 4e-3)
+    L.fdmi_tune_set(14, 1)
+    try:
+        got, ggot, n1, tot1 = run()
+    finally:
+        L.fdmi_tune_set(14, 0)
+    assert n0 == 0 and tot0 == tot1 == 61 and n1 >= 12, (n0, n1, tot1)
+    assert torch.isfinite(got).all() and rel_err(got, ref) <= 4 * noise, (rel_err(got, ref), noise)
+    assert rel_err(ggot, gref) <= 4 * gnoise, (rel_err(ggot, gref), gnoise)
