@@ -64,12 +64,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16 (8 for pixart: C4)")
-    ap.add_argument("--hw", type=int, default=None, help="latent height = width; default 64 (128 for pixart: C4)")
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (weak scaling); default 16 (C2); 8 for sdxl / pixart "
+                                                            "(C3 / C4), 4 for sd3 (C5)")
+    ap.add_argument("--hw", type=int, default=None, help="latent height = width; default 64 (C2); 128 for sdxl / pixart / sd3")
     ap.add_argument("--teacher-steps", type=int, default=4)
     ap.add_argument("--arch", default="sd15", choices=["sd15", "sdxl", "tiny", "pixart", "tiny_pixart", "sd3", "tiny_sd3"],
-                    help="sd15 = the headline workload C2; the others are developer legs (SURVEY 8a C3 / C4 shapes)")
-    ap.add_argument("--lora-rank", type=int, default=None, help="default 128 (sd15/sdxl), 64 (pixart), 8 (tiny*)")
+                    help="sd15 = the headline workload C2; the others are developer legs at BASELINE.json's C3 / C4 / C5 "
+                         "per-GPU shapes (sdxl: B=8, 128x128 latents, r64; --batch 16 --hw 64 --lora-rank 128 reproduces "
+                         "profiles/r1_bench_sdxl_b16_64x64.json)")
+    ap.add_argument("--lora-rank", type=int, default=None, help="default 128 (sd15), 64 (sdxl / pixart / sd3: SURVEY C.4), 8 (tiny*)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (sampler, 2-optimizer step)")
@@ -99,10 +102,10 @@ def main():
     dit = args.arch.endswith("pixart")
     sd3 = args.arch.endswith("sd3")
     if args.batch is None:
-        args.batch = {"pixart": 8, "sd3": 4}.get(args.arch, 16)
+        args.batch = {"sdxl": 8, "pixart": 8, "sd3": 4}.get(args.arch, 16)
     if args.hw is None:
-        args.hw = 128 if args.arch in ("pixart", "sd3") else (16 if args.arch.startswith("tiny_") else 64)
-    rank_r = args.lora_rank or (8 if args.arch.startswith("tiny") else (64 if (dit or sd3) else 128))
+        args.hw = 128 if args.arch in ("sdxl", "pixart", "sd3") else (16 if args.arch.startswith("tiny_") else 64)
+    rank_r = args.lora_rank or (8 if args.arch.startswith("tiny") else (64 if (dit or sd3 or args.arch == "sdxl") else 128))
     if sd3:
         model = build_flash_sd3(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, B=args.batch,
                                 L=333 if args.arch == "sd3" else 7, device="cuda", seed=0)

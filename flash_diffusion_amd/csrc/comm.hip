@@ -37,7 +37,8 @@ int bind_rccl() {
   for (const char* n : names)
     if (!h) h = dlopen(n, RTLD_NOW | RTLD_LOCAL);
   if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
-  FDMI_CHECK(h != nullptr, std::string("allreduce: cannot load librccl.so: ") + (dlerror() ? dlerror() : "?"));
+  const char* why = h ? nullptr : dlerror();   // (dlerror() clears the message: read it once)
+  FDMI_CHECK(h != nullptr, std::string("allreduce: cannot load librccl.so: ") + (why ? why : "?"));
   Rccl r;
   r.h = h;
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
