@@ -181,14 +181,19 @@ def main():
         ach = tfl / (tms * 1e-3) / 1e12
         # HBM bytes per launch of that kernel family: PMC numbers cannot be collected from inside this process, so the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command is read back (null if absent)
-        traffic = None
-        try:
-            with open(os.path.join(ROOT, "profiles", "r1_traffic.json")) as fh:
+        traffic = traffic_src = None
+        try:   # the newest round's summary (profiles/rN_traffic.json, written by scripts/rocprof_to_profiles.py)
+            import glob
+            import re
+            cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")),
+                           key=lambda f: int(re.search(r"r(\d+)_traffic", f).group(1)))
+            with open(cands[-1]) as fh:
                 traffic = json.load(fh)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
-        except (OSError, ValueError, KeyError):
+            traffic_src = os.path.relpath(cands[-1], ROOT)
+        except (OSError, ValueError, KeyError, IndexError, AttributeError):
             traffic = None
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
-                    "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic, "launches_per_step": int(tln),
+                    "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": int(tln),
                     "avg_launch_us": tms * 1e3 / tln, "algorithmic_gflop_per_launch": tfl / tln / 1e9,
                     "all_mfma_kernels": {r[0]: {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),
                                                 "launches": int(r[3])} for r in rows},
