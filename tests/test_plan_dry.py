@@ -157,6 +157,7 @@ def test_plan_takes_groupnorm_sums_from_the_epilogue_only_behind_knob_14():
         assert on2[2] >= on[2]                     # the 2B teacher batch fills the 256x320 grid at the 32x32 level too
         sv = counts(16, FDMI_UNET_SAVE)
         assert sv[2] == on[2]                      # same forward when the tape is recorded
+        assert counts(8, FDMI_UNET_SAVE | FDMI_UNET_INPUT_GRAD)[2] == 15     # the configuration of the GPU test (test_zz_dit_gpu.py)
         null = (C.c_void_p * 4)()
         assert lib.fdmi_unet_set_down_residuals(plan.handle, null, 4, C.c_float(1.0)) == 0
         assert counts(16, 0)[2] == 0
