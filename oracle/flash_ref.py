@@ -156,12 +156,23 @@ def predicted_x0_eps(eps, t, x_t, sqrt_ac, sigmas, fallback):
     return out
 
 
-def distill_loss(kind, s, t):
-    """FD:368-382 (l2 / l1; lpips needs pretrained VAE+VGG weights -> out of scope here)."""
+def distill_loss(kind, s, t, vae=None, lpips_model=None):
+    """FD:368-399.  lpips: the centre 64x64 latent crop of both outputs (the reference's slice expression verbatim -- for latents
+    smaller than 64 its negative start selects the trailing rows / columns) is decoded by the VAE, clamped to [-1, 1] and
+    compared by the LPIPS network; the pretrained VAE / VGG weights are not available offline, so the two modules are the
+    caller's (tests: oracle.unet_cpu.TinyVAE / TinyLPIPS)."""
     if kind == "l2":
         return torch.mean(((s - t) ** 2).reshape(s.shape[0], -1), 1).mean()
     if kind == "l1":
         return torch.mean(torch.abs(s - t).reshape(s.shape[0], -1), 1).mean()
+    if kind == "lpips":
+        crop_h = (s.shape[2] - 64) // 2                                                  # FD:385-386
+        crop_w = (s.shape[3] - 64) // 2
+        s = s[:, :, crop_h:crop_h + 64, crop_w:crop_w + 64]
+        t = t[:, :, crop_h:crop_h + 64, crop_w:crop_w + 64]
+        ds = vae.decode(s).clamp(-1, 1)                                                  # FD:394-395
+        dt = vae.decode(t).clamp(-1, 1)
+        return lpips_model(ds, dt).mean()                                                # FD:397
     raise NotImplementedError(kind)
 
 
@@ -204,9 +215,8 @@ class FlashDiffusionRef(torch.nn.Module):
 
     def __init__(self, config, student_denoiser, teacher_denoiser=None, teacher_noise_scheduler=None,
                  teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None, vae=None,
-                 conditioner=None, adapter=None, discriminator=None):
+                 conditioner=None, adapter=None, discriminator=None, lpips_model=None):
         super().__init__()
-        assert vae is None, "VAE is out of scope (SURVEY.md 2.1 row 6)"
         self.adapter = adapter                                               # FD:91-94 (T2I adapter: image -> residual list)
         self.adapter_conditioning_scale = config.adapter_conditioning_scale
         self.adapter_input_key = config.adapter_input_key
@@ -217,7 +227,12 @@ class FlashDiffusionRef(torch.nn.Module):
         self.teacher_noise_scheduler = teacher_noise_scheduler
         self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
         self.sampling_noise_scheduler = sampling_noise_scheduler
-        self.vae = None
+        # FD:67: any module with the AutoencoderKLDiffusers surface the step touches (config.input_key, encode, decode,
+        # latent_channels, downsampling_factor; vae/autoencoderKL.py:11-128); the pretrained network itself is out of scope
+        self.vae = vae
+        if config.distill_loss_type == "lpips":                              # FD:102-103 builds lpips.LPIPS(net="vgg") itself;
+            assert vae is not None and lpips_model is not None               # that package / its weights are absent here
+            self.lpips = lpips_model
         self.conditioner = conditioner
         self.discriminator = discriminator
         self.iter_steps = 0
@@ -235,7 +250,7 @@ class FlashDiffusionRef(torch.nn.Module):
         if self.conditioner is None:
             return None
         return self.conditioner(batch, ucg_keys=ucg_keys, set_ucg_rate_zero=set_ucg_rate_zero,
-                                vae=None, *a, **k)
+                                vae=self.vae, *a, **k)
 
     def forward(self, batch, batch_idx=0, step=0, *args, **kwargs):
         cfg = self.config
@@ -243,7 +258,11 @@ class FlashDiffusionRef(torch.nn.Module):
         d = self.draws if self.draws is not None else Draws()
         self.last_draws = d
         self.iter_steps += 1                                                  # FD:181
-        z = batch[self.input_key]                                             # FD:185
+        if self.vae is not None:                                              # FD:128-133, 182-183
+            with torch.no_grad():
+                z = self.vae.encode(batch[self.vae.config.input_key])
+        else:
+            z = batch[self.input_key]                                         # FD:185
         conditioning = self._cond(batch, set_ucg_rate_zero=True, *args, **kwargs)   # FD:188
         student_conditioning = self._cond(batch, *args, **kwargs)                   # FD:192
         if cfg.use_empty_prompt and "text" in cfg.ucg_keys:                   # FD:194-199
@@ -297,7 +316,8 @@ class FlashDiffusionRef(torch.nn.Module):
                 x = sch.step(e, t, x, return_dict=False)[0]
         teacher_output = x
         student_output = c_skip * x_init + c_out * x0_s                       # FD:328
-        l_distill = distill_loss(cfg.distill_loss_type, student_output, teacher_output)
+        l_distill = distill_loss(cfg.distill_loss_type, student_output, teacher_output, self.vae,
+                                 getattr(self, "lpips", None))
         loss = l_distill * cfg.distill_loss_scale[K_step]
         self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": float(g)}
         if cfg.use_dmd_loss:                                                  # FD:335-345
@@ -405,7 +425,7 @@ class FlashDiffusionRef(torch.nn.Module):
                                         down_intrablock_additional_residuals=res)
             e = guidance_scale * e_c + (1 - guidance_scale) * e_u
             sample = ss.step(e, t, sample, return_dict=False)[0]
-        decoded = sample                                                                       # vae is None (FD:869-872)
+        decoded = self.vae.decode(sample) if self.vae is not None else sample                  # FD:865-868
         decoded_ref = None
         if log_teacher_samples:                                                                # FD:876-913
             ts = self.teacher_sampling_noise_scheduler
@@ -420,7 +440,7 @@ class FlashDiffusionRef(torch.nn.Module):
                                             down_intrablock_additional_residuals=res)
                 e = teacher_guidance_scale * e_c + (1 - teacher_guidance_scale) * e_u
                 ref = ts.step(e, t, ref, return_dict=False)[0]
-                decoded_ref = ref
+                decoded_ref = self.vae.decode(ref) if self.vae is not None else ref            # FD:910-913 (every step)
         return decoded, decoded_ref
 
     # ---- FD:917-1019 ----
@@ -449,7 +469,12 @@ class FlashDiffusionRef(torch.nn.Module):
         else:
             batch_uncond = None
         if input_shape is None:
-            raise ValueError("input_shape must be passed when no VAE is used in the model")   # FD:985-988
+            if self.vae is not None:                                                           # FD:977-984
+                px = batch[self.vae.config.input_key].shape[2:]
+                input_shape = (self.vae.latent_channels, px[0] // self.vae.downsampling_factor,
+                               px[1] // self.vae.downsampling_factor)
+            else:
+                raise ValueError("input_shape must be passed when no VAE is used in the model")   # FD:985-988
         for n in num_steps:
             z = torch.randn(N, *input_shape).to(device)                                        # FD:992
             samples, samples_ref = self.sample(z, num_steps=n, conditioner_inputs=batch,

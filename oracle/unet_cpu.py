@@ -484,3 +484,65 @@ class TinyT2IAdapter(nn.Module):
             x = F.avg_pool2d(cond, 1 << i) if i else cond
             out.append(c(x))
         return out
+
+
+class TinyVAE(nn.Module):
+    """Test stand-in for flash.models.vae.AutoencoderKLDiffusers (vae/autoencoderKL.py:11-128; diffusers' AutoencoderKL and its
+    pretrained weights are absent): exactly the surface FlashDiffusion touches -- `config.input_key`, `latent_channels`,
+    `downsampling_factor`, `encode(images) -> latents * scaling_factor` (deterministic here: the posterior mean),
+    `decode(latents) -> images` with the division by the scaling factor (autoencoderKL.py:78-79) -- around a frozen
+    two-conv encoder / decoder."""
+
+    def __init__(self, latent_channels=4, downsampling_factor=2, input_key="image", scaling_factor=0.18215, seed=21):
+        super().__init__()
+        from types import SimpleNamespace
+        self.config = SimpleNamespace(input_key=input_key)
+        self.latent_channels, self.downsampling_factor, self.scaling_factor = latent_channels, downsampling_factor, scaling_factor
+        f = downsampling_factor
+        self.enc = nn.Conv2d(3, latent_channels, f, f)
+        self.dec1 = nn.Conv2d(latent_channels, 12, 3, 1, 1)
+        self.dec2 = nn.Conv2d(12, 3, 3, 1, 1)
+        g = torch.Generator().manual_seed(seed)
+        for p in self.parameters():
+            p.data.copy_(torch.randn(p.shape, generator=g) * (0.5 / max(1, p[0].numel()) ** 0.5 if p.dim() > 1 else 0.05))
+            p.requires_grad = False
+
+    def encode(self, x):
+        return self.enc(x) * self.scaling_factor
+
+    def decode(self, z):
+        h = F.interpolate(z / self.scaling_factor, scale_factor=float(self.downsampling_factor), mode="nearest")
+        return 0.6 * self.dec2(F.silu(self.dec1(h)))   # (for unit-variance latents ~10 % of the pixels leave [-1, 1]: the clamp of FD:394 acts)
+
+
+class TinyLPIPS(nn.Module):
+    """Test stand-in for lpips.LPIPS(net="vgg") (lpips==0.1.4, setup.py:40; package and VGG16 weights absent), same structure
+    at toy width: fixed input shift / scale, a ReLU conv feature pyramid with 2x2 max-pools between its slices, per-layer
+    channel-unit-normalisation, squared difference, a non-negative 1x1 `lin` head, spatial mean, sum over layers ->
+    [B, 1, 1, 1].  Frozen (the reference never trains it)."""
+
+    def __init__(self, widths=(8, 12, 16), seed=22):
+        super().__init__()
+        self.register_buffer("shift", torch.tensor([-.030, -.088, -.188])[None, :, None, None])
+        self.register_buffer("scale", torch.tensor([.458, .448, .450])[None, :, None, None])
+        chans = (3,) + tuple(widths)
+        self.slices = nn.ModuleList([nn.Conv2d(chans[i], chans[i + 1], 3, 1, 1) for i in range(len(widths))])
+        self.lins = nn.ModuleList([nn.Conv2d(c, 1, 1, bias=False) for c in widths])
+        g = torch.Generator().manual_seed(seed)
+        for p in self.parameters():
+            p.data.copy_(torch.randn(p.shape, generator=g) * (1.0 / max(1, p[0].numel()) ** 0.5 if p.dim() > 1 else 0.05))
+            p.requires_grad = False
+        for l in self.lins:
+            l.weight.data.abs_()
+
+    def forward(self, in0, in1):
+        f0, f1 = (in0 - self.shift) / self.scale, (in1 - self.shift) / self.scale
+        total = 0
+        for i, (conv, lin) in enumerate(zip(self.slices, self.lins)):
+            if i:
+                f0, f1 = F.max_pool2d(f0, 2), F.max_pool2d(f1, 2)
+            f0, f1 = F.relu(conv(f0)), F.relu(conv(f1))
+            n0 = f0 / (torch.sqrt(torch.sum(f0 ** 2, dim=1, keepdim=True)) + 1e-10)
+            n1 = f1 / (torch.sqrt(torch.sum(f1 ** 2, dim=1, keepdim=True)) + 1e-10)
+            total = total + lin((n0 - n1) ** 2).mean([2, 3], keepdim=True)
+        return total

@@ -340,3 +340,76 @@ def test_adapter_residuals_in_the_sampler_are_bit_identical():
                              adapter_conditioning_scale=0.5))
     (a, ar), (b, br) = outs
     assert torch.equal(a, b) and torch.equal(ar, br)
+
+
+# ---- VAE in the loop + LPIPS distillation loss (FD:128-133, 182-185, 383-397, 865-868, 910-913, 977-984) -------
+def _build_lpips(cls, cfg_cls, **kw):
+    """the pretrained AutoencoderKL / lpips.LPIPS are absent offline: both classes get the same frozen stand-ins
+    (oracle.unet_cpu.TinyVAE / TinyLPIPS); the reference builds its own `self.lpips` (FD:102-103: the shim's stub), replaced here"""
+    from oracle.unet_cpu import TinyLPIPS, TinyVAE
+    torch.manual_seed(0)
+    teacher = seeded_init_(UNet2DConditionRef(tiny_config()), 1)
+    student = copy.deepcopy(teacher)
+    student.add_adapter(8)
+    seeded_init_(student, 2)
+    student.load_state_dict(dict(teacher.state_dict()), strict=False)
+    teacher.freeze()
+    disc = seeded_init_(make_discriminator("sd15", color_dim=64, feat=16, last_k=2), 3)
+    common = dict(student_denoiser=student, teacher_denoiser=teacher, teacher_noise_scheduler=DPMSolverMultistepSchedulerRef(),
+                  conditioner=TensorConditioner(), discriminator=disc, vae=TinyVAE())
+    if cls is FlashDiffusionRef:
+        return cls(cfg_cls(**kw), lpips_model=TinyLPIPS(), **common)
+    m = cls(cfg_cls(**kw), **common)
+    if kw.get("distill_loss_type") == "lpips":
+        m.lpips = TinyLPIPS()
+    return m
+
+
+def _pixel_batch(px):
+    g = torch.Generator().manual_seed(5)
+    return {"image": torch.randn(2, 3, px, px, generator=g) * 0.5, "crossattn": torch.randn(2, 77, 64, generator=g),
+            "text": ["a", "b"]}
+
+
+# latents 32x32 (the slice's negative start selects the trailing 16 rows / columns) on both steps; 72x72 (a real centre crop) once
+@pytest.mark.parametrize("step,px", [(0, 64), (1, 64), (0, 144)])
+def test_lpips_distill_with_vae_restatement_is_bit_identical(step, px):
+    FD, FDC = shim_import.import_reference()
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="lpips", gan_loss_type="lsgan",
+              use_dmd_loss=px == 64, guidance_scale_min=3.0, guidance_scale_max=13.0)
+    outs = []
+    for cls, ccls in ((FD, FDC), (FlashDiffusionRef, FlashConfigRef)):
+        m = _build_lpips(cls, ccls, **kw)
+        torch.manual_seed(77)
+        out = m(_pixel_batch(px), step=step, device="cpu")
+        out["loss"][step].backward()
+        outs.append((out, {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (o1, g1), (o2, g2) = outs
+    assert o2["student_output"].shape[-1] == px // 2
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert torch.equal(o1[k], o2[k]), k
+    assert float(o1["loss"][0]) == float(o2["loss"][0]) and float(o1["loss"][1]) == float(o2["loss"][1])
+    assert set(g1) == set(g2) and len(g1) > 0 and all(torch.equal(g1[n], g2[n]) for n in g1)
+    assert not any(n.startswith(("vae.", "lpips.")) for n in g2)            # both networks stay frozen
+    if step == 0:
+        assert float(o2["loss"][0]) > 0 and any(float(g.abs().max()) > 0 for n, g in g2.items() if "lora" in n)
+
+
+def test_sampler_decodes_through_the_vae_bit_identically():
+    from oracle.sched_cpu import LCMSchedulerRef
+    FD, FDC = shim_import.import_reference()
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform")
+    outs, logs = [], []
+    for cls, ccls in ((FD, FDC), (FlashDiffusionRef, FlashConfigRef)):
+        m = _build_lpips(cls, ccls, **kw)
+        m.sampling_noise_scheduler = LCMSchedulerRef()
+        m.teacher_sampling_noise_scheduler = DPMSolverMultistepSchedulerRef()
+        ci = {k: v for k, v in _pixel_batch(64).items() if k != "image"}
+        z = torch.randn(2, 4, 32, 32, generator=torch.Generator().manual_seed(9))
+        torch.manual_seed(3)
+        outs.append(m.sample(z, num_steps=3, guidance_scale=1.5, conditioner_inputs=ci, log_teacher_samples=True))
+        torch.manual_seed(4)
+        logs.append(m.log_samples(_pixel_batch(64), num_steps=2, max_samples=2))      # latent shape inferred from the VAE
+    (a, ar), (b, br) = outs
+    assert a.shape == (2, 3, 64, 64) and torch.equal(a, b) and torch.equal(ar, br)
+    assert list(logs[0]) == list(logs[1]) and all(torch.equal(logs[0][k], logs[1][k]) for k in logs[0])
