@@ -208,10 +208,8 @@ def ss_name(s):
 class FlashDiffusion(nn.Module):
     def __init__(self, config: FlashDiffusionConfig, student_denoiser, teacher_denoiser=None,
                  teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
-                 vae=None, conditioner=None, adapter=None, discriminator: nn.Module = None):
+                 vae=None, conditioner=None, adapter=None, discriminator: nn.Module = None, lpips_model: nn.Module = None):
         super().__init__()
-        if vae is not None:
-            raise NotImplementedError("the VAE is outside the hot-path scope (SURVEY.md 2.1 row 6): pass latents")
         self.config = config
         self.input_key = config.input_key
         self.student_denoiser = student_denoiser
@@ -219,7 +217,11 @@ class FlashDiffusion(nn.Module):
         self.teacher_noise_scheduler = teacher_noise_scheduler
         self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
         self.sampling_noise_scheduler = sampling_noise_scheduler
-        self.vae = None
+        # VAE (FD:67): optional, any frozen module with the surface of the reference's AutoencoderKLDiffusers that the step touches
+        # (vae/autoencoderKL.py:11-128: config.input_key, encode, decode, latent_channels, downsampling_factor).  The network itself
+        # is outside the hand-written hot path: it runs as the caller's torch module on the same
+        # device; with vae=None the batch carries latents (the benchmark's case, FD:184-185).
+        self.vae = vae
         # T2I adapter (FD:91-94): any frozen module mapping batch[adapter_input_key] to one residual per UNet down block
         # (the diffusers T2IAdapter network itself is outside the hot path); its features are threaded to every denoiser
         # call exactly as the reference does (FD:207-218, 264, 301, 310, 436-450, 555-567, 820-899)
@@ -240,8 +242,17 @@ class FlashDiffusion(nn.Module):
                   "use_dmd_loss", "dmd_loss_scale", "distill_loss_scale", "adversarial_loss_scale", "gan_loss_type",
                   "mode_probs", "use_teacher_as_real", "use_empty_prompt"):
             setattr(self, f, getattr(config, f))
-        if self.distill_loss_type == "lpips":
-            raise NotImplementedError("lpips distill loss needs pretrained VAE+VGG weights: a 'next' row (SURVEY.md 8f)")
+        if self.distill_loss_type == "lpips":                  # FD:102-103: self.lpips = lpips.LPIPS(net="vgg")
+            if vae is None:
+                raise ValueError("distill_loss_type='lpips' decodes both outputs: a vae is required (FD:394-395)")
+            if lpips_model is None:
+                try:
+                    import lpips
+                except ImportError as e:
+                    raise ImportError("distill_loss_type='lpips': the `lpips` package (setup.py:40) is not installed; pass the "
+                                      "perceptual network as lpips_model=<module(img0, img1) -> [B,1,1,1]>") from e
+                lpips_model = lpips.LPIPS(net="vgg")
+            self.lpips = lpips_model
         self.iter_steps = 0
         self.disc_update_counter = 0
         self.disc_backbone = self.teacher_denoiser
@@ -341,8 +352,8 @@ class FlashDiffusion(nn.Module):
     def sample(self, z, num_steps=20, guidance_scale=1.0, teacher_guidance_scale=5.0, conditioner_inputs=None,
                uncond_conditioner_inputs=None, max_samples=None, verbose=False, log_teacher_samples=False,
                adapter_conditioning_scale=1.0):
-        """Same contract as the reference (FD:755-915) with vae = adapter = None: returns (samples, teacher_samples or
-        None) as latents.  Student: `sampling_noise_scheduler` (LCM) on the teacher scheduler's schedule when it accepts
+        """Same contract as the reference (FD:755-915): returns (samples, teacher_samples or None) -- latents, or images when a
+        vae is attached.  Student: `sampling_noise_scheduler` (LCM) on the teacher scheduler's schedule when it accepts
         custom timesteps; teacher (optional): `teacher_sampling_noise_scheduler` with its own CFG scale."""
         assert self.sampling_noise_scheduler is not None, "sample() needs a sampling_noise_scheduler (e.g. LCMScheduler)"
         self.teacher_noise_scheduler.set_timesteps(num_steps)
@@ -370,6 +381,8 @@ class FlashDiffusion(nn.Module):
             tt = torch.full((x.shape[0],), float(t), device=z.device)
             e = self._cfg_pair(self.student_denoiser, x, tt, cond, uncond, guidance_scale, res=res)
             sample = ss.step(e, t, sample, return_dict=False)[0]
+        if self.vae is not None:                                                 # FD:865-868
+            sample = self.vae.decode(sample)
         decoded_ref = None
         if log_teacher_samples:
             ts = self.teacher_sampling_noise_scheduler
@@ -382,13 +395,14 @@ class FlashDiffusion(nn.Module):
                 e = self._cfg_pair(self.teacher_denoiser, x, tt, cond, uncond, teacher_guidance_scale,
                                    ctx_cache="fill" if it == 0 else "reuse", res=res)
                 ref = ts.step(e, t, ref, return_dict=False)[0]
-                decoded_ref = ref
+            decoded_ref = self.vae.decode(ref) if self.vae is not None else ref  # FD:910-913 (the reference decodes every step)
         return sample, decoded_ref
 
     def log_samples(self, batch, input_shape=None, guidance_scale=1.0, teacher_guidance_scale=5.0, max_samples=8,
                     num_steps=20, device="cpu", log_teacher_samples=False, conditioner_inputs=None,
                     conditioner_uncond_inputs=None, adapter_conditioning_scale=1.0):
-        """FD:917-1019 (no VAE: `input_shape` = latent shape is mandatory, as in the reference's ValueError branch)."""
+        """FD:917-1019 (`input_shape` = latent shape; inferred from the VAE when one is attached, else mandatory as in the
+        reference's ValueError branch)."""
         if isinstance(num_steps, int):
             num_steps = [num_steps]
         logs = {}
@@ -410,7 +424,12 @@ class FlashDiffusion(nn.Module):
         else:
             batch_uncond = None
         if input_shape is None:
-            raise ValueError("input_shape must be passed when no VAE is used in the model")
+            if self.vae is not None:                                             # FD:977-984
+                px = batch[self.vae.config.input_key].shape[2:]
+                input_shape = (self.vae.latent_channels, px[0] // self.vae.downsampling_factor,
+                               px[1] // self.vae.downsampling_factor)
+            else:
+                raise ValueError("input_shape must be passed when no VAE is used in the model")
         for n in num_steps:
             z = torch.randn(N, *input_shape).to(device)
             samples, samples_ref = self.sample(z, num_steps=n, conditioner_inputs=batch,
@@ -460,7 +479,11 @@ class FlashDiffusion(nn.Module):
         d = self.draws if self.draws is not None else Draws()
         self.last_draws = d
         self.iter_steps += 1
-        z = batch[self.input_key].float().contiguous()
+        if self.vae is not None:                                                # FD:128-133, 182-183
+            with torch.no_grad():
+                z = self.vae.encode(batch[self.vae.config.input_key]).float().contiguous()
+        else:
+            z = batch[self.input_key].float().contiguous()
         B = z.shape[0]
         conditioning = self._get_conditioning(batch, set_ucg_rate_zero=True, *args, **kwargs)
         student_conditioning = self._get_conditioning(batch, *args, **kwargs)
@@ -553,7 +576,16 @@ class FlashDiffusion(nn.Module):
 
     # ---- losses --------------------------------------------------------------------------------------
     def _distill_loss(self, s, t):
-        """FD:368-382"""
+        """FD:368-399.  l2 / l1: one fused HIP launch (+ one for the gradient).  lpips: the centre 64x64 latent crop of both
+        outputs (the reference's slice expression verbatim) goes through the caller's VAE decoder and perceptual network --
+        torch modules on the same device, outside the hand-written kernels; the gradient returns to the
+        student through torch autograd into the HIP backward."""
+        if self.distill_loss_type == "lpips":
+            crop_h = (s.shape[2] - 64) // 2
+            crop_w = (s.shape[3] - 64) // 2
+            s = s[:, :, crop_h:crop_h + 64, crop_w:crop_w + 64]
+            t = t[:, :, crop_h:crop_h + 64, crop_w:crop_w + 64]
+            return self.lpips(self.vae.decode(s).clamp(-1, 1), self.vae.decode(t).clamp(-1, 1)).mean()
         return _DistillLoss.apply(s, t.detach(), self.distill_loss_type == "l1")
 
     def _dmd_loss(self, d, s, student_cond, cond, uncond, K_step, res=None):

@@ -42,6 +42,23 @@ ADAPTER_CASES = {
 }
 
 
+# VAE in the loop + LPIPS distillation loss (FD:128-133, 182-185, 383-397): the batch carries PIXELS, the frozen stand-in VAE
+# (oracle.unet_cpu.TinyVAE, downsampling 2) encodes them to the 32x32 latents of the other cases, both outputs are decoded again
+# for the perceptual term (oracle.unet_cpu.TinyLPIPS)
+LPIPS_CASES = {
+    "g_lpips_dmd_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="lpips",
+                               gan_loss_type="lsgan", use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=13.0,
+                               dmd_loss_scale=0.3, adversarial_loss_scale=0.1), "dpm", 0, 16),
+}
+
+
+def make_pixel_batch(B=2, px=64, ctx_dim=64, seed=6):
+    rs = np.random.RandomState(seed)
+    x = torch.from_numpy((0.5 * rs.standard_normal((B, 3, px, px))).astype(np.float32))
+    c = torch.from_numpy(rs.standard_normal((B, 77, ctx_dim)).astype(np.float32))
+    return {"image": x, "crossattn": c, "text": ["a"] * B}
+
+
 def make_edge(B=2, hw=32, seed=8):
     return torch.randn(B, 1, hw, hw, generator=torch.Generator().manual_seed(seed))
 

@@ -30,15 +30,16 @@ def _record_draws(seed, model_fn):
 
 def main(cases=None):
     from .flash_ref import FlashConfigRef, FlashDiffusionRef
-    from .golden_cases import ADAPTER_CASES, make_edge
-    from .unet_cpu import TinyT2IAdapter, tiny_config
+    from .golden_cases import ADAPTER_CASES, LPIPS_CASES, make_edge, make_pixel_batch
+    from .unet_cpu import TinyLPIPS, TinyT2IAdapter, TinyVAE, tiny_config
     FD, FDC = shim_import.import_reference()
     os.makedirs(OUT, exist_ok=True)
     for name, (kw, sched, step, seed) in (cases if cases is not None else CASES).items():
         with_adapter = name in ADAPTER_CASES
+        with_vae = name in LPIPS_CASES
 
         def make_batch_():
-            b = make_batch()
+            b = make_pixel_batch() if with_vae else make_batch()
             if with_adapter:
                 b["edge"] = make_edge()
             return b
@@ -46,7 +47,10 @@ def main(cases=None):
         teacher, student, disc = build_models()
         ref = FD(FDC(**kw), student_denoiser=student, teacher_denoiser=teacher,
                  teacher_noise_scheduler=SCHEDS[sched](), conditioner=TensorConditioner(),
-                 discriminator=disc, adapter=TinyT2IAdapter(tiny_config()) if with_adapter else None)
+                 discriminator=disc, adapter=TinyT2IAdapter(tiny_config()) if with_adapter else None,
+                 vae=TinyVAE() if with_vae else None)
+        if with_vae:
+            ref.lpips = TinyLPIPS()       # FD:102-103 built the shim's lpips.LPIPS stub (package and VGG weights are absent)
         batch = make_batch_()
         torch.manual_seed(seed)
         out = ref(batch, step=step, device="cpu")
@@ -57,7 +61,8 @@ def main(cases=None):
         teacher, student, disc = build_models()
         ora = FlashDiffusionRef(FlashConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
                                 teacher_noise_scheduler=SCHEDS[sched](), conditioner=TensorConditioner(),
-                                discriminator=disc, adapter=TinyT2IAdapter(tiny_config()) if with_adapter else None)
+                                discriminator=disc, adapter=TinyT2IAdapter(tiny_config()) if with_adapter else None,
+                                vae=TinyVAE() if with_vae else None, lpips_model=TinyLPIPS() if with_vae else None)
         torch.manual_seed(seed)
         out2 = ora(make_batch_(), step=step, device="cpu")
         for k in ("teacher_output", "student_output", "noisy_sample"):
@@ -203,10 +208,14 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "adapter":
         from .golden_cases import ADAPTER_CASES
         main(ADAPTER_CASES)
+    elif len(sys.argv) > 1 and sys.argv[1] == "lpips":
+        from .golden_cases import LPIPS_CASES
+        main(LPIPS_CASES)
     else:
         main()
-        from .golden_cases import ADAPTER_CASES
+        from .golden_cases import ADAPTER_CASES, LPIPS_CASES
         main(ADAPTER_CASES)
+        main(LPIPS_CASES)
         make_sample_golden()
         make_sd3_golden()
         make_dit_golden()

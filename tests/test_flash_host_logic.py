@@ -109,6 +109,46 @@ def test_sd3_step_orchestration_matches_reference_golden(monkeypatch, name):
     assert seen == [1] and m2.terms["guidance"] == 4.0 and abs(o2["start_timestep"] - float(m2.teacher_noise_scheduler.timesteps[0])) < 1e-3
 
 
+def test_lpips_step_with_vae_matches_reference_golden(monkeypatch):
+    """distill_loss_type="lpips" with a VAE attached (FD:128-133, 182-185, 383-397): the product encodes the pixel batch, runs the
+    step on the latents, decodes the centre crop of both outputs through the caller's VAE and perceptual network (torch modules;
+    the frozen stand-ins of the fixture) and sends the gradient back into the student -- fixture by the real reference"""
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import LPIPS_CASES
+    from oracle.unet_cpu import TinyLPIPS, TinyVAE
+    _patch(monkeypatch)
+    (name, (kw, sched, step, _)), = LPIPS_CASES.items()
+    g = load_case(name)
+    teacher, student, disc = build_models()
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                       discriminator=_Head(disc), vae=TinyVAE(), lpips_model=TinyLPIPS())
+    m.draws = Draws(g["draws"])
+    out = m({"image": g["z"], "crossattn": g["crossattn"], "text": ["a"] * g["z"].shape[0]}, step=step, device="cpu")
+    assert out["start_timestep"] == g["start_timestep"]
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert rel_err(out[k], g["out"][k]) < 1e-4, (k, rel_err(out[k], g["out"][k]))
+    for i in (0, 1):
+        assert abs(float(out["loss"][i]) - g["loss"][i]) <= 1e-4 * max(1.0, abs(g["loss"][i])), i
+    out["loss"][step].backward()
+    _check_grads(m, g, lambda k: k.replace("discriminator.seq.", "discriminator."))
+    assert all(p.grad is None for n, p in m.named_parameters() if n.startswith(("vae.", "lpips.")))
+    # the constructor's contract
+    with pytest.raises(ValueError, match="vae"):
+        FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), lpips_model=TinyLPIPS())
+    with pytest.raises(ImportError, match="lpips_model"):
+        FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), vae=TinyVAE())
+    # the sampler decodes, log_samples infers the latent shape from the VAE (FD:865-868, 977-984)
+    from flash_diffusion_amd.schedulers import LCMScheduler
+    m.sampling_noise_scheduler = LCMScheduler()
+    logs = m.log_samples({"image": g["z"], "crossattn": g["crossattn"], "text": ["a", "a"]}, num_steps=2, max_samples=2)
+    (k, v), = logs.items()
+    assert v.shape == (2, 3, 64, 64) and torch.isfinite(v).all()
+
+
 def test_sampler_orchestration_matches_reference_golden(monkeypatch):
     """FlashDiffusion.sample (FD:754-915) with the product LCM / DPM-Solver++ schedulers on the stand-in ops: 4-step student
     sampler + the teacher's own sampler, fixture by the real reference (LCM re-noising draws replayed)"""

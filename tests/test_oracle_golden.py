@@ -170,3 +170,25 @@ def test_oracle_reproduces_adapter_golden():
     out["loss"][step].backward()
     n = sum(1 for pn, p in m.named_parameters() if p.grad is not None and rel_err(p.grad, g["grads"][pn]) < 1e-4)
     assert n == len(g["grads"])
+
+
+def test_oracle_reproduces_lpips_golden():
+    """VAE-encoded pixel batch + LPIPS distillation term (FD:128-133, 182-185, 383-397): fixture by the real reference with the
+    frozen stand-in VAE / LPIPS networks (the pretrained ones are not available offline)"""
+    from oracle.golden_cases import LPIPS_CASES
+    from oracle.unet_cpu import TinyLPIPS, TinyVAE
+    (name, (kw, sched, step, _)), = LPIPS_CASES.items()
+    g = load_case(name)
+    teacher, student, disc = build_models()
+    m = FlashDiffusionRef(FlashConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=SCHEDS[sched](), conditioner=TensorConditioner(), discriminator=disc,
+                          vae=TinyVAE(), lpips_model=TinyLPIPS())
+    m.draws = Draws(g["draws"])
+    assert g["z"].shape == (2, 3, 64, 64)                       # pixels: the latents come out of vae.encode
+    out = m({"image": g["z"], "crossattn": g["crossattn"], "text": ["a"] * g["z"].shape[0]}, step=step)
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert out[k].shape == (2, 4, 32, 32) and rel_err(out[k], g["out"][k]) < 1e-5, k
+    assert abs(float(out["loss"][0]) - g["loss"][0]) <= 1e-5 * max(1.0, abs(g["loss"][0]))
+    out["loss"][step].backward()
+    n = sum(1 for pn, p in m.named_parameters() if p.grad is not None and rel_err(p.grad, g["grads"][pn]) < 1e-4)
+    assert n == len(g["grads"]) and n > 0

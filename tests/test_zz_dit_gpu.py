@@ -484,3 +484,45 @@ def _body_test_unet_forward_with_epilogue_groupnorm_statistics():
     assert n0 == 0 and tot0 == tot1 == 61 and n1 >= 12, (n0, n1, tot1)
     assert torch.isfinite(got).all() and rel_err(got, ref) <= 4 * noise, (rel_err(got, ref), noise)
     assert rel_err(ggot, gref) <= 4 * gnoise, (rel_err(ggot, gref), gnoise)
+
+
+# ---- VAE in the loop + LPIPS distillation term (FD:128-133, 383-397; SURVEY 8f row 3: plumbing, the two networks are torch modules) ----
+def test_step_with_vae_and_lpips_matches_reference_golden():
+    run_isolated(__name__, "_body_test_step_with_vae_and_lpips_matches_reference_golden", ())
+
+
+def _body_test_step_with_vae_and_lpips_matches_reference_golden():
+    """the HIP student / teacher UNets inside a step whose batch is pixels (encoded by the VAE) and whose distillation term is
+    LPIPS on the decoded centre crops: outputs, loss and LoRA gradient against the fixture of the real reference (bf16
+    tolerances of tests/test_flash_gpu.py); the VAE / LPIPS stand-ins are plain torch modules on the GPU"""
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import LORA_RANK, LPIPS_CASES, build_models
+    from oracle.unet_cpu import TinyLPIPS, TinyVAE
+    from tests.unet_util import mi_from_oracle
+    import copy
+    (name, (kw, sched, step, _)), = LPIPS_CASES.items()
+    g = load_case(name)
+    teacher_o, student_o, disc_o = build_models()
+    teacher = mi_from_oracle(teacher_o)
+    teacher.freeze()
+    student = mi_from_oracle(student_o, lora_rank=LORA_RANK)
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                       discriminator=copy.deepcopy(disc_o).cuda(), vae=TinyVAE().cuda(), lpips_model=TinyLPIPS().cuda()).cuda()
+    m.draws = Draws(g["draws"])
+    B = g["z"].shape[0]
+    out = m({"image": g["z"].cuda(), "crossattn": g["crossattn"].cuda(), "text": ["a"] * B}, step=step, device="cuda")
+    assert out["start_timestep"] == g["start_timestep"]
+    for k in ("teacher_output", "student_output"):
+        assert rel_err(out[k], g["out"][k]) < 4e-2, (k, rel_err(out[k], g["out"][k]))
+    assert abs(float(out["loss"][0]) - g["loss"][0]) < 6e-2 * abs(g["loss"][0])
+    out["loss"][step].backward()
+    torch.cuda.synchronize()
+    fa, fb = [], []
+    for pn, p in m.named_parameters():
+        if ".lora_" in pn and p.grad is not None:
+            ref = [v for k, v in g["grads"].items() if k.replace(".base_layer.", ".") == pn][0]
+            fa.append(p.grad.detach().float().cpu().flatten())
+            fb.append(ref.float().flatten())
+    assert len(fa) > 0 and _cos(torch.cat(fa), torch.cat(fb)) > 0.99
