@@ -11,7 +11,7 @@ with the latent algebra on the HIP element-wise kernels of libfdmi.so:
 The denoisers are whatever honours the reference's wrapper contract (``sample, timestep, conditioning, **kwargs``): the SD3
 transformer itself (TW:113-155) is NOT part of this module -- its HIP plan is the next build.
 Same constructor and return contract as the reference class, including the scalar ``loss`` when no discriminator is given
-(FD3:357-364) and ``return_post_mid_blocks=True`` on the discriminator backbone call (FD3:563).  ``vae`` must be None.
+(FD3:357-364) and ``return_post_mid_blocks=True`` on the discriminator backbone call (FD3:563).  ``vae`` / ``lpips_model`` are optional torch-module slots threaded as in flash.py.
 """
 from __future__ import annotations
 
@@ -51,7 +51,7 @@ class FlashDiffusionSD3Config:
     input_key: str = "image"
 
     def __post_init__(self):
-        assert self.distill_loss_type in ("l2", "l1"), "lpips needs the VAE decoder + VGG (DESIGN.md section 8)"
+        assert self.distill_loss_type in ("l2", "l1", "lpips")
         assert self.timestep_distribution in ("gaussian", "uniform", "mixture")
         assert self.gan_loss_type in ("hinge", "vanilla", "non-saturating", "wgan", "lsgan")
         n = len(self.K)
@@ -116,10 +116,9 @@ def get_sigmas(scheduler, timesteps):
 class FlashDiffusionSD3(nn.Module):
     def __init__(self, config: FlashDiffusionSD3Config, student_denoiser, teacher_denoiser=None,
                  teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
-                 vae=None, conditioner=None, discriminator=None, pipeline=None, cpu_offload: bool = False):
+                 vae=None, conditioner=None, discriminator=None, pipeline=None, cpu_offload: bool = False,
+                 lpips_model: nn.Module = None):
         super().__init__()
-        if vae is not None:
-            raise NotImplementedError("VAE encode/decode is out of the hot-path scope: feed latents")
         self.config = config
         self.input_key = config.input_key
         self.student_denoiser = student_denoiser
@@ -128,7 +127,19 @@ class FlashDiffusionSD3(nn.Module):
         self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
         self.sampling_noise_scheduler = sampling_noise_scheduler
         self.teacher_noise_scheduler_copy = copy.deepcopy(teacher_noise_scheduler)   # FD3:116 (1000-step copy)
-        self.vae = None
+        # optional, the caller's torch module with the AutoencoderKLDiffusers surface the step touches (FD3:93; see flash.py)
+        self.vae = vae
+        if config.distill_loss_type == "lpips":                # FD3:130-131: self.lpips = lpips.LPIPS(net="vgg")
+            if vae is None:
+                raise ValueError("distill_loss_type='lpips' decodes both outputs: a vae is required (FD3:409-410)")
+            if lpips_model is None:
+                try:
+                    import lpips
+                except ImportError as e:
+                    raise ImportError("distill_loss_type='lpips': the `lpips` package (setup.py:40) is not installed; pass the "
+                                      "perceptual network as lpips_model=<module(img0, img1) -> [B,1,1,1]>") from e
+                lpips_model = lpips.LPIPS(net="vgg")
+            self.lpips = lpips_model
         self.conditioner = conditioner
         self.pipeline = pipeline
         self.cpu_offload = cpu_offload
@@ -219,7 +230,7 @@ class FlashDiffusionSD3(nn.Module):
     def sample(self, z, num_steps=20, guidance_scale=1.0, teacher_guidance_scale=5.0, conditioner_inputs=None,
                uncond_conditioner_inputs=None, max_samples=None, verbose=False, log_teacher_samples=False):
         """FD3:682-843: few-step Euler sampling of the student from latent noise `z` (and, with ``log_teacher_samples``,
-        the teacher's samples from the same noise).  Returns latents: the VAE decode is out of scope."""
+        the teacher's samples from the same noise).  Returns latents, or decoded images when a vae is attached."""
         self.teacher_noise_scheduler.set_timesteps(num_steps)
         ss = self.sampling_noise_scheduler
         ss.set_timesteps(num_steps)
@@ -234,12 +245,16 @@ class FlashDiffusionSD3(nn.Module):
         if hasattr(ss, "init_noise_sigma"):
             x = x * ss.init_noise_sigma
         out = self._euler_cfg(self.student_denoiser, ss, ss.timesteps, x, cond, uncond, float(guidance_scale))
+        if self.vae is not None:                                                  # FD3:794-797
+            out = self.vae.decode(out)
         ref = None
         if log_teacher_samples:
             ts = self.teacher_sampling_noise_scheduler
             ts.set_timesteps(num_steps)
             ref = x0 * ts.init_noise_sigma if hasattr(ts, "init_noise_sigma") else x0
             ref = self._euler_cfg(self.teacher_denoiser, ts, ts.timesteps, ref, cond, uncond, float(teacher_guidance_scale))
+            if self.vae is not None:                                              # FD3:838-841
+                ref = self.vae.decode(ref)
         return out, ref
 
     def log_samples(self, batch, input_shape=None, guidance_scale=1.0, teacher_guidance_scale=5.0, max_samples=8,
@@ -267,7 +282,12 @@ class FlashDiffusionSD3(nn.Module):
         else:
             batch_uncond = None
         if input_shape is None:
-            raise ValueError("input_shape must be passed when no VAE is used in the model")       # FD3:904-907
+            if self.vae is not None:                                                               # FD3:904-912
+                px = batch[self.vae.config.input_key].shape[2:]
+                input_shape = (self.vae.latent_channels, px[0] // self.vae.downsampling_factor,
+                               px[1] // self.vae.downsampling_factor)
+            else:
+                raise ValueError("input_shape must be passed when no VAE is used in the model")   # FD3:913-916
         for n in num_steps:
             z = torch.randn(N, *input_shape).to(device)                                            # FD3:911
             samples, samples_ref = self.sample(z, num_steps=n, conditioner_inputs=batch,
@@ -285,7 +305,11 @@ class FlashDiffusionSD3(nn.Module):
         d = self.draws if self.draws is not None else Draws()
         self.last_draws = d
         self.iter_steps += 1
-        z = batch[self.input_key].float().contiguous()
+        if self.vae is not None:                                                  # FD3:138-144, 190-191
+            with torch.no_grad():
+                z = self.vae.encode(batch[self.vae.config.input_key]).float().contiguous()
+        else:
+            z = batch[self.input_key].float().contiguous()
         B = z.shape[0]
         cond, uncond = self._embeddings(batch, z.device)
         if self.iter_steps > self.K_steps[-1]:
@@ -327,7 +351,15 @@ class FlashDiffusionSD3(nn.Module):
             hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
         v_s = self.student_denoiser(sample=x_init, timestep=start_t, conditioning=cond)
         student_output = _PerSampleAffine.apply(v_s.float(), x_init, torch.ones_like(sig), (-sig).contiguous())   # FD3:325
-        l_distill = _DistillLoss.apply(student_output, teacher_output.detach(), self.distill_loss_type == "l1")
+        if self.distill_loss_type == "lpips":     # FD3:391-411 (clamped crop bounds); the caller's VAE / LPIPS torch modules
+            so, to = student_output, teacher_output.detach()
+            crop_h = max((so.shape[2] - 64) // 2, 0)
+            crop_w = max((so.shape[3] - 64) // 2, 0)
+            so = so[:, :, crop_h:min(crop_h + 64, so.shape[2]), crop_w:min(crop_w + 64, so.shape[3])]
+            to = to[:, :, crop_h:min(crop_h + 64, to.shape[2]), crop_w:min(crop_w + 64, to.shape[3])]
+            l_distill = self.lpips(self.vae.decode(so).clamp(-1, 1), self.vae.decode(to).clamp(-1, 1)).mean()
+        else:
+            l_distill = _DistillLoss.apply(student_output, teacher_output.detach(), self.distill_loss_type == "l1")
         loss = l_distill * self.distill_loss_scale[K_step]
         self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": g}
         if self.use_dmd_loss:

@@ -83,9 +83,12 @@ def get_sigmas(scheduler, timesteps, n_dim=4, dtype=torch.float32, device="cpu")
 class FlashDiffusionSD3Ref(torch.nn.Module):
     def __init__(self, config, student_denoiser, teacher_denoiser=None, teacher_noise_scheduler=None,
                  teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None, vae=None, conditioner=None,
-                 discriminator=None, pipeline=None, cpu_offload=False):
+                 discriminator=None, pipeline=None, cpu_offload=False, lpips_model=None):
         super().__init__()
-        assert vae is None, "VAE is out of scope (SURVEY.md 2.1)"
+        self.vae = vae                     # FD3:93: any module with the AutoencoderKLDiffusers surface the step touches
+        if config.distill_loss_type == "lpips":                                          # FD3:130-131 builds lpips.LPIPS itself
+            assert vae is not None and lpips_model is not None                           # (package / weights absent here)
+            self.lpips = lpips_model
         self.config = config
         self.input_key = config.input_key
         self.student_denoiser = student_denoiser
@@ -111,7 +114,11 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
         d = self.draws if self.draws is not None else Draws()
         self.last_draws = d
         self.iter_steps += 1
-        z = batch[self.input_key]
+        if self.vae is not None:                                                         # FD3:138-144, 190-191
+            with torch.no_grad():
+                z = self.vae.encode(batch[self.vae.config.input_key])
+        else:
+            z = batch[self.input_key]
         with torch.no_grad():                                                            # FD3:196-219
             pe, npe, ppe, nppe = self.pipeline.encode_prompt(prompt=batch["text"], device=z.device)
         cond = {"cond": {"vector": ppe, "crossattn": pe}}
@@ -149,7 +156,15 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
         teacher_output = x
         v_s = self.student_denoiser(sample=x_student, timestep=start_t, conditioning=cond)    # FD3:318-323
         student_output = x_student - v_s * sig                                            # FD3:325
-        l_distill = distill_loss(cfg.distill_loss_type, student_output, teacher_output)
+        if cfg.distill_loss_type == "lpips":                                             # FD3:391-411: clamped crop bounds
+            so, to = student_output, teacher_output
+            crop_h = max((so.shape[2] - 64) // 2, 0)
+            crop_w = max((so.shape[3] - 64) // 2, 0)
+            so = so[:, :, crop_h:min(crop_h + 64, so.shape[2]), crop_w:min(crop_w + 64, so.shape[3])]
+            to = to[:, :, crop_h:min(crop_h + 64, to.shape[2]), crop_w:min(crop_w + 64, to.shape[3])]
+            l_distill = self.lpips(self.vae.decode(so).clamp(-1, 1), self.vae.decode(to).clamp(-1, 1)).mean()
+        else:
+            l_distill = distill_loss(cfg.distill_loss_type, student_output, teacher_output)
         loss = l_distill * cfg.distill_loss_scale[K_step]
         self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": float(g)}
         if cfg.use_dmd_loss:
@@ -226,6 +241,7 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
             e_u = self.student_denoiser(sample=sample, timestep=tt, conditioning=uncond)
             e = guidance_scale * e_c + (1 - guidance_scale) * e_u
             sample = ss.step(e, t, sample, return_dict=False)[0]
+        decoded = self.vae.decode(sample) if self.vae is not None else sample                   # FD3:794-797
         ref = None
         if log_teacher_samples:                                                                 # FD3:804-841
             ts = self.teacher_sampling_noise_scheduler
@@ -237,7 +253,9 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
                 e_u = self.teacher_denoiser(sample=ref, timestep=tt, conditioning=uncond)
                 e = teacher_guidance_scale * e_c + (1 - teacher_guidance_scale) * e_u
                 ref = ts.step(e, t, ref, return_dict=False)[0]
-        return sample, ref
+            if self.vae is not None:                                                            # FD3:838-841
+                ref = self.vae.decode(ref)
+        return decoded, ref
 
 
     def log_samples(self, batch, input_shape=None, guidance_scale=1.0, teacher_guidance_scale=5.0, max_samples=8,
@@ -265,7 +283,12 @@ class FlashDiffusionSD3Ref(torch.nn.Module):
         else:
             batch_uncond = None
         if input_shape is None:
-            raise ValueError("input_shape must be passed when no VAE is used in the model")       # FD3:904-907
+            if self.vae is not None:                                                               # FD3:904-912
+                px = batch[self.vae.config.input_key].shape[2:]
+                input_shape = (self.vae.latent_channels, px[0] // self.vae.downsampling_factor,
+                               px[1] // self.vae.downsampling_factor)
+            else:
+                raise ValueError("input_shape must be passed when no VAE is used in the model")       # FD3:913-916
         for n in num_steps:
             z = torch.randn(N, *input_shape).to(device)                                            # FD3:911
             samples, samples_ref = self.sample(z, num_steps=n, conditioner_inputs=batch,

@@ -109,6 +109,43 @@ def test_sd3_step_orchestration_matches_reference_golden(monkeypatch, name):
     assert seen == [1] and m2.terms["guidance"] == 4.0 and abs(o2["start_timestep"] - float(m2.teacher_noise_scheduler.timesteps[0])) < 1e-3
 
 
+def test_sd3_lpips_step_with_vae_matches_the_pinned_oracle(monkeypatch):
+    """FlashDiffusionSD3 with a VAE attached and distill_loss_type="lpips" (FD3:138-144, 190-191, 391-411): the product on the
+    stand-in ops against the oracle restatement (itself bit-identical to the real class, tests/test_oracle_vs_reference.py), the
+    oracle's draws replayed"""
+    from flash_diffusion_amd.flash import Draws
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    from oracle.flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    from oracle.unet_cpu import TinyLPIPS, TinyVAE
+    _patch(monkeypatch)
+    kw = dict(SD3_CASES["sd3_g_dmd_lsgan"][0], distill_loss_type="lpips")
+    teacher, student, disc, pipe, _ = build_sd3_models()
+    gp = torch.Generator().manual_seed(5)
+    batch = {"image": torch.randn(2, 3, 32, 32, generator=gp) * 0.5, "text": ["a", "b"]}
+    ora = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**kw), student_denoiser=copy.deepcopy(student), teacher_denoiser=teacher,
+                               teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=copy.deepcopy(disc),
+                               pipeline=pipe, vae=TinyVAE(), lpips_model=TinyLPIPS())
+    torch.manual_seed(11)
+    ref = ora(batch, step=0)
+    ref["loss"][0].backward()
+    m = FlashDiffusionSD3(FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), discriminator=_Head(disc), pipeline=pipe,
+                          vae=TinyVAE(), lpips_model=TinyLPIPS())
+    m.draws = Draws(dict(ora.last_draws.values))
+    out = m(batch, step=0)
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert out[k].shape == (2, 4, 16, 16) and rel_err(out[k], ref[k]) < 1e-4, (k, rel_err(out[k], ref[k]))
+    assert abs(float(out["loss"][0]) - float(ref["loss"][0])) <= 1e-4 * max(1.0, abs(float(ref["loss"][0])))
+    out["loss"][0].backward()
+    want = {n: p.grad for n, p in ora.named_parameters() if p.grad is not None and float(p.grad.norm()) > 1e-12}
+    got = {n.replace("discriminator.seq.", "discriminator."): p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert len(want) > 0 and all(rel_err(got[n], want[n]) < 2e-3 for n in want), [n for n in want if n not in got]
+    with pytest.raises(ValueError, match="vae"):
+        FlashDiffusionSD3(FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), pipeline=pipe, lpips_model=TinyLPIPS())
+
+
 def test_lpips_step_with_vae_matches_reference_golden(monkeypatch):
     """distill_loss_type="lpips" with a VAE attached (FD:128-133, 182-185, 383-397): the product encodes the pixel batch, runs the
     step on the latents, decodes the centre crop of both outputs through the caller's VAE and perceptual network (torch modules;

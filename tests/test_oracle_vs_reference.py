@@ -122,7 +122,7 @@ def test_log_samples_restatement_is_bit_identical():
 
 
 # ---- FlashDiffusionSD3.forward (flow matching): oracle/flash_sd3_ref.py vs the real class ----
-def _build_sd3(cls, cfg_cls, with_disc=True, **cfg_kw):
+def _build_sd3(cls, cfg_cls, with_disc=True, extra=None, **cfg_kw):
     from oracle.flash_sd3_ref import EmbeddingPipeline, TinyFlowDenoiser
     from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
     teacher = TinyFlowDenoiser(seed=1)
@@ -142,7 +142,7 @@ def _build_sd3(cls, cfg_cls, with_disc=True, **cfg_kw):
     pipe = EmbeddingPipeline(torch.randn(2, 5, 10, generator=ge), torch.randn(2, 12, generator=ge),
                              torch.randn(2, 5, 10, generator=ge), torch.randn(2, 12, generator=ge))
     m = cls(cfg_cls(**cfg_kw), student_denoiser=student, teacher_denoiser=teacher,
-            teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc, pipeline=pipe)
+            teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc, pipeline=pipe, **(extra or {}))
     return m
 
 
@@ -413,3 +413,46 @@ def test_sampler_decodes_through_the_vae_bit_identically():
     (a, ar), (b, br) = outs
     assert a.shape == (2, 3, 64, 64) and torch.equal(a, b) and torch.equal(ar, br)
     assert list(logs[0]) == list(logs[1]) and all(torch.equal(logs[0][k], logs[1][k]) for k in logs[0])
+
+
+@pytest.mark.parametrize("step,px", [(0, 32), (1, 32), (0, 144)])   # latents 16x16 (crop clamps to the whole map) and 72x72 (centre crop)
+def test_sd3_lpips_distill_with_vae_restatement_is_bit_identical(step, px):
+    """FlashDiffusionSD3 with a VAE attached and distill_loss_type="lpips" (FD3:138-144, 190-191, 391-411), same stand-ins"""
+    from oracle.flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from oracle.unet_cpu import TinyLPIPS, TinyVAE
+    FD3, FD3C = shim_import.import_reference_sd3()
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="lsgan", use_dmd_loss=True,
+              distill_loss_type="lpips")
+    outs = []
+    for cls, ccls in ((FD3, FD3C), (FlashDiffusionSD3Ref, FlashSD3ConfigRef)):
+        extra = dict(vae=TinyVAE(), lpips_model=TinyLPIPS()) if cls is FlashDiffusionSD3Ref else dict(vae=TinyVAE())
+        m = _build_sd3(cls, ccls, with_disc=px == 32, extra=extra, **kw)      # (the test head's geometry fits 16x16 latents only)
+        m.lpips = TinyLPIPS()        # (the real class built the shim's lpips.LPIPS stub, FD3:130-131)
+        g = torch.Generator().manual_seed(5)
+        batch = {"image": torch.randn(2, 3, px, px, generator=g) * 0.5, "text": ["a", "b"]}
+        torch.manual_seed(101)
+        out = m(batch, step=step)
+        loss = out["loss"][step] if isinstance(out["loss"], (list, tuple)) else out["loss"]
+        loss.backward()
+        outs.append((out, float(loss), {n: p.grad.clone() for n, p in m.named_parameters() if p.grad is not None}))
+    (o1, l1, g1), (o2, l2, g2) = outs
+    assert o2["student_output"].shape[-1] == px // 2 and l1 == l2
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert torch.equal(o1[k], o2[k]), k
+    assert set(g1) == set(g2) and len(g1) > 0 and all(torch.equal(g1[n], g2[n]) for n in g1)
+    # and the samplers decode (FD3:794-797, 838-841), log_samples infers the latent shape (FD3:904-912)
+    if step == 0 and px == 32:
+        from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+        res = []
+        for cls, ccls in ((FD3, FD3C), (FlashDiffusionSD3Ref, FlashSD3ConfigRef)):
+            extra = dict(vae=TinyVAE(), lpips_model=TinyLPIPS()) if cls is FlashDiffusionSD3Ref else dict(vae=TinyVAE())
+            m = _build_sd3(cls, ccls, extra=extra, **kw)
+            m.lpips = TinyLPIPS()
+            m.sampling_noise_scheduler = FlowMatchEulerDiscreteSchedulerRef()
+            m.teacher_sampling_noise_scheduler = FlowMatchEulerDiscreteSchedulerRef()
+            torch.manual_seed(7)
+            res.append(m.log_samples({"image": torch.zeros(2, 3, 32, 32), "text": ["a", "b"]}, num_steps=2, max_samples=2,
+                                     log_teacher_samples=True))
+        assert list(res[0]) == list(res[1]) and len(res[0]) == 2
+        for k in res[0]:
+            assert res[0][k].shape == (2, 3, 32, 32) and torch.equal(res[0][k], res[1][k]), k
