@@ -175,6 +175,8 @@ def test_lpips_step_with_vae_matches_reference_golden(monkeypatch):
     with pytest.raises(ValueError, match="vae"):
         FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
                        teacher_noise_scheduler=DPMSolverMultistepScheduler(), lpips_model=TinyLPIPS())
+    import sys
+    monkeypatch.setitem(sys.modules, "lpips", None)      # (the oracle's shim may have registered a stub module earlier in the run)
     with pytest.raises(ImportError, match="lpips_model"):
         FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
                        teacher_noise_scheduler=DPMSolverMultistepScheduler(), vae=TinyVAE())
