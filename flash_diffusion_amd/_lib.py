@@ -51,6 +51,7 @@ _SIGS = {
     "fdmi_unet_backward": (i32, [vp, i32, vp, vp, vp]),
     "fdmi_unet_last_flops": (C.c_double, [vp]),
     "fdmi_unet_last_gn_epilogue": (i32, [vp, C.POINTER(i32)]),
+    "fdmi_unet_last_hbm_bytes": (C.c_double, [vp, i32]),
     "fdmi_unet_set_down_residuals": (i32, [vp, vp, i32, f32]),
     "fdmi_teacher_loop_scratch_bytes": (i64, [vp, i32, i32, i32]),
     "fdmi_teacher_loop": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, vp]),

@@ -21,6 +21,9 @@
 
 namespace {
 
+enum { HBM_GN_REDUCE = 0, HBM_GN_APPLY, HBM_LN, HBM_TRANSPOSE2D, HBM_TRANSPOSE_HEADS, HBM_COPY2D, HBM_GEGLU_BWD, HBM_POOL,
+       FDMI_HBM_FAMILIES };
+
 struct Arena {
   char* base = nullptr;
   size_t cap = 0, off = 0, peak = 0;
@@ -169,6 +172,9 @@ struct fdmi_unet {
   Run runs[8];
   double last_flops = 0;     // algorithmic MFMA flops of the last forward/backward call
   int last_gn = 0, last_gn_epi = 0;  // GroupNorms of the last forward / how many took their sums from a GEMM epilogue
+  // algorithmic HBM bytes of the HBM-bound kernel families of the last forward (+ backward): every operand touched once
+  // (fdmi_unet_last_hbm_bytes; DESIGN.md section 5 prices the measured kernel times against these)
+  double hbm[FDMI_HBM_FAMILIES] = {0};
 
   ~fdmi_unet() {
     for (void* p : owned) (void)hipFree(p);
@@ -537,6 +543,7 @@ struct Exec {
     const int64_t rp = (x->rows + 7) & ~(int64_t)7;
     x->tr = (bf16_t*)R.arena.alloc((size_t)x->cols * rp * 2);
     if (!x->tr) return nullptr;
+    U->hbm[HBM_TRANSPOSE2D] += 4.0 * x->rows * x->cols;
     if (!R.dry() && launch_transpose2d_pad(x->p, x->cols, x->tr, rp, x->rows, x->cols, rp, st)) return nullptr;
     return x->tr;
   }
@@ -613,6 +620,7 @@ struct Exec {
         FDMI_HIP(hipMemsetAsync(g, 0, (size_t)dst->rows * dst->cols * 2, st));
       RET_IF(launch_copy2d(src, ld_src, sc0, g, dst->cols, dc0, dst->rows, cols, dst->ginit ? 1 : 0, st));
     }
+    U->hbm[HBM_COPY2D] += (dst->ginit ? 6.0 : 4.0) * dst->rows * cols;
     dst->ginit = true;
     return 0;
   }
@@ -661,6 +669,7 @@ struct Exec {
           FDMI_CHECK(tmp, "unet: workspace exhausted");
           d.C = tmp; d.ldc = x->cols;
           RET_IF(E.gemm(d));
+          E.U->hbm[HBM_POOL] += 2.0 * x->rows * x->cols * (4 + 1 + (x->ginit ? 1 : 0));
           if (!E.R.dry()) RET_IF(launch_pool2x2_sum(tmp, dx, x->B, x->H, x->W, x->cols, x->ginit ? 1 : 0, E.st));
         } else {
           d.C = dx; d.ldc = x->cols;
@@ -682,6 +691,9 @@ struct Exec {
     const bool ready = x->gn != nullptr;   // the producing GEMM's epilogue already left the sums (want_gn)
     ++U->last_gn;
     if (ready) ++U->last_gn_epi;
+    const double el = (double)x->rows * x->cols;
+    if (!ready) U->hbm[HBM_GN_REDUCE] += 2 * el;   // one read of the tensor
+    U->hbm[HBM_GN_APPLY] += 4 * el;                // read + write
     float* stats = ready ? x->gn : R.zalloc(sbytes);
     const bool zeroed = stats != nullptr;
     if (!stats) stats = (float*)R.arena.alloc(sbytes);
@@ -697,6 +709,8 @@ struct Exec {
         const bool bzeroed = bst != nullptr;
         if (!bst) bst = (float*)E.R.arena.alloc((size_t)x->B * G * 2 * sizeof(float));
         FDMI_CHECK(dx && bst, "unet: workspace exhausted (grad)");
+        E.U->hbm[HBM_GN_REDUCE] += 4.0 * x->rows * x->cols;                            // reads x and dy
+        E.U->hbm[HBM_GN_APPLY] += (x->ginit ? 8.0 : 6.0) * x->rows * x->cols;        // reads x, dy (, dx), writes dx
         if (!E.R.dry())
           RET_IF(launch_groupnorm_bwd(x->p, y->g, n.gamma, n.beta, stats, bst, dx, x->B, HW, x->cols, G, eps, silu,
                                       x->ginit ? 1 : 0, E.st, bzeroed));
@@ -710,12 +724,14 @@ struct Exec {
   T* layernorm(T* x, Norm& n) {
     T* y = R.mk(x->rows, x->cols, x->B, x->H, x->W);
     if (!y) return nullptr;
+    U->hbm[HBM_LN] += 4.0 * x->rows * x->cols;
     if (!R.dry()) NULL_IF(launch_layernorm_fwd(x->p, n.gamma, n.beta, nullptr, nullptr, 0, 1, y->p, x->rows, x->cols, 1e-5f, st));
     if (R.save) {
       R.tape.push_back([x, y, &n](Exec& E) -> int {
         if (!y->g) return 0;
         bf16_t* dx = E.grad_of(x);
         FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
+        E.U->hbm[HBM_LN] += (x->ginit ? 8.0 : 6.0) * x->rows * x->cols;
         if (!E.R.dry())
           RET_IF(launch_layernorm_bwd(x->p, y->g, n.gamma, nullptr, 0, 1, dx, x->rows, x->cols, 1e-5f, x->ginit ? 1 : 0, E.st));
         x->ginit = true;
@@ -739,6 +755,7 @@ struct Exec {
     a.lse = lse; a.out = o->p; a.ldout = o->cols; a.vt_ones = 1;
     a.B = Bn; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.f / sqrtf((float)d);
     flops += 4.0 * Bn * H * (double)Sq * Skv * d;
+    if (!vt_ready) U->hbm[HBM_TRANSPOSE_HEADS] += 4.0 * Bn * Skv * H * d;
     if (!R.dry()) {
       if (!vt_ready) NULL_IF(launch_transpose_heads(v->p, v->cols, VT, Bn, H, Skv, d, st, 1));
       NULL_IF(launch_attn_fwd(a, st));
@@ -753,6 +770,7 @@ struct Exec {
         bf16_t *dq = E.grad_of(q), *dk = E.grad_of(k), *dv = E.grad_of(v);
         FDMI_CHECK(QT && dOT && KT && delta && dq && dk && dv, "unet: workspace exhausted (attn bwd)");
         E.flops += 2.0 * 4.0 * Bn * H * (double)Sq * Skv * d;  // algorithmic: 2x forward
+        E.U->hbm[HBM_TRANSPOSE_HEADS] += 4.0 * Bn * H * d * (2.0 * Sq + Skv);
         if (!E.R.dry()) {
           RET_IF(launch_transpose_heads(q->p, q->cols, QT, Bn, H, Sq, d, E.st));
           RET_IF(launch_transpose_heads(o->g, o->cols, dOT, Bn, H, Sq, d, E.st));
@@ -785,6 +803,7 @@ struct Exec {
         T* dpre = E.R.mk(x->rows, w.N);
         bf16_t* dx = E.grad_of(x);
         FDMI_CHECK(dpre && dx, "unet: workspace exhausted (geglu bwd)");
+        E.U->hbm[HBM_GEGLU_BWD] += 2.0 * x->rows * (2.0 * F + F + 2.0 * F);   // reads pre [2F], dy [F]; writes dpre [2F]
         if (!E.R.dry()) RET_IF(launch_geglu_bwd(pre->p, y->g, dpre->p, x->rows, F, E.st));
         RET_IF(E.gemm_rows(dpre->p, w.N, x->rows, w.wt, w.K, w.N, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
         x->ginit = true;
@@ -797,6 +816,7 @@ struct Exec {
   T* cat(T* a, T* b) {
     T* y = R.mk(a->rows, a->cols + b->cols, a->B, a->H, a->W);
     if (!y) return nullptr;
+    U->hbm[HBM_COPY2D] += 4.0 * y->rows * y->cols;
     if (!R.dry()) {
       NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0, st));
       NULL_IF(launch_copy2d(b->p, b->cols, 0, y->p, y->cols, a->cols, b->rows, b->cols, 0, st));
@@ -816,6 +836,7 @@ struct Exec {
   T* dup(T* a) {
     T* y = R.mk(2 * a->rows, a->cols, 2 * a->B, a->H, a->W);
     if (!y) return nullptr;
+    U->hbm[HBM_COPY2D] += 6.0 * a->rows * a->cols;
     if (!R.dry()) {
       NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0, st));
       NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p + (int64_t)a->rows * a->cols, y->cols, 0, a->rows, a->cols, 0, st));
@@ -921,6 +942,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   // in place AFTER their tensor was produced, so a forward that carries them keeps the reduce kernel everywhere.
   E.gn_epi = fdmi_tune_get(14) != 0 && U->down_res.empty();
   U->last_gn = U->last_gn_epi = 0;
+  for (double& b : U->hbm) b = 0;
   R.tensors.clear();
   R.tape.clear();
   R.arena.off = 0;
@@ -1185,6 +1207,9 @@ int fdmi_unet_backward(fdmi_unet* U, int slot, const float* grad_out, float* gra
 }
 
 double fdmi_unet_last_flops(fdmi_unet* U) { return U ? U->last_flops : 0.0; }
+double fdmi_unet_last_hbm_bytes(fdmi_unet* U, int family) {
+  return (U && family >= 0 && family < FDMI_HBM_FAMILIES) ? U->hbm[family] : -1.0;
+}
 int fdmi_unet_last_gn_epilogue(fdmi_unet* U, int* total) {
   if (total) *total = U ? U->last_gn : 0;
   return U ? U->last_gn_epi : 0;

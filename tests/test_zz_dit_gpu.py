@@ -526,3 +526,45 @@ def _body_test_step_with_vae_and_lpips_matches_reference_golden():
             fa.append(p.grad.detach().float().cpu().flatten())
             fb.append(ref.float().flatten())
     assert len(fa) > 0 and _cos(torch.cat(fa), torch.cat(fb)) > 0.99
+
+
+# ---- GroupNorm reduction pass with four rows in flight per thread (developer knob 15) ---------------------------------------------
+# row counts around the unroll boundaries: fewer rows per thread than one unrolled trip, exact multiples, ragged tails, C > 2048
+GN_UNR = [(2, 64, 32, 32), (2, 256, 320, 32), (1, 100, 960, 32), (2, 16, 2560, 32), (3, 64, 128, 4), (2, 1024, 640, 32),
+          (1, 4099, 320, 32), (2, 37, 1280, 32)]
+
+
+@pytest.mark.parametrize("cfg", GN_UNR)
+def test_groupnorm_unrolled_reduction(cfg):
+    run_isolated(__name__, "_body_test_groupnorm_unrolled_reduction", (cfg,))
+
+
+def _body_test_groupnorm_unrolled_reduction(cfg):
+    """knob 15: forward statistics and backward sums of the unrolled kernel against the plain kernel (same accumulation per
+    thread up to the order of four adds) and against torch"""
+    from flash_diffusion_amd import _lib
+    ops = _ops()
+    L = _lib.lib()
+    B, HW, Cc, G = cfg
+    x = b16(rnd(B, HW, Cc, seed=1) * 1.5 + 0.3)
+    gamma, beta = 1 + 0.1 * rnd(Cc, seed=2), 0.1 * rnd(Cc, seed=3)
+    dy = b16(rnd(B, HW, Cc, seed=4))
+    for silu in (0, 1):
+        xr = x.float().permute(0, 2, 1).requires_grad_()
+        ref = F.group_norm(xr, G, gamma, beta, 1e-5)
+        if silu:
+            ref = F.silu(ref)
+        ref.backward(dy.float().permute(0, 2, 1))
+        y0, st0 = ops.groupnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), G, 1e-5, silu)
+        dx0 = ops.groupnorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), st0, G, 1e-5, silu)
+        L.fdmi_tune_set(15, 1)
+        try:
+            y1, st1 = ops.groupnorm_fwd(x.cuda(), gamma.cuda(), beta.cuda(), G, 1e-5, silu)
+            dx1 = ops.groupnorm_bwd(x.cuda(), dy.cuda(), gamma.cuda(), beta.cuda(), st1, G, 1e-5, silu)
+            torch.cuda.synchronize()
+        finally:
+            L.fdmi_tune_set(15, 0)
+        close(f"gn_unr_stats{cfg}_{silu}", st1[..., 1], st0[..., 1].float(), tol_el=1e-4, tol_fro=1e-5)
+        close(f"gn_unr_fwd{cfg}_{silu}", y1, ref.permute(0, 2, 1))
+        close(f"gn_unr_bwd{cfg}_{silu}", dx1, xr.grad.permute(0, 2, 1), tol_el=2 ** -6, tol_fro=6e-3)
+        close(f"gn_unr_bwd_vs_plain{cfg}_{silu}", dx1, dx0.float(), tol_el=2 ** -7, tol_fro=2e-3)
