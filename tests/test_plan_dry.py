@@ -167,3 +167,29 @@ def test_plan_takes_groupnorm_sums_from_the_epilogue_only_behind_knob_14():
         assert lib.fdmi_unet_last_gn_epilogue(pt.handle, None) == 0     # nothing in the tiny plan reaches a 256-row kernel
     finally:
         lib.fdmi_tune_set(14, 0)
+
+
+def test_hbm_byte_counters_of_the_memory_bound_families():
+    """fdmi_unet_last_hbm_bytes (scripts/hbm_table.py prices the measured kernel times against these): linear in the batch, the
+    GroupNorm apply pass moves twice the bytes of the reduce pass over the same tensors, the backward adds its share, knob 14
+    removes the reduce bytes of the tensors whose sums come from a GEMM epilogue"""
+    lib = _lib.lib()
+    m, plan = _plan(SD15)
+
+    def fam(B, flags):
+        _query(plan, B, 64, 77, flags)
+        return [lib.fdmi_unet_last_hbm_bytes(plan.handle, i) for i in range(8)]
+
+    f16, f32 = fam(16, 0), fam(32, 0)
+    assert all(abs(b - 2 * a) <= 1e-9 * max(b, 1.0) for a, b in zip(f16, f32))
+    assert f16[0] > 0 and abs(f16[1] - 2 * f16[0]) < 1e-9 * f16[1]            # forward: reduce reads x, apply reads x + writes y
+    assert f16[2] > 0 and f16[4] > 0 and f16[5] > 0 and f16[6] == 0 and f16[7] == 0   # (GEGLU backward / pooling: backward only)
+    assert lib.fdmi_unet_last_hbm_bytes(plan.handle, 8) == -1.0
+    sv = fam(16, FDMI_UNET_SAVE)
+    assert all(s >= f for s, f in zip(sv, f16)) and sv[6] > 0 and sv[7] > 0 and sv[0] > 2.5 * f16[0]
+    lib.fdmi_tune_set(14, 1)
+    try:
+        on = fam(16, 0)
+    finally:
+        lib.fdmi_tune_set(14, 0)
+    assert on[1] == f16[1] and 0.2 * f16[0] < on[0] < 0.6 * f16[0], (on[0], f16[0])   # the up path's concatenated inputs remain
