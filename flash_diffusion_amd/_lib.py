@@ -66,6 +66,7 @@ _SIGS = {
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "fdmi_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
+    "fdmi_wgrad_tn": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]),
     "fdmi_gemm_gn_ok": (i32, [C.POINTER(GemmDesc), i32, i32]),
     "fdmi_gemm_gn": (i32, [C.POINTER(GemmDesc), vp, i32, i32, vp]),
     "fdmi_groupnorm_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),

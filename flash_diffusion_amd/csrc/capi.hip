@@ -88,6 +88,10 @@ int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_
   return 0;
 }
 
+int fdmi_wgrad_tn(const void* X, int64_t ldx, const void* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
+                  void* stream) {
+  return launch_wgrad_tn((const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, M, N1, N2, C, ldc, (hipStream_t)stream);
+}
 static GemmArgs gemm_gn_args_from(const fdmi_gemm_desc* d, float* gn_stats, int gn_rows, int gn_G) {
   GemmArgs a = gemm_args_from(d);
   a.gn_stats = gn_stats; a.gn_rows = gn_rows; a.gn_G = gn_G;

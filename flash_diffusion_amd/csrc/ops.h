@@ -3,6 +3,10 @@
 #include "common.h"
 #include "gemm.h"
 
+// ---- wgrad.hip ----  C[n1][n2] += sum_m X[m][n1] * Y[m][n2] (fp32 atomics; both operands row-major, contraction over rows)
+int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, int64_t M, int N1, int N2, float* C,
+                    int64_t ldc, hipStream_t st);
+
 // ---- norm.hip ----
 int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta, float* stats,
                          bf16_t* y, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,

@@ -584,6 +584,19 @@ struct Exec {
           T* dt = E.R.mk(x->rows, lo->r);
           FDMI_CHECK(dt, "unet: workspace exhausted (lora)");
           RET_IF(E.gemm_rows(y->g, w.N, x->rows, lo->BT, lo->r, lo->out, nullptr, dt->p, lo->r, nullptr, 0));
+          if (fdmi_tune_get(16)) {
+            // developer knob 16: both gradients straight from the row-major operands (wgrad.hip), no transposed copies
+            E.flops += 2.0 * x->rows * lo->r * ((double)lo->out + lo->in);
+            if (!E.R.dry()) {
+              RET_IF(launch_wgrad_tn(y->g, w.N, t->p, lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
+              RET_IF(launch_wgrad_tn(dt->p, lo->r, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
+            }
+            if (need_dx) {
+              bf16_t* dx = E.grad_of(x);
+              RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
+            }
+            return 0;
+          }
           T ygrad = *y;
           ygrad.p = y->g; ygrad.tr = nullptr;
           bf16_t* dyT = E.transposed(&ygrad);

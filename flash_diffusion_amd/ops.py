@@ -88,6 +88,15 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
     return out
 
 
+def wgrad_tn(X, Y, out):
+    """out[N1, N2] (f32, accumulated) += X[M, N1]^T @ Y[M, N2]: both operands row-major bf16, contraction over the rows"""
+    M = X.shape[0]
+    assert Y.shape[0] == M and X.stride(1) == 1 and Y.stride(1) == 1 and out.dtype == torch.float32 and out.stride(1) == 1
+    check(lib().fdmi_wgrad_tn(ptr(X), X.stride(0), ptr(Y), Y.stride(0), M, X.shape[1], Y.shape[1], ptr(out), out.stride(0),
+                              stream_ptr()))
+    return out
+
+
 def gemm_gn_ok(M, N, K, rows_per_sample, G, conv=None, ldc=None, **fields):
     """host-only: would fdmi_gemm_gn accept this problem (a 256-row kernel, no split-K, full tiles inside one sample)?"""
     d = GemmDesc()

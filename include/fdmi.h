@@ -75,6 +75,12 @@ int fdmi_gemm_gn(const fdmi_gemm_desc* d, float* gn_stats, int gn_rows, int gn_G
 int fdmi_groupnorm_apply(const void* x, const float* gamma, const float* beta, const float* stats /*[B][G][2] sums*/,
                          void* y, int B, int HW, int C, int G, float eps, int silu, void* stream);
 
+/* TN product for weight gradients that contract over the ROWS of two row-major bf16 activations (the LoRA gradients
+ * dB = dY^T t, dA = dt^T x of peft's y = W x + B A x, examples/train_flash_sd.py:191-200):
+ * C[n1][n2] += sum_m X[m][n1] * Y[m][n2], C fp32 [N1][ldc] accumulated with atomics (caller zeroes it once per step).  */
+int fdmi_wgrad_tn(const void* X, int64_t ldx, const void* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
+                  void* stream);
+
 /* ---------------- normalisation (NHWC / token-major bf16, fp32 statistics) -------------------- */
 int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, float* stats /*[B][G][2]*/,
                        void* y, int B, int HW, int C, int G, float eps, int silu, void* stream);

@@ -27,7 +27,8 @@ run 09c_bench_c2_teacher_loop_dedup env FDMI_TEACHER_LOOP=1 FDMI_TUNE=13=1 timeo
 # 6. C2 with the GroupNorm sums taken from the producing GEMM's epilogue (knob 14), alone and with the other levers
 run 09d_bench_c2_gn_epilogue env FDMI_TUNE=14=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
 run 09f_bench_c2_gn_unrolled env FDMI_TUNE=15=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
-run 09e_bench_c2_all_levers env FDMI_TEACHER_LOOP=1 FDMI_TUNE=13=1,14=1,15=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
+run 09g_bench_c2_wgrad_tn env FDMI_TUNE=16=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
+run 09e_bench_c2_all_levers env FDMI_TEACHER_LOOP=1 FDMI_TUNE=13=1,14=1,15=1,16=1 timeout 900 python bench.py --steps 5 --warmup 2 --no-secondary --no-cpu-baseline
 grep -h '"metric"' "$out"/0[3-9]*.log | python -c "
 import sys, json
 for l in sys.stdin:

@@ -1,0 +1,79 @@
+"""CPU: the index bookkeeping of the TN weight-gradient kernel (csrc/wgrad.hip) restated in numpy on top of the MFMA operand
+convention the validated NT kernels use (gemm.hip: a fragment = 8 consecutive k of index lane & 15, k-block lane >> 4; lane (g, j)
+of the 16x16 result holds first-operand indices g*4 .. g*4+3 and second-operand index j): the transposing scatter of a 64-row
+slab into the swizzled [index][64 k] LDS image, the fragment reads at that image's addresses, the wave / fragment -> (n1, n2)
+mapping of the epilogue, zero fill past M / N1 / N2 and the row splits -- against X^T Y.  It restates the index math (the kernel
+itself runs in tests/test_zz_dit_gpu.py on the GPU): a change to one must be mirrored in the other."""
+import numpy as np
+import pytest
+
+BN1, BN2, BK = 64, 128, 64
+
+
+def img_off(row, k):
+    return ((row * 8 + ((k >> 3) ^ ((row >> 1) & 7))) << 4) + ((k & 7) << 1)
+
+
+def emulate(M, N1, N2, rows_per_split, seed=0):
+    rng = np.random.default_rng(seed)
+    X = rng.integers(-3, 4, (M, N1)).astype(np.float64)     # small integers: every partial sum is exact
+    Y = rng.integers(-3, 4, (M, N2)).astype(np.float64)
+    C = np.zeros((N1, N2))
+    for bz in range((M + rows_per_split - 1) // rows_per_split):
+        m_beg, m_end = bz * rows_per_split, min(M, (bz + 1) * rows_per_split)
+        for by in range((N1 + BN1 - 1) // BN1):
+            for bx in range((N2 + BN2 - 1) // BN2):
+                n1_0, n2_0 = by * BN1, bx * BN2
+                acc = np.zeros((4, 2, 4, 64, 4))                       # [wave][f1][f2][lane][r]
+                for kt in range((m_end - m_beg + BK - 1) // BK):
+                    m0 = m_beg + kt * BK
+                    sx, sy = np.zeros(BN1 * 64), np.zeros(BN2 * 64)    # images indexed by byte offset / 2
+                    for img, src, n0, N, BN in ((sx, X, n1_0, N1, BN1), (sy, Y, n2_0, N2, BN2)):
+                        for q in range(BK * (BN // 8)):                 # chunk q: source row m = q / (BN/8), columns c*8 .. +7
+                            m, c = q // (BN // 8), q % (BN // 8)
+                            n = n0 + c * 8
+                            v = src[m0 + m, n:n + 8] if (m0 + m < m_end and n < N) else np.zeros(8)
+                            for e in range(8):
+                                img[img_off(c * 8 + e, m) // 2] = v[e]
+                    for wave in range(4):
+                        w1, w2 = wave >> 1, wave & 1
+                        for ks in range(2):
+                            xf = np.zeros((2, 64, 8))
+                            yf = np.zeros((4, 64, 8))
+                            for lane in range(64):
+                                g, j = lane >> 4, lane & 15
+                                pc = (ks * 4 + g) ^ (j >> 1)
+                                for f in range(2):
+                                    base = (((w1 * 32 + f * 16 + j) * 8 + pc) * 16) // 2
+                                    xf[f, lane] = sx[base:base + 8]
+                                for f in range(4):
+                                    base = (((w2 * 64 + f * 16 + j) * 8 + pc) * 16) // 2
+                                    yf[f, lane] = sy[base:base + 8]
+                            for f1 in range(2):
+                                for f2 in range(4):
+                                    A = np.zeros((16, 32))
+                                    Bm = np.zeros((32, 16))
+                                    for lane in range(64):              # the MFMA operand convention
+                                        A[lane & 15, (lane >> 4) * 8:(lane >> 4) * 8 + 8] = xf[f1, lane]
+                                        Bm[(lane >> 4) * 8:(lane >> 4) * 8 + 8, lane & 15] = yf[f2, lane]
+                                    D = A @ Bm
+                                    for lane in range(64):
+                                        for r in range(4):
+                                            acc[wave, f1, f2, lane, r] += D[(lane >> 4) * 4 + r, lane & 15]
+                for wave in range(4):
+                    w1, w2 = wave >> 1, wave & 1
+                    for f1 in range(2):
+                        for f2 in range(4):
+                            for lane in range(64):
+                                g, j = lane >> 4, lane & 15
+                                n2 = n2_0 + w2 * 64 + f2 * 16 + j
+                                for r in range(4):
+                                    n1 = n1_0 + w1 * 32 + f1 * 16 + g * 4 + r
+                                    if n1 < N1 and n2 < N2:
+                                        C[n1, n2] += acc[wave, f1, f2, lane, r]
+    return np.abs(C - X.T @ Y).max()
+
+
+@pytest.mark.parametrize("M,N1,N2,rps", [(128, 64, 128, 64), (200, 64, 128, 128), (77, 128, 320, 64), (130, 72, 40, 192)])
+def test_tn_kernel_bookkeeping_equals_xt_y(M, N1, N2, rps):
+    assert emulate(M, N1, N2, rps) == 0.0

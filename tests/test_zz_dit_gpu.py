@@ -568,3 +568,68 @@ def _body_test_groupnorm_unrolled_reduction(cfg):
         close(f"gn_unr_fwd{cfg}_{silu}", y1, ref.permute(0, 2, 1))
         close(f"gn_unr_bwd{cfg}_{silu}", dx1, xr.grad.permute(0, 2, 1), tol_el=2 ** -6, tol_fro=6e-3)
         close(f"gn_unr_bwd_vs_plain{cfg}_{silu}", dx1, dx0.float(), tol_el=2 ** -7, tol_fro=2e-3)
+
+
+# ---- TN weight-gradient kernel (csrc/wgrad.hip, developer knob 16): LoRA gradients without transposed operand copies ------------
+@pytest.mark.parametrize("shape", [(4096, 320, 128), (65536, 128, 320), (1232, 640, 128), (1232, 128, 768), (16384, 1280, 128),
+                                   (130, 72, 40), (64, 64, 128), (100000, 128, 1280)])
+def test_wgrad_tn(shape):
+    run_isolated(__name__, "_body_test_wgrad_tn", (shape,))
+
+
+def _body_test_wgrad_tn(shape):
+    """C += X^T Y on row-major bf16 operands (fp32 atomics), against torch in fp64 on the same bf16 values; accumulation into a
+    non-zero C and a strided view of X (the gradient of a fused buffer)"""
+    ops = _ops()
+    M, N1, N2 = shape
+    X, Y = b16(rnd(M, N1 + 8, seed=1)), b16(rnd(M, N2, seed=2))
+    Xv = X[:, 8:]                                         # leading dimension N1 + 8, 16-byte aligned start
+    C0 = rnd(N1, N2, seed=3)
+    ref = C0.double() + Xv.double().t() @ Y.double()
+    out = C0.clone().cuda()
+    ops.wgrad_tn(X.cuda()[:, 8:], Y.cuda(), out)
+    torch.cuda.synchronize()
+    err = (out.double().cpu() - ref).abs().max().item()
+    scale = ref.abs().max().item()
+    assert err <= 2e-5 * scale + 1e-4, (err, scale)       # fp32 accumulation of exact bf16 products, split / atomic order
+
+
+def test_lora_gradients_with_the_tn_kernel_match_the_transposed_path():
+    run_isolated(__name__, "_body_test_lora_gradients_with_the_tn_kernel_match_the_transposed_path", ())
+
+
+def _body_test_lora_gradients_with_the_tn_kernel_match_the_transposed_path():
+    """knob 16 inside the UNet plan: the flat LoRA gradient and the input gradient of a backward pass equal the ones of the
+    transposed-copy path up to fp32 summation order (same bf16 operands, same products)"""
+    from flash_diffusion_amd import _lib
+    from flash_diffusion_amd.unet import MiUNet2DConditionModel
+    from flash_diffusion_amd.workloads import TINY
+    L = _lib.lib()
+    torch.manual_seed(0)
+    net = MiUNet2DConditionModel(**TINY).cuda()
+    net.add_adapter(8, init_std_b=0.05, generator=torch.Generator().manual_seed(1))
+    net._reflatten_lora(torch.device("cuda"))
+    g = torch.Generator(device="cpu").manual_seed(2)
+    x = torch.randn(2, 4, 32, 32, generator=g).cuda()
+    t = torch.tensor([700.0, 200.0]).cuda()
+    ctx = {"cond": {"crossattn": torch.randn(2, 77, TINY["cross_attention_dim"], generator=g).cuda()}}
+    w = torch.randn(2, 4, 32, 32, generator=g).cuda()
+
+    def grads():
+        net.lora_flat_grad().zero_()
+        xr = x.clone().requires_grad_()
+        (net(xr, t, ctx) * w).sum().backward()
+        torch.cuda.synchronize()
+        return net.lora_flat_grad().clone(), xr.grad.clone()
+
+    g0, gx0 = grads()
+    g0b, gx0b = grads()
+    noise = max(rel_err(g0b, g0), 1e-4)
+    L.fdmi_tune_set(16, 1)
+    try:
+        g1, gx1 = grads()
+    finally:
+        L.fdmi_tune_set(16, 0)
+    assert float(g0.abs().max()) > 0 and torch.isfinite(g1).all()
+    assert rel_err(g1, g0) <= 5 * noise + 1e-3, (rel_err(g1, g0), noise)
+    assert rel_err(gx1, gx0) <= 5 * max(rel_err(gx0b, gx0), 1e-4) + 1e-3
