@@ -62,6 +62,7 @@ _SIGS = {
     "fdmi_allreduce_world": (i32, []),
     "fdmi_allreduce_destroy": (i32, []),
     "fdmi_tune_set": (i32, [i32, i32]),
+    "fdmi_tune_value": (i32, [i32]),
     "fdmi_prof_enable": (i32, [i32]),
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),

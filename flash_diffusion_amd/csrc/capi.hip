@@ -19,8 +19,8 @@ hipEvent_t prof_event() {
   return e;
 }
 }  // namespace
-static int g_tune[16] = {0};
-int fdmi_tune_get(int key) { return (key >= 0 && key < 16) ? g_tune[key] : 0; }
+static int g_tune[32] = {0};
+int fdmi_tune_get(int key) { return (key >= 0 && key < 32) ? g_tune[key] : 0; }
 bool fdmi_prof_on() { return g_prof; }
 void fdmi_prof_begin(hipStream_t st, int bucket, double flops) {
   ProfRec r{prof_event(), prof_event(), flops, bucket};
@@ -32,10 +32,11 @@ void fdmi_prof_end(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); 
 extern "C" {
 
 int fdmi_tune_set(int key, int value) {
-  FDMI_CHECK(key >= 0 && key < 16, "tune key out of range");
+  FDMI_CHECK(key >= 0 && key < 32, "tune key out of range");
   g_tune[key] = value;
   return 0;
 }
+int fdmi_tune_value(int key) { return fdmi_tune_get(key); }
 int fdmi_prof_enable(int on) { g_prof = on != 0; return 0; }
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches) {
   FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (17) buckets");

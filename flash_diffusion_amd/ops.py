@@ -88,6 +88,11 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
     return out
 
 
+def tune(key):
+    """current value of a developer knob (fdmi_tune_set / FDMI_TUNE)"""
+    return lib().fdmi_tune_value(key)
+
+
 def wgrad_tn(X, Y, out):
     """out[N1, N2] (f32, accumulated) += X[M, N1]^T @ Y[M, N2]: both operands row-major bf16, contraction over the rows"""
     M = X.shape[0]

@@ -32,7 +32,8 @@ int fdmi_version(void);
 /* Optional per-launch HIP-event timing of the MFMA kernels on the stream they are launched on
  * (bench.py roofline leg).  Buckets 0-7: gemm_kernel<BM,BN,mode> = mode*4 + (BM==64)*2 + (BN==64);
  * 8: attention fwd, 9: attention dQ, 10: attention dK/dV.  collect() synchronises, sums and resets. */
-int fdmi_tune_set(int key, int value);   /* developer knobs for kernel-variant A/B runs (default 0) */
+int fdmi_tune_set(int key, int value);   /* developer knobs for kernel-variant A/B runs (keys 0..31, default 0) */
+int fdmi_tune_value(int key);            /* current value of a knob (0 for an unknown key) */
 int fdmi_prof_enable(int on);
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches);
 

@@ -43,6 +43,22 @@ def gemm(A, W, *, bias=None, residual=None, act=ACT_NONE, preact=None, out=None,
     return v if out_f32 else v.to(BF16)
 
 
+TUNE = {}          # developer knobs as the host code sees them (ops.tune)
+
+
+def tune(key):
+    return TUNE.get(key, 0)
+
+
+def wgrad_tn(X, Y, out):
+    """out[N1, N2] (f32) += X[M, N1]^T @ Y[M, N2]"""
+    assert X.dtype == BF16 and Y.dtype == BF16 and X.shape[0] == Y.shape[0] and out.dtype == torch.float32
+    assert X.stride(1) == 1 and Y.stride(1) == 1 and X.stride(0) % 8 == 0 and Y.stride(0) % 8 == 0 and out.stride(1) == 1
+    assert X.shape[1] % 8 == 0 and Y.shape[1] % 8 == 0 and out.shape == (X.shape[1], Y.shape[1])
+    out.add_(X.float().t() @ Y.float())
+    return out
+
+
 def cast_transpose(w):
     assert w.dtype == torch.float32 and w.dim() == 2
     return w.to(BF16).contiguous(), w.t().to(BF16).contiguous()

@@ -138,3 +138,14 @@ def test_ctypes_argument_types_match_the_header_prototypes():
         res, at = sigs[name]
         assert [from_ctypes(x) for x in at] == hdr, (name, hdr, [from_ctypes(x) for x in at])
         assert from_ctypes(res) == from_c(ret), (name, ret)
+
+
+def test_developer_knobs_cover_the_keys_in_use():
+    """fdmi_tune_set / fdmi_tune_value: keys 0..31 (knobs 9..16 are in use), unknown keys fail to set and read as 0"""
+    from flash_diffusion_amd import _lib
+    L = _lib.lib()
+    for k in (9, 10, 11, 12, 13, 14, 15, 16, 31):
+        assert L.fdmi_tune_value(k) == 0
+        assert L.fdmi_tune_set(k, 3) == 0 and L.fdmi_tune_value(k) == 3
+        assert L.fdmi_tune_set(k, 0) == 0
+    assert L.fdmi_tune_set(32, 1) != 0 and L.fdmi_tune_value(32) == 0 and L.fdmi_tune_value(-1) == 0
