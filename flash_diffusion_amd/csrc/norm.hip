@@ -114,7 +114,9 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_b
 // apply pass: thread t owns channel chunk t % CPR for rows t / CPR, +R, +2R, ... of its row block, so
 // the per-channel affine coefficients (mean/rstd/gamma/beta -> a, b) are derived ONCE per thread and
 // the row loop is a 16-byte load, 8 fmas (+SiLU) and a 16-byte store.
-template <bool BWD>
+// UNR (forward only): rows fetched per trip before the first store -- x and y may alias as far as the compiler knows, so the
+// plain loop cannot start row r+1's load before row r's store; developer knob 15 (with the reduction pass) until its first GPU run
+template <bool BWD, int UNR = 1>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a, int rows_per_block) {
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -153,7 +155,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a, int rows_per_bl
         m2[e] = a.bstats[((int64_t)b * a.G + gi) * 2 + 1] * inv_n;
       }
     }
-    for (int r = row0 + roff; r < row1; r += R) {
+    int r = row0 + roff;
+    if constexpr (!BWD && UNR > 1) {
+      for (; r + (UNR - 1) * R < row1; r += UNR * R) {
+        u16x8 xu[UNR];
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) xu[u] = *(const u16x8*)(a.x + ((int64_t)b * a.HW + r + u * R) * a.C + c0);
+#pragma unroll
+        for (int u = 0; u < UNR; ++u) {
+          u16x8 ov;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            float z = fmaf(ca[e], bf2f(xu[u][e]), cb[e]);
+            if (a.silu) z = silu_f(z);
+            ov[e] = f2bf(z);
+          }
+          *(u16x8*)(a.y + ((int64_t)b * a.HW + r + u * R) * a.C + c0) = ov;
+        }
+      }
+    }
+    for (; r < row1; r += R) {
       const int64_t off = ((int64_t)b * a.HW + r) * a.C + c0;
       const u16x8 xv = *(const u16x8*)(a.x + off);
       u16x8 ov;
@@ -203,7 +224,8 @@ int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
     if (fdmi_tune_get(15)) hipLaunchKernelGGL((gn_reduce_kernel<false, 4>), dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
     else hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   }
-  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+  if (fdmi_tune_get(15)) hipLaunchKernelGGL((gn_apply_kernel<false, 4>), dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
