@@ -22,7 +22,7 @@
 namespace {
 
 enum { HBM_GN_REDUCE = 0, HBM_GN_APPLY, HBM_LN, HBM_TRANSPOSE2D, HBM_TRANSPOSE_HEADS, HBM_COPY2D, HBM_GEGLU_BWD, HBM_POOL,
-       FDMI_HBM_FAMILIES };
+       HBM_SPLITK, FDMI_HBM_FAMILIES };
 
 struct Arena {
   char* base = nullptr;
@@ -482,6 +482,7 @@ struct Exec {
         a.ws = (float*)R.arena.alloc(wsb);
         FDMI_CHECK(a.ws, "unet: workspace exhausted (split-K)");
         a.splitk = 0;
+        U->hbm[HBM_SPLITK] += (double)wsb + 2.0 * a.M * a.N;   // what the finalize pass reads (fp32 slabs) and writes (bf16)
       }
     }
     if (R.dry()) return 0;

@@ -225,7 +225,7 @@ int fdmi_unet_last_gn_epilogue(fdmi_unet* u, int* total);
 /* Algorithmic HBM bytes (every operand touched once) that the HBM-bound kernel families of the last forward -- plus its backward
  * once that ran -- move: family 0 GroupNorm reduce, 1 GroupNorm apply, 2 LayerNorm, 3 2-D transposes (LoRA wgrad operands),
  * 4 head transposes (attention V^T / Q^T / K^T / dO^T), 5 strided copies (skip concatenation, gradient scatter), 6 GEGLU backward,
- * 7 2x2 pooling (upsample backward); -1.0 for an unknown family.  Works in workspace-query mode (no GPU).               */
+ * 7 2x2 pooling (upsample backward), 8 the split-K finalize pass (fp32 slabs read + bf16 result written); -1.0 for an unknown family.  Works in workspace-query mode (no GPU).               */
 double fdmi_unet_last_hbm_bytes(fdmi_unet* u, int family);
 /* T2I-adapter residuals (`down_intrablock_additional_residuals`, unet.py:100-106 / flash_diffusion_model.py:208-218) for the
  * NEXT fdmi_unet_forward on this plan, consumed by it: residuals[i] is an f32 NCHW tensor with the shape of down block i's

@@ -14,9 +14,10 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 PEAK = 8.0e12   # B/s, /opt/skills/guides/MI355X_MICROARCH.md
-FAMILIES = ["gn_reduce", "gn_apply", "layernorm", "transpose2d", "transpose_heads", "copy2d", "geglu_bwd", "pool2x2"]
+FAMILIES = ["gn_reduce", "gn_apply", "layernorm", "transpose2d", "transpose_heads", "copy2d", "geglu_bwd", "pool2x2", "splitk_finalize"]
 KERNELS = {"gn_reduce": ["gn_reduce_kernel"], "gn_apply": ["gn_apply_kernel"], "layernorm": ["ln_kernel"],
-           "transpose_heads": ["transpose_heads_kernel"], "copy2d": ["copy2d_kernel"], "geglu_bwd": ["geglu_bwd_kernel"]}
+           "transpose_heads": ["transpose_heads_kernel"], "copy2d": ["copy2d_kernel"], "geglu_bwd": ["geglu_bwd_kernel"],
+           "splitk_finalize": ["gemm_finalize_kernel"]}
 
 
 def step_bytes(teacher_steps=4, B=16, hw=64, L=77):

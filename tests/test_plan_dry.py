@@ -178,13 +178,13 @@ def test_hbm_byte_counters_of_the_memory_bound_families():
 
     def fam(B, flags):
         _query(plan, B, 64, 77, flags)
-        return [lib.fdmi_unet_last_hbm_bytes(plan.handle, i) for i in range(8)]
+        return [lib.fdmi_unet_last_hbm_bytes(plan.handle, i) for i in range(9)]
 
     f16, f32 = fam(16, 0), fam(32, 0)
-    assert all(abs(b - 2 * a) <= 1e-9 * max(b, 1.0) for a, b in zip(f16, f32))
+    assert all(abs(b - 2 * a) <= 1e-9 * max(b, 1.0) for a, b in zip(f16[:8], f32[:8]))   # (split-K choices depend on the row count)
     assert f16[0] > 0 and abs(f16[1] - 2 * f16[0]) < 1e-9 * f16[1]            # forward: reduce reads x, apply reads x + writes y
     assert f16[2] > 0 and f16[4] > 0 and f16[5] > 0 and f16[6] == 0 and f16[7] == 0   # (GEGLU backward / pooling: backward only)
-    assert lib.fdmi_unet_last_hbm_bytes(plan.handle, 8) == -1.0
+    assert lib.fdmi_unet_last_hbm_bytes(plan.handle, 9) == -1.0 and f16[8] > 0      # (the deep levels run split-K)
     sv = fam(16, FDMI_UNET_SAVE)
     assert all(s >= f for s, f in zip(sv, f16)) and sv[6] > 0 and sv[7] > 0 and sv[0] > 2.5 * f16[0]
     lib.fdmi_tune_set(14, 1)
