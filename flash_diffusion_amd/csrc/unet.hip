@@ -9,6 +9,8 @@
 // activations bump-allocated from a caller-owned workspace; when `save` is set it records a tape of
 // backward closures (dgrad everywhere -- base weights are frozen -- and wgrad for the LoRA A/B
 // matrices only), which backward() replays in reverse.
+#include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <deque>
 #include <functional>
@@ -462,6 +464,11 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
 // ---------------------------------------------------------------------------------------------
 // ops with tape (forward + recorded input-gradient closure)
 // ---------------------------------------------------------------------------------------------
+static bool plan_log() {
+  static const bool on = getenv("FDMI_PLAN_LOG") != nullptr;
+  return on;
+}
+
 struct Exec {
   fdmi_unet* U;
   Run& R;
@@ -476,6 +483,13 @@ struct Exec {
   }
   int gemm(GemmArgs& a) {
     flops += gemm_flops(a);
+    if (R.dry() && plan_log()) {   // developer aid: FDMI_PLAN_LOG=1 lists every GEMM / conv of a workspace-query walk (no GPU needed)
+      GemmArgs q = a;
+      if (!q.accum_atomic && q.splitk == 1 && gemm_ws_bytes(q)) q.splitk = 0;
+      const GemmPlan p = plan_gemm(q, true);
+      fprintf(stderr, "PLANGEMM mode=%d M=%d N=%d K=%d act=%d res=%d dgrad=%d atomic=%d kernel=%d BM=%d BN=%d splitk=%d\n", a.mode, a.M, a.N,
+              a.K, a.act, a.residual ? 1 : 0, a.dgrad, a.accum_atomic, p.big, p.big ? 256 : p.BM, p.BN, p.splitk);
+    }
     if (!a.accum_atomic && a.splitk == 1) {  // let the launcher split K when the tile grid under-fills the chip
       const size_t wsb = gemm_ws_bytes(a);
       if (wsb) {

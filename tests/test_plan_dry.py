@@ -193,3 +193,23 @@ def test_hbm_byte_counters_of_the_memory_bound_families():
     finally:
         lib.fdmi_tune_set(14, 0)
     assert on[1] == f16[1] and 0.2 * f16[0] < on[0] < 0.6 * f16[0], (on[0], f16[0])   # the up path's concatenated inputs remain
+
+
+def test_plan_report_lists_the_forward_work_list():
+    """scripts/plan_report.py (FDMI_PLAN_LOG=1 on a workspace-query walk): the GEMM / conv FLOPs it lists plus the attention FLOPs
+    are the plan's own total; the C2 teacher forward runs 70 % of its contraction FLOPs on the 256x320 kernel without split-K"""
+    import os
+    import re
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "scripts", "plan_report.py"), "sd15", "32", "64"], capture_output=True,
+                         text=True, check=True).stdout
+    head = re.match(r"sd15 B=32 64x64 flags=8: (\d+) GEMM/conv launches, ([\d.]+) TFLOP", out)
+    assert head and int(head.group(1)) > 200
+    m, plan = _plan(SD15)
+    _, total = _query(plan, 32, 64, 77, FDMI_UNET_CTX_FILL)
+    attention = 32 * 0.1261e12
+    assert abs(float(head.group(2)) * 1e12 + attention - total) < 5e-3 * total
+    share = float(re.search(r"gemm4\s+BN=320\s+(\d+\.\d)%", out).group(1))
+    assert 60 < share < 80
