@@ -260,7 +260,10 @@ def main():
                                    f"{'DiT' if dit else ('MMDiT' if sd3 else 'UNet')} teacher + LoRA r{rank_r} student, {B} images/GPU, "
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
-                       "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world},
+                       "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world,
+                       # opt-in developer switches in effect for this line (none = the default, judged configuration)
+                       "dev_switches": {k: os.environ[k] for k in ("FDMI_TUNE", "FDMI_TEACHER_LOOP", "FDMI_CFG_DEDUP",
+                                                                   "FDMI_NO_CTX_CACHE") if os.environ.get(k)}},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler, "two_optimizer_step": two_opt},
         }
         print(json.dumps(line))
