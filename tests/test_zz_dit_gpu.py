@@ -378,6 +378,7 @@ def _body_test_rccl_allreduce_entry_points_world_1():
 
 
 # ---- GroupNorm statistics in the producing GEMM's epilogue (fdmi_gemm_gn, developer knob 14) ------------------------------
+# (never-launched kernel instantiations, like every knob-gated variant below: behind FDMI_RUN_DEV_KNOBS=1, see `dev_knob` above)
 # (B, H = W, Cin, Cout, kind): conv3x3 / 1x1-as-row-GEMM problems.  The planner (fdmi_gemm_plan, checked on CPU in
 # tests/test_plan_dry.py) sends the first three to the 256 x 320 kernel (M = 65536 / 32768 rows), the next ones to the
 # 256 x 160 ring kernel (5 fragments per wave: pairs + the 4-column tail path; group widths 10 and 15 straddle the 8-column
@@ -387,6 +388,7 @@ GN_EPI = [(16, 64, 64, 320, "conv"), (16, 64, 320, 320, "row"), (8, 64, 128, 640
           (1, 32, 128, 640, "conv"), (2, 32, 128, 256, "row")]
 
 
+@dev_knob
 @pytest.mark.parametrize("cfg", GN_EPI)
 def test_gemm_epilogue_groupnorm_statistics(cfg):
     run_isolated(__name__, "_body_test_gemm_epilogue_groupnorm_statistics", (cfg,))
@@ -441,6 +443,7 @@ def _body_test_gemm_gn_refuses_ineligible_problems():
         ops.gemm(A, w, gn=(stats, 128))
 
 
+@dev_knob
 def test_unet_forward_with_epilogue_groupnorm_statistics():
     run_isolated(__name__, "_body_test_unet_forward_with_epilogue_groupnorm_statistics", (), timeout=900)
 
@@ -534,6 +537,7 @@ GN_UNR = [(2, 64, 32, 32), (2, 256, 320, 32), (1, 100, 960, 32), (2, 16, 2560, 3
           (1, 4099, 320, 32), (2, 37, 1280, 32)]
 
 
+@dev_knob
 @pytest.mark.parametrize("cfg", GN_UNR)
 def test_groupnorm_unrolled_reduction(cfg):
     run_isolated(__name__, "_body_test_groupnorm_unrolled_reduction", (cfg,))
@@ -571,6 +575,7 @@ def _body_test_groupnorm_unrolled_reduction(cfg):
 
 
 # ---- TN weight-gradient kernel (csrc/wgrad.hip, developer knob 16): LoRA gradients without transposed operand copies ------------
+@dev_knob
 @pytest.mark.parametrize("shape", [(4096, 320, 128), (65536, 128, 320), (1232, 640, 128), (1232, 128, 768), (16384, 1280, 128),
                                    (130, 72, 40), (64, 64, 128), (100000, 128, 1280)])
 def test_wgrad_tn(shape):
@@ -594,6 +599,7 @@ def _body_test_wgrad_tn(shape):
     assert err <= 2e-5 * scale + 1e-4, (err, scale)       # fp32 accumulation of exact bf16 products, split / atomic order
 
 
+@dev_knob
 def test_lora_gradients_with_the_tn_kernel_match_the_transposed_path():
     run_isolated(__name__, "_body_test_lora_gradients_with_the_tn_kernel_match_the_transposed_path", ())
 
