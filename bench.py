@@ -27,16 +27,31 @@ BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<6
            "gemm4_kernel<256x320,row>", "gemm4_kernel<256x320,conv>"]
 
 
-def cpu_baseline(n_teacher_steps):
-    """The oracle (CPU fp32 restatement of the reference step, oracle/flash_ref.py -- kind "port") timed on
-    this box's host cores on a bounded sample of the SAME workload: SD1.5, r128 LoRA, 64x64 latents, n teacher
-    steps, but B=1 and ONE generator iteration."""
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            return int(n)
+    except Exception:
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
+
+
+def cpu_baseline(n_teacher_steps, budget_s=75.0):
+    """The oracle (CPU fp32 restatement of the reference step, oracle/flash_ref.py -- kind "port") timed on this box's host
+    cores on a bounded sample of the SAME workload (SD1.5, r128 LoRA, 64x64 latents, n teacher steps): whole generator
+    iterations (forward + backward + AdamW) at B=1 -- one warm-up UNet forward, then the median of up to 3 timed
+    iterations -- and, if the time budget allows, one iteration at B=2 (the batch-scaling point).  Threads = physical
+    cores (FDMI_CPU_THREADS overrides)."""
     import copy
+    import statistics
     import torch
-    from oracle.flash_ref import FlashConfigRef, FlashDiffusionRef, TensorConditioner
+    from oracle.flash_ref import Draws, FlashConfigRef, FlashDiffusionRef, TensorConditioner
     from oracle.sched_cpu import DPMSolverMultistepSchedulerRef
     from oracle.unet_cpu import UNet2DConditionRef, sd15_config
-    B = 1
+    threads = int(os.environ.get("FDMI_CPU_THREADS", "0")) or _physical_cores()
+    torch.set_num_threads(threads)
     torch.manual_seed(0)
     teacher = UNet2DConditionRef(sd15_config())
     student = copy.deepcopy(teacher)
@@ -45,18 +60,73 @@ def cpu_baseline(n_teacher_steps):
     m = FlashDiffusionRef(FlashConfigRef(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform"),
                           student_denoiser=student, teacher_denoiser=teacher,
                           teacher_noise_scheduler=DPMSolverMultistepSchedulerRef(), conditioner=TensorConditioner())
-    from oracle.flash_ref import Draws
-    batch = {"image": torch.randn(B, 4, 64, 64), "crossattn": torch.randn(B, 77, 768), "text": ["s"] * B}
-    m.draws = Draws({"noise": torch.randn(B, 4, 64, 64), "start_idx": torch.tensor([0]), "guidance": torch.tensor([0.5])})
     opt = torch.optim.AdamW([p for p in student.parameters() if p.requires_grad], lr=1e-5)
-    t0 = time.perf_counter()
-    out = m(batch, step=0)
-    out["loss"][0].backward()
-    opt.step()
-    dt = time.perf_counter() - t0
-    return {"value": B / dt, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 generator iteration (fwd+bwd+AdamW) of the same SD1.5 r128 step at B={B}, {n_teacher_steps} teacher "
-                      f"CFG steps, fp32 PyTorch-CPU oracle, {dt:.1f} s"}
+
+    def iteration(B):
+        batch = {"image": torch.randn(B, 4, 64, 64), "crossattn": torch.randn(B, 77, 768), "text": ["s"] * B}
+        m.draws = Draws({"noise": torch.randn(B, 4, 64, 64), "start_idx": torch.tensor([0]), "guidance": torch.tensor([0.5])})
+        t0 = time.perf_counter()
+        out = m(batch, step=0)
+        opt.zero_grad()
+        out["loss"][0].backward()
+        opt.step()
+        return time.perf_counter() - t0
+
+    t_begin = time.perf_counter()
+    with torch.no_grad():   # warm-up: thread pool, allocator, oneDNN primitive caches
+        teacher(torch.randn(1, 4, 64, 64), torch.tensor([999]), {"cond": {"crossattn": torch.randn(1, 77, 768)}})
+    t1 = []
+    while len(t1) < 3 and (not t1 or time.perf_counter() - t_begin + t1[-1] < budget_s):
+        t1.append(iteration(1))
+    med1 = statistics.median(t1)
+    t2 = None
+    if time.perf_counter() - t_begin + 2.2 * med1 < budget_s * 1.5:
+        t2 = iteration(2)
+    best = max(1.0 / med1, (2.0 / t2) if t2 else 0.0)
+    return {"value": best, "unit": "images/s", "cores": threads, "kind": "port",
+            "b1_s_per_iteration": [round(x, 2) for x in t1], "b1_images_per_s": 1.0 / med1,
+            "b2_s_per_iteration": round(t2, 2) if t2 else None, "b2_images_per_s": (2.0 / t2) if t2 else None,
+            "sample": f"whole generator iterations (fwd+bwd+AdamW) of the same SD1.5 r128 step, {n_teacher_steps} teacher CFG steps, "
+                      f"fp32 PyTorch-CPU oracle on {threads} threads (physical cores): 1 warm-up UNet forward, B=1 median of "
+                      f"{len(t1)} = {med1:.1f} s" + (f", B=2 one iteration = {t2:.1f} s" if t2 else "") +
+                      "; value = the better of the two batch sizes"}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` without torch.distributed.run: spawn N ranks of this script (one per GPU, RCCL rendezvous on
+    127.0.0.1) and wait.  Rank 0's stdout is ours (it prints the JSON line)."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), LOCAL_WORLD_SIZE=str(args.gpus),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            time.sleep(0.2)
+            bad = [p for p in procs if p.poll() not in (None, 0)]
+            if bad:                       # one rank died: the others would wait in a collective forever
+                rc = bad[0].returncode
+                for p in procs:
+                    if p.poll() is None:
+                        p.terminate()
+                break
+        for p in procs:
+            p.wait()
+            rc = rc or p.returncode
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    sys.exit(rc)
 
 
 def main():
@@ -78,6 +148,8 @@ def main():
     ap.add_argument("--no-secondary", action="store_true", help="skip the secondary legs (sampler, 2-optimizer step)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)             # plain `python bench.py --gpus N`: become the launcher (never returns)
     import torch
     import torch.distributed as dist
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +163,8 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
     from flash_diffusion_amd import _lib, unet as _unet
     from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
@@ -188,8 +261,14 @@ def main():
             cands = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_traffic.json")),
                            key=lambda f: int(re.search(r"r(\d+)_traffic", f).group(1)))
             with open(cands[-1]) as fh:
-                traffic = json.load(fh)["kernels"].get(name, {}).get("hbm_bytes_per_launch")
-            traffic_src = os.path.relpath(cands[-1], ROOT)
+                tj = json.load(fh)
+            # PMC traffic describes ONE build of the kernels: it is reported only when the summary was collected from the
+            # csrc/ sources this libfdmi.so was built from (hash written by scripts/rocprof_to_profiles.py), else null
+            if tj.get("csrc_sha") == _lib.source_hash():
+                traffic = tj["kernels"].get(name, {}).get("hbm_bytes_per_launch")
+                traffic_src = os.path.relpath(cands[-1], ROOT)
+            else:
+                traffic_src = os.path.relpath(cands[-1], ROOT) + " (stale: collected from other kernel sources; not used)"
         except (OSError, ValueError, KeyError, IndexError, AttributeError):
             traffic = None
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
@@ -251,8 +330,11 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.arch == "sd15":
         cpu = cpu_baseline(args.teacher_steps)
     if rank == 0:
+        headline = args.arch == "sd15" and B == 16 and args.hw == 64
+        metric = ("distillation images/sec/GPU (SD1.5 64x64 latent, bs=16); 1->8 GPU scaling" if headline else
+                  f"distillation images/sec/GPU ({args.arch.upper()} {args.hw}x{args.hw} latent, bs={B}); developer leg")
         line = {
-            "metric": "distillation images/sec/GPU (SD1.5 64x64 latent, bs=16); 1->8 GPU scaling",
+            "metric": metric, "value_is": "whole-job aggregate over n_gpus (per-GPU rate: config.images_per_sec_per_gpu)",
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",

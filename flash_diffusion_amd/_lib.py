@@ -136,6 +136,19 @@ def lib():
     return _lib
 
 
+def source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources of this build (csrc/*.hip, *.h, include/fdmi.h): ties measured
+    artefacts under profiles/ (PMC traffic) to the build they describe"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(_HERE, "csrc", "*.hip")) + glob.glob(os.path.join(_HERE, "csrc", "*.h")) +
+                    [os.path.join(os.path.dirname(_HERE), "include", "fdmi.h")]):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def check(rc):
     if rc != 0:
         raise RuntimeError("fdmi: " + lib().fdmi_last_error().decode())

@@ -206,6 +206,8 @@ def ss_name(s):
 
 
 class FlashDiffusion(nn.Module):
+    calls_before_student = True   # forward() calls the trainer's before_student hook right before the student call
+
     def __init__(self, config: FlashDiffusionConfig, student_denoiser, teacher_denoiser=None,
                  teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
                  vae=None, conditioner=None, adapter=None, discriminator: nn.Module = None, lpips_model: nn.Module = None):

@@ -29,6 +29,12 @@ from . import ops
 from .flash import Draws, _DistillLoss, _DmdLoss, _PerSampleAffine, gaussian_mixture_pmf
 
 
+# the reference's fixed unconditional prompt (FD3:207-209 in forward, 726-728 in sample): a value of its recipe, not code
+NEGATIVE_PROMPT = ("deformed, distorted, disfigured, poorly drawn, bad anatomy, wrong anatomy, extra limb, missing limb, "
+                   "floating limbs, mutated hands and fingers, disconnected limbs, mutation, mutated, ugly, disgusting, blurry, "
+                   "amputation, NSFW")
+
+
 @dataclass
 class FlashDiffusionSD3Config:
     """flash_sd3/flash_diffusion_config.py, with its __post_init__ list expansion"""
@@ -114,6 +120,8 @@ def get_sigmas(scheduler, timesteps):
 
 
 class FlashDiffusionSD3(nn.Module):
+    calls_before_student = True   # forward() calls the trainer's before_student hook right before the student call
+
     def __init__(self, config: FlashDiffusionSD3Config, student_denoiser, teacher_denoiser=None,
                  teacher_noise_scheduler=None, teacher_sampling_noise_scheduler=None, sampling_noise_scheduler=None,
                  vae=None, conditioner=None, discriminator=None, pipeline=None, cpu_offload: bool = False,
@@ -187,12 +195,16 @@ class FlashDiffusionSD3(nn.Module):
         return gaussian_mixture_pmf(K, locs, self.mixture_var[K_step], mp if mp is not None else [1 / M] * M)
 
     def _embeddings(self, batch, device):
-        """FD3:196-229: (cond, uncond) from ``pipeline.encode_prompt``"""
+        """FD3:196-229 / 716-746: (cond, uncond) from ``pipeline.encode_prompt``, called with exactly the reference's keyword
+        arguments -- in particular its fixed negative prompts (FD3:207-209, 726-728: the unconditional branch is the
+        embedding of that string, not of "") and ``clip_skip=False``."""
         self.pipeline.to(device)
         with torch.no_grad():
-            pe, npe, ppe, nppe = self.pipeline.encode_prompt(prompt=batch["text"], prompt_2=batch["text"],
-                                                             prompt_3=batch["text"], do_classifier_free_guidance=True,
-                                                             device=device)
+            pe, npe, ppe, nppe = self.pipeline.encode_prompt(
+                prompt=batch["text"], prompt_2=batch["text"], prompt_3=batch["text"],
+                negative_prompt=NEGATIVE_PROMPT, negative_prompt_2=NEGATIVE_PROMPT, negative_prompt_3=NEGATIVE_PROMPT,
+                do_classifier_free_guidance=True, prompt_embeds=None, negative_prompt_embeds=None,
+                pooled_prompt_embeds=None, negative_pooled_prompt_embeds=None, clip_skip=False, device=device)
         if self.cpu_offload:
             self.pipeline.to("cpu")
         return ({"cond": {"vector": ppe, "crossattn": pe}}, {"cond": {"vector": nppe, "crossattn": npe}})

@@ -33,6 +33,9 @@ class TrainingConfig:
     optimizers_kwargs: List[dict] = field(default_factory=lambda: [{}])
     learning_rates: List[float] = field(default_factory=lambda: [1e-3])
     lr_schedulers_name: List[Optional[str]] = field(default_factory=lambda: [None])
+    lr_schedulers_kwargs: List[dict] = field(default_factory=lambda: [{}])
+    lr_schedulers_interval: List[Optional[str]] = field(default_factory=lambda: ["step"])
+    lr_schedulers_frequency: List[Optional[int]] = field(default_factory=lambda: [1])
     trainable_params: List[List[str]] = field(default_factory=lambda: [[".*"]])
     log_keys: Any = "txt"
     log_samples_model_kwargs: dict = field(default_factory=dict)
@@ -45,6 +48,18 @@ class TrainingConfig:
             self.trainable_params = [[".*"] for _ in self.optimizers_name]
         assert len(self.optimizers_name) == len(self.trainable_params)
         assert len(self.optimizers_name) == len(self.learning_rates)
+        # training_config.py:96-136: one scheduler entry per optimizer, defaults broadcast
+        n = len(self.optimizers_name)
+        if self.lr_schedulers_name == [None]:
+            self.lr_schedulers_name = [None] * n
+        if self.lr_schedulers_kwargs == [{}]:
+            self.lr_schedulers_kwargs = [{} for _ in range(n)]
+        if self.lr_schedulers_interval == ["step"]:
+            self.lr_schedulers_interval = ["step"] * n
+        if self.lr_schedulers_frequency == [1]:
+            self.lr_schedulers_frequency = [1] * n
+        for f in (self.lr_schedulers_name, self.lr_schedulers_kwargs, self.lr_schedulers_interval, self.lr_schedulers_frequency):
+            assert len(f) == n, "one lr-scheduler entry per optimizer"
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -52,7 +67,13 @@ class FusedAdamW(torch.optim.Optimizer):
     fdmi_adamw launch per contiguous fp32 buffer.  Parameters that are views into one flat buffer
     (the LoRA tensors) are updated with a single launch."""
 
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flat=None, flat_grad=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, flat=None, flat_grad=None,
+                 amsgrad=False, maximize=False, foreach=None, capturable=False, differentiable=False, fused=None):
+        # torch.optim.AdamW's remaining keywords are accepted at the values that leave its update rule unchanged; anything
+        # that would change the arithmetic this kernel implements is refused, not ignored
+        if amsgrad or maximize or capturable or differentiable:
+            raise NotImplementedError("FusedAdamW implements plain AdamW: amsgrad / maximize / capturable / differentiable "
+                                      "must be False")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self.flat, self.flat_grad = flat, flat_grad
         self.grad_scale = 1.0
@@ -97,6 +118,9 @@ class TrainingPipeline(nn.Module):
         self._pending = None      # event recorded on the comm stream after the deferred optimizer step
         self.global_rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
+        # a process group of ONE rank still runs the collective (a no-op exchange): the RCCL path of a single-GPU box is
+        # then the same code the 8-GPU job runs
+        self.distributed = torch.distributed.is_initialized()
         self.timer = None
 
     @property
@@ -130,6 +154,7 @@ class TrainingPipeline(nn.Module):
         if len(optimizers) > 1:
             self.automatic_optimization = False
         self.optims = optimizers
+        self.lr_schedulers = self.configure_lr_schedulers()
         for pname, p in self.model.named_parameters():
             keep = any(re.match(re.compile(rx), pname) for rxs in cfg.trainable_params for rx in rxs) and p.requires_grad
             if not keep:
@@ -139,7 +164,40 @@ class TrainingPipeline(nn.Module):
         if self.overlap and torch.cuda.is_available():
             self._comm_stream = torch.cuda.Stream()
             self.model.before_student = self._wait_pending
+        if any(sc is not None for sc in self.lr_schedulers):
+            return optimizers, [sc for sc in self.lr_schedulers]
         return optimizers
+
+    def configure_lr_schedulers(self):
+        """TR:140-166: torch.optim.lr_scheduler classes by name on the matching optimizer (FusedAdamW reads its group's lr
+        at every step, so any torch scheduler drives it).  Without Lightning the stepping is this class's job: interval
+        "step" schedulers advance every `frequency` optimizer steps in the one-optimizer (automatic) mode; in the manual
+        several-optimizer loop Lightning leaves scheduler stepping to the user and the reference never does it (TR:194-217),
+        so they stay untouched there; interval "epoch" ones advance in on_train_epoch_end()."""
+        import importlib
+        cfg = self.pipeline_config
+        out = []
+        for i, name in enumerate(cfg.lr_schedulers_name):
+            if name is None:
+                out.append(None)
+                continue
+            cls = getattr(importlib.import_module("torch.optim.lr_scheduler"), name)
+            out.append({"scheduler": cls(self.optims[i], **cfg.lr_schedulers_kwargs[i]),
+                        "interval": cfg.lr_schedulers_interval[i], "monitor": "val_loss",
+                        "frequency": cfg.lr_schedulers_frequency[i] or 1})
+        return out
+
+    def _lr_step(self, i, interval):
+        sc = self.lr_schedulers[i] if i < len(getattr(self, "lr_schedulers", [])) else None
+        if sc is None or sc["interval"] != interval:
+            return
+        sc["_n"] = sc.get("_n", 0) + 1
+        if sc["_n"] % sc["frequency"] == 0:
+            sc["scheduler"].step()
+
+    def on_train_epoch_end(self):
+        for i in range(len(self.optims)):
+            self._lr_step(i, "epoch")
 
     def optimizers(self):
         return self.optims
@@ -158,7 +216,7 @@ class TrainingPipeline(nn.Module):
             side.wait_stream(torch.cuda.current_stream())
         ctx = torch.cuda.stream(side) if side is not None else _null()
         with ctx:
-            if self.world > 1:
+            if self.distributed:
                 if isinstance(opt, FusedAdamW) and opt.flat_grad is not None:
                     torch.distributed.all_reduce(opt.flat_grad)
                 else:
@@ -192,6 +250,10 @@ class TrainingPipeline(nn.Module):
     def training_step(self, train_batch: Dict[str, Any], batch_idx: int = 0) -> dict:
         if not self.optims:
             self.configure_optimizers()
+        if not getattr(self.model, "calls_before_student", False):
+            # a model whose forward never calls the before_student hook would read parameters the deferred step is
+            # still writing: wait here instead (FlashDiffusion / FlashDiffusionSD3 call the hook after their teacher loop)
+            self._wait_pending()
         if self.automatic_optimization:
             opt = self.optims[0]
             out = self.model(train_batch, device=self.device)
@@ -201,6 +263,7 @@ class TrainingPipeline(nn.Module):
             self._zero_grad(opt)
             loss.backward()
             self._reduce_and_step(opt)
+            self._lr_step(0, "step")
             return {"loss": loss.detach(), "batch_idx": batch_idx, "start_timestep": out.get("start_timestep")}
         outputs = {"batch_idx": batch_idx}
         for i, opt in enumerate(self.optims):
@@ -240,6 +303,29 @@ class TrainingPipeline(nn.Module):
         self._wait_pending()
         if torch.cuda.is_available():
             torch.cuda.synchronize()
+
+    # every reader of the trainable parameters other than the training step itself first drains the deferred
+    # all-reduce + AdamW (it runs on a side stream while the next teacher loop is in flight)
+    def state_dict(self, *a, **k):
+        self.finish()
+        return super().state_dict(*a, **k)
+
+    def log_samples(self, batch: Dict[str, Any]):
+        """TR:227-251"""
+        self.finish()
+        logs = self.model.log_samples(batch, device=self.device, **self.log_samples_model_kwargs)
+        N = min(logs[k].shape[0] for k in logs) if logs else 0
+        keys = self.pipeline_config.log_keys
+        if keys is not None:
+            for key in ([keys] if isinstance(keys, str) else keys):
+                if key in batch:
+                    logs = logs if logs is not None else {}
+                    logs[key] = batch[key][:N] if N > 0 else batch[key]
+        return logs
+
+    def sample(self, *a, **k):
+        self.finish()
+        return self.model.sample(*a, **k)
 
     # ---- TR:58-74 --------------------------------------------------------------------------------------
     def on_train_start(self):

@@ -134,6 +134,11 @@ class _Plan:
         self.workspaces: Dict[int, torch.Tensor] = {}
         self.next_slot = 1
         self.busy = set()
+        self.gen: Dict[int, int] = {}   # per-slot generation: a stale finalizer / backward must not free a re-acquired slot
+
+    def release(self, slot, gen):
+        if self.gen.get(slot) == gen:
+            self.busy.discard(slot)
 
     def close(self):
         if self.handle:
@@ -145,10 +150,12 @@ class _UNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, mod, sample, t, enc, vec, flags, *params):
         out, slot = mod._run_forward(sample, t, enc, vec, flags)
-        ctx.mod, ctx.slot = mod, slot
+        plan = mod._plan()
+        ctx.mod, ctx.slot, ctx.gen = mod, slot, plan.gen[slot]
         # a saved run whose graph is dropped without backward (e.g. the detached D-step branch,
-        # flash_diffusion_model.py:583) must give its slot back
-        weakref.finalize(ctx, mod._plan().busy.discard, slot)
+        # flash_diffusion_model.py:583) must give its slot back -- but only while the slot still holds THIS run (the
+        # graph of step n is usually dropped after step n+1 re-acquired the slot its backward had freed)
+        weakref.finalize(ctx, plan.release, slot, ctx.gen)
         ctx.needs_x = sample.requires_grad
         ctx.nparams = len(params)
         ctx.xshape = sample.shape
@@ -156,7 +163,9 @@ class _UNetFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, grad_out):
-        gx = ctx.mod._run_backward(ctx.slot, grad_out, ctx.needs_x, ctx.xshape)
+        if ctx.mod._plan().gen.get(ctx.slot) != ctx.gen:
+            raise RuntimeError("fdmi: backward of a denoiser call whose saved activations were released (slot reused)")
+        gx = ctx.mod._run_backward(ctx.slot, grad_out, ctx.needs_x, ctx.xshape, ctx.gen)
         return (None, gx, None, None, None, None) + (None,) * ctx.nparams
 
 
@@ -465,6 +474,7 @@ class MiUNet2DConditionModel(nn.Module):
         if save:
             slot = next(s for s in range(1, 8) if s not in plan.busy)
             plan.busy.add(slot)
+            plan.gen[slot] = plan.gen.get(slot, 0) + 1
             qflags = flags | (FDMI_UNET_INPUT_GRAD if sample.requires_grad else 0)
         else:
             slot, qflags = 0, flags
@@ -529,7 +539,7 @@ class MiUNet2DConditionModel(nn.Module):
         self.step_flops += self.last_flops
         return x
 
-    def _run_backward(self, slot, grad_out, needs_x, xshape):
+    def _run_backward(self, slot, grad_out, needs_x, xshape, gen=None):
         plan = self._plan()
         L = _lib.lib()
         if self.lora_rank:
@@ -539,7 +549,10 @@ class MiUNet2DConditionModel(nn.Module):
         try:
             check(L.fdmi_unet_backward(plan.handle, slot, ptr(g), ptr(gx), stream_ptr()))
         finally:
-            plan.busy.discard(slot)
+            if gen is None:
+                plan.busy.discard(slot)
+            else:
+                plan.release(slot, gen)
         self.last_flops = L.fdmi_unet_last_flops(plan.handle)
         self.step_flops += self.last_flops
         return gx

@@ -66,6 +66,7 @@ class EmbeddingPipeline:
         return self
 
     def encode_prompt(self, *a, **k):
+        self.calls = getattr(self, "calls", []) + [dict(k, _args=a)]   # what the caller asked for (kwargs parity tests)
         return self.e
 
 

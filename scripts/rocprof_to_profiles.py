@@ -145,6 +145,9 @@ def main():
     for b, (c, f, w) in per_bucket.items():
         out["kernels"][b] = {"hbm_bytes_per_launch": (f + w) / c * 1e6, "fetch_MB_corrected": round(f / c, 2),
                              "write_MB": round(w / c, 2), "launches_sampled": c}
+    sys.path.insert(0, ROOT)
+    from flash_diffusion_amd import _lib
+    out["csrc_sha"] = _lib.source_hash()   # bench.py reports this traffic only for the build it was measured on
     with open(f"{pre}_traffic{a.tag}.json", "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote", f"{pre}_traffic{a.tag}.json")

@@ -210,3 +210,33 @@ def test_dpm_loop_coefficients_reproduce_the_stepwise_scheduler(monkeypatch, K, 
         assert prev is not None or a[5] == 0.0
         prev = x0
     assert torch.allclose(got, want, rtol=1e-5, atol=1e-5), float((got - want).abs().max())
+
+
+def test_lr_schedulers_are_built_and_stepped_like_the_reference_recipe():
+    """TR:140-166: a torch.optim.lr_scheduler class by name per optimizer; one-optimizer (automatic) mode steps an
+    interval="step" scheduler every `frequency` optimizer steps; a None entry means no scheduler."""
+    m = _Toy()
+    pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-2], trainable_params=[["student_denoiser"]],
+                                              lr_schedulers_name=["StepLR"], lr_schedulers_kwargs=[dict(step_size=1, gamma=0.5)],
+                                              lr_schedulers_interval=["step"], lr_schedulers_frequency=[2]), overlap=False)
+    ret = pipe.configure_optimizers()
+    assert isinstance(ret, tuple) and ret[1][0]["interval"] == "step" and ret[1][0]["frequency"] == 2
+    lrs = []
+    for i in range(4):
+        pipe.training_step({"x": torch.randn(8, 4)}, i)
+        lrs.append(pipe.optims[0].param_groups[0]["lr"])
+    assert lrs == [1e-2, 5e-3, 5e-3, 2.5e-3]
+    p2 = TrainingPipeline(_Toy(), TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-2],
+                                                 trainable_params=[["student_denoiser"]]), overlap=False)
+    assert isinstance(p2.configure_optimizers(), list) and p2.lr_schedulers == [None]
+
+
+def test_fused_adamw_refuses_keywords_it_does_not_implement():
+    from flash_diffusion_amd.trainer import FusedAdamW
+    p = [torch.nn.Parameter(torch.zeros(4))]
+    FusedAdamW(p, lr=1e-3, amsgrad=False, foreach=None, fused=None)       # torch.optim.AdamW defaults are accepted
+    for kw in (dict(amsgrad=True), dict(maximize=True)):
+        with pytest.raises(NotImplementedError):
+            FusedAdamW(p, lr=1e-3, **kw)
+    with pytest.raises(TypeError):
+        FusedAdamW(p, lr=1e-3, nesterov=True)

@@ -227,6 +227,39 @@ def test_sd3_sample_restatement_is_bit_identical(kw):
         assert torch.equal(ar, orf) and not torch.equal(ar, a)
 
 
+def test_sd3_product_asks_the_pipeline_what_the_reference_asks(monkeypatch):
+    """FD3:203-217 (forward) and 722-736 (sample): the PRODUCT's ``pipeline.encode_prompt`` calls carry exactly the reference's
+    keyword arguments -- the fixed negative prompts and clip_skip=False included (an unconditional branch fed with "" instead
+    would change every teacher CFG target).  The stub pipeline records what it is asked."""
+    from flash_diffusion_amd import flash, flash_sd3, schedulers
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    from oracle.sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    from tests import fake_ops
+    for mod in (flash, flash_sd3, schedulers):
+        monkeypatch.setattr(mod, "ops", fake_ops)
+    for mod in (flash, flash_sd3):
+        monkeypatch.setattr(mod, "_DistillLoss", fake_ops.FakeDistillLoss)
+        monkeypatch.setattr(mod, "_DmdLoss", fake_ops.FakeDmdLoss)
+    FD3, FD3C = shim_import.import_reference_sd3()
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform")
+    real = _build_sd3(FD3, FD3C, with_disc=False, **kw)
+    real.sampling_noise_scheduler = FlowMatchEulerDiscreteSchedulerRef()
+    mine = _build_sd3(FlashDiffusionSD3, FlashDiffusionSD3Config, with_disc=False, **kw)
+    mine.teacher_noise_scheduler = FlowMatchEulerDiscreteScheduler()
+    mine.sampling_noise_scheduler = FlowMatchEulerDiscreteScheduler()
+    gb = torch.Generator().manual_seed(5)
+    batch = {"image": torch.randn(2, 4, 16, 16, generator=gb), "text": ["a", "b"]}
+    z = torch.randn(2, 4, 16, 16, generator=gb)
+    for m in (real, mine):
+        torch.manual_seed(0)
+        m(batch, step=0)
+        m.sample(z, num_steps=2, conditioner_inputs={"text": ["a", "b"]})
+    norm = lambda calls: [{k: (str(v) if k == "device" else v) for k, v in c.items()} for c in calls]
+    a, b = norm(real.pipeline.calls), norm(mine.pipeline.calls)
+    assert len(a) == len(b) == 2 and a == b
+    assert a[0]["negative_prompt"].startswith("deformed, distorted") and a[0]["clip_skip"] is False and a[0]["_args"] == ()
+
+
 # ---- PixArt DiT wrapper (SURVEY 8a row a17): the reference's REAL wrapper + AdaLayerNormSingle on the restated base ----------
 @pytest.mark.parametrize("masked,concat_vec", [(False, True), (True, True), (False, False)])
 def test_dit_wrapper_restatement_is_bit_identical(masked, concat_vec):

@@ -193,3 +193,40 @@ def test_ctx_cache_reuse_matches_recompute():
     noise = max([rel_err(r, ref1) for r in reps] + [5e-3])
     assert rel_err(a, ref1) <= 3 * noise and rel_err(b, ref2) <= 3 * noise and rel_err(c, ref3) <= 3 * noise
     assert rel_err(b, ref1) > 10 * noise  # (a different sample really gives a different output)
+
+
+def test_two_saved_forwards_and_a_stale_graph_keep_their_slots():
+    """Two grad-enabled calls on one plan before either backward (two losses summed), with the graph of an EARLIER step dropped
+    in between: the finalizer of the old graph must not hand the re-acquired slot to the second call (per-slot generation),
+    so the summed gradient equals the sum of the two separately computed ones."""
+    import gc
+    o = seeded_init_(UNet2DConditionRef(tiny_config()), 1)
+    o.add_adapter(8)
+    seeded_init_(o, 2)
+    m = mi_from_oracle(o, lora_rank=8)
+    x, t, cond = _inputs(2, 16, 64)
+    xs = [x.cuda(), (x * 0.5 + 0.1).cuda()]
+    c = _cuda(cond)
+
+    def grads():
+        return torch.cat([p.grad.detach().flatten().clone() for p in m.lora_parameters()])
+
+    def zero():
+        for p in m.lora_parameters():
+            p.grad = None
+    sep = []
+    for xi in xs:
+        zero()
+        m(xi, t.cuda(), c).square().mean().backward()
+        sep.append(grads())
+    zero()
+    old = m(xs[0], t.cuda(), c)          # step n: forward + backward, graph kept alive by `old`
+    old.square().mean().backward()
+    zero()
+    a = m(xs[0], t.cuda(), c)            # step n+1 re-acquires the slot step n's backward freed ...
+    del old
+    gc.collect()                         # ... and the old graph's finalizer fires now
+    b = m(xs[1], t.cuda(), c)            # must NOT be given a's slot
+    (a.square().mean() + b.square().mean()).backward()
+    both = grads()
+    assert rel_err(both, sep[0] + sep[1]) < 2e-2, rel_err(both, sep[0] + sep[1])

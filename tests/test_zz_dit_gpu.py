@@ -5,10 +5,8 @@ against fixtures made by the reference's REAL wrapper classes (tests/golden/dit_
 Tolerance for (2): bf16 activations through 2 blocks: outputs 2e-2 relative, LoRA gradients cosine > 0.999 and 6e-2 relative
 (what the same composition gives on CPU with bf16 storage mimicked, tests/test_dit_host_logic.py: 0.8e-2 / 2.5e-2).
 
-This file was written in a round whose GPU budget was already spent: its first run on an MI355X is the driver's round-end
-run, hence the non-strict xfail marker (an XPASS is the expected outcome; the marker goes once a GPU run has confirmed it).
-It sorts last so that nothing else depends on it, and every test body runs in its own interpreter (tests/isolate.py): a memory
-fault or a hang in a kernel that has never run costs that one test, not the pytest process holding the other results."""
+Every test body runs in its own interpreter (tests/isolate.py): a memory fault or a hang in one kernel costs that one test,
+not the pytest process holding the other results.  Plain tests: a failure here is a failure of the suite."""
 import os
 
 import pytest
@@ -20,8 +18,7 @@ from tests.golden_util import load_case, rel_err
 from tests.isolate import run_isolated
 from tests.test_kernels_gpu import b16, close, rnd
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.xfail(strict=False, reason="written without GPU access (round-1 budget spent); first GPU run")]
+pytestmark = [pytest.mark.gpu]
 
 
 def _ops():
@@ -319,7 +316,10 @@ def _body_test_step_with_adapter_matches_reference_golden():
             ref = [v for k, v in g["grads"].items() if k.replace(".base_layer.", ".") == pn][0]
             fa.append(p.grad.detach().float().cpu().flatten())
             fb.append(ref.float().flatten())
-    assert len(fa) > 0 and _cos(torch.cat(fa), torch.cat(fb)) > 0.99
+    gc = _cos(torch.cat(fa), torch.cat(fb)) if fa else float("nan")
+    print(f"lpips step: {len(fa)} LoRA grad tensors, global cosine {gc:.4f}, norm ratio "
+          f"{float(torch.cat(fa).norm() / torch.cat(fb).norm()) if fa else float('nan'):.3f}", flush=True)
+    assert len(fa) > 0 and gc > 0.99, (len(fa), gc)
 
 
 def test_cfg_halves_prefix_dedupe_matches_the_plain_call():
@@ -528,7 +528,10 @@ def _body_test_step_with_vae_and_lpips_matches_reference_golden():
             ref = [v for k, v in g["grads"].items() if k.replace(".base_layer.", ".") == pn][0]
             fa.append(p.grad.detach().float().cpu().flatten())
             fb.append(ref.float().flatten())
-    assert len(fa) > 0 and _cos(torch.cat(fa), torch.cat(fb)) > 0.99
+    gc = _cos(torch.cat(fa), torch.cat(fb)) if fa else float("nan")
+    print(f"lpips step: {len(fa)} LoRA grad tensors, global cosine {gc:.4f}, norm ratio "
+          f"{float(torch.cat(fa).norm() / torch.cat(fb).norm()) if fa else float('nan'):.3f}", flush=True)
+    assert len(fa) > 0 and gc > 0.99, (len(fa), gc)
 
 
 # ---- GroupNorm reduction pass with four rows in flight per thread (developer knob 15) ---------------------------------------------
