@@ -17,10 +17,9 @@ struct GnArgs {
   int B, HW, C, G; float eps; int silu; int accumulate;
 };
 
-// UNR: rows fetched per loop trip before any of them is consumed (UNR 16-byte loads in flight per thread instead of one; the
-// plain loop waits for each load before issuing the next: round 1 measured it at 1.6 TB/s, 20 % of the HBM roofline, against
-// 4.4 TB/s for the apply pass that also stores).  UNR = 4 is developer knob 15 until its first GPU run.
-template <bool BWD, int UNR = 1>
+// UNR: rows fetched per loop trip before any of them is consumed (UNR 16-byte loads in flight per thread instead of one; a
+// plain loop waits for each load before issuing the next: round 1 measured that at 1.6 TB/s, 20 % of the HBM roofline).
+template <bool BWD, int UNR = 4>
 __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_block) {
   __shared__ float sred[64][2];
   const int tid = threadIdx.x;
@@ -114,9 +113,9 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_b
 // apply pass: thread t owns channel chunk t % CPR for rows t / CPR, +R, +2R, ... of its row block, so
 // the per-channel affine coefficients (mean/rstd/gamma/beta -> a, b) are derived ONCE per thread and
 // the row loop is a 16-byte load, 8 fmas (+SiLU) and a 16-byte store.
-// UNR (forward only): rows fetched per trip before the first store -- x and y may alias as far as the compiler knows, so the
-// plain loop cannot start row r+1's load before row r's store; developer knob 15 (with the reduction pass) until its first GPU run
-template <bool BWD, int UNR = 1>
+// UNR (forward only): rows fetched per trip before the first store -- x and y may alias as far as the compiler knows, so a
+// plain loop cannot start row r+1's load before row r's store
+template <bool BWD, int UNR = 4>
 __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a, int rows_per_block) {
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
@@ -221,11 +220,9 @@ int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
   const int rpb = gn_rows_per_block(B, HW);
   if (!stats_ready) {
     if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
-    if (fdmi_tune_get(15)) hipLaunchKernelGGL((gn_reduce_kernel<false, 4>), dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
-    else hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+    hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   }
-  if (fdmi_tune_get(15)) hipLaunchKernelGGL((gn_apply_kernel<false, 4>), dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
-  else hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+  hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
@@ -237,8 +234,7 @@ int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, 
   GnArgs a{x, dy, gamma, beta, (float*)stats, bstats, dx, B, HW, C, G, eps, silu, accumulate};
   if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(bstats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
-  if (fdmi_tune_get(15)) hipLaunchKernelGGL((gn_reduce_kernel<true, 4>), dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
-  else hipLaunchKernelGGL(gn_reduce_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+  hipLaunchKernelGGL(gn_reduce_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
   return 0;

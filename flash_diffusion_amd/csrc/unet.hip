@@ -42,7 +42,6 @@ struct Arena {
 struct T {  // NHWC / token-major bf16 activation [rows][cols] (+ lazily allocated gradient)
   bf16_t* p = nullptr;
   bf16_t* g = nullptr;
-  bf16_t* tr = nullptr;  // cached transpose [cols][rows_pad] (LoRA wgrad)
   int64_t rows = 0;
   int cols = 0;
   int B = 0, H = 0, W = 0;
@@ -475,7 +474,7 @@ struct Exec {
   hipStream_t st;
   double flops = 0;
   int ctx_mode = 0;  // 0: none, 1: fill the cross-attention K/V cache, 2: reuse it (FDMI_UNET_CTX_*)
-  bool gn_epi = false;  // developer knob 14: GroupNorm statistics in the producing GEMM's epilogue (see want_gn)
+  bool gn_epi = false;  // GroupNorm statistics in the producing GEMM's epilogue (see want_gn)
 
   bf16_t* grad_of(T* t) {  // lazily allocate the gradient buffer
     if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * 2);
@@ -552,17 +551,6 @@ struct Exec {
     return launch_cast_transpose_jobs(U->cast_jobs, U->n_cast_jobs, st);
   }
 
-  // transposed copy [cols][rows_pad] of a token tensor (cached), zero padded
-  bf16_t* transposed(T* x) {
-    if (x->tr) return x->tr;
-    const int64_t rp = (x->rows + 7) & ~(int64_t)7;
-    x->tr = (bf16_t*)R.arena.alloc((size_t)x->cols * rp * 2);
-    if (!x->tr) return nullptr;
-    U->hbm[HBM_TRANSPOSE2D] += 4.0 * x->rows * x->cols;
-    if (!R.dry() && launch_transpose2d_pad(x->p, x->cols, x->tr, rp, x->rows, x->cols, rp, st)) return nullptr;
-    return x->tr;
-  }
-
   // y = x W^T + b (+ residual) (+ LoRA)
   T* linear(T* x, LinearW& L, T* residual = nullptr) { return linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr); }
   // gn_rows > 0: the output feeds a GroupNorm over samples of gn_rows rows (want_gn)
@@ -599,35 +587,12 @@ struct Exec {
           T* dt = E.R.mk(x->rows, lo->r);
           FDMI_CHECK(dt, "unet: workspace exhausted (lora)");
           RET_IF(E.gemm_rows(y->g, w.N, x->rows, lo->BT, lo->r, lo->out, nullptr, dt->p, lo->r, nullptr, 0));
-          if (fdmi_tune_get(16)) {
-            // developer knob 16: both gradients straight from the row-major operands (wgrad.hip), no transposed copies
-            E.flops += 2.0 * x->rows * lo->r * ((double)lo->out + lo->in);
-            if (!E.R.dry()) {
-              RET_IF(launch_wgrad_tn(y->g, w.N, t->p, lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
-              RET_IF(launch_wgrad_tn(dt->p, lo->r, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
-            }
-            if (need_dx) {
-              bf16_t* dx = E.grad_of(x);
-              RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
-            }
-            return 0;
+          // dB += dy^T t and dA += dt^T x straight from the row-major operands (wgrad.hip): no transposed copies
+          E.flops += 2.0 * x->rows * lo->r * ((double)lo->out + lo->in);
+          if (!E.R.dry()) {
+            RET_IF(launch_wgrad_tn(y->g, w.N, t->p, lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
+            RET_IF(launch_wgrad_tn(dt->p, lo->r, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
           }
-          T ygrad = *y;
-          ygrad.p = y->g; ygrad.tr = nullptr;
-          bf16_t* dyT = E.transposed(&ygrad);
-          bf16_t* tT = E.transposed(t);
-          bf16_t* dtT = E.transposed(dt);
-          bf16_t* xT = E.transposed(x);
-          FDMI_CHECK(dyT && tT && dtT && xT, "unet: workspace exhausted (lora transposes)");
-          const int64_t rp = (x->rows + 7) & ~(int64_t)7;
-          GemmArgs a;
-          a.M = lo->out; a.N = lo->r; a.K = (int)rp; a.A = dyT; a.lda = rp; a.W = tT; a.ldw = rp;
-          a.C = lo->B_grad; a.ldc = lo->r; a.out_f32 = 1; a.accum_atomic = 1; a.splitk = 0;
-          RET_IF(E.gemm(a));
-          GemmArgs b;
-          b.M = lo->r; b.N = lo->in; b.K = (int)rp; b.A = dtT; b.lda = rp; b.W = xT; b.ldw = rp;
-          b.C = lo->A_grad; b.ldc = lo->in; b.out_f32 = 1; b.accum_atomic = 1; b.splitk = 0;
-          RET_IF(E.gemm(b));
           if (need_dx) {
             bf16_t* dx = E.grad_of(x);
             RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
@@ -966,9 +931,9 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   const fdmi_unet_config& c = U->cfg;
   Exec E{U, R, R.st};
   E.ctx_mode = (flags & FDMI_UNET_CTX_REUSE) ? 2 : ((flags & FDMI_UNET_CTX_FILL) ? 1 : 0);
-  // developer knob 14 (FDMI_TUNE=14=1): GroupNorm statistics from the producing GEMM's epilogue.  Adapter residuals are added
-  // in place AFTER their tensor was produced, so a forward that carries them keeps the reduce kernel everywhere.
-  E.gn_epi = fdmi_tune_get(14) != 0 && U->down_res.empty();
+  // GroupNorm statistics from the producing GEMM's epilogue (A/B switch: FDMI_TUNE=14=1 turns it off).  Adapter residuals are
+  // added in place AFTER their tensor was produced, so a forward that carries them keeps the reduce kernel everywhere.
+  E.gn_epi = fdmi_tune_get(14) == 0 && U->down_res.empty();
   U->last_gn = U->last_gn_epi = 0;
   for (double& b : U->hbm) b = 0;
   R.tensors.clear();
@@ -1291,7 +1256,7 @@ int fdmi_teacher_loop(fdmi_unet* U, int slot, float* x, const float* timesteps, 
     memcpy(&tbits, &timesteps[i], 4);
     FDMI_HIP(hipMemsetD32Async((hipDeviceptr_t)tt, (int)tbits, 2 * (size_t)B, st));
     int rc = run_forward(U, R, xx, tt, ctx2, cls2, eps, 2 * B, H, W, L,
-                         (i == 0 ? FDMI_UNET_CTX_FILL : FDMI_UNET_CTX_REUSE) | (fdmi_tune_get(13) ? FDMI_UNET_CFG_HALVES : 0));
+                         (i == 0 ? FDMI_UNET_CTX_FILL : FDMI_UNET_CTX_REUSE) | (fdmi_tune_get(13) ? 0 : FDMI_UNET_CFG_HALVES));
     if (rc) return rc;
     flops += U->last_flops;
     float* cur = x0[i & 1];

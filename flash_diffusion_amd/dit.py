@@ -66,7 +66,6 @@ class _LinearFn(torch.autograd.Function):
         if ctx.out_f32:
             dy = ops.f32_to_bf16(dy)
         M = x.shape[0]
-        Mp = _pad8(M)
         dx = dA = dB = None
         _, wtb = lin.base16()
         flops = 0.0
@@ -74,26 +73,16 @@ class _LinearFn(torch.autograd.Function):
             _, abt, _, bbt = lin.lora16()
             u = ops.gemm(dy, bbt)                                       # dL/d(A x)            [M, r]
             gv = lin._gviews           # views into the model's flat LoRA gradient (set by _reflatten_lora) or None
-            if ops.tune(16):           # developer knob 16: TN kernel on the row-major operands, no transposed copies (wgrad.hip)
-                r = lin.rank
-                dB = gv[1] if gv is not None else torch.zeros(lin.out_features, r, dtype=torch.float32, device=dy.device)
-                dA = gv[0] if gv is not None else torch.zeros(r, x.shape[1], dtype=torch.float32, device=dy.device)
-                ops.wgrad_tn(dy, t, dB)                                     # [N, r] += dy^T t
-                ops.wgrad_tn(u, x, dA)                                      # [r, K] += u^T x
-                if gv is not None:
-                    dA = dB = None
-                else:          # (a patch-embedding conv keeps its LoRA tensors 4-D)
-                    dA, dB = dA.view(ctx.ashape[0]), dB.view(ctx.ashape[1])
-                flops += 6.0 * M * lin.rank * lin.out_features + 2.0 * M * lin.rank * lin.in_features
-                return _LinearFn._finish(ctx, lin, dy, u, wtb, flops, dA, dB)
-            dB = ops.gemm(ops.transpose2d_pad(dy, Mp), ops.transpose2d_pad(t, Mp), out_f32=True, splitk=0,    # [N, r]
-                          out=None if gv is None else gv[1], accum_atomic=gv is not None)
-            dA = ops.gemm(ops.transpose2d_pad(u, Mp), ops.transpose2d_pad(x, Mp), out_f32=True, splitk=0,     # [r, K]
-                          out=None if gv is None else gv[0], accum_atomic=gv is not None)
-            if gv is None:
-                dA, dB = dA.view(ctx.ashape[0]), dB.view(ctx.ashape[1])
-            else:              # accumulated in place (fp32 atomics) where .grad already points: nothing for autograd to add
+            # weight gradients by the TN kernel on the row-major operands (wgrad.hip): no transposed copies
+            r = lin.rank
+            dB = gv[1] if gv is not None else torch.zeros(lin.out_features, r, dtype=torch.float32, device=dy.device)
+            dA = gv[0] if gv is not None else torch.zeros(r, x.shape[1], dtype=torch.float32, device=dy.device)
+            ops.wgrad_tn(dy, t, dB)                                     # [N, r] += dy^T t
+            ops.wgrad_tn(u, x, dA)                                      # [r, K] += u^T x
+            if gv is not None:     # accumulated in place (fp32 atomics) where .grad already points: nothing for autograd to add
                 dA = dB = None
+            else:                  # (a patch-embedding conv keeps its LoRA tensors 4-D)
+                dA, dB = dA.view(ctx.ashape[0]), dB.view(ctx.ashape[1])
             flops += 6.0 * M * lin.rank * lin.out_features + 2.0 * M * lin.rank * lin.in_features
         return _LinearFn._finish(ctx, lin, dy, u if ctx.lora else None, wtb, flops, dA, dB)
 

@@ -459,8 +459,8 @@ class FlashDiffusion(nn.Module):
         if (ctx_cache is not None and getattr(self.teacher_denoiser, "supports_ctx_cache", False)
                 and not os.environ.get("FDMI_NO_CTX_CACHE")):
             kwargs = dict(kwargs, ctx_cache=ctx_cache)  # same [cond | uncond] context at every step of this loop
-        if (os.environ.get("FDMI_CFG_DEDUP") == "1" and getattr(self.teacher_denoiser, "supports_cfg_halves", False)
-                and res is None):   # [x | x]: layers before the first cross-attention once (opt-in until its first GPU run)
+        if (os.environ.get("FDMI_CFG_DEDUP", "1") == "1" and getattr(self.teacher_denoiser, "supports_cfg_halves", False)
+                and res is None):   # [x | x]: layers before the first cross-attention once (A/B switch: FDMI_CFG_DEDUP=0)
             kwargs = dict(kwargs, cfg_halves=True)
         e = self.teacher_denoiser(sample=torch.cat([x, x], dim=0), timestep=torch.cat([tt, tt], dim=0),
                                   conditioning=cfg_cond, down_intrablock_additional_residuals=self._dup(res), *args,
@@ -527,11 +527,11 @@ class FlashDiffusion(nn.Module):
             x = x_init
             fused = hasattr(sch, "fused_cfg_step")
             cfg_cond = self._cat_cond(conditioning, uncond)
-            one_call = (os.environ.get("FDMI_TEACHER_LOOP") == "1" and cfg_cond is not None
+            one_call = (os.environ.get("FDMI_TEACHER_LOOP", "1") == "1" and cfg_cond is not None
                         and getattr(self, "batch_cfg", True) and hasattr(sch, "loop_coefficients")
                         and hasattr(self.teacher_denoiser, "teacher_loop") and not args and set(kwargs) <= {"device"}
                         and set(cfg_cond["cond"]) <= {"crossattn", "vector"} and res is None)
-            if one_call:   # the whole loop inside the library (fdmi_teacher_loop): opt-in until confirmed on the GPU
+            if one_call:   # the whole loop inside the library (fdmi_teacher_loop; A/B switch: FDMI_TEACHER_LOOP=0)
                 x = self.teacher_denoiser.teacher_loop(x, [float(t) for t in sch.timesteps[si:]],
                                                        cfg_cond["cond"]["crossattn"], cfg_cond["cond"].get("vector"),
                                                        sch.loop_coefficients(si, g))

@@ -84,9 +84,8 @@ def test_frozen_forward_and_input_gradient(monkeypatch, masked):
     assert _cos(xb.grad, xa.grad) > 0.995 and _rel(xb.grad, xa.grad) < 8e-2, (_cos(xb.grad, xa.grad), _rel(xb.grad, xa.grad))
 
 
-@pytest.mark.parametrize("masked,tn", [(False, 0), (True, 0), (False, 1)])   # tn: developer knob 16 (TN weight-gradient kernel)
-def test_lora_student_gradients(monkeypatch, masked, tn):
-    monkeypatch.setattr(fake_ops, "TUNE", {16: tn})
+@pytest.mark.parametrize("masked", [False, True])
+def test_lora_student_gradients(monkeypatch, masked):
     ref = dit_cpu.seeded_init_(dit_cpu.PixartTransformerRef(**dit_cpu.TINY_DIT), 3)
     dit_cpu.add_lora_(ref, 8, seed=4, b_std=0.05)
     mine = _product_from(ref, monkeypatch, lora_r=8)
@@ -262,12 +261,11 @@ def test_sd3_sampler_over_the_mmdit_batches_cfg(monkeypatch, kw):
         assert _rel(got_ref, want_ref) < 3e-2
 
 
-@pytest.mark.parametrize("kind,tn", [("pixart", 0), ("sd3", 0), ("pixart", 1)])   # tn: knob 16, gradients into the flat views
-def test_flat_lora_buffer_and_fused_adamw(monkeypatch, kind, tn):
+@pytest.mark.parametrize("kind", ["pixart", "sd3"])
+def test_flat_lora_buffer_and_fused_adamw(monkeypatch, kind):
     """trainer.py's data-parallel path wants the LoRA tensors of the student in ONE flat fp32 buffer with ONE flat gradient
     (one all-reduce, one AdamW launch): _reflatten_lora re-homes them; the backward GEMMs then accumulate straight into the
     gradient views"""
-    monkeypatch.setattr(fake_ops, "TUNE", {16: tn})
     from flash_diffusion_amd import dit, trainer
     from oracle.golden_cases import build_dit, build_mmdit
     monkeypatch.setattr(dit, "ops", fake_ops)

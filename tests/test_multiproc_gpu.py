@@ -47,9 +47,17 @@ def _body_rccl_world_1():
         if with_group:
             dist.destroy_process_group()
         return flat
-    a = run(False)
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), orig(*a, **k))[1]
+    a, a2 = run(False), run(False)
+    assert calls == []
     b = run(True)
-    assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 1e-6 * max(1.0, float(a.abs().max())), float((a - b).abs().max())
+    # the step is not bit-reproducible (float atomics in the GroupNorm sums and the weight gradients) and AdamW turns a sign
+    # flip of a near-zero gradient into a +-lr move: the yardstick is the distance between two runs WITHOUT a process group
+    noise = float((a - a2).abs().max())
+    assert len(calls) == 3 and all(n == a.numel() for n in calls), calls      # ONE collective on the flat gradient per step
+    assert torch.isfinite(b).all() and float((a - b).abs().max()) <= 3 * noise + 1e-6, (float((a - b).abs().max()), noise)
 
 
 def test_bench_launches_its_own_ranks():

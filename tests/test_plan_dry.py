@@ -133,8 +133,8 @@ def test_gn_epilogue_eligibility():
     assert not ops.gemm_gn_ok(200, 320, 320, 100, 32)                               # too small for a 256-row kernel
 
 
-def test_plan_takes_groupnorm_sums_from_the_epilogue_only_behind_knob_14():
-    """workspace-query walk of the SD1.5 plan: with the knob, the GroupNorms fed by an eligible conv / linear (64x64 and 32x32
+def test_plan_takes_groupnorm_sums_from_the_epilogue():
+    """workspace-query walk of the SD1.5 plan (A/B switch 14 = 1 turns the feature off): the GroupNorms fed by an eligible conv / linear (64x64 and 32x32
     levels; the up path's concatenated inputs and the small levels keep the reduce kernel) skip their reduction; FLOPs and
     workspace are unchanged; a forward carrying T2I-adapter residuals (added in place after production) never uses it"""
     import ctypes as C
@@ -147,10 +147,13 @@ def test_plan_takes_groupnorm_sums_from_the_epilogue_only_behind_knob_14():
         n = lib.fdmi_unet_last_gn_epilogue(plan.handle, C.byref(tot))
         return ws, fl, n, tot.value
 
-    base = counts(16, 0)
-    assert base[2] == 0 and base[3] == 61
     lib.fdmi_tune_set(14, 1)
     try:
+        base = counts(16, 0)
+    finally:
+        lib.fdmi_tune_set(14, 0)
+    assert base[2] == 0 and base[3] == 61
+    if True:
         on = counts(16, 0)
         assert on[:2] == base[:2] and on[3] == 61 and 20 <= on[2] <= 25, on
         on2 = counts(32, FDMI_UNET_CTX_FILL | FDMI_UNET_CFG_HALVES)
@@ -165,14 +168,12 @@ def test_plan_takes_groupnorm_sums_from_the_epilogue_only_behind_knob_14():
         mt, pt = _plan(TINY)
         _query(pt, 2, 32, 77, 0)
         assert lib.fdmi_unet_last_gn_epilogue(pt.handle, None) == 0     # nothing in the tiny plan reaches a 256-row kernel
-    finally:
-        lib.fdmi_tune_set(14, 0)
 
 
 def test_hbm_byte_counters_of_the_memory_bound_families():
     """fdmi_unet_last_hbm_bytes (scripts/hbm_table.py prices the measured kernel times against these): linear in the batch, the
-    GroupNorm apply pass moves twice the bytes of the reduce pass over the same tensors, the backward adds its share, knob 14
-    removes the reduce bytes of the tensors whose sums come from a GEMM epilogue"""
+    GroupNorm apply pass moves twice the bytes of the reduce pass over the same tensors, the backward adds its share, the epilogue
+    statistics remove the reduce bytes of the tensors whose sums come from a GEMM epilogue"""
     lib = _lib.lib()
     m, plan = _plan(SD15)
 
@@ -180,18 +181,16 @@ def test_hbm_byte_counters_of_the_memory_bound_families():
         _query(plan, B, 64, 77, flags)
         return [lib.fdmi_unet_last_hbm_bytes(plan.handle, i) for i in range(9)]
 
+    on = fam(16, 0)
+    lib.fdmi_tune_set(14, 1)       # the byte model below is the one of the plain reduce + apply passes
     f16, f32 = fam(16, 0), fam(32, 0)
     assert all(abs(b - 2 * a) <= 1e-9 * max(b, 1.0) for a, b in zip(f16[:8], f32[:8]))   # (split-K choices depend on the row count)
     assert f16[0] > 0 and abs(f16[1] - 2 * f16[0]) < 1e-9 * f16[1]            # forward: reduce reads x, apply reads x + writes y
     assert f16[2] > 0 and f16[4] > 0 and f16[5] > 0 and f16[6] == 0 and f16[7] == 0   # (GEGLU backward / pooling: backward only)
     assert lib.fdmi_unet_last_hbm_bytes(plan.handle, 9) == -1.0 and f16[8] > 0      # (the deep levels run split-K)
     sv = fam(16, FDMI_UNET_SAVE)
+    lib.fdmi_tune_set(14, 0)
     assert all(s >= f for s, f in zip(sv, f16)) and sv[6] > 0 and sv[7] > 0 and sv[0] > 2.5 * f16[0]
-    lib.fdmi_tune_set(14, 1)
-    try:
-        on = fam(16, 0)
-    finally:
-        lib.fdmi_tune_set(14, 0)
     assert on[1] == f16[1] and 0.2 * f16[0] < on[0] < 0.6 * f16[0], (on[0], f16[0])   # the up path's concatenated inputs remain
 
 
