@@ -50,13 +50,30 @@ def cpu_baseline(n_teacher_steps, budget_s=75.0):
     from oracle.flash_ref import Draws, FlashConfigRef, FlashDiffusionRef, TensorConditioner
     from oracle.sched_cpu import DPMSolverMultistepSchedulerRef
     from oracle.unet_cpu import UNet2DConditionRef, sd15_config
-    threads = int(os.environ.get("FDMI_CPU_THREADS", "0")) or _physical_cores()
-    torch.set_num_threads(threads)
     torch.manual_seed(0)
     teacher = UNet2DConditionRef(sd15_config())
     student = copy.deepcopy(teacher)
     student.add_adapter(128)
     teacher.freeze()
+    # thread count: the fastest of {physical/8, physical/4, physical/2, physical} on ONE teacher forward each (PyTorch's CPU
+    # kernels stop scaling long before a 128-core host is full: profiles/r2_cpu_thread_sweep.txt); FDMI_CPU_THREADS overrides
+    phys = _physical_cores()
+    probe = (torch.randn(1, 4, 64, 64), torch.tensor([999]), {"cond": {"crossattn": torch.randn(1, 77, 768)}})
+    t_begin = time.perf_counter()
+    sweep = {}
+    forced = int(os.environ.get("FDMI_CPU_THREADS", "0"))
+    for n in ([forced] if forced else sorted({max(1, phys // 8), max(1, phys // 4), max(1, phys // 2), phys})):
+        torch.set_num_threads(n)
+        with torch.no_grad():
+            if not sweep:
+                teacher(*probe)          # warm-up: allocator, oneDNN primitive caches
+            t0 = time.perf_counter()
+            teacher(*probe)
+            sweep[n] = time.perf_counter() - t0
+        if len(sweep) > 1 and sweep[n] > 1.3 * min(sweep.values()):
+            break                        # past the knee
+    threads = min(sweep, key=sweep.get)
+    torch.set_num_threads(threads)
     m = FlashDiffusionRef(FlashConfigRef(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform"),
                           student_denoiser=student, teacher_denoiser=teacher,
                           teacher_noise_scheduler=DPMSolverMultistepSchedulerRef(), conditioner=TensorConditioner())
@@ -72,9 +89,6 @@ def cpu_baseline(n_teacher_steps, budget_s=75.0):
         opt.step()
         return time.perf_counter() - t0
 
-    t_begin = time.perf_counter()
-    with torch.no_grad():   # warm-up: thread pool, allocator, oneDNN primitive caches
-        teacher(torch.randn(1, 4, 64, 64), torch.tensor([999]), {"cond": {"crossattn": torch.randn(1, 77, 768)}})
     t1 = []
     while len(t1) < 3 and (not t1 or time.perf_counter() - t_begin + t1[-1] < budget_s):
         t1.append(iteration(1))
@@ -83,11 +97,12 @@ def cpu_baseline(n_teacher_steps, budget_s=75.0):
     if time.perf_counter() - t_begin + 2.2 * med1 < budget_s * 1.5:
         t2 = iteration(2)
     best = max(1.0 / med1, (2.0 / t2) if t2 else 0.0)
-    return {"value": best, "unit": "images/s", "cores": threads, "kind": "port",
+    return {"value": best, "unit": "images/s", "cores": threads, "physical_cores": phys, "kind": "port",
+            "thread_sweep_s_per_unet_forward": {str(k): round(v, 2) for k, v in sweep.items()},
             "b1_s_per_iteration": [round(x, 2) for x in t1], "b1_images_per_s": 1.0 / med1,
             "b2_s_per_iteration": round(t2, 2) if t2 else None, "b2_images_per_s": (2.0 / t2) if t2 else None,
             "sample": f"whole generator iterations (fwd+bwd+AdamW) of the same SD1.5 r128 step, {n_teacher_steps} teacher CFG steps, "
-                      f"fp32 PyTorch-CPU oracle on {threads} threads (physical cores): 1 warm-up UNet forward, B=1 median of "
+                      f"fp32 PyTorch-CPU oracle on {threads} threads (fastest of a sweep up to the {phys} physical cores), B=1 median of "
                       f"{len(t1)} = {med1:.1f} s" + (f", B=2 one iteration = {t2:.1f} s" if t2 else "") +
                       "; value = the better of the two batch sizes"}
 

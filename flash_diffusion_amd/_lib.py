@@ -35,7 +35,7 @@ class UNetCfg(C.Structure):
     _fields_ = [("in_channels", i32), ("out_channels", i32), ("n_levels", i32), ("block_out", i32 * 4),
                 ("down_attn", i32 * 4), ("up_attn", i32 * 4), ("layers_per_block", i32), ("tlayers", i32 * 4),
                 ("heads", i32 * 4), ("cross_dim", i32), ("groups", i32), ("eps", f32), ("class_embed_dim", i32),
-                ("flip_sin_to_cos", i32), ("freq_shift", f32)]
+                ("flip_sin_to_cos", i32), ("freq_shift", f32), ("precision", i32)]
 
 
 _SIGS = {
@@ -106,6 +106,28 @@ _SIGS = {
     "fdmi_distill_loss": (i32, [vp, vp, i64, i32, vp, vp]),
     "fdmi_distill_grad": (i32, [vp, vp, i64, i32, f32, vp, vp]),
     "fdmi_dmd_loss": (i32, [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i64, vp]),
+    # fp32 validation mode (csrc/ref32.hip)
+    "fdmi_gemm_f32": (i32, [C.POINTER(GemmDesc), vp]),
+    "fdmi_wgrad_tn_f32": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]),
+    "fdmi_attn_scratch_elems_f32": (i64, [i32, i32, i32, i32, i32]),
+    "fdmi_attn_fwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, i64, vp]),
+    "fdmi_attn_bwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp,
+                                i64, vp]),
+    "fdmi_groupnorm_fwd_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "fdmi_groupnorm_bwd_f32": (i32, [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]),
+    "fdmi_layernorm_fwd_f32": (i32, [vp, vp, vp, vp, vp, i64, i32, vp, vp, i64, i32, f32, vp]),
+    "fdmi_layernorm_bwd_f32": (i32, [vp, vp, vp, vp, i64, i32, vp, i64, i32, f32, i32, vp]),
+    "fdmi_nchw_to_nhwc_f32": (i32, [vp, vp, i32, i32, i32, i32, vp]),
+    "fdmi_nhwc_to_nchw_f32": (i32, [vp, i64, vp, i32, i32, i32, i32, vp]),
+    "fdmi_silu_f32": (i32, [vp, vp, i64, vp]),
+    "fdmi_silu_bwd_f32": (i32, [vp, vp, vp, i64, vp]),
+    "fdmi_gelu_tanh_f32": (i32, [vp, vp, i64, vp]),
+    "fdmi_gelu_tanh_bwd_f32": (i32, [vp, vp, vp, i64, vp]),
+    "fdmi_gate_residual_f32": (i32, [vp, vp, i64, vp, vp, i64, i32, i32, vp]),
+    "fdmi_batch_colsum_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
+    "fdmi_im2col_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "fdmi_colsum_f32": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "fdmi_pad_cols_f32": (i32, [vp, i32, vp, i32, i64, vp]),
 }
 # extended lazily by unet.py for the plan API
 EXTRA_SIGS = {}

@@ -279,4 +279,77 @@ int fdmi_dmd_loss(const float* s, const float* noisy, const float* real, const f
   return launch_dmd_loss(s, noisy, real, fake, inv_alpha, msig_alpha, kb, w, grad, loss, B, per, (hipStream_t)stream);
 }
 
+// ---- fp32 validation mode, op level (csrc/ref32.hip): float twins of the entry points above.  Operand conventions are the
+// bf16 ones with float storage; GroupNorm statistics are (mean, rstd) per (sample, group). ----
+int fdmi_gemm_f32(const fdmi_gemm_desc* d, void* stream) {
+  FDMI_CHECK(d != nullptr, "null descriptor");
+  GemmArgs a = gemm_args_from(d);
+  a.f32 = 1; a.out_f32 = 1; a.splitk = 1; a.ws = nullptr;
+  return launch_gemm32(a, (hipStream_t)stream);
+}
+int fdmi_wgrad_tn_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
+                      void* stream) {
+  return launch_wgrad_tn32(X, ldx, Y, ldy, M, N1, N2, C, ldc, (hipStream_t)stream);
+}
+int64_t fdmi_attn_scratch_elems_f32(int B, int H, int Sq, int Skv, int bwd) { return attn32_scratch_elems(B, H, Sq, Skv, bwd); }
+int fdmi_attn_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
+                      int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream) {
+  return launch_attn32_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, d, scale, scratch, scratch_elems, (hipStream_t)stream);
+}
+int fdmi_attn_bwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
+                      int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
+                      int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream) {
+  return launch_attn32_bwd(Q, ldq, K, ldk, V, ldv, dO, lddo, dQ, lddq, dK, lddk, dV, lddv, B, H, Sq, Skv, d, scale, scratch,
+                           scratch_elems, (hipStream_t)stream);
+}
+int fdmi_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* stats, float* y, int B, int HW, int C, int G,
+                           float eps, int silu, void* stream) {
+  return launch_groupnorm32_fwd(x, gamma, beta, stats, y, B, HW, C, G, eps, silu, (hipStream_t)stream);
+}
+int fdmi_groupnorm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta, const float* stats, float* dx,
+                           int B, int HW, int C, int G, int silu, int accumulate, void* stream) {
+  return launch_groupnorm32_bwd(x, dy, gamma, beta, stats, dx, B, HW, C, G, silu, accumulate, (hipStream_t)stream);
+}
+int fdmi_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* shift, const float* scale,
+                           int64_t mod_ld, int rows_per_batch, float* y, float* stats, int64_t rows, int C, float eps, void* stream) {
+  return launch_layernorm32_fwd(x, gamma, beta, shift, scale, mod_ld, rows_per_batch, y, rows, C, eps, (hipStream_t)stream, stats);
+}
+int fdmi_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* scale, int64_t mod_ld,
+                           int rows_per_batch, float* dx, int64_t rows, int C, float eps, int accumulate, void* stream) {
+  return launch_layernorm32_bwd(x, dy, gamma, scale, mod_ld, rows_per_batch, dx, rows, C, eps, accumulate, (hipStream_t)stream);
+}
+int fdmi_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int HW, int Cpad, void* stream) {
+  return launch_nchw_to_nhwc32(x, y, B, C, HW, Cpad, (hipStream_t)stream);
+}
+int fdmi_nhwc_to_nchw_f32(const float* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate, void* stream) {
+  return launch_nhwc_to_nchw32(x, ldx, y, B, C, HW, accumulate, (hipStream_t)stream);
+}
+int fdmi_silu_f32(const float* x, float* y, int64_t n, void* stream) { return launch_silu32(x, y, n, (hipStream_t)stream); }
+int fdmi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  return launch_silu32_bwd(x, dy, dx, n, (hipStream_t)stream);
+}
+int fdmi_gelu_tanh_f32(const float* x, float* y, int64_t n, void* stream) { return launch_gelu_tanh32(x, y, n, (hipStream_t)stream); }
+int fdmi_gelu_tanh_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream) {
+  return launch_gelu_tanh32_bwd(x, dy, dx, n, (hipStream_t)stream);
+}
+int fdmi_gate_residual_f32(const float* x, const float* gate, int64_t gate_ld, const float* res, float* y, int64_t rows, int C,
+                           int rows_per_batch, void* stream) {
+  return launch_gate_residual32(x, gate, gate_ld, res, y, rows, C, rows_per_batch, (hipStream_t)stream);
+}
+int fdmi_batch_colsum_f32(const float* dy, const float* x, const float* stats, float* out0, float* out1, int B, int rows_per_batch,
+                          int C, void* stream) {
+  return launch_batch_colsum32(dy, x, stats, out0, out1, B, rows_per_batch, C, (hipStream_t)stream);
+}
+int fdmi_im2col_f32(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                    void* stream) {
+  return launch_im2col32(x, out, B, H, W, C, Ho, Wo, KH, KW, stride, pad, (hipStream_t)stream);
+}
+int fdmi_colsum_f32(const float* dy, const float* x, const float* stats, float* out0, float* out1, int64_t rows, int C, int HW, int G,
+                    void* stream) {
+  return launch_colsum32(dy, x, stats, out0, out1, rows, C, HW, G, (hipStream_t)stream);
+}
+int fdmi_pad_cols_f32(const float* src, int cols, float* dst, int cols_pad, int64_t rows, void* stream) {
+  return launch_pad_cols32(src, cols, dst, cols_pad, rows, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -32,9 +32,17 @@ struct GemmArgs {
   // gn_stats[m / gn_rows][gn_G][2] += (sum, sum of squares) over the group's gn_cpg channels (pre-zeroed by the caller) so
   // that the consuming GroupNorm skips its reduction pass.  Only honoured when gemm_gn_ok(args): ask first.
   float* gn_stats = nullptr; int gn_rows = 0, gn_cpg = 0, gn_G = 0;
+  // fp32 validation mode (ref32.hip, launch_gemm32): every `bf16_t*` operand above then points to float data and the
+  // output is float.  Operands may be strided along the reduction index and batched over a (b1, b2) grid -- the attention
+  // products and the TN weight gradients are this same kernel.  The bf16 kernels ignore these fields (f32 must be 0).
+  int f32 = 0;
+  int64_t a_sk = 1, w_sk = 1;          // element stride along k (lda / ldw stay the row strides)
+  int nb1 = 1, nb2 = 1;                // batch grid
+  int64_t a_b1 = 0, a_b2 = 0, w_b1 = 0, w_b2 = 0, c_b1 = 0, c_b2 = 0;   // element offsets per batch index
 };
 
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
+int launch_gemm32(const GemmArgs& a, hipStream_t stream);   // a.f32 == 1 (launch_gemm forwards to it)
 // kernel / tile / split-K selection (shared by the launcher and by callers that must size `ws`)
 struct GemmPlan { int big = 0;  /* 0: gemm.hip tiles, 1: gemm3 (256 x BN), 2: gemm4 (256 x BN, BN = 320 | 192) */ int BM = 128, BN = 128, splitk = 1; };
 GemmPlan plan_gemm(const GemmArgs& a, bool ws_available);

@@ -512,6 +512,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
 }
 
 bool gemm_gn_ok(const GemmArgs& a, bool ws_available) {
+  if (a.f32) return false;
   if (!a.gn_stats || a.gn_cpg < 8 || a.gn_G < 1 || a.gn_G > 32 || a.N != a.gn_cpg * a.gn_G) return false;
   if (a.gn_rows <= 0 || (a.gn_rows & 255) != 0 || (a.M & 255) != 0 || (a.M % a.gn_rows) != 0) return false;
   if (a.out_f32 || a.accum_atomic || a.act == ACT_GEGLU || a.preact || a.force_tile || a.splitk > 1) return false;
@@ -521,6 +522,7 @@ bool gemm_gn_ok(const GemmArgs& a, bool ws_available) {
 }
 
 size_t gemm_ws_bytes(const GemmArgs& a) {
+  if (a.f32) return 0;
   GemmArgs b = a;
   b.splitk = 0;
   const GemmPlan p = plan_gemm(b, true);
@@ -547,6 +549,7 @@ struct GemmLog {
 }  // namespace
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
+  if (a_in.f32) return launch_gemm32(a_in, stream);   // fp32 validation mode: its own kernel family (ref32.hip)
   GemmArgs a = a_in;
   FDMI_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
   FDMI_CHECK((a.K % 8) == 0 && (a.ldw % 8) == 0, "gemm: K and ldw must be multiples of 8");

@@ -111,3 +111,44 @@ int launch_add_noise(const float* z, const float* noise, const float* sa, const 
                      int B, int64_t per, hipStream_t st);
 int launch_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
                   const float* x3, float c3, float* out, int64_t n, hipStream_t st);
+
+// ---- ref32.hip: fp32 validation mode (exact-f32 MFMA contractions, fp32 storage, fp64 statistics) ----
+int launch_wgrad_tn32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
+                      hipStream_t st);
+int64_t attn32_scratch_elems(int B, int H, int Sq, int Skv, int bwd);   // floats of scratch the two calls below want
+int launch_attn32_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
+                      int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st);
+int launch_attn32_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
+                      int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
+                      int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st);
+// stats[b][g] = (mean, rstd)
+int launch_groupnorm32_fwd(const float* x, const float* gamma, const float* beta, float* stats, float* y, int B, int HW, int C, int G,
+                           float eps, int silu, hipStream_t st);
+int launch_groupnorm32_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* stats, float* dx,
+                           int B, int HW, int C, int G, int silu, int accumulate, hipStream_t st);
+int launch_layernorm32_fwd(const float* x, const float* gamma, const float* beta, const float* shift, const float* scale,
+                           int64_t mod_ld, int rows_per_batch, float* y, int64_t rows, int C, float eps, hipStream_t st,
+                           float* stats = nullptr);
+int launch_layernorm32_bwd(const float* x, const float* dy, const float* gamma, const float* scale, int64_t mod_ld, int rows_per_batch,
+                           float* dx, int64_t rows, int C, float eps, int accumulate, hipStream_t st);
+int launch_nchw_to_nhwc32(const float* x, float* y, int B, int C, int HW, int Cpad, hipStream_t st);
+int launch_nhwc_to_nchw32(const float* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate, hipStream_t st);
+int launch_add_nchw_to_nhwc32(const float* r, float scale, float* y, int B, int C, int HW, hipStream_t st);
+int launch_timestep_embed32(const float* t, float* out, int B, int dim, int flip, float shift, hipStream_t st);
+int launch_silu32(const float* x, float* y, int64_t n, hipStream_t st);
+int launch_silu32_bwd(const float* x, const float* dy, float* dx, int64_t n, hipStream_t st);
+int launch_gelu_tanh32(const float* x, float* y, int64_t n, hipStream_t st);
+int launch_gelu_tanh32_bwd(const float* x, const float* dy, float* dx, int64_t n, hipStream_t st);
+int launch_copy2d32(const float* src, int64_t lds, int sc0, float* dst, int64_t ldd, int dc0, int64_t rows, int cols, int accumulate,
+                    hipStream_t st);
+int launch_pool2x2_sum32(const float* dy, float* dx, int B, int H, int W, int C, int accumulate, hipStream_t st);
+int launch_geglu32_bwd(const float* pre, const float* dout, float* dpre, int64_t M, int F, hipStream_t st);
+int launch_pad_cols32(const float* src, int cols, float* dst, int cols_pad, int64_t rows, hipStream_t st);
+int launch_im2col32(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                    hipStream_t st);
+int launch_colsum32(const float* dy, const float* x, const float* stats, float* out0, float* out1, int64_t rows, int C, int HW, int G,
+                    hipStream_t st);
+int launch_gate_residual32(const float* x, const float* gate, int64_t gate_ld, const float* res, float* y, int64_t rows, int C,
+                           int rows_per_batch, hipStream_t st);
+int launch_batch_colsum32(const float* dy, const float* x, const float* stats, float* out0, float* out1, int B, int rows_per_batch,
+                          int C, hipStream_t st);

@@ -119,6 +119,9 @@ struct Run {
   std::deque<T> tensors;
   std::vector<std::function<int(Exec&)>> tape;
   bool save = false;
+  int es = 2;            // bytes per activation element: 2 = bf16 (the measured path), 4 = fp32 validation plan
+  float* sc32 = nullptr; // fp32 plans: scratch of the materialised attention scores (grown on demand, reused serially)
+  int64_t sc32_elems = 0;
   hipStream_t st = nullptr;
   // pool of fp32 accumulators (GroupNorm statistics, forward and backward) cleared by ONE memset per forward
   char* zpool = nullptr;
@@ -137,7 +140,7 @@ struct Run {
     tensors.emplace_back();
     T* t = &tensors.back();
     t->rows = rows; t->cols = cols; t->B = B; t->H = H; t->W = W;
-    t->p = (bf16_t*)arena.alloc((size_t)rows * cols * 2);
+    t->p = (bf16_t*)arena.alloc((size_t)rows * cols * es);
     return t->p ? t : nullptr;
   }
   // tensor header over caller-provided storage (no arena allocation)
@@ -157,6 +160,7 @@ struct fdmi_unet {
   std::vector<const float*> down_res;
   float down_res_scale = 1.f;
   fdmi_unet_config cfg;
+  bool f32 = false;      // cfg.precision == 1: fp32 validation plan (ref32.hip kernels, fp32 storage; T::p / Weight::w then hold floats)
   int nl = 0, temb_ch = 0, temb_total = 0;
   Weight conv_in, conv_out, te1, te2, ce1, ce2, temb_proj;
   Norm norm_out;
@@ -192,8 +196,11 @@ namespace {
 // ---------------------------------------------------------------------------------------------
 // weight packing kernels (init time)
 // ---------------------------------------------------------------------------------------------
-// conv OIHW f32 -> out[rows][KH][KW][cpad] bf16; transpose=0: rows=O, ch=I ; transpose=1: rows=I, ch=O
-__global__ void pack_conv_kernel(const float* w, bf16_t* out, int O, int I, int KH, int KW, int cpad,
+__device__ __forceinline__ void put_w(bf16_t* o, float v) { *o = f2bf(v); }
+__device__ __forceinline__ void put_w(float* o, float v) { *o = v; }
+// conv OIHW f32 -> out[rows][KH][KW][cpad] (bf16, or f32 for a validation plan); transpose=0: rows=O, ch=I ; transpose=1: rows=I, ch=O
+template <typename TO>
+__global__ void pack_conv_kernel(const float* w, TO* out, int O, int I, int KH, int KW, int cpad,
                                  int transpose) {
   const int rows = transpose ? I : O, ch = transpose ? O : I;
   const int64_t total = (int64_t)rows * KH * KW * cpad;
@@ -208,11 +215,12 @@ __global__ void pack_conv_kernel(const float* w, bf16_t* out, int O, int I, int 
       const int o = transpose ? c : r, ii = transpose ? r : c;
       v = w[(((int64_t)o * I + ii) * KH + ky) * KW + kx];
     }
-    out[i] = f2bf(v);
+    put_w(out + i, v);
   }
 }
-// linear [N][K] f32 -> w[N][K] bf16 (rows optionally GEGLU-permuted) and wt[K][N] bf16
-__global__ void pack_linear_kernel(const float* w, bf16_t* out, bf16_t* outT, int N, int K, int geglu) {
+// linear [N][K] f32 -> w[N][K] (rows optionally GEGLU-permuted) and, when asked for, wt[K][N]
+template <typename TO>
+__global__ void pack_linear_kernel(const float* w, TO* out, TO* outT, int N, int K, int geglu) {
   const int64_t total = (int64_t)N * K;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
     const int k = (int)(i % K);
@@ -222,9 +230,9 @@ __global__ void pack_linear_kernel(const float* w, bf16_t* out, bf16_t* outT, in
       const int blk = n >> 5, off = n & 31;
       src = off < 16 ? blk * 16 + off : N / 2 + blk * 16 + off - 16;
     }
-    const bf16_t v = f2bf(w[(int64_t)src * K + k]);
-    out[i] = v;
-    outT[(int64_t)k * N + n] = v;
+    const float v = w[(int64_t)src * K + k];
+    put_w(out + i, v);
+    if (outT) put_w(outT + (int64_t)k * N + n, v);
   }
 }
 __global__ void pack_vec_kernel(const float* b, float* out, int N, int geglu) {
@@ -237,8 +245,9 @@ __global__ void pack_vec_kernel(const float* b, float* out, int N, int geglu) {
     out[n] = b[src];
   }
 }
-__global__ void f32_to_bf16_rows(const float* x, bf16_t* y, int64_t n) {
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) y[i] = f2bf(x[i]);
+template <typename TO>
+__global__ void cvt_rows_kernel(const float* x, TO* y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) put_w(y + i, x[i]);
 }
 static inline int gridfor(int64_t n) {
   int64_t b = (n + 255) / 256;
@@ -400,25 +409,34 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
   switch (s.kind) {
     case S_CONV_W: {
       Weight& w = *s.w;
+      const size_t k = U->f32 ? 2 : 1;   // (dmalloc counts bf16 elements: an fp32 plan takes twice as many)
       if (!w.w) {
-        RET_IF(dmalloc(U, &w.w, (size_t)w.Cout * w.KH * w.KW * w.Cin_pad));
-        RET_IF(dmalloc(U, &w.wt, (size_t)w.Cin * w.KH * w.KW * w.Cout_pad));
+        RET_IF(dmalloc(U, &w.w, k * w.Cout * w.KH * w.KW * w.Cin_pad));
+        RET_IF(dmalloc(U, &w.wt, k * w.Cin * w.KH * w.KW * w.Cout_pad));
       }
-      hipLaunchKernelGGL(pack_conv_kernel, dim3(gridfor((int64_t)w.Cout * w.K)), dim3(256), 0, st, src, w.w,
-                         w.Cout, w.Cin, w.KH, w.KW, w.Cin_pad, 0);
-      hipLaunchKernelGGL(pack_conv_kernel, dim3(gridfor((int64_t)w.Cin * w.KH * w.KW * w.Cout_pad)), dim3(256), 0,
-                         st, src, w.wt, w.Cout, w.Cin, w.KH, w.KW, w.Cout_pad, 1);
+      const int g1 = gridfor((int64_t)w.Cout * w.K), g2 = gridfor((int64_t)w.Cin * w.KH * w.KW * w.Cout_pad);
+      if (U->f32) {
+        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g1), dim3(256), 0, st, src, (float*)w.w, w.Cout, w.Cin, w.KH, w.KW, w.Cin_pad, 0);
+        hipLaunchKernelGGL(pack_conv_kernel<float>, dim3(g2), dim3(256), 0, st, src, (float*)w.wt, w.Cout, w.Cin, w.KH, w.KW, w.Cout_pad, 1);
+      } else {
+        hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(g1), dim3(256), 0, st, src, w.w, w.Cout, w.Cin, w.KH, w.KW, w.Cin_pad, 0);
+        hipLaunchKernelGGL(pack_conv_kernel<bf16_t>, dim3(g2), dim3(256), 0, st, src, w.wt, w.Cout, w.Cin, w.KH, w.KW, w.Cout_pad, 1);
+      }
       w.set |= 1;
       break;
     }
     case S_LIN_W: {
       Weight& w = *s.w;
       if (!w.w) {
-        RET_IF(dmalloc(U, &w.w, (size_t)w.N * w.K));
-        RET_IF(dmalloc(U, &w.wt, (size_t)w.N * w.K));
+        RET_IF(dmalloc(U, &w.w, (size_t)w.N * w.K * (U->f32 ? 2 : 1)));
+        if (!U->f32) RET_IF(dmalloc(U, &w.wt, (size_t)w.N * w.K));   // (an fp32 plan reads the one copy with strides)
       }
-      hipLaunchKernelGGL(pack_linear_kernel, dim3(gridfor((int64_t)w.N * w.K)), dim3(256), 0, st, src, w.w, w.wt,
-                         w.N, w.K, w.geglu ? 1 : 0);
+      if (U->f32)
+        hipLaunchKernelGGL(pack_linear_kernel<float>, dim3(gridfor((int64_t)w.N * w.K)), dim3(256), 0, st, src, (float*)w.w,
+                           (float*)nullptr, w.N, w.K, w.geglu ? 1 : 0);
+      else
+        hipLaunchKernelGGL(pack_linear_kernel<bf16_t>, dim3(gridfor((int64_t)w.N * w.K)), dim3(256), 0, st, src, w.w, w.wt,
+                           w.N, w.K, w.geglu ? 1 : 0);
       w.set |= 1;
       break;
     }
@@ -442,12 +460,16 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
     case S_TEMB_B: {
       Weight& w = *s.w;
       if (!w.w) {
-        RET_IF(dmalloc(U, &w.w, (size_t)w.N * w.K));
+        RET_IF(dmalloc(U, &w.w, (size_t)w.N * w.K * (U->f32 ? 2 : 1)));
         RET_IF(dmalloc(U, &w.bias, (size_t)w.N));
       }
       if (s.kind == S_TEMB_W) {
-        hipLaunchKernelGGL(f32_to_bf16_rows, dim3(gridfor((int64_t)s.rows * w.K)), dim3(256), 0, st, src,
-                           w.w + (size_t)s.row_off * w.K, (int64_t)s.rows * w.K);
+        if (U->f32)
+          hipLaunchKernelGGL(cvt_rows_kernel<float>, dim3(gridfor((int64_t)s.rows * w.K)), dim3(256), 0, st, src,
+                             (float*)w.w + (size_t)s.row_off * w.K, (int64_t)s.rows * w.K);
+        else
+          hipLaunchKernelGGL(cvt_rows_kernel<bf16_t>, dim3(gridfor((int64_t)s.rows * w.K)), dim3(256), 0, st, src,
+                             w.w + (size_t)s.row_off * w.K, (int64_t)s.rows * w.K);
       } else {
         hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(s.rows)), dim3(256), 0, st, src, w.bias + s.row_off,
                            s.rows, 0);
@@ -476,12 +498,43 @@ struct Exec {
   int ctx_mode = 0;  // 0: none, 1: fill the cross-attention K/V cache, 2: reuse it (FDMI_UNET_CTX_*)
   bool gn_epi = false;  // GroupNorm statistics in the producing GEMM's epilogue (see want_gn)
 
+  // ---- precision dispatch: an fp32 validation plan stores floats behind the same (opaque) bf16_t* handles and runs the
+  // ref32.hip kernels; everything below picks the kernel family by U->f32 ----
+  bool f32() const { return U->f32; }
+  int es() const { return U->f32 ? 4 : 2; }
+  bf16_t* off(const bf16_t* p, int64_t elems) const { return (bf16_t*)((char*)p + elems * es()); }
+  static float* F(const bf16_t* p) { return (float*)p; }
+  int l_copy2d(const bf16_t* src, int64_t lds, int sc0, bf16_t* dst, int64_t ldd, int dc0, int64_t rows, int cols, int acc) {
+    return f32() ? launch_copy2d32(F(src), lds, sc0, F(dst), ldd, dc0, rows, cols, acc, st)
+                 : launch_copy2d(src, lds, sc0, dst, ldd, dc0, rows, cols, acc, st);
+  }
+  float* attn_scratch(int Bn, int H, int Sq, int Skv, int bwd) {   // fp32 plans: room for the materialised scores
+    const int64_t need = attn32_scratch_elems(Bn, H, Sq, Skv, bwd);
+    if (need > R.sc32_elems) {
+      R.sc32 = (float*)R.arena.alloc((size_t)need * 4);
+      R.sc32_elems = R.sc32 ? need : 0;
+    }
+    return R.sc32;
+  }
+  // C = A W^T with W read through strides: element (n, k) at W[n * ldw + k * w_sk] (fp32 plans: dgrad operands without copies)
+  int gemm_rows_strided(const bf16_t* A, int64_t lda, int64_t M, const void* W, int N, int K, int64_t ldw, int64_t w_sk,
+                        bf16_t* C, int64_t ldc, const bf16_t* residual, int64_t ldr) {
+    GemmArgs a = rows_args(A, lda, M, (const bf16_t*)W, N, K, nullptr, C, ldc, residual, ldr);
+    a.ldw = ldw; a.w_sk = w_sk;
+    return gemm(a);
+  }
+
   bf16_t* grad_of(T* t) {  // lazily allocate the gradient buffer
-    if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * 2);
+    if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * es());
     return t->g;
   }
   int gemm(GemmArgs& a) {
     flops += gemm_flops(a);
+    if (f32()) {   // exact-f32 MFMA kernel, no split-K bookkeeping
+      a.f32 = 1; a.out_f32 = 1;
+      if (R.dry()) return 0;
+      return launch_gemm(a, st);
+    }
     if (R.dry() && plan_log()) {   // developer aid: FDMI_PLAN_LOG=1 lists every GEMM / conv of a workspace-query walk (no GPU needed)
       GemmArgs q = a;
       if (!q.accum_atomic && q.splitk == 1 && gemm_ws_bytes(q)) q.splitk = 0;
@@ -530,7 +583,7 @@ struct Exec {
   }
 
   int lora_refresh() {
-    if (R.dry()) return 0;
+    if (R.dry() || f32()) return 0;   // (an fp32 plan reads the fp32 masters directly)
     if (U->cast_dirty) {  // (re)build the tile table of the one-launch refresh
       std::vector<CastJob> jobs;
       auto add = [&](const float* src, bf16_t* dst, bf16_t* dstT, int rows, int cols) {
@@ -568,8 +621,10 @@ struct Exec {
     if (lo) {
       t = R.mk(x->rows, lo->r);
       if (!t) return nullptr;
-      NULL_IF(gemm_rows(x->p, x->cols, x->rows, lo->A, lo->r, lo->in, nullptr, t->p, lo->r, nullptr, 0));
-      NULL_IF(gemm_rows(t->p, lo->r, x->rows, lo->B, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N));
+      const bf16_t* LA = f32() ? (const bf16_t*)lo->A_master : lo->A;
+      const bf16_t* LB = f32() ? (const bf16_t*)lo->B_master : lo->B;
+      NULL_IF(gemm_rows(x->p, x->cols, x->rows, LA, lo->r, lo->in, nullptr, t->p, lo->r, nullptr, 0));
+      NULL_IF(gemm_rows(t->p, lo->r, x->rows, LB, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N));
     }
     if (R.save) {
       R.tape.push_back([x, y, residual, lo, t, need_dx, &w](Exec& E) -> int {
@@ -578,24 +633,38 @@ struct Exec {
         if (need_dx) {
           bf16_t* dx = E.grad_of(x);
           FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
-          RET_IF(E.gemm_rows(y->g, w.N, x->rows, w.wt, w.K, w.N, nullptr, dx, x->cols, x->ginit ? dx : nullptr,
-                           x->cols));
+          if (E.f32())   // dx = dy W: the one [N][K] copy read k-strided
+            RET_IF(E.gemm_rows_strided(y->g, w.N, x->rows, w.w, w.K, w.N, 1, w.K, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
+          else
+            RET_IF(E.gemm_rows(y->g, w.N, x->rows, w.wt, w.K, w.N, nullptr, dx, x->cols, x->ginit ? dx : nullptr,
+                               x->cols));
           x->ginit = true;
         }
         if (lo) {
           // dt = dy B ; dB += dy^T t ; dA += dt^T x ; dx += dt A
           T* dt = E.R.mk(x->rows, lo->r);
           FDMI_CHECK(dt, "unet: workspace exhausted (lora)");
-          RET_IF(E.gemm_rows(y->g, w.N, x->rows, lo->BT, lo->r, lo->out, nullptr, dt->p, lo->r, nullptr, 0));
+          if (E.f32())
+            RET_IF(E.gemm_rows_strided(y->g, w.N, x->rows, lo->B_master, lo->r, lo->out, 1, lo->r, dt->p, lo->r, nullptr, 0));
+          else
+            RET_IF(E.gemm_rows(y->g, w.N, x->rows, lo->BT, lo->r, lo->out, nullptr, dt->p, lo->r, nullptr, 0));
           // dB += dy^T t and dA += dt^T x straight from the row-major operands (wgrad.hip): no transposed copies
           E.flops += 2.0 * x->rows * lo->r * ((double)lo->out + lo->in);
           if (!E.R.dry()) {
-            RET_IF(launch_wgrad_tn(y->g, w.N, t->p, lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
-            RET_IF(launch_wgrad_tn(dt->p, lo->r, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
+            if (E.f32()) {
+              RET_IF(launch_wgrad_tn32(F(y->g), w.N, F(t->p), lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
+              RET_IF(launch_wgrad_tn32(F(dt->p), lo->r, F(x->p), x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
+            } else {
+              RET_IF(launch_wgrad_tn(y->g, w.N, t->p, lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
+              RET_IF(launch_wgrad_tn(dt->p, lo->r, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
+            }
           }
           if (need_dx) {
             bf16_t* dx = E.grad_of(x);
-            RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
+            if (E.f32())
+              RET_IF(E.gemm_rows_strided(dt->p, lo->r, x->rows, lo->A_master, lo->in, lo->r, 1, lo->in, dx, x->cols, dx, x->cols));
+            else
+              RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
           }
         }
         return 0;
@@ -610,8 +679,8 @@ struct Exec {
     FDMI_CHECK(g, "unet: workspace exhausted (grad)");
     if (!R.dry()) {
       if (!dst->ginit && (dc0 != 0 || cols != dst->cols))
-        FDMI_HIP(hipMemsetAsync(g, 0, (size_t)dst->rows * dst->cols * 2, st));
-      RET_IF(launch_copy2d(src, ld_src, sc0, g, dst->cols, dc0, dst->rows, cols, dst->ginit ? 1 : 0, st));
+        FDMI_HIP(hipMemsetAsync(g, 0, (size_t)dst->rows * dst->cols * es(), st));
+      RET_IF(l_copy2d(src, ld_src, sc0, g, dst->cols, dc0, dst->rows, cols, dst->ginit ? 1 : 0));
     }
     U->hbm[HBM_COPY2D] += (dst->ginit ? 6.0 : 4.0) * dst->rows * cols;
     dst->ginit = true;
@@ -644,9 +713,11 @@ struct Exec {
         const bf16_t* dy = y->g;
         int64_t dy_cols = y->cols;
         if (y->cols != w.Cout_pad) {  // e.g. conv_out (4 -> 8 channels): zero-padded copy
-          bf16_t* pd = (bf16_t*)E.R.arena.alloc((size_t)y->rows * w.Cout_pad * 2);
+          bf16_t* pd = (bf16_t*)E.R.arena.alloc((size_t)y->rows * w.Cout_pad * E.es());
           FDMI_CHECK(pd, "unet: workspace exhausted");
-          if (!E.R.dry()) RET_IF(launch_pad_cols(y->g, y->cols, pd, w.Cout_pad, y->rows, E.st));
+          if (!E.R.dry())
+            RET_IF(E.f32() ? launch_pad_cols32(F(y->g), y->cols, F(pd), w.Cout_pad, y->rows, E.st)
+                           : launch_pad_cols(y->g, y->cols, pd, w.Cout_pad, y->rows, E.st));
           dy = pd;
           dy_cols = w.Cout_pad;
         }
@@ -658,17 +729,19 @@ struct Exec {
         bf16_t* dx = E.grad_of(x);
         FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
         if (ups) {
-          bf16_t* tmp = (bf16_t*)E.R.arena.alloc((size_t)d.M * x->cols * 2);
+          bf16_t* tmp = (bf16_t*)E.R.arena.alloc((size_t)d.M * x->cols * E.es());
           FDMI_CHECK(tmp, "unet: workspace exhausted");
           d.C = tmp; d.ldc = x->cols;
           RET_IF(E.gemm(d));
           E.U->hbm[HBM_POOL] += 2.0 * x->rows * x->cols * (4 + 1 + (x->ginit ? 1 : 0));
-          if (!E.R.dry()) RET_IF(launch_pool2x2_sum(tmp, dx, x->B, x->H, x->W, x->cols, x->ginit ? 1 : 0, E.st));
+          if (!E.R.dry())
+            RET_IF(E.f32() ? launch_pool2x2_sum32(F(tmp), F(dx), x->B, x->H, x->W, x->cols, x->ginit ? 1 : 0, E.st)
+                           : launch_pool2x2_sum(tmp, dx, x->B, x->H, x->W, x->cols, x->ginit ? 1 : 0, E.st));
         } else {
           d.C = dx; d.ldc = x->cols;
           if (x->ginit) { d.residual = dx; d.ldr = x->cols; }
           if (w.Cin != x->cols && !x->ginit && !E.R.dry())  // padded input channels (conv_in): zero the pad
-            FDMI_HIP(hipMemsetAsync(dx, 0, (size_t)x->rows * x->cols * 2, E.st));
+            FDMI_HIP(hipMemsetAsync(dx, 0, (size_t)x->rows * x->cols * E.es(), E.st));
           RET_IF(E.gemm(d));
         }
         x->ginit = true;
@@ -693,7 +766,8 @@ struct Exec {
     if (!y || !stats) return nullptr;
     const int HW = x->H * x->W, G = U->cfg.groups;
     if (!R.dry())
-      NULL_IF(launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st, zeroed, ready));
+      NULL_IF(f32() ? launch_groupnorm32_fwd(F(x->p), n.gamma, n.beta, stats, F(y->p), x->B, HW, x->cols, G, eps, silu, st)
+                    : launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st, zeroed, ready));
     if (R.save) {
       R.tape.push_back([x, y, &n, stats, HW, G, eps, silu](Exec& E) -> int {
         if (!y->g) return 0;
@@ -705,8 +779,10 @@ struct Exec {
         E.U->hbm[HBM_GN_REDUCE] += 4.0 * x->rows * x->cols;                            // reads x and dy
         E.U->hbm[HBM_GN_APPLY] += (x->ginit ? 8.0 : 6.0) * x->rows * x->cols;        // reads x, dy (, dx), writes dx
         if (!E.R.dry())
-          RET_IF(launch_groupnorm_bwd(x->p, y->g, n.gamma, n.beta, stats, bst, dx, x->B, HW, x->cols, G, eps, silu,
-                                      x->ginit ? 1 : 0, E.st, bzeroed));
+          RET_IF(E.f32() ? launch_groupnorm32_bwd(F(x->p), F(y->g), n.gamma, n.beta, stats, F(dx), x->B, HW, x->cols, G, silu,
+                                                  x->ginit ? 1 : 0, E.st)
+                         : launch_groupnorm_bwd(x->p, y->g, n.gamma, n.beta, stats, bst, dx, x->B, HW, x->cols, G, eps, silu,
+                                                x->ginit ? 1 : 0, E.st, bzeroed));
         x->ginit = true;
         return 0;
       });
@@ -718,7 +794,9 @@ struct Exec {
     T* y = R.mk(x->rows, x->cols, x->B, x->H, x->W);
     if (!y) return nullptr;
     U->hbm[HBM_LN] += 4.0 * x->rows * x->cols;
-    if (!R.dry()) NULL_IF(launch_layernorm_fwd(x->p, n.gamma, n.beta, nullptr, nullptr, 0, 1, y->p, x->rows, x->cols, 1e-5f, st));
+    if (!R.dry())
+      NULL_IF(f32() ? launch_layernorm32_fwd(F(x->p), n.gamma, n.beta, nullptr, nullptr, 0, 1, F(y->p), x->rows, x->cols, 1e-5f, st)
+                    : launch_layernorm_fwd(x->p, n.gamma, n.beta, nullptr, nullptr, 0, 1, y->p, x->rows, x->cols, 1e-5f, st));
     if (R.save) {
       R.tape.push_back([x, y, &n](Exec& E) -> int {
         if (!y->g) return 0;
@@ -726,7 +804,10 @@ struct Exec {
         FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
         E.U->hbm[HBM_LN] += (x->ginit ? 8.0 : 6.0) * x->rows * x->cols;
         if (!E.R.dry())
-          RET_IF(launch_layernorm_bwd(x->p, y->g, n.gamma, nullptr, 0, 1, dx, x->rows, x->cols, 1e-5f, x->ginit ? 1 : 0, E.st));
+          RET_IF(E.f32() ? launch_layernorm32_bwd(F(x->p), F(y->g), n.gamma, nullptr, 0, 1, F(dx), x->rows, x->cols, 1e-5f,
+                                                  x->ginit ? 1 : 0, E.st)
+                         : launch_layernorm_bwd(x->p, y->g, n.gamma, nullptr, 0, 1, dx, x->rows, x->cols, 1e-5f, x->ginit ? 1 : 0,
+                                                E.st));
         x->ginit = true;
         return 0;
       });
@@ -737,6 +818,7 @@ struct Exec {
   // vt_ext: caller-owned V^T buffer; vt_ready: it already holds the transposed V (cached context)
   T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, bf16_t* vt_ext = nullptr, bool vt_ready = false) {
     const int d = q->cols / H;
+    if (f32()) return attention32(q, k, v, Bn, H, Sq, Skv, d);
     T* o = R.mk(q->rows, q->cols, q->B, q->H, q->W);
     const int64_t tr_kv = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Skv);
     const int64_t tr_q = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Sq);
@@ -782,6 +864,33 @@ struct Exec {
     return o;
   }
 
+  // fp32 validation plan: materialised scores, exact-f32 MFMA products, fp32 softmax (ref32.hip)
+  T* attention32(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, int d) {
+    T* o = R.mk(q->rows, H * d, q->B, q->H, q->W);
+    float* sc = attn_scratch(Bn, H, Sq, Skv, 0);
+    if (!o || !sc) return nullptr;
+    const float scale = 1.f / sqrtf((float)d);
+    flops += 4.0 * Bn * H * (double)Sq * Skv * d;
+    if (!R.dry())
+      NULL_IF(launch_attn32_fwd(F(q->p), q->cols, F(k->p), k->cols, F(v->p), v->cols, F(o->p), o->cols, Bn, H, Sq, Skv, d, scale,
+                                sc, R.sc32_elems, st));
+    if (R.save) {
+      R.tape.push_back([o, q, k, v, Bn, H, Sq, Skv, d, scale](Exec& E) -> int {
+        if (!o->g) return 0;
+        float* sc2 = E.attn_scratch(Bn, H, Sq, Skv, 1);
+        bf16_t *dq = E.grad_of(q), *dk = E.grad_of(k), *dv = E.grad_of(v);
+        FDMI_CHECK(sc2 && dq && dk && dv, "unet: workspace exhausted (attn bwd)");
+        E.flops += 2.0 * 4.0 * Bn * H * (double)Sq * Skv * d;
+        if (!E.R.dry())
+          RET_IF(launch_attn32_bwd(F(q->p), q->cols, F(k->p), k->cols, F(v->p), v->cols, F(o->g), o->cols, F(dq), q->cols, F(dk),
+                                   k->cols, F(dv), v->cols, Bn, H, Sq, Skv, d, scale, sc2, E.R.sc32_elems, E.st));
+        q->ginit = k->ginit = v->ginit = true;
+        return 0;
+      });
+    }
+    return o;
+  }
+
   // GEGLU feed-forward input projection: [M,C] -> [M,4C]
   T* geglu(T* x, Weight& w) {
     const int F = w.N / 2;
@@ -797,8 +906,13 @@ struct Exec {
         bf16_t* dx = E.grad_of(x);
         FDMI_CHECK(dpre && dx, "unet: workspace exhausted (geglu bwd)");
         E.U->hbm[HBM_GEGLU_BWD] += 2.0 * x->rows * (2.0 * F + F + 2.0 * F);   // reads pre [2F], dy [F]; writes dpre [2F]
-        if (!E.R.dry()) RET_IF(launch_geglu_bwd(pre->p, y->g, dpre->p, x->rows, F, E.st));
-        RET_IF(E.gemm_rows(dpre->p, w.N, x->rows, w.wt, w.K, w.N, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
+        if (!E.R.dry())
+          RET_IF(E.f32() ? launch_geglu32_bwd(Exec::F(pre->p), Exec::F(y->g), Exec::F(dpre->p), x->rows, F, E.st)
+                         : launch_geglu_bwd(pre->p, y->g, dpre->p, x->rows, F, E.st));
+        if (E.f32())
+          RET_IF(E.gemm_rows_strided(dpre->p, w.N, x->rows, w.w, w.K, w.N, 1, w.K, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
+        else
+          RET_IF(E.gemm_rows(dpre->p, w.N, x->rows, w.wt, w.K, w.N, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
         x->ginit = true;
         return 0;
       });
@@ -811,8 +925,8 @@ struct Exec {
     if (!y) return nullptr;
     U->hbm[HBM_COPY2D] += 4.0 * y->rows * y->cols;
     if (!R.dry()) {
-      NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0, st));
-      NULL_IF(launch_copy2d(b->p, b->cols, 0, y->p, y->cols, a->cols, b->rows, b->cols, 0, st));
+      NULL_IF(l_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0));
+      NULL_IF(l_copy2d(b->p, b->cols, 0, y->p, y->cols, a->cols, b->rows, b->cols, 0));
     }
     if (R.save) {
       R.tape.push_back([y, a, b](Exec& E) -> int {
@@ -831,8 +945,8 @@ struct Exec {
     if (!y) return nullptr;
     U->hbm[HBM_COPY2D] += 6.0 * a->rows * a->cols;
     if (!R.dry()) {
-      NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0, st));
-      NULL_IF(launch_copy2d(a->p, a->cols, 0, y->p + (int64_t)a->rows * a->cols, y->cols, 0, a->rows, a->cols, 0, st));
+      NULL_IF(l_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0));
+      NULL_IF(l_copy2d(a->p, a->cols, 0, off(y->p, (int64_t)a->rows * a->cols), y->cols, 0, a->rows, a->cols, 0));
     }
     return y;
   }
@@ -843,7 +957,7 @@ struct Exec {
     const fdmi_unet_config& c = U->cfg;
     T* a = groupnorm(x, r.n1, c.eps, 1);
     if (!a) return nullptr;
-    T* h = conv(a, r.c1, 1, 0, temb_all->p + r.temb_off, temb_all->cols, nullptr, true);
+    T* h = conv(a, r.c1, 1, 0, off(temb_all->p, r.temb_off), temb_all->cols, nullptr, true);
     if (!h) return nullptr;
     T* a2 = groupnorm(h, r.n2, c.eps, 1);
     if (!a2) return nullptr;
@@ -889,8 +1003,8 @@ struct Exec {
         const int Cc = b.a2.k.w.N, dd = Cc / t.heads;
         const int64_t rows = (int64_t)Bn * L, vt = (int64_t)Bn * t.heads * attn_dvpad(dd) * attn_spad(L);
         if (!R.dry() && (b.c_rows != rows || b.c_vt != vt || !b.ck)) {  // (re)size the plan-owned buffers
-          NULL_IF(dmalloc(U, &b.ck, (size_t)rows * Cc));
-          NULL_IF(dmalloc(U, &b.cv, (size_t)rows * Cc));
+          NULL_IF(dmalloc(U, &b.ck, (size_t)rows * Cc * (f32() ? 2 : 1)));
+          NULL_IF(dmalloc(U, &b.cv, (size_t)rows * Cc * (f32() ? 2 : 1)));
           NULL_IF(dmalloc(U, &b.cvt, (size_t)vt));
           b.c_rows = rows; b.c_vt = vt; b.c_valid = false;
         }
@@ -933,12 +1047,15 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   E.ctx_mode = (flags & FDMI_UNET_CTX_REUSE) ? 2 : ((flags & FDMI_UNET_CTX_FILL) ? 1 : 0);
   // GroupNorm statistics from the producing GEMM's epilogue (A/B switch: FDMI_TUNE=14=1 turns it off).  Adapter residuals are
   // added in place AFTER their tensor was produced, so a forward that carries them keeps the reduce kernel everywhere.
-  E.gn_epi = fdmi_tune_get(14) == 0 && U->down_res.empty();
+  E.gn_epi = fdmi_tune_get(14) == 0 && U->down_res.empty() && !U->f32;
   U->last_gn = U->last_gn_epi = 0;
   for (double& b : U->hbm) b = 0;
   R.tensors.clear();
   R.tape.clear();
   R.arena.off = 0;
+  R.es = U->f32 ? 4 : 2;
+  R.sc32 = nullptr;
+  R.sc32_elems = 0;
   R.save = (flags & FDMI_UNET_SAVE) != 0;
   const bool inter = (flags & FDMI_UNET_INTERMEDIATE) != 0;
   hipStream_t st = R.st;
@@ -959,20 +1076,26 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   const int Bx = halves ? B / 2 : B;
   // ---- inputs ----
   T* x0 = R.mk((int64_t)Bx * H * W, cin_pad, Bx, H, W);
-  T* ctxb = R.mk((int64_t)B * L, c.cross_dim);
-  float* tf = (float*)R.arena.alloc((size_t)B * 4);
-  FAIL_IF_NULL(x0); FAIL_IF_NULL(ctxb); FAIL_IF_NULL(tf);
+  T* ctxb = R.mk((int64_t)B * L, c.cross_dim);   // (a copy: the tape may outlive the caller's tensor)
+  FAIL_IF_NULL(x0); FAIL_IF_NULL(ctxb);
   R.x0 = x0;
   if (!R.dry()) {
-    RET_IF(launch_nchw_to_nhwc(x, x0->p, Bx, c.in_channels, H * W, cin_pad, st));
-    RET_IF(launch_f32_to_bf16(ctx, ctxb->p, (int64_t)B * L * c.cross_dim, st));
+    if (U->f32) {
+      RET_IF(launch_nchw_to_nhwc32(x, Exec::F(x0->p), Bx, c.in_channels, H * W, cin_pad, st));
+      FDMI_HIP(hipMemcpyAsync(ctxb->p, ctx, (size_t)B * L * c.cross_dim * 4, hipMemcpyDeviceToDevice, st));
+    } else {
+      RET_IF(launch_nchw_to_nhwc(x, x0->p, Bx, c.in_channels, H * W, cin_pad, st));
+      RET_IF(launch_f32_to_bf16(ctx, ctxb->p, (int64_t)B * L * c.cross_dim, st));
+    }
   }
   // ---- time embedding ----
   T* te = R.mk(B, c.block_out[0]);
   T* e1 = R.mk(B, U->temb_ch);
   T* emb = R.mk(B, U->temb_ch);
   FAIL_IF_NULL(te); FAIL_IF_NULL(e1); FAIL_IF_NULL(emb);
-  if (!R.dry()) RET_IF(launch_timestep_embed(t, te->p, B, c.block_out[0], c.flip_sin_to_cos, c.freq_shift, st));
+  if (!R.dry())
+    RET_IF(U->f32 ? launch_timestep_embed32(t, Exec::F(te->p), B, c.block_out[0], c.flip_sin_to_cos, c.freq_shift, st)
+                  : launch_timestep_embed(t, te->p, B, c.block_out[0], c.flip_sin_to_cos, c.freq_shift, st));
   RET_IF(E.gemm_rows(te->p, te->cols, B, U->te1.w, U->te1.N, U->te1.K, U->te1.bias, e1->p, e1->cols, nullptr, 0, ACT_SILU));
   RET_IF(E.gemm_rows(e1->p, e1->cols, B, U->te2.w, U->te2.N, U->te2.K, U->te2.bias, emb->p, emb->cols, nullptr, 0));
   if (c.class_embed_dim > 0) {
@@ -980,14 +1103,19 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
     T* cb = R.mk(B, c.class_embed_dim);
     T* c1 = R.mk(B, U->temb_ch);
     FAIL_IF_NULL(cb); FAIL_IF_NULL(c1);
-    if (!R.dry()) RET_IF(launch_f32_to_bf16(cls, cb->p, (int64_t)B * c.class_embed_dim, st));
+    if (!R.dry()) {
+      if (U->f32) FDMI_HIP(hipMemcpyAsync(cb->p, cls, (size_t)B * c.class_embed_dim * 4, hipMemcpyDeviceToDevice, st));
+      else RET_IF(launch_f32_to_bf16(cls, cb->p, (int64_t)B * c.class_embed_dim, st));
+    }
     RET_IF(E.gemm_rows(cb->p, cb->cols, B, U->ce1.w, U->ce1.N, U->ce1.K, U->ce1.bias, c1->p, c1->cols, nullptr, 0, ACT_SILU));
     RET_IF(E.gemm_rows(c1->p, c1->cols, B, U->ce2.w, U->ce2.N, U->ce2.K, U->ce2.bias, emb->p, emb->cols, emb->p, emb->cols));
   }
   T* semb = R.mk(B, U->temb_ch);
   T* temb_all = R.mk(B, U->temb_total);
   FAIL_IF_NULL(semb); FAIL_IF_NULL(temb_all);
-  if (!R.dry()) RET_IF(launch_silu(emb->p, semb->p, (int64_t)B * U->temb_ch, st));
+  if (!R.dry())
+    RET_IF(U->f32 ? launch_silu32(Exec::F(emb->p), Exec::F(semb->p), (int64_t)B * U->temb_ch, st)
+                  : launch_silu(emb->p, semb->p, (int64_t)B * U->temb_ch, st));
   RET_IF(E.gemm_rows(semb->p, semb->cols, B, U->temb_proj.w, U->temb_proj.N, U->temb_proj.K, U->temb_proj.bias,
                      temb_all->p, temb_all->cols, nullptr, 0));
   // ---- down ----
@@ -1008,7 +1136,9 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   auto add_res = [&](T* t) -> int {
     if (dres.empty()) return 0;
     const float* r = dres[di++];
-    if (r && !R.dry()) RET_IF(launch_add_nchw_to_nhwc(r, U->down_res_scale, t->p, t->B, t->cols, t->H * t->W, st));
+    if (r && !R.dry())
+      RET_IF(U->f32 ? launch_add_nchw_to_nhwc32(r, U->down_res_scale, Exec::F(t->p), t->B, t->cols, t->H * t->W, st)
+                    : launch_add_nchw_to_nhwc(r, U->down_res_scale, t->p, t->B, t->cols, t->H * t->W, st));
     return 0;
   };
   for (auto& sp : U->down) {
@@ -1071,7 +1201,9 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   }
   R.out = h;
   R.outC = h->cols;
-  if (!R.dry()) RET_IF(launch_nhwc_to_nchw(h->p, h->cols, out, B, h->cols, h->H * h->W, 0, st));
+  if (!R.dry())
+    RET_IF(U->f32 ? launch_nhwc_to_nchw32(Exec::F(h->p), h->cols, out, B, h->cols, h->H * h->W, 0, st)
+                  : launch_nhwc_to_nchw(h->p, h->cols, out, B, h->cols, h->H * h->W, 0, st));
   U->last_flops = E.flops;
   return 0;
 }
@@ -1082,13 +1214,17 @@ int run_backward(fdmi_unet* U, Run& R, const float* grad_out, float* grad_x) {
   T* o = R.out;
   bf16_t* g = E.grad_of(o);
   FDMI_CHECK(g, "unet: workspace exhausted (grad)");
-  if (!R.dry()) RET_IF(launch_nchw_grad_to_nhwc(grad_out, g, o->cols, o->B, o->cols, o->H * o->W, R.st));
+  if (!R.dry())   // (fp32: NCHW -> NHWC rows of the same width)
+    RET_IF(U->f32 ? launch_nchw_to_nhwc32(grad_out, Exec::F(g), o->B, o->cols, o->H * o->W, o->cols, R.st)
+                  : launch_nchw_grad_to_nhwc(grad_out, g, o->cols, o->B, o->cols, o->H * o->W, R.st));
   o->ginit = true;
   for (auto it = R.tape.rbegin(); it != R.tape.rend(); ++it) RET_IF((*it)(E));
   if (grad_x) {
     FDMI_CHECK(R.x0->g && R.x0->ginit, "unet: no gradient reached the input");
     if (!R.dry())
-      RET_IF(launch_nhwc_to_nchw(R.x0->g, R.x0->cols, grad_x, R.x0->B, U->cfg.in_channels, R.x0->H * R.x0->W, 0, R.st));
+      RET_IF(U->f32 ? launch_nhwc_to_nchw32(Exec::F(R.x0->g), R.x0->cols, grad_x, R.x0->B, U->cfg.in_channels,
+                                            R.x0->H * R.x0->W, 0, R.st)
+                    : launch_nhwc_to_nchw(R.x0->g, R.x0->cols, grad_x, R.x0->B, U->cfg.in_channels, R.x0->H * R.x0->W, 0, R.st));
   }
   R.save = false;  // tape consumed
   R.tape.clear();
@@ -1121,6 +1257,12 @@ fdmi_unet* fdmi_unet_create(const fdmi_unet_config* cfg) {
   if (!cfg) { fdmi_set_error("null config"); return nullptr; }
   auto* U = new fdmi_unet();
   U->cfg = *cfg;
+  U->f32 = cfg->precision == 1;
+  if (cfg->precision != 0 && cfg->precision != 1) {
+    fdmi_set_error("unet: precision must be 0 (bf16 MFMA) or 1 (fp32 validation mode)");
+    delete U;
+    return nullptr;
+  }
   if (build_plan(U)) { delete U; return nullptr; }
   return U;
 }

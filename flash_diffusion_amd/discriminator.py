@@ -18,9 +18,9 @@ BF16 = torch.bfloat16
 
 
 def _conv_fwd(x, w, bias, stride, pad):
-    """x [B,H,W,Cp] bf16 NHWC (Cp = Cin padded to 8) ; w OIHW f32"""
+    """x [B,H,W,Cp] NHWC (Cp = Cin padded to 8; bf16, or fp32 in validation mode) ; w OIHW f32"""
     O, I, KH, KW = w.shape
-    return ops.conv2d_nhwc(x, ops.pack_conv_weight(w.detach()), KH=KH, KW=KW, stride=stride, pad=pad,
+    return ops.conv2d_nhwc(x, ops.pack_conv_weight(w.detach(), x.dtype), KH=KH, KW=KW, stride=stride, pad=pad,
                            bias=bias.detach().float().contiguous() if bias is not None else None)
 
 
@@ -30,7 +30,8 @@ class _DiscFn(torch.autograd.Function):
         L = lib()
         B, Cin, H, W = x.shape
         Cp = (Cin + 7) // 8 * 8
-        h = ops.nchw_to_nhwc(x.float().contiguous(), Cp)           # [B,H,W,Cp] bf16
+        DT = torch.float32 if getattr(mod, "precision", "bf16") == "fp32" else BF16
+        h = ops.nchw_to_nhwc(x.float().contiguous(), Cp, DT)       # [B,H,W,Cp] bf16 (fp32: validation mode)
         saved = []
         pi = 0
         for layer in mod:
@@ -43,8 +44,7 @@ class _DiscFn(torch.autograd.Function):
                 saved.append(("conv", h, w, b is not None, layer.stride[0], layer.padding[0]))
                 h = y
             elif isinstance(layer, nn.SiLU):
-                y = torch.empty_like(h)
-                check(L.fdmi_silu(ptr(h), ptr(y), h.numel(), stream_ptr()))
+                y = ops.silu(h)
                 saved.append(("silu", h))
                 h = y
             elif isinstance(layer, nn.GroupNorm):
@@ -58,7 +58,7 @@ class _DiscFn(torch.autograd.Function):
                 saved.append(("flatten",))
             else:
                 raise NotImplementedError(f"MiDiscriminator: unsupported layer {type(layer).__name__}")
-        ctx.saved, ctx.mod, ctx.xshape, ctx.cp = saved, mod, x.shape, Cp
+        ctx.saved, ctx.mod, ctx.xshape, ctx.cp, ctx.dt = saved, mod, x.shape, Cp, DT
         ctx.needs_x = x.requires_grad
         Bn, Hh, Ww, Cc = h.shape
         out = h.float().permute(0, 3, 1, 2).reshape(Bn, -1)        # Flatten of NCHW (tiny: B x k logits)
@@ -69,25 +69,22 @@ class _DiscFn(torch.autograd.Function):
     def backward(ctx, gout):
         L = lib()
         Bn, Hh, Ww, Cc = ctx.out_shape
-        dy = gout.reshape(Bn, Cc, Hh, Ww).permute(0, 2, 3, 1).contiguous().to(BF16)   # NHWC bf16
+        DT = ctx.dt
+        dy = gout.reshape(Bn, Cc, Hh, Ww).permute(0, 2, 3, 1).contiguous().to(DT)    # NHWC, the forward's precision
         grads = []
         for rec in reversed(ctx.saved):
             kind = rec[0]
             if kind == "flatten":
                 continue
             if kind == "silu":
-                x = rec[1]
-                dx = torch.empty_like(x)
-                check(L.fdmi_silu_bwd(ptr(x), ptr(dy.contiguous()), ptr(dx), x.numel(), stream_ptr()))
-                dy = dx
+                dy = ops.silu_bwd(rec[1], dy.contiguous())
             elif kind == "gn":
                 _, x, g, stats, G, eps = rec
                 Bq, Hq, Wq, Cq = x.shape
                 dyc = dy.contiguous()
                 dgam = torch.zeros(Cq, dtype=torch.float32, device=x.device)
                 dbet = torch.zeros(Cq, dtype=torch.float32, device=x.device)
-                check(L.fdmi_colsum(ptr(dyc), ptr(x), ptr(stats), ptr(dbet), ptr(dgam), Bq * Hq * Wq, Cq, Hq * Wq, G, eps,
-                                    stream_ptr()))
+                ops.colsum(dyc, x, stats, dbet, dgam, Bq * Hq * Wq, Cq, Hq * Wq, G, eps)
                 dx = ops.groupnorm_bwd(x.view(Bq, Hq * Wq, Cq), dyc.view(Bq, Hq * Wq, Cq), g.detach().float().contiguous(),
                                        torch.zeros(Cq, device=x.device), stats, G, eps, 0)
                 grads.append(dbet)
@@ -102,29 +99,29 @@ class _DiscFn(torch.autograd.Function):
                 dyc = dy.contiguous().view(M, O)
                 if has_b:
                     db = torch.zeros(O, dtype=torch.float32, device=x.device)
-                    check(L.fdmi_colsum(ptr(dyc), None, None, ptr(db), None, M, O, 1, 1, 0.0, stream_ptr()))
+                    ops.colsum(dyc, None, None, db, None, M, O, 1, 1, 0.0)
                 # ---- weight gradient: dW[O][KH*KW*Cp] += dY^T [O][M] * im2col(X)^T [K][M] ----
                 K = KH * KW * Cp
-                Mp = (M + 7) // 8 * 8
-                xcol = torch.empty(M, K, dtype=BF16, device=x.device)
-                check(L.fdmi_im2col(ptr(x), ptr(xcol), Bq, Hq, Wq, Cp, Ho, Wo, KH, KW, stride, pad, stream_ptr()))
-                xcolT = torch.empty(K, Mp, dtype=BF16, device=x.device)
-                check(L.fdmi_transpose2d_pad(ptr(xcol), K, ptr(xcolT), Mp, M, K, Mp, stream_ptr()))
-                Op = (O + 7) // 8 * 8
-                dyT = torch.zeros(Op, Mp, dtype=BF16, device=x.device)
-                check(L.fdmi_transpose2d_pad(ptr(dyc), O, ptr(dyT), Mp, M, O, Mp, stream_ptr()))
+                xcol = ops.im2col(x, Ho, Wo, KH, KW, stride, pad)
                 dwp = torch.zeros(O, K, dtype=torch.float32, device=x.device)
-                ops.gemm(dyT, xcolT, M=O, N=K, K=Mp, out=dwp, accum_atomic=True)
+                if x.dtype == torch.float32:          # validation mode: the TN product straight from the row-major operands
+                    ops.wgrad_tn(dyc, xcol, dwp)
+                else:
+                    Mp = (M + 7) // 8 * 8
+                    xcolT = torch.empty(K, Mp, dtype=BF16, device=x.device)
+                    check(L.fdmi_transpose2d_pad(ptr(xcol), K, ptr(xcolT), Mp, M, K, Mp, stream_ptr()))
+                    Op8 = (O + 7) // 8 * 8
+                    dyT = torch.zeros(Op8, Mp, dtype=BF16, device=x.device)
+                    check(L.fdmi_transpose2d_pad(ptr(dyc), O, ptr(dyT), Mp, M, O, Mp, stream_ptr()))
+                    ops.gemm(dyT, xcolT, M=O, N=K, K=Mp, out=dwp, accum_atomic=True)
                 dw = dwp.view(O, KH, KW, Cp)[..., :I].permute(0, 3, 1, 2).contiguous()
                 # ---- input gradient (gather form of the transposed conv) ----
-                dyp = dyc
-                if Op != O:
-                    dyp = torch.empty(M, Op, dtype=BF16, device=x.device)
-                    check(L.fdmi_pad_cols(ptr(dyc), O, ptr(dyp), Op, M, stream_ptr()))
-                dx = ops.conv2d_nhwc(dyp.view(Bq, Ho, Wo, Op), ops.pack_conv_weight_dgrad(w.detach()), KH=KH, KW=KW,
+                Op = (O + 7) // 8 * 8
+                dyp = dyc if Op == O else ops.pad_cols(dyc, Op)
+                dx = ops.conv2d_nhwc(dyp.view(Bq, Ho, Wo, Op), ops.pack_conv_weight_dgrad(w.detach(), x.dtype), KH=KH, KW=KW,
                                      stride=stride, pad=pad, dgrad=1, out_hw=(Hq, Wq))
                 if dx.shape[-1] != Cp:   # N = true Cin; re-pad channels for the next dgrad
-                    t = torch.zeros(Bq, Hq, Wq, Cp, dtype=BF16, device=x.device)
+                    t = torch.zeros(Bq, Hq, Wq, Cp, dtype=x.dtype, device=x.device)
                     t[..., :dx.shape[-1]] = dx
                     dx = t
                 if has_b:
@@ -138,6 +135,8 @@ class _DiscFn(torch.autograd.Function):
 
 
 class MiDiscriminator(nn.Sequential):
+    precision = "bf16"   # "fp32": the validation kernels (csrc/ref32.hip), for the parity gate against the fp32 oracle
+
     def forward(self, x):
         assert x.is_cuda, "MiDiscriminator runs on the GPU only (no CPU fallback)"
         params = []

@@ -238,6 +238,9 @@ class FlashDiffusion(nn.Module):
                     discriminator = MiDiscriminator.convert(discriminator)
             except Exception:
                 pass
+        if getattr(discriminator, "precision", None) is not None and \
+                getattr(student_denoiser, "config_dict", {}).get("precision") == "fp32":
+            discriminator.precision = "fp32"   # an fp32 validation student: the head runs the validation kernels too
         self.discriminator = discriminator
         for f in ("guidance_scale_min", "guidance_scale_max", "ucg_keys", "K", "num_iterations_per_K",
                   "distill_loss_type", "timestep_distribution", "mixture_num_components", "mixture_var",

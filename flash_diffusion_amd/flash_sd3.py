@@ -161,6 +161,9 @@ class FlashDiffusionSD3(nn.Module):
                 discriminator = MiDiscriminator.convert(discriminator)
             except Exception:
                 pass   # not the conv / GroupNorm / SiLU PatchGAN shape: keep the module as given (boundary item 3)
+        if getattr(discriminator, "precision", None) is not None and \
+                getattr(student_denoiser, "config_dict", {}).get("precision") == "fp32":
+            discriminator.precision = "fp32"   # an fp32 validation student: the head runs the validation kernels too
         self.discriminator = discriminator
         self.use_adversarial_loss = discriminator is not None
         self.disc_backbone = self.teacher_denoiser

@@ -9,7 +9,15 @@ import torch
 from ._lib import GemmDesc, check, lib, ptr, stream_ptr
 
 BF16 = torch.bfloat16
+F32 = torch.float32
 ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+# Every activation op below dispatches on the dtype of its operand: bf16 tensors run the measured MFMA path, fp32 tensors the
+# fp32 VALIDATION kernels (csrc/ref32.hip: exact-f32 MFMA, fp32 storage, fp64 statistics) -- the parity gate against the fp32
+# oracle.  A model picks one of the two with its `precision` argument; nothing mixes them.
+
+
+def _f32(t):
+    return t.dtype == F32
 
 
 def _dev(t):
@@ -18,22 +26,22 @@ def _dev(t):
 
 
 # ---- weight packing (one-off, init time) ---------------------------------------------------------
-def pack_conv_weight(w):
-    """OIHW f32 -> [O][KH][KW][I] bf16 rows (K = KH*KW*I contiguous); I zero-padded to a multiple of 8."""
+def pack_conv_weight(w, dtype=BF16):
+    """OIHW f32 -> [O][KH][KW][I] rows (K = KH*KW*I contiguous) in `dtype`; I zero-padded to a multiple of 8."""
     O, I, KH, KW = w.shape
     Ip = (I + 7) // 8 * 8
     p = torch.zeros(O, KH, KW, Ip, dtype=torch.float32, device=w.device)
     p[..., :I] = w.permute(0, 2, 3, 1)
-    return p.reshape(O, KH * KW * Ip).to(BF16).contiguous()
+    return p.reshape(O, KH * KW * Ip).to(dtype).contiguous()
 
 
-def pack_conv_weight_dgrad(w):
-    """OIHW f32 -> dgrad operand [I][KH][KW][O] bf16 (rows = input channels)."""
+def pack_conv_weight_dgrad(w, dtype=BF16):
+    """OIHW f32 -> dgrad operand [I][KH][KW][O] in `dtype` (rows = input channels)."""
     O, I, KH, KW = w.shape
     Op = (O + 7) // 8 * 8
     p = torch.zeros(I, KH, KW, Op, dtype=torch.float32, device=w.device)
     p[..., :O] = w.permute(1, 2, 3, 0)
-    return p.reshape(I, KH * KW * Op).to(BF16).contiguous()
+    return p.reshape(I, KH * KW * Op).to(dtype).contiguous()
 
 
 def geglu_perm(n_half, device=None):
@@ -71,6 +79,13 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
     d.act = act
     d.preact, d.ldp = ptr(preact), (preact.stride(0) if preact is not None else 0)
     Nout = N // 2 if act == ACT_GEGLU else N
+    if _f32(A):   # fp32 validation kernels: every operand float, float output, no split-K workspace
+        assert W.dtype == F32 and gn is None and all(t is None or t.dtype == F32 for t in (rowvec, residual, preact, out))
+        if out is None:
+            out = torch.empty(M, Nout, dtype=F32, device=A.device)
+        d.C, d.ldc, d.out_f32, d.alpha, d.splitk, d.accum_atomic = ptr(out), out.stride(0), 1, alpha, 1, int(accum_atomic)
+        check(lib().fdmi_gemm_f32(C.byref(d), stream_ptr()))
+        return out
     if out is None:
         out = torch.empty(M, Nout, dtype=torch.float32 if out_f32 else BF16, device=A.device)
     d.C, d.ldc, d.out_f32 = ptr(out), out.stride(0), int(out.dtype == torch.float32)
@@ -97,6 +112,10 @@ def wgrad_tn(X, Y, out):
     """out[N1, N2] (f32, accumulated) += X[M, N1]^T @ Y[M, N2]: both operands row-major bf16, contraction over the rows"""
     M = X.shape[0]
     assert Y.shape[0] == M and X.stride(1) == 1 and Y.stride(1) == 1 and out.dtype == torch.float32 and out.stride(1) == 1
+    if _f32(X):
+        check(lib().fdmi_wgrad_tn_f32(ptr(X), X.stride(0), ptr(Y), Y.stride(0), M, X.shape[1], Y.shape[1], ptr(out), out.stride(0),
+                                      stream_ptr()))
+        return out
     check(lib().fdmi_wgrad_tn(ptr(X), X.stride(0), ptr(Y), Y.stride(0), M, X.shape[1], Y.shape[1], ptr(out), out.stride(0),
                               stream_ptr()))
     return out
@@ -136,6 +155,10 @@ def groupnorm_fwd(x, gamma, beta, G, eps, silu):
     B, HW, Cc = x.shape
     y = torch.empty_like(x)
     stats = torch.empty(B, G, 2, dtype=torch.float32, device=x.device)
+    if _f32(x):   # stats = (mean, rstd) per (sample, group)
+        check(lib().fdmi_groupnorm_fwd_f32(ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(y), B, HW, Cc, G, eps, int(silu),
+                                           stream_ptr()))
+        return y, stats
     check(lib().fdmi_groupnorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(y), B, HW, Cc, G, eps,
                                    int(silu), stream_ptr()))
     return y, stats
@@ -155,6 +178,10 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, G, eps, silu, dx=None):
     acc = dx is not None
     if dx is None:
         dx = torch.empty_like(x)
+    if _f32(x):
+        check(lib().fdmi_groupnorm_bwd_f32(ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(stats), ptr(dx), B, HW, Cc, G, int(silu),
+                                           int(acc), stream_ptr()))
+        return dx
     bstats = torch.empty(B, G, 2, dtype=torch.float32, device=x.device)
     check(lib().fdmi_groupnorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(beta), ptr(stats), ptr(bstats), ptr(dx), B,
                                    HW, Cc, G, eps, int(silu), int(acc), stream_ptr()))
@@ -164,6 +191,10 @@ def groupnorm_bwd(x, dy, gamma, beta, stats, G, eps, silu, dx=None):
 def layernorm_fwd(x, gamma, beta, eps):
     y = torch.empty_like(x)
     rows = x.numel() // x.shape[-1]
+    if _f32(x):
+        check(lib().fdmi_layernorm_fwd_f32(ptr(x), ptr(gamma), ptr(beta), None, None, 0, 1, ptr(y), None, rows, x.shape[-1], eps,
+                                           stream_ptr()))
+        return y
     check(lib().fdmi_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(y), rows, x.shape[-1], eps, stream_ptr()))
     return y
 
@@ -173,6 +204,10 @@ def layernorm_bwd(x, dy, gamma, eps, dx=None):
     if dx is None:
         dx = torch.empty_like(x)
     rows = x.numel() // x.shape[-1]
+    if _f32(x):
+        check(lib().fdmi_layernorm_bwd_f32(ptr(x), ptr(dy), ptr(gamma), None, 0, 1, ptr(dx), rows, x.shape[-1], eps, int(acc),
+                                           stream_ptr()))
+        return dx
     check(lib().fdmi_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(dx), rows, x.shape[-1], eps, int(acc),
                                    stream_ptr()))
     return dx
@@ -185,6 +220,12 @@ def attn_fwd(q, k, v, H, scale, need_lse=False, out=None, lse_out=None):
     Skv = k.shape[1]
     d = Cc // H
     o = torch.empty_like(q) if out is None else out
+    if _f32(q):   # materialised scores in scratch; the backward recomputes them, so there is no log-sum-exp to hand on
+        n = lib().fdmi_attn_scratch_elems_f32(B, H, Sq, Skv, 0)
+        sc = torch.empty(n, dtype=F32, device=q.device)
+        check(lib().fdmi_attn_fwd_f32(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1), B, H, Sq,
+                                      Skv, d, scale, ptr(sc), n, stream_ptr()))
+        return (o, lse_out) if need_lse else o
     vt = torch.empty(lib().fdmi_attn_tr_elems(B, H, Skv, d), dtype=BF16, device=q.device)
     lse = lse_out if lse_out is not None else (
         torch.empty(B, H, Sq, dtype=torch.float32, device=q.device) if need_lse else None)
@@ -198,6 +239,13 @@ def attn_bwd(q, k, v, o, do, lse, H, scale, out=None):
     Skv = k.shape[1]
     d = Cc // H
     dq, dk, dv = (torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)) if out is None else out
+    if _f32(q):
+        n = lib().fdmi_attn_scratch_elems_f32(B, H, Sq, Skv, 1)
+        sc = torch.empty(n, dtype=F32, device=q.device)
+        check(lib().fdmi_attn_bwd_f32(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(do), do.stride(1), ptr(dq),
+                                      dq.stride(1), ptr(dk), dk.stride(1), ptr(dv), dv.stride(1), B, H, Sq, Skv, d, scale, ptr(sc), n,
+                                      stream_ptr()))
+        return dq, dk, dv
     ws = torch.empty(lib().fdmi_attn_bwd_ws_bytes(B, H, Sq, Skv, d), dtype=torch.uint8, device=q.device)
     check(lib().fdmi_attn_bwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
                               ptr(do), do.stride(1), ptr(lse), ptr(dq), dq.stride(1), ptr(dk), dk.stride(1),
@@ -206,17 +254,19 @@ def attn_bwd(q, k, v, o, do, lse, H, scale, out=None):
 
 
 # ---- misc --------------------------------------------------------------------------------------
-def nchw_to_nhwc(x, Cpad):
+def nchw_to_nhwc(x, Cpad, dtype=BF16):
     B, Cc, H, W = x.shape
-    y = torch.empty(B, H, W, Cpad, dtype=BF16, device=x.device)
-    check(lib().fdmi_nchw_to_nhwc(ptr(x.contiguous()), ptr(y), B, Cc, H * W, Cpad, stream_ptr()))
+    y = torch.empty(B, H, W, Cpad, dtype=dtype, device=x.device)
+    fn = lib().fdmi_nchw_to_nhwc_f32 if dtype == F32 else lib().fdmi_nchw_to_nhwc
+    check(fn(ptr(x.contiguous()), ptr(y), B, Cc, H * W, Cpad, stream_ptr()))
     return y
 
 
 def nhwc_to_nchw(x, Cc):
     B, H, W, ld = x.shape
     y = torch.empty(B, Cc, H, W, dtype=torch.float32, device=x.device)
-    check(lib().fdmi_nhwc_to_nchw(ptr(x), ld, ptr(y), B, Cc, H * W, 0, stream_ptr()))
+    fn = lib().fdmi_nhwc_to_nchw_f32 if _f32(x) else lib().fdmi_nhwc_to_nchw
+    check(fn(ptr(x), ld, ptr(y), B, Cc, H * W, 0, stream_ptr()))
     return y
 
 
@@ -272,14 +322,38 @@ def f32_to_bf16(x):
 
 def silu(x):
     y = torch.empty_like(x)
-    check(lib().fdmi_silu(ptr(x), ptr(y), x.numel(), stream_ptr()))
+    check((lib().fdmi_silu_f32 if _f32(x) else lib().fdmi_silu)(ptr(x), ptr(y), x.numel(), stream_ptr()))
     return y
 
 
 def silu_bwd(x, dy):
     dx = torch.empty_like(x)
-    check(lib().fdmi_silu_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), stream_ptr()))
+    check((lib().fdmi_silu_bwd_f32 if _f32(x) else lib().fdmi_silu_bwd)(ptr(x), ptr(dy), ptr(dx), x.numel(), stream_ptr()))
     return dx
+
+
+def im2col(x, Ho, Wo, KH, KW, stride, pad):
+    """x [B,H,W,C] NHWC -> explicit patch matrix [B*Ho*Wo, KH*KW*C] (the discriminator's weight gradient)"""
+    B, H, W, Cc = x.shape
+    out = torch.empty(B * Ho * Wo, KH * KW * Cc, dtype=x.dtype, device=x.device)
+    check((lib().fdmi_im2col_f32 if _f32(x) else lib().fdmi_im2col)(ptr(x), ptr(out), B, H, W, Cc, Ho, Wo, KH, KW, stride, pad,
+                                                                    stream_ptr()))
+    return out
+
+
+def colsum(dy, x, stats, out0, out1, rows, Cc, HW, G, eps):
+    """out0[c] += sum_r dy ; out1[c] += sum_r dy * xhat (xhat from the GroupNorm stats of the same precision when given)"""
+    if _f32(dy):
+        check(lib().fdmi_colsum_f32(ptr(dy), ptr(x), ptr(stats), ptr(out0), ptr(out1), rows, Cc, HW, G, stream_ptr()))
+    else:
+        check(lib().fdmi_colsum(ptr(dy), ptr(x), ptr(stats), ptr(out0), ptr(out1), rows, Cc, HW, G, eps, stream_ptr()))
+
+
+def pad_cols(x, cols_pad):
+    rows, cols = x.shape
+    out = torch.empty(rows, cols_pad, dtype=x.dtype, device=x.device)
+    check((lib().fdmi_pad_cols_f32 if _f32(x) else lib().fdmi_pad_cols)(ptr(x), cols, ptr(out), cols_pad, rows, stream_ptr()))
+    return out
 
 
 # ---- adaLN-single DiT element-wise ops (csrc/dit.hip) --------------------------------------------------------------

@@ -179,8 +179,12 @@ class MiUNet2DConditionModel(nn.Module):
                  up_block_types=("UpBlock2D",) + ("CrossAttnUpBlock2D",) * 3, block_out_channels=(320, 640, 1280, 1280),
                  layers_per_block=2, cross_attention_dim=768, transformer_layers_per_block=1, attention_head_dim=8,
                  norm_num_groups=32, norm_eps=1e-5, class_embed_type=None, projection_class_embeddings_input_dim=None,
-                 flip_sin_to_cos=True, freq_shift=0, use_linear_projection=True, **unused):
+                 flip_sin_to_cos=True, freq_shift=0, use_linear_projection=True, precision="bf16", **unused):
+        """precision: "bf16" = the measured path (bf16 MFMA, fp32 accumulation: the reference's bf16-mixed); "fp32" = the
+        VALIDATION plan (fp32 storage, exact-f32 MFMA, fp64 norm statistics -- csrc/ref32.hip), the parity gate against the
+        fp32 CPU oracle at north_star's 1e-3."""
         super().__init__()
+        assert precision in ("bf16", "fp32"), precision
         assert use_linear_projection, "only use_linear_projection=True (as in every reference example)"
         for k, allowed in (("mid_block_type", ("UNetMidBlock2DCrossAttn",)), ("act_fn", ("silu",)),
                            ("resnet_time_scale_shift", ("default",)), ("time_embedding_type", ("positional",)),
@@ -199,7 +203,7 @@ class MiUNet2DConditionModel(nn.Module):
                                 norm_eps=norm_eps,
                                 class_embed_dim=(projection_class_embeddings_input_dim or 0)
                                 if class_embed_type == "projection" else 0,
-                                flip_sin_to_cos=flip_sin_to_cos, freq_shift=freq_shift)
+                                flip_sin_to_cos=flip_sin_to_cos, freq_shift=freq_shift, precision=precision)
         c = self.config_dict
         self._shapes = unet_param_shapes(boc, c["down_block_types"], c["up_block_types"], layers_per_block,
                                          cross_attention_dim, c["transformer_layers_per_block"],
@@ -238,6 +242,7 @@ class MiUNet2DConditionModel(nn.Module):
         s.groups, s.eps = c["norm_num_groups"], c["norm_eps"]
         s.class_embed_dim = c["class_embed_dim"]
         s.flip_sin_to_cos, s.freq_shift = int(c["flip_sin_to_cos"]), float(c["freq_shift"])
+        s.precision = 1 if c.get("precision", "bf16") == "fp32" else 0
         return s
 
     def _plan(self) -> _Plan:

@@ -161,6 +161,49 @@ int fdmi_dmd_loss(const float* s, const float* noisy, const float* real, const f
                   const float* msig_alpha, const float* kb, float* w, float* grad, float* loss, int B, int64_t per,
                   void* stream);
 
+/* ---------------- fp32 VALIDATION MODE, op level (csrc/ref32.hip) --------------------------------------------------
+ * north_star asks for loss parity with the reference's CPU path to 1e-3 relative; bf16 storage cannot give that on a
+ * loss that sits behind nine denoiser evaluations (and neither can the reference's own bf16-mixed run).
+ * These are the float twins of the building blocks above: fp32 storage, every contraction on the exact-f32 matrix
+ * instruction v_mfma_f32_32x32x2_f32, fp64 normalisation statistics.  Same operand conventions with float data
+ * (fdmi_gemm_desc: A / W / rowvec / residual / preact / C are float*, out_f32 implied, no split-K workspace);
+ * GroupNorm `stats` hold (mean, rstd) per (sample, group); attention materialises the scores in caller scratch of
+ * fdmi_attn_scratch_elems_f32 floats (forward: bwd = 0).  fdmi_unet_config.precision = 1 builds a whole plan on them.   */
+int fdmi_gemm_f32(const fdmi_gemm_desc* d, void* stream);
+int fdmi_wgrad_tn_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
+                      void* stream);
+int64_t fdmi_attn_scratch_elems_f32(int B, int H, int Sq, int Skv, int bwd);
+int fdmi_attn_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
+                      int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream);
+int fdmi_attn_bwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
+                      int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
+                      int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream);
+int fdmi_groupnorm_fwd_f32(const float* x, const float* gamma, const float* beta, float* stats /*[B][G][2] = mean, rstd*/, float* y,
+                           int B, int HW, int C, int G, float eps, int silu, void* stream);
+int fdmi_groupnorm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* beta, const float* stats, float* dx,
+                           int B, int HW, int C, int G, int silu, int accumulate, void* stream);
+/* gamma / beta and shift / scale are each optional (NULL): plain, affine, or adaLN-modulated LayerNorm */
+int fdmi_layernorm_fwd_f32(const float* x, const float* gamma, const float* beta, const float* shift, const float* scale,
+                           int64_t mod_ld, int rows_per_batch, float* y, float* stats /*[rows][2] or NULL*/, int64_t rows, int C,
+                           float eps, void* stream);
+int fdmi_layernorm_bwd_f32(const float* x, const float* dy, const float* gamma, const float* scale, int64_t mod_ld,
+                           int rows_per_batch, float* dx, int64_t rows, int C, float eps, int accumulate, void* stream);
+int fdmi_nchw_to_nhwc_f32(const float* x, float* y, int B, int C, int HW, int Cpad, void* stream);
+int fdmi_nhwc_to_nchw_f32(const float* x, int64_t ldx, float* y, int B, int C, int HW, int accumulate, void* stream);
+int fdmi_silu_f32(const float* x, float* y, int64_t n, void* stream);
+int fdmi_silu_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int fdmi_gelu_tanh_f32(const float* x, float* y, int64_t n, void* stream);
+int fdmi_gelu_tanh_bwd_f32(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+int fdmi_gate_residual_f32(const float* x, const float* gate, int64_t gate_ld, const float* res, float* y, int64_t rows, int C,
+                           int rows_per_batch, void* stream);
+int fdmi_batch_colsum_f32(const float* dy, const float* x, const float* stats, float* out0, float* out1, int B, int rows_per_batch,
+                          int C, void* stream);
+int fdmi_im2col_f32(const float* x, float* out, int B, int H, int W, int C, int Ho, int Wo, int KH, int KW, int stride, int pad,
+                    void* stream);
+int fdmi_colsum_f32(const float* dy, const float* x, const float* stats, float* out0, float* out1, int64_t rows, int C, int HW, int G,
+                    void* stream);
+int fdmi_pad_cols_f32(const float* src, int cols, float* dst, int cols_pad, int64_t rows, void* stream);
+
 /* ---------------- UNet2DCondition plan: forward + input/LoRA-gradient backward -------------------
  * Replaces DiffusersUNet2DCondWrapper.forward -> UNet2DConditionModel.forward(...).sample
  * (/root/reference/src/flash/models/unets/unet.py:66-119) and its autograd backward.  Architecture
@@ -185,6 +228,9 @@ typedef struct fdmi_unet_config {
   int32_t groups; float eps;    /* norm_num_groups, norm_eps */
   int32_t class_embed_dim;      /* projection_class_embeddings_input_dim, 0 = no class embedding */
   int32_t flip_sin_to_cos; float freq_shift;
+  int32_t precision;            /* 0: bf16 MFMA with fp32 accumulation (the measured path, the reference's bf16-mixed);
+                                   1: fp32 VALIDATION plan -- fp32 storage, every contraction on v_mfma_f32_32x32x2_f32,
+                                   fp64 norm statistics (csrc/ref32.hip): the parity gate against the fp32 CPU oracle */
 } fdmi_unet_config;
 enum { FDMI_UNET_SAVE = 1,          /* record what backward needs (student / GAN backbone) */
        FDMI_UNET_INTERMEDIATE = 2,  /* return_intermediate=True: output the mid-block features */

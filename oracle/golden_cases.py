@@ -30,6 +30,17 @@ CASES = {
                                    use_dmd_loss=True, use_teacher_as_real=True), "dpm", 0, 13),
     "g_noreg_vanilla": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform",
                              distill_loss_scale=0.0, gan_loss_type="vanilla"), "dpm", 0, 14),
+    # the remaining GAN branches of FD:573-662 -- wgan (its weight clamp +-0.01 mutates the discriminator IN
+    # the forward, FD:573-585; the fixtures also carry the post-forward discriminator weights) on both steps, and the
+    # discriminator step of lsgan / vanilla / non-saturating
+    "g_wgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="wgan",
+                    adversarial_loss_scale=0.2), "dpm", 0, 17),
+    "d_wgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="wgan"), "dpm", 1, 18),
+    "d_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="gaussian", gan_loss_type="lsgan"), "dpm", 1, 19),
+    "d_vanilla": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="vanilla",
+                       use_teacher_as_real=True), "dpm", 1, 20),
+    "d_nonsat": (dict(K=[6], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="non-saturating"),
+                 "dpm", 1, 21),
 }
 
 
@@ -165,3 +176,32 @@ def build_mmdit(name, lora_r=0):
             "vector": torch.randn(2, cfg["pooled_projection_dim"], generator=g)}
     w = torch.randn(2, 16, 16, 16, generator=g)
     return cfg, m, (x, t, {"cond": cond}), w
+
+
+# ---- the full-size C1 step (BASELINE.json configs[0]): fixture tests/golden/c1_sd15_full.npz (oracle/make_golden.py c1) ----
+C1_LORA_RANK = 16
+C1_SEED = 31
+
+
+def build_c1_models():
+    """BASELINE.json configs[0] / SURVEY 8a "C1": the full-size SD1.5 UNet (examples/train_flash_sd.py:56-114), B = 1, one
+    teacher step (K = [1]), seeded weights; the student carries a small-rank LoRA with non-zero B so that every gradient is
+    exercised, the PatchGAN head is the reference's SD1.5 one (examples/train_flash_sd.py:225-240)."""
+    from .unet_cpu import sd15_config
+    teacher = seeded_init_(UNet2DConditionRef(sd15_config()), 1)
+    student = copy.deepcopy(teacher)
+    student.add_adapter(C1_LORA_RANK)
+    seeded_init_(student, 2)
+    student.load_state_dict(dict(teacher.state_dict()), strict=False)
+    teacher.freeze()
+    disc = seeded_init_(make_discriminator(kind="sd15", color_dim=1280, feat=64, last_k=4), 3)
+    return teacher, student, disc
+
+
+C1_KW = dict(K=[1], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="l2", gan_loss_type="lsgan",
+             use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=13.0, dmd_loss_scale=0.3, adversarial_loss_scale=0.1)
+
+
+def c1_grad_probe(numel, seed):
+    """fixed pseudo-random direction a gradient tensor is projected on (fixtures cannot carry 3 M LoRA gradient values)"""
+    return torch.randn(numel, generator=torch.Generator().manual_seed(seed))

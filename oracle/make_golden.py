@@ -79,6 +79,8 @@ def main(cases=None):
             blob["term:" + k] = np.float64(float(v))
         for n, g in grads.items():
             blob["grad:" + n] = g.numpy()
+        for n, p_ in ref.discriminator.named_parameters():   # (wgan clamps the weights inside the forward, FD:573-585)
+            blob["post:discriminator." + n] = p_.detach().numpy()
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **blob)
         print(name, "loss", blob["loss:0"], blob["loss:1"], "ngrads", len(grads),
@@ -159,6 +161,8 @@ def make_sd3_golden():
             blob[f"loss:{i}"] = np.float64(float(out["loss"][i]))
         for n, g in grads.items():
             blob["grad:" + n] = g.numpy()
+        for n, p_ in ref.discriminator.named_parameters():   # (wgan clamps the weights inside the forward, FD:573-585)
+            blob["post:discriminator." + n] = p_.detach().numpy()
         path = os.path.join(OUT, name + ".npz")
         np.savez_compressed(path, **blob)
         print(name, "loss", blob["loss:0"], blob["loss:1"], "ngrads", len(grads), "start_t", out["start_timestep"],
@@ -197,9 +201,63 @@ def make_dit_golden():
         print(name, "ngrads", sum(k.startswith("grad:") for k in blob), os.path.getsize(path) // 1024, "KiB")
 
 
+from .golden_cases import C1_KW, C1_SEED, build_c1_models, c1_grad_probe  # noqa: E402
+
+
+def make_c1_golden():
+    """One full-size step (fixture tests/golden/c1_sd15_full.npz): inputs, draws, outputs, every loss term, and for each of
+    the 256 LoRA / discriminator gradient tensors its norm and its projection on a seeded random direction (plus the first
+    and last LoRA pair in full)."""
+    from .flash_ref import FlashConfigRef, FlashDiffusionRef
+    FD, FDC = shim_import.import_reference()
+    batch = make_batch(B=1, hw=64, ctx_dim=768, seed=7)
+    teacher, student, disc = build_c1_models()
+    ref = FD(FDC(**C1_KW), student_denoiser=student, teacher_denoiser=teacher,
+             teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=TensorConditioner(), discriminator=disc)
+    torch.manual_seed(C1_SEED)
+    out = ref(batch, step=0, device="cpu")
+    out["loss"][0].backward()
+    grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+    teacher, student, disc = build_c1_models()
+    ora = FlashDiffusionRef(FlashConfigRef(**C1_KW), student_denoiser=student, teacher_denoiser=teacher,
+                            teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=TensorConditioner(), discriminator=disc)
+    torch.manual_seed(C1_SEED)
+    out2 = ora(make_batch(B=1, hw=64, ctx_dim=768, seed=7), step=0, device="cpu")
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert torch.equal(out[k], out2[k]), k
+    blob = {"z": batch["image"].numpy(), "crossattn": batch["crossattn"].numpy(), "step": np.int64(0),
+            "start_timestep": np.int64(out["start_timestep"])}
+    for k, v in ora.last_draws.values.items():
+        blob["draw:" + k] = v.numpy()
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        blob["out:" + k] = out[k].detach().numpy()
+    for i in (0, 1):
+        blob[f"loss:{i}"] = np.float64(float(out["loss"][i]))
+    for k, v in ora.terms.items():
+        blob["term:" + k] = np.float64(float(v))
+    names = sorted(grads)
+    blob["gradnames"] = np.array(names)
+    blob["gradnorm"] = np.array([float(grads[n].double().norm()) for n in names])
+    blob["gradproj"] = np.array([float(grads[n].double().flatten() @ c1_grad_probe(grads[n].numel(), 1000 + i).double())
+                                 for i, n in enumerate(names)])
+    lora = [n for n in names if ".lora_" in n]
+    for n in lora[:2] + lora[-2:]:
+        blob["grad:" + n] = grads[n].numpy()
+    path = os.path.join(OUT, "c1_sd15_full.npz")
+    np.savez_compressed(path, **blob)
+    print("c1_sd15_full loss", blob["loss:0"], "terms", {k: float(blob[k]) for k in blob if k.startswith("term:")},
+          "ngrads", len(names), os.path.getsize(path) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     import sys
-    if len(sys.argv) > 1 and sys.argv[1] == "sample":
+    if len(sys.argv) > 1 and sys.argv[1] == "c1":
+        make_c1_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "gan":
+        from .golden_cases import CASES as _C
+        want = sys.argv[2:] or ("g_wgan", "d_wgan", "d_lsgan", "d_vanilla", "d_nonsat")
+        main({k: v for k, v in _C.items() if k in want})
+    elif len(sys.argv) > 1 and sys.argv[1] == "sample":
         make_sample_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "sd3":
         make_sd3_golden()
@@ -219,3 +277,4 @@ if __name__ == "__main__":
         make_sample_golden()
         make_sd3_golden()
         make_dit_golden()
+        make_c1_golden()

@@ -9,7 +9,7 @@ GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 def load_case(name):
     blob = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
-    g = {"draws": {}, "out": {}, "grads": {}, "terms": {}, "loss": [None, None]}
+    g = {"draws": {}, "out": {}, "grads": {}, "terms": {}, "loss": [None, None], "post": {}}
     for k in blob.files:
         v = blob[k]
         if k.startswith("draw:"):
@@ -18,6 +18,8 @@ def load_case(name):
             g["out"][k[4:]] = torch.from_numpy(v)
         elif k.startswith("grad:"):
             g["grads"][k[5:]] = torch.from_numpy(v)
+        elif k.startswith("post:"):
+            g["post"][k[5:]] = torch.from_numpy(v)
         elif k.startswith("term:"):
             g["terms"][k[5:]] = float(v)
         elif k.startswith("loss:"):

@@ -35,7 +35,8 @@ def test_oracle_reproduces_golden(name):
     if step == 0:
         assert g["loss"][0] > 0 and g["loss"][1] == 0.0
     else:
-        assert g["loss"][1] > 0
+        # (a Wasserstein critic loss has no sign: the reference's `> 0` invariant is for its own lsgan test configuration)
+        assert g["loss"][1] > 0 or (kw.get("gan_loss_type") == "wgan" and g["loss"][1] != 0)
 
 
 def test_scheduler_trailing_timesteps():
