@@ -353,7 +353,7 @@ def main():
             "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": f"{ {'sd15': 'C2', 'sdxl': 'C3-single-GPU', 'pixart': 'C4', 'sd3': 'C5-single-GPU (distill only)'}.get(args.arch, 'dev')}: Flash-{args.arch.upper()} "
+            "config": {"workload": f"{ {'sd15': 'C2', 'sdxl': 'C3-single-GPU', 'pixart': 'C4', 'sd3': 'C5-single-GPU (l2 distill + DMD + lsgan GAN on the full-model backbone at 2B)'}.get(args.arch, 'dev')}: Flash-{args.arch.upper()} "
                                    f"{'DiT' if dit else ('MMDiT' if sd3 else 'UNet')} teacher + LoRA r{rank_r} student, {B} images/GPU, "
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",

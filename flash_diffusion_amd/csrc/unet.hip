@@ -1056,6 +1056,19 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   R.es = U->f32 ? 4 : 2;
   R.sc32 = nullptr;
   R.sc32_elems = 0;
+  if (U->f32) {   // one scratch region for the materialised attention scores, sized for the largest attention of the plan
+    int64_t need = 0;
+    for (int i = 0; i < U->nl; ++i) {
+      if (!c.down_attn[i] && !c.up_attn[U->nl - 1 - i] && i != U->nl - 1) continue;
+      const int S = (H >> i) * (W >> i), bw = (flags & FDMI_UNET_SAVE) ? 1 : 0;
+      const int64_t a = attn32_scratch_elems(B, c.heads[i], S, S, bw), b = attn32_scratch_elems(B, c.heads[i], S, L, bw);
+      need = a > need ? a : need;
+      need = b > need ? b : need;
+    }
+    R.sc32 = (float*)R.arena.alloc((size_t)need * 4);
+    FAIL_IF_NULL(R.sc32);
+    R.sc32_elems = need;
+  }
   R.save = (flags & FDMI_UNET_SAVE) != 0;
   const bool inter = (flags & FDMI_UNET_INTERMEDIATE) != 0;
   hipStream_t st = R.st;

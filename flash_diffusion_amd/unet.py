@@ -524,7 +524,9 @@ class MiUNet2DConditionModel(nn.Module):
         x = x.float().contiguous().clone()
         enc = crossattn2.float().contiguous()
         vec = vector2.float().contiguous() if vector2 is not None else None
-        need = L.fdmi_unet_workspace_bytes(plan.handle, 2 * B, H, W, Lc, FDMI_UNET_CTX_FILL)
+        # (the loop runs its forwards with CTX_FILL / CTX_REUSE and, by default, the [x | x] prefix dedupe)
+        need = max(L.fdmi_unet_workspace_bytes(plan.handle, 2 * B, H, W, Lc, FDMI_UNET_CTX_FILL),
+                   L.fdmi_unet_workspace_bytes(plan.handle, 2 * B, H, W, Lc, FDMI_UNET_CTX_FILL | FDMI_UNET_CFG_HALVES))
         sneed = L.fdmi_teacher_loop_scratch_bytes(plan.handle, B, H, W)
         if need < 0 or sneed < 0:
             raise RuntimeError("fdmi: " + L.fdmi_last_error().decode())

@@ -98,9 +98,23 @@ class SyntheticPromptEncoder:
         return self.pe, torch.zeros_like(self.pe), self.pp, torch.zeros_like(self.pp)
 
 
-def build_flash_sd3(arch=SD3, lora_rank=64, n_teacher_steps=4, B=4, L=333, device="cuda", seed=0, guidance=5.0):
-    """C5-shaped single-GPU leg: frozen MMDiT teacher + LoRA student (examples/train_flash_sd3.py:100-121), flow-matching
-    Euler teacher loop with K = n_teacher_steps and the start index pinned to 0, l2 distillation."""
+def sd3_discriminator(color_dim=16, feat=64):
+    """the PatchGAN head of examples/train_flash_sd3.py:145-183 on the [B, 16, 128, 128] prediction (the DiT wrappers ignore
+    return_intermediate, so the head sees the full model output): four strided 4x4 convs + GroupNorm + SiLU -> 5x5 logits"""
+    import torch.nn as nn
+    return nn.Sequential(nn.Conv2d(color_dim, feat, 4, 2, 1, bias=False), nn.SiLU(True),
+                         nn.Conv2d(feat, feat * 2, 4, 2, 1, bias=False), nn.GroupNorm(4, feat * 2), nn.SiLU(True),
+                         nn.Conv2d(feat * 2, feat * 4, 4, 2, 1, bias=False), nn.GroupNorm(4, feat * 4), nn.SiLU(True),
+                         nn.Conv2d(feat * 4, feat * 8, 4, 2, 1, bias=False), nn.GroupNorm(4, feat * 8), nn.SiLU(True),
+                         nn.Conv2d(feat * 8, 1, 4, 1, 0, bias=False), nn.Flatten())
+
+
+def build_flash_sd3(arch=SD3, lora_rank=64, n_teacher_steps=4, B=4, L=333, device="cuda", seed=0, guidance=5.0,
+                    use_dmd_loss=True, discriminator="sd3", gan_loss_type="lsgan"):
+    """BASELINE.json configs[4] (C5) on one GPU: frozen MMDiT teacher + LoRA student (examples/train_flash_sd3.py:100-121),
+    flow-matching Euler teacher loop with K = n_teacher_steps and the start index pinned to 0, l2 distillation PLUS the DMD
+    term (three more denoiser calls, FD3:415-497) and the lsgan GAN term (the full teacher at 2B as backbone + the example's
+    PatchGAN head, FD3:498-560) -- what C5 names.  discriminator=None / use_dmd_loss=False give the distillation-only step."""
     from .dit import MiSD3Transformer2DModel
     from .flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
     torch.manual_seed(seed)
@@ -110,10 +124,14 @@ def build_flash_sd3(arch=SD3, lora_rank=64, n_teacher_steps=4, B=4, L=333, devic
     teacher.freeze()
     student = student.to(device)
     student.add_adapter(lora_rank)
+    if discriminator == "sd3":
+        discriminator = sd3_discriminator(arch["in_channels"]).to(device) if arch["sample_size"] >= 64 else None
     cfg = FlashDiffusionSD3Config(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform",
-                                  distill_loss_type="l2", guidance_scale_min=3.0, guidance_scale_max=7.0)
+                                  distill_loss_type="l2", guidance_scale_min=3.0, guidance_scale_max=7.0,
+                                  use_dmd_loss=use_dmd_loss, gan_loss_type=gan_loss_type, dmd_loss_scale=0.3,
+                                  adversarial_loss_scale=0.1)
     m = FlashDiffusionSD3(cfg, student_denoiser=student, teacher_denoiser=teacher,
-                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(),
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), discriminator=discriminator,
                           pipeline=SyntheticPromptEncoder(B, L, arch["joint_attention_dim"], arch["pooled_projection_dim"],
                                                           device))
     m.fixed_start_idx = 0

@@ -205,3 +205,44 @@ C1_KW = dict(K=[1], num_iterations_per_K=[10], timestep_distribution="uniform", 
 def c1_grad_probe(numel, seed):
     """fixed pseudo-random direction a gradient tensor is projected on (fixtures cannot carry 3 M LoRA gradient values)"""
     return torch.randn(numel, generator=torch.Generator().manual_seed(seed))
+
+
+# ---- FlashDiffusionSD3 over the MMDiT denoiser itself (SURVEY 8a row a18, BASELINE.json configs[4] in miniature): the
+# reference's REAL step class on the reference's REAL wrapper (restated diffusers base), DMD + lsgan head ----------------------
+SD3_MMDIT_CASES = {
+    # name: (config kwargs, mmdit case, step, seed)
+    "sd3_mmdit_g_dmd_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="lsgan",
+                                   use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=7.0), "mmdit_tiny", 0, 41),
+    "sd3_mmdit_d_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", gan_loss_type="lsgan"),
+                          "mmdit_tiny", 1, 42),
+}
+
+
+def sd3_mmdit_head(in_ch=16):
+    """examples/train_flash_sd3.py:148-183 in miniature: strided 4x4 convs + GroupNorm + SiLU on the [B, 16, 16, 16] prediction"""
+    d = torch.nn.Sequential(torch.nn.Conv2d(in_ch, 16, 4, 2, 1, bias=False), torch.nn.SiLU(),
+                            torch.nn.Conv2d(16, 32, 4, 2, 1, bias=False), torch.nn.GroupNorm(4, 32), torch.nn.SiLU(),
+                            torch.nn.Conv2d(32, 1, 4, 1, 0, bias=False), torch.nn.Flatten())
+    g3 = torch.Generator().manual_seed(3)
+    for p in d.parameters():
+        p.data.copy_(torch.randn(p.shape, generator=g3) * 0.1 + (1.0 if p.dim() == 1 and p is d[3].weight else 0.0))
+    return d
+
+
+def build_sd3_mmdit_inputs(case="mmdit_tiny"):
+    """(cfg, teacher oracle module (frozen), student oracle module with LoRA, head, embedding pipeline, batch)"""
+    from . import dit_cpu
+    from .flash_sd3_ref import EmbeddingPipeline
+    cfg, teacher, (x, t, cond), _ = build_mmdit(case, lora_r=0)
+    _, student, _, _ = build_mmdit(case, lora_r=8)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    teacher.eval()
+    ge = torch.Generator().manual_seed(9)
+    L, D, P = 7, cfg["joint_attention_dim"], cfg["pooled_projection_dim"]
+    pipe = EmbeddingPipeline(torch.randn(2, L, D, generator=ge), torch.randn(2, P, generator=ge),
+                             torch.randn(2, L, D, generator=ge), torch.randn(2, P, generator=ge))
+    gb = torch.Generator().manual_seed(5)
+    batch = {"image": torch.randn(2, 16, 16, 16, generator=gb), "text": ["a", "b"]}
+    return cfg, teacher, student, sd3_mmdit_head(), pipe, batch
+

@@ -201,6 +201,54 @@ def make_dit_golden():
         print(name, "ngrads", sum(k.startswith("grad:") for k in blob), os.path.getsize(path) // 1024, "KiB")
 
 
+def make_sd3_mmdit_golden():
+    """FlashDiffusionSD3 (the REAL class) over the REAL DiffusersSD3Transformer2DWrapper (restated diffusers base) holding the
+    seeded tiny-MMDiT weights: fixtures tests/golden/sd3_mmdit_*.npz for the step over the HIP MMDiT."""
+    from . import dit_cpu
+    from .flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from .golden_cases import SD3_MMDIT_CASES, build_sd3_mmdit_inputs
+    from .sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    FD3, FD3C = shim_import.import_reference_sd3()
+    Wrapper = shim_import.import_reference_sd3_wrapper()
+    for name, (kw, case, step, seed) in SD3_MMDIT_CASES.items():
+        def models():
+            cfg, t_o, s_o, head, pipe, batch = build_sd3_mmdit_inputs(case)
+            teacher = Wrapper(**cfg)
+            teacher.load_state_dict(t_o.state_dict())
+            teacher.freeze()
+            student = Wrapper(**cfg)
+            dit_cpu.add_lora_(student, 8, seed=4, b_std=0.05)
+            student.load_state_dict(s_o.state_dict())
+            return teacher, student, head, pipe, batch
+        teacher, student, head, pipe, batch = models()
+        ref = FD3(FD3C(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                  teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=head, pipeline=pipe)
+        torch.manual_seed(seed)
+        out = ref(batch, step=step)
+        out["loss"][step].backward()
+        grads = {n.replace(".base_layer.", "."): p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+        teacher, student, head, pipe, batch2 = models()
+        ora = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                                   teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=head, pipeline=pipe)
+        torch.manual_seed(seed)
+        out2 = ora(batch2, step=step)
+        for k in ("teacher_output", "student_output", "noisy_sample"):
+            assert torch.equal(out[k], out2[k]), (name, k)
+        blob = {"z": batch["image"].numpy(), "step": np.int64(step), "start_timestep": np.float64(out["start_timestep"])}
+        for k, v in ora.last_draws.values.items():
+            blob["draw:" + k] = v.numpy()
+        for k in ("teacher_output", "student_output", "noisy_sample"):
+            blob["out:" + k] = out[k].detach().numpy()
+        for i in (0, 1):
+            blob[f"loss:{i}"] = np.float64(float(out["loss"][i]))
+        for n, g in grads.items():
+            blob["grad:" + n] = g.numpy()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, "loss", blob["loss:0"], blob["loss:1"], "ngrads", len(grads), "start_t", out["start_timestep"],
+              os.path.getsize(path) // 1024, "KiB")
+
+
 from .golden_cases import C1_KW, C1_SEED, build_c1_models, c1_grad_probe  # noqa: E402
 
 
@@ -253,6 +301,8 @@ if __name__ == "__main__":
     import sys
     if len(sys.argv) > 1 and sys.argv[1] == "c1":
         make_c1_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "sd3_mmdit":
+        make_sd3_mmdit_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "gan":
         from .golden_cases import CASES as _C
         want = sys.argv[2:] or ("g_wgan", "d_wgan", "d_lsgan", "d_vanilla", "d_nonsat")
@@ -278,3 +328,4 @@ if __name__ == "__main__":
         make_sd3_golden()
         make_dit_golden()
         make_c1_golden()
+        make_sd3_mmdit_golden()

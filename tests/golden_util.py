@@ -25,7 +25,7 @@ def load_case(name):
         elif k.startswith("loss:"):
             g["loss"][int(k[5:])] = float(v)
         else:
-            g[k] = torch.from_numpy(v) if v.ndim else v.item()
+            g[k] = v if v.dtype.kind in "US" else (torch.from_numpy(v) if v.ndim else v.item())
     return g
 
 
