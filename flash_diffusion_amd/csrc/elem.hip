@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void cast_transpose_jobs_kernel(const CastJob*
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int c = i >> 6, r = i & 63;
-    if (c0 + c < cols && r0 + r < rows) jb.dstT[(int64_t)(c0 + c) * rows + r0 + r] = tile[r][c];
+    if (c0 + c < cols && r0 + r < rows) jb.dstT[(int64_t)(c0 + c) * (jb.ldT ? jb.ldT : rows) + r0 + r] = tile[r][c];
   }
 }
 

@@ -500,8 +500,9 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
     if (a.act != ACT_GEGLU && gemm3_pick_bn(a) == 160 && (a.N % 128) == 0) consider(1, 256, 128, 256, 3.4);
   }
   if (gemm4_eligible(a)) consider(2, 256, 320, 256, 4.8);
-  // 256 x 192 (widths of the transformer denoisers): developer knob 12 until its rate has been measured (est. 110 flop/B)
-  if (fdmi_tune_get(12) && gemm4_eligible(a, 192)) consider(2, 256, 192, 256, 3.9);
+  // 256 x 192 (the widths of the transformer denoisers, which 320 does not divide): measured -6.6 % on the C4 step against the
+  // 256 x 128 ring kernel it displaces (profiles/r2_knob12_c4.txt); A/B switch 12 = 1 takes it out of the planner
+  if (!fdmi_tune_get(12) && gemm4_eligible(a, 192)) consider(2, 256, 192, 256, 3.9);
   const bool geglu = a.act == ACT_GEGLU;
   consider(0, 128, 128, 512, 1.05);
   consider(0, 128, 64, 768, 0.60);

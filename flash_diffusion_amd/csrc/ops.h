@@ -78,7 +78,7 @@ int launch_pad_cols(const bf16_t* src, int cols, bf16_t* dst, int cols_pad, int6
 // LoRA refresh: f32 master W[rows][cols] -> bf16 copy and bf16 transpose
 int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int cols, hipStream_t st);
 // one 64x64 tile of an f32 [rows][cols] -> bf16 copy + bf16 transposed copy (LoRA refresh of a whole plan in one launch)
-struct CastJob { const float* src; bf16_t* dst; bf16_t* dstT; int rows, cols, r0, c0; };
+struct CastJob { const float* src; bf16_t* dst; bf16_t* dstT; int rows, cols, r0, c0; int ldT; /* row stride of dstT (0: rows) */ };
 int launch_cast_transpose_jobs(const CastJob* jobs, int njobs, hipStream_t st);
 // fused AdamW on a flat f32 buffer
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,

@@ -46,7 +46,12 @@ struct T {  // NHWC / token-major bf16 activation [rows][cols] (+ lazily allocat
   int cols = 0;
   int B = 0, H = 0, W = 0;
   bool ginit = false;
-  float* gn = nullptr;   // GroupNorm sums [B][G][2] of this tensor, left by the producing GEMM's epilogue (knob 14)
+  float* gn = nullptr;   // GroupNorm sums [B][G][2] of this tensor, left by the producing GEMM's epilogue
+  // column-slice view of another tensor (the q / k / v parts of a fused projection): row stride and gradient are the parent's
+  T* parent = nullptr;
+  int col0 = 0;
+  int64_t ldv = 0;
+  int64_t ld() const { return ldv ? ldv : cols; }
 };
 
 struct Weight {
@@ -68,6 +73,9 @@ struct Lora {
   const float *A_master = nullptr, *B_master = nullptr;
   float *A_grad = nullptr, *B_grad = nullptr;
   bf16_t *A = nullptr, *AT = nullptr, *B = nullptr, *BT = nullptr;
+  // where the refresh writes the bf16 A / A^T copies: the own buffers above, or slices of a block's fused [3r][in] / [in][3r]
+  bf16_t *A_dst = nullptr, *AT_dst = nullptr;
+  int AT_ld = 0;
   int r = 0, in = 0, out = 0;
   bool on = false;
 };
@@ -86,6 +94,11 @@ struct TBlockW {
   Norm ln1, ln2, ln3;
   AttnW a1, a2;
   Weight ff1, ff2;
+  // attn1's q / k / v projections as ONE GEMM (x is read once): plan-owned concatenated operands qkv.w [3C][C], qkv.wt [C][3C]
+  // copied from the three packed weights, and -- LoRA on all three -- the concatenated A operands A3 [3r][C], AT3 [C][3r]
+  Weight qkv;
+  bf16_t *A3 = nullptr, *AT3 = nullptr;
+  int fused_r = 0;
   // cross-attention K / V / V^T of a fixed context (FDMI_UNET_CTX_FILL / _REUSE), plan-owned
   bf16_t *ck = nullptr, *cv = nullptr, *cvt = nullptr;
   int64_t c_rows = 0, c_vt = 0;
@@ -150,6 +163,14 @@ struct Run {
     t->rows = rows; t->cols = cols; t->p = p;
     return t;
   }
+  // columns col0 .. col0 + cols of `parent` (bf16 plans)
+  T* view(T* parent, int col0, int cols) {
+    tensors.emplace_back();
+    T* t = &tensors.back();
+    t->rows = parent->rows; t->cols = cols; t->B = parent->B; t->H = parent->H; t->W = parent->W;
+    t->p = parent->p + col0; t->parent = parent; t->col0 = col0; t->ldv = parent->ld();
+    return t;
+  }
   bool dry() const { return arena.dry; }
 };
 
@@ -174,6 +195,8 @@ struct fdmi_unet {
   CastJob* cast_jobs = nullptr;   // device table of the LoRA refresh (rebuilt when a master pointer changes)
   int n_cast_jobs = 0;
   bool cast_dirty = true;
+  bool fused_dirty = true;   // a q / k / v weight changed: the concatenated operands are rebuilt at the next forward
+  int cast_mode = -1;        // value of A/B switch 17 the LoRA refresh table was built for
   Run runs[8];
   double last_flops = 0;     // algorithmic MFMA flops of the last forward/backward call
   int last_gn = 0, last_gn_epi = 0;  // GroupNorms of the last forward / how many took their sums from a GEMM epilogue
@@ -431,6 +454,7 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
         RET_IF(dmalloc(U, &w.w, (size_t)w.N * w.K * (U->f32 ? 2 : 1)));
         if (!U->f32) RET_IF(dmalloc(U, &w.wt, (size_t)w.N * w.K));   // (an fp32 plan reads the one copy with strides)
       }
+      U->fused_dirty = true;
       if (U->f32)
         hipLaunchKernelGGL(pack_linear_kernel<float>, dim3(gridfor((int64_t)w.N * w.K)), dim3(256), 0, st, src, (float*)w.w,
                            (float*)nullptr, w.N, w.K, w.geglu ? 1 : 0);
@@ -490,6 +514,51 @@ static bool plan_log() {
   return on;
 }
 
+template <typename F>
+void for_each_tblock(fdmi_unet* U, F fn) {
+  auto stage = [&](StageW& s) {
+    for (auto& t : s.attn)
+      for (auto& b : t->blocks) fn(*t, *b);
+  };
+  for (auto& s : U->down) stage(*s);
+  if (U->mid_attn)
+    for (auto& b : U->mid_attn->blocks) fn(*U->mid_attn, *b);
+  for (auto& s : U->up) stage(*s);
+}
+// attn1's three projections can run as one GEMM when none of them or all of them carry a LoRA of one rank (bf16 plans;
+// A/B switch 17 = 1 keeps the three separate launches)
+static bool qkv_fusable(const fdmi_unet* U, const TBlockW& b) {
+  if (U->f32 || fdmi_tune_get(17)) return false;
+  const Lora &q = b.a1.q.lora, &k = b.a1.k.lora, &v = b.a1.v.lora;
+  if (!q.on && !k.on && !v.on) return true;
+  return q.on && k.on && v.on && q.r == k.r && q.r == v.r;
+}
+// (re)build the concatenated operands of every fusable block from the packed per-projection weights
+int build_fused_operands(fdmi_unet* U, hipStream_t st) {
+  int rc = 0;
+  for_each_tblock(U, [&](TransformerW& t, TBlockW& b) {
+    if (rc || U->f32) return;
+    const int C = t.C;
+    const Weight *w[3] = {&b.a1.q.w, &b.a1.k.w, &b.a1.v.w};
+    if (!w[0]->w || !w[1]->w || !w[2]->w) return;
+    if (!b.qkv.w) {
+      b.qkv.N = 3 * C; b.qkv.K = C; b.qkv.has_bias = false;
+      if ((rc = dmalloc(U, &b.qkv.w, (size_t)3 * C * C))) return;
+      if ((rc = dmalloc(U, &b.qkv.wt, (size_t)3 * C * C))) return;
+    }
+    for (int s = 0; s < 3 && !rc; ++s) {
+      if (hipMemcpyAsync(b.qkv.w + (size_t)s * C * C, w[s]->w, (size_t)C * C * 2, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+          hipMemcpy2DAsync(b.qkv.wt + (size_t)s * C, (size_t)3 * C * 2, w[s]->wt, (size_t)C * 2, (size_t)C * 2, C,
+                           hipMemcpyDeviceToDevice, st) != hipSuccess) {
+        fdmi_set_error("unet: copying the fused q/k/v operands failed");
+        rc = -2;
+      }
+    }
+  });
+  if (!rc) U->fused_dirty = false;
+  return rc;
+}
+
 struct Exec {
   fdmi_unet* U;
   Run& R;
@@ -525,6 +594,11 @@ struct Exec {
   }
 
   bf16_t* grad_of(T* t) {  // lazily allocate the gradient buffer
+    if (t->parent) {      // a column slice: the same columns of the parent's gradient
+      bf16_t* pg = grad_of(t->parent);
+      t->g = pg ? pg + t->col0 : nullptr;
+      return t->g;
+    }
     if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * es());
     return t->g;
   }
@@ -584,15 +658,35 @@ struct Exec {
 
   int lora_refresh() {
     if (R.dry() || f32()) return 0;   // (an fp32 plan reads the fp32 masters directly)
-    if (U->cast_dirty) {  // (re)build the tile table of the one-launch refresh
+    if (U->cast_mode != fdmi_tune_get(17)) U->cast_dirty = true;
+    if (U->cast_dirty) {
+      U->cast_mode = fdmi_tune_get(17);  // (re)build the tile table of the one-launch refresh
       std::vector<CastJob> jobs;
-      auto add = [&](const float* src, bf16_t* dst, bf16_t* dstT, int rows, int cols) {
+      auto add = [&](const float* src, bf16_t* dst, bf16_t* dstT, int rows, int cols, int ldT) {
         for (int r0 = 0; r0 < rows; r0 += 64)
-          for (int c0 = 0; c0 < cols; c0 += 64) jobs.push_back(CastJob{src, dst, dstT, rows, cols, r0, c0});
+          for (int c0 = 0; c0 < cols; c0 += 64) jobs.push_back(CastJob{src, dst, dstT, rows, cols, r0, c0, ldT});
       };
+      for (Lora* l : U->loras) { l->A_dst = l->A; l->AT_dst = l->AT; l->AT_ld = 0; }
+      // blocks whose attn1 projections run fused: the three A copies land in one [3r][in] / [in][3r] pair
+      int rc = 0;
+      for_each_tblock(U, [&](TransformerW& t, TBlockW& b) {
+        Lora* l3[3] = {&b.a1.q.lora, &b.a1.k.lora, &b.a1.v.lora};
+        if (rc || !l3[0]->on || !qkv_fusable(U, b)) return;
+        const int r = l3[0]->r, in = l3[0]->in;
+        if (!b.A3 || b.fused_r != r) {
+          if ((rc = dmalloc(U, &b.A3, (size_t)3 * r * in)) || (rc = dmalloc(U, &b.AT3, (size_t)3 * r * in))) return;
+          b.fused_r = r;
+        }
+        for (int s = 0; s < 3; ++s) {
+          l3[s]->A_dst = b.A3 + (size_t)s * r * in;
+          l3[s]->AT_dst = b.AT3 + (size_t)s * r;
+          l3[s]->AT_ld = 3 * r;
+        }
+      });
+      RET_IF(rc);
       for (Lora* l : U->loras) {
-        add(l->A_master, l->A, l->AT, l->r, l->in);
-        add(l->B_master, l->B, l->BT, l->out, l->r);
+        add(l->A_master, l->A_dst, l->AT_dst, l->r, l->in, l->AT_ld);
+        add(l->B_master, l->B, l->BT, l->out, l->r, 0);
       }
       if (U->cast_jobs) FDMI_HIP(hipFree(U->cast_jobs));
       U->cast_jobs = nullptr;
@@ -666,6 +760,51 @@ struct Exec {
             else
               RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
           }
+        }
+        return 0;
+      });
+    }
+    return y;
+  }
+
+  // attn1's q, k, v projections of one input as ONE GEMM: y [M, 3C] = x Wqkv^T (+ per-slice LoRA deltas); x is read once
+  // instead of three times, the backward's input gradient is one GEMM over K = 3C.  bf16 plans (qkv_fusable).
+  T* linear_qkv(T* x, TBlockW& b, int C) {
+    Lora* l3[3] = {&b.a1.q.lora, &b.a1.k.lora, &b.a1.v.lora};
+    const bool lora = l3[0]->on;
+    const int r = lora ? l3[0]->r : 0;
+    T* y = R.mk(x->rows, 3 * C, x->B, x->H, x->W);
+    if (!y) return nullptr;
+    NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.qkv.w, 3 * C, C, nullptr, y->p, 3 * C, nullptr, 0));
+    T* t3 = nullptr;
+    if (lora) {
+      t3 = R.mk(x->rows, 3 * r);
+      if (!t3) return nullptr;
+      NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.A3, 3 * r, C, nullptr, t3->p, 3 * r, nullptr, 0));
+      for (int s = 0; s < 3; ++s)
+        NULL_IF(gemm_rows(t3->p + s * r, 3 * r, x->rows, l3[s]->B, C, r, nullptr, y->p + s * C, 3 * C, y->p + s * C, 3 * C));
+    }
+    if (R.save) {
+      R.tape.push_back([x, y, t3, &b, C, r, lora](Exec& E) -> int {
+        if (!y->g) return 0;
+        Lora* l3[3] = {&b.a1.q.lora, &b.a1.k.lora, &b.a1.v.lora};
+        bf16_t* dx = E.grad_of(x);
+        FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
+        RET_IF(E.gemm_rows(y->g, 3 * C, x->rows, b.qkv.wt, C, 3 * C, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
+        x->ginit = true;
+        if (lora) {   // per slice s: dt_s = dy_s B_s ; dB_s += dy_s^T t_s ; dA_s += dt_s^T x ; then dx += [dt_q | dt_k | dt_v] A3
+          T* dt3 = E.R.mk(x->rows, 3 * r);
+          FDMI_CHECK(dt3, "unet: workspace exhausted (lora)");
+          for (int s = 0; s < 3; ++s)
+            RET_IF(E.gemm_rows(y->g + s * C, 3 * C, x->rows, l3[s]->BT, r, C, nullptr, dt3->p + s * r, 3 * r, nullptr, 0));
+          E.flops += 3 * 2.0 * x->rows * r * (2.0 * C);
+          if (!E.R.dry()) {
+            for (int s = 0; s < 3; ++s) {
+              RET_IF(launch_wgrad_tn(y->g + s * C, 3 * C, t3->p + s * r, 3 * r, x->rows, C, r, l3[s]->B_grad, r, E.st));
+              RET_IF(launch_wgrad_tn(dt3->p + s * r, 3 * r, x->p, x->cols, x->rows, r, C, l3[s]->A_grad, C, E.st));
+            }
+          }
+          RET_IF(E.gemm_rows(dt3->p, 3 * r, x->rows, b.AT3, C, 3 * r, nullptr, dx, x->cols, dx, x->cols));
         }
         return 0;
       });
@@ -826,13 +965,13 @@ struct Exec {
     float* lse = R.save ? (float*)R.arena.alloc((size_t)Bn * H * Sq * 4) : nullptr;
     if (!o || !VT || (R.save && !lse)) return nullptr;
     AttnArgs a{};
-    a.Q = q->p; a.ldq = q->cols; a.K = k->p; a.ldk = k->cols; a.V = v->p; a.ldv = v->cols; a.VT = VT;
+    a.Q = q->p; a.ldq = q->ld(); a.K = k->p; a.ldk = k->ld(); a.V = v->p; a.ldv = v->ld(); a.VT = VT;
     a.lse = lse; a.out = o->p; a.ldout = o->cols; a.vt_ones = 1;
     a.B = Bn; a.H = H; a.Sq = Sq; a.Skv = Skv; a.d = d; a.scale = 1.f / sqrtf((float)d);
     flops += 4.0 * Bn * H * (double)Sq * Skv * d;
     if (!vt_ready) U->hbm[HBM_TRANSPOSE_HEADS] += 4.0 * Bn * Skv * H * d;
     if (!R.dry()) {
-      if (!vt_ready) NULL_IF(launch_transpose_heads(v->p, v->cols, VT, Bn, H, Skv, d, st, 1));
+      if (!vt_ready) NULL_IF(launch_transpose_heads(v->p, v->ld(), VT, Bn, H, Skv, d, st, 1));
       NULL_IF(launch_attn_fwd(a, st));
     }
     if (R.save) {
@@ -847,17 +986,18 @@ struct Exec {
         E.flops += 2.0 * 4.0 * Bn * H * (double)Sq * Skv * d;  // algorithmic: 2x forward
         E.U->hbm[HBM_TRANSPOSE_HEADS] += 4.0 * Bn * H * d * (2.0 * Sq + Skv);
         if (!E.R.dry()) {
-          RET_IF(launch_transpose_heads(q->p, q->cols, QT, Bn, H, Sq, d, E.st));
+          RET_IF(launch_transpose_heads(q->p, q->ld(), QT, Bn, H, Sq, d, E.st));
           RET_IF(launch_transpose_heads(o->g, o->cols, dOT, Bn, H, Sq, d, E.st));
-          RET_IF(launch_transpose_heads(k->p, k->cols, KT, Bn, H, Skv, d, E.st));
+          RET_IF(launch_transpose_heads(k->p, k->ld(), KT, Bn, H, Skv, d, E.st));
           RET_IF(launch_attn_delta(o->p, o->cols, o->g, o->cols, delta, Bn, H, Sq, d, E.st));
           AttnArgs b = a;
           b.dO = o->g; b.lddo = o->cols; b.QT = QT; b.KT = KT; b.dOT = dOT; b.delta = delta;
-          b.out = dq; b.ldout = q->cols; b.dK = dk; b.lddk = k->cols; b.dV = dv; b.lddv = v->cols;
+          b.out = dq; b.ldout = q->ld(); b.dK = dk; b.lddk = k->ld(); b.dV = dv; b.lddv = v->ld();
           RET_IF(launch_attn_bwd_dq(b, E.st));
           RET_IF(launch_attn_bwd_dkv(b, E.st));
         }
         q->ginit = k->ginit = v->ginit = true;
+        if (q->parent) q->parent->ginit = true;   // (the three slices of a fused projection are written together)
         return 0;
       });
     }
@@ -982,7 +1122,14 @@ struct Exec {
       TBlockW& b = *bp;
       T* n = layernorm(h, b.ln1);
       if (!n) return nullptr;
-      T *q = linear(n, b.a1.q), *k = linear(n, b.a1.k), *v = linear(n, b.a1.v);
+      T *q, *k, *v;
+      if (qkv_fusable(U, b) && (R.dry() || b.qkv.w)) {
+        T* qkv = linear_qkv(n, b, t.C);
+        if (!qkv) return nullptr;
+        q = R.view(qkv, 0, t.C); k = R.view(qkv, t.C, t.C); v = R.view(qkv, 2 * t.C, t.C);
+      } else {
+        q = linear(n, b.a1.q); k = linear(n, b.a1.k); v = linear(n, b.a1.v);
+      }
       if (!q || !k || !v) return nullptr;
       T* o = attention(q, k, v, Bn, t.heads, S, S);
       if (!o) return nullptr;
@@ -1072,6 +1219,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   R.save = (flags & FDMI_UNET_SAVE) != 0;
   const bool inter = (flags & FDMI_UNET_INTERMEDIATE) != 0;
   hipStream_t st = R.st;
+  if (!R.dry() && U->fused_dirty) RET_IF(build_fused_operands(U, st));
   if (!U->loras.empty()) RET_IF(E.lora_refresh());
   {  // accumulator pool: every GroupNorm of the plan, forward + backward, 2 * B * groups floats each
     const size_t per = (((size_t)B * c.groups * 2 * sizeof(float)) + 255) & ~(size_t)255;

@@ -84,14 +84,14 @@ def test_gemm_planner_choices_for_the_benchmark_shapes():
     assert sk == 16 and k == 0
 
 
-def test_planner_offers_the_256x192_tile_only_behind_its_knob():
+def test_planner_offers_the_256x192_tile_for_the_transformer_widths():
     from flash_diffusion_amd import _lib
     L = _lib.lib()
-    assert _plan(32768, 1152, 1152)[:3] == (1, 256, 128)
-    L.fdmi_tune_set(12, 1)
+    assert _plan(32768, 1152, 1152)[:3] == (2, 256, 192) and _plan(16384, 6144, 1536)[:3] == (2, 256, 192)
+    assert _plan(65536, 320, 320)[:3] == (2, 256, 320)            # widths that 320 divides keep the larger tile
+    L.fdmi_tune_set(12, 1)                                        # A/B switch: the planner without the tile
     try:
-        assert _plan(32768, 1152, 1152)[:3] == (2, 256, 192) and _plan(16384, 6144, 1536)[:3] == (2, 256, 192)
-        assert _plan(65536, 320, 320)[:3] == (2, 256, 320)            # widths that 320 divides keep the larger tile
+        assert _plan(32768, 1152, 1152)[:3] == (1, 256, 128)
     finally:
         L.fdmi_tune_set(12, 0)
 
