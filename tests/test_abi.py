@@ -71,14 +71,14 @@ def _plan(M, N, K, splitk=1, **kw):
 
 
 def test_gemm_planner_choices_for_the_benchmark_shapes():
-    """host-only planner query (fdmi_gemm_plan): the 256x320 LDS-DMA kernel takes the C2 linears whose N divides by 320, the
-    256-row ring kernel every large DiT / MMDiT linear (N = 1152 / 1536 / 4608 / 6144 divide by 128, not by 320), the small
+    """host-only planner query (fdmi_gemm_plan): the 256x320 LDS-DMA kernel takes the C2 linears whose N divides by 320, its
+    256x192 variant every large DiT / MMDiT linear (N = 1152 / 1536 / 4608 / 6144 divide by 192, not by 320), the small
     tiles the per-sample-vector GEMMs; LoRA weight gradients (long contraction, tiny output) are split 16 ways"""
     assert _plan(65536, 320, 320)[:3] == (2, 256, 320) and _plan(65536, 2560, 320)[:3] == (2, 256, 320)   # SD1.5 level 0
     assert _plan(16384, 640, 640)[0] == 1 and _plan(4096, 1280, 1280)[0] == 1
     for shape in [(32768, 1152, 1152), (65536, 1152, 1152), (32768, 4608, 1152), (32768, 1152, 4608),     # PixArt C4
                   (16384, 1536, 1536), (16384, 6144, 1536), (16384, 1536, 6144)]:                         # SD3 C5
-        assert _plan(*shape)[:3] == (1, 256, 128), shape
+        assert _plan(*shape)[:3] == (2, 256, 192), shape
     assert _plan(8, 6912, 1152)[0] == 0 and _plan(32768, 32, 1152)[0] == 0
     k, bm, bn, sk = _plan(1152, 64, 32768, splitk=0, accum_atomic=1, out_f32=1)
     assert sk == 16 and k == 0
