@@ -22,7 +22,10 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   const fdmi_f2 v = {lo, hi};
   return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, fdmi_b2));
 }
-__device__ __forceinline__ float silu_f(float x) { return x / (1.f + __expf(-x)); }
+// (v_rcp_f32, 1 ulp: the IEEE-exact `/` and __frcp_rn expand to a ~10-instruction v_div_scale / v_div_fmas / v_div_fixup
+// sequence per element, which made the GEGLU epilogue as long as its main loop at K = 320)
+__device__ __forceinline__ float rcp_fast(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float silu_f(float x) { return x * rcp_fast(1.f + __expf(-x)); }
 __device__ __forceinline__ float dsilu_f(float x) {
   float s = 1.f / (1.f + __expf(-x));
   return s * (1.f + x * (1.f - s));
@@ -31,7 +34,7 @@ __device__ __forceinline__ float dsilu_f(float x) {
 // one rcp and five fmas instead of the ~40-instruction branchy libm erff in the GEGLU epilogues.
 __device__ __forceinline__ float erf_fast(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(1.f + 0.3275911f * ax);
+  const float t = rcp_fast(1.f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
   const float r = 1.f - poly * __expf(-ax * ax);
   return copysignf(r, x);

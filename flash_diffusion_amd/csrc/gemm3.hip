@@ -220,7 +220,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  auto epilogue = [&](const Item& it) { tile_epilogue<NF, MF, 2, GN>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j); };
+  auto epilogue = [&](const Item& it) { tile_epilogue<NF, MF, 2, GN, false, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j); };
 
   // ---- flattened 3-stage ring across items: counted vmcnt, one raw barrier per K tile ----
   int inflight = 0;

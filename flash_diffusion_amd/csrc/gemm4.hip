@@ -248,7 +248,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       cslot ^= 1;
     }
     // the next item's first tile is landing meanwhile
-    tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+    tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN, true, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);   // (whole tiles only)
   }
   wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
 }
@@ -291,6 +291,7 @@ bool gemm4_eligible(const GemmArgs& a, int BN) {
   return true;
 }
 int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
+  FDMI_CHECK((a.M & 255) == 0 && (a.N % BN) == 0 && (a.K & 63) == 0, "gemm4: whole 256 x BN x 64 tiles only (its epilogue has no bounds checks)");
   if (BN == 192) {
     FDMI_CHECK(a.act != ACT_GEGLU, "gemm4: the 256 x 192 tile has no GEGLU epilogue");
     return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 192>(a, stream) : launch4_t<GEMM_CONV, false, 192>(a, stream);

@@ -103,12 +103,17 @@ __device__ __forceinline__ void epi_terms8(const GemmArgs& a, int64_t m, int n, 
     for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
   }
 }
+// activation + store of 8 consecutive columns (the residual, if any, already added)
+__device__ __forceinline__ void epi_finish8(const GemmArgs& a, int act, int64_t m, int nout, float v[8]);
 __device__ __forceinline__ void epi_store8(const GemmArgs& a, int act, int64_t m, int nout, float v[8]) {
   if (a.residual) {
     const u16x8 t = *(const u16x8*)(a.residual + m * a.ldr + nout);
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] += bf2f(t[r]);
   }
+  epi_finish8(a, act, m, nout, v);
+}
+__device__ __forceinline__ void epi_finish8(const GemmArgs& a, int act, int64_t m, int nout, float v[8]) {
   if (act == ACT_SILU) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
@@ -178,7 +183,10 @@ __device__ __forceinline__ void wait_vmcnt() {
 // epilogue of one wave: rows mw + mf*16 + j, columns nw + nf*16 + g*4 .. +3; z = split-K slab index
 // EPI selects the compiled paths: 0 = everything but GEGLU, 1 = GEGLU only, 2 = all
 // GN: also accumulate the consumer's GroupNorm statistics (full tiles, `wide` layout, no split-K: gemm_gn_ok)
-template <int NF, int MF, int EPI = 2, bool GN = false>
+// FULL: the caller guarantees whole tiles (M % 256 == 0, N % BN == 0: gemm4's eligibility) -- no per-lane bounds checks
+// PF: fetch the residual one column pair ahead of its use (16 more live registers: the row-GEMM kernels have them in their
+// epilogue, the conv kernels -- whose gather state stays live across items -- do not, and their long K loops need it least)
+template <int NF, int MF, int EPI = 2, bool GN = false, bool FULL = false, bool PF = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw, int z, f32x4 (&acc)[NF][MF], int g, int j) {
   if (EPI != 1 && a.accum_atomic) {
 #pragma unroll
@@ -228,6 +236,16 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
 #pragma unroll
       for (int t = 0; t < NQUAD; ++t) {
         // pair value fragments (4t, 4t+2) and gate fragments (4t+1, 4t+3): even lane groups get pair 2t, odd 2t+1
+        const int q = g & 1;
+        const int n = nw + t * 64 + q * 32 + (g >> 1) * 8;  // value cols n..n+7, gate cols n+16..n+23
+        const bool nok = FULL || n < a.N;
+        float bv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, bg[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (a.bias && nok) {   // the bias of this column group: once, not once per row fragment
+          const float4 v0 = *(const float4*)(a.bias + n), v1 = *(const float4*)(a.bias + n + 4);
+          const float4 g0 = *(const float4*)(a.bias + n + 16), g1 = *(const float4*)(a.bias + n + 20);
+          bv[0] = v0.x; bv[1] = v0.y; bv[2] = v0.z; bv[3] = v0.w; bv[4] = v1.x; bv[5] = v1.y; bv[6] = v1.z; bv[7] = v1.w;
+          bg[0] = g0.x; bg[1] = g0.y; bg[2] = g0.z; bg[3] = g0.w; bg[4] = g1.x; bg[5] = g1.y; bg[6] = g1.z; bg[7] = g1.w;
+        }
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf) {
 #pragma unroll
@@ -236,17 +254,24 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
             SWAP16(acc[4 * t + 1][mf][r], acc[4 * t + 3][mf][r]);
           }
           const int64_t m = mw + mf * 16 + j;
-          const int q = g & 1;
-          const int n = nw + t * 64 + q * 32 + (g >> 1) * 8;  // value cols n..n+7, gate cols n+16..n+23
-          if (m < a.M && n < a.N) {
+          if ((FULL || m < a.M) && nok) {
             float val[8], gate[8], o[8];
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               val[r] = acc[4 * t][mf][r]; val[4 + r] = acc[4 * t + 2][mf][r];
               gate[r] = acc[4 * t + 1][mf][r]; gate[4 + r] = acc[4 * t + 3][mf][r];
             }
-            epi_terms8(a, m, n, val);
-            epi_terms8(a, m, n + 16, gate);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              val[r] = fmaf(val[r], a.alpha, bv[r]);
+              gate[r] = fmaf(gate[r], a.alpha, bg[r]);
+            }
+            if (a.rowvec) {
+              const bf16_t* rvp = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
+              const u16x8 rv0 = *(const u16x8*)rvp, rv1 = *(const u16x8*)(rvp + 16);
+#pragma unroll
+              for (int r = 0; r < 8; ++r) { val[r] += bf2f(rv0[r]); gate[r] += bf2f(rv1[r]); }
+            }
             if (a.preact) {
               uint4 pk;
               pk.x = pack2bf(val[0], val[1]); pk.y = pack2bf(val[2], val[3]); pk.z = pack2bf(val[4], val[5]); pk.w = pack2bf(val[6], val[7]);
@@ -296,6 +321,15 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
     if (wide) {   // (launch_gemm only picks a GN instantiation when gemm_gn_ok: gn_stats set, wide operands)
       // column-pair outer, row fragment inner: the per-lane partial sums of a column chunk run over the wave's 16 * MF rows
       // (all of one sample: gn_rows % 256 == 0) before ONE cross-lane reduction per chunk
+      // row kernels: the residual one column pair ahead (see the plain path below) -- where the registers allow it: with
+      // the statistics' partial sums live, the 40-fragment accumulator of the 256 x 320 tile leaves no room
+      const bool pf = PF && NF * MF <= 24 && a.residual != nullptr;
+      u16x8 rnext[MF];
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        rnext[mf] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+        if (pf) rnext[mf] = *(const u16x8*)(a.residual + (int64_t)(mw + mf * 16 + j) * a.ldr + nw + (g & 1) * 16 + (g >> 1) * 8);
+      }
 #pragma unroll
       for (int pr = 0; pr < NF / 2; ++pr) {
         const int nf = 2 * pr;
@@ -307,6 +341,8 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
           const int64_t m = mw + mf * 16 + j;
 #pragma unroll
           for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
+          const u16x8 rcur = rnext[mf];
+          if (pf && pr + 1 < NF / 2) rnext[mf] = *(const u16x8*)(a.residual + m * a.ldr + n + 32);   // (full tiles: gemm_gn_ok)
           if (m < a.M && n < a.N) {
             float v[8];
 #pragma unroll
@@ -315,7 +351,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
               v[4 + r] = acc[nf + 1][mf][r];
             }
             epi_terms8(a, m, n, v);
-            epi_store8(a, a.act, m, n, v);   // leaves the stored (pre-rounding) values in v
+            if (pf) {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += bf2f(rcur[r]);
+              epi_finish8(a, a.act, m, n, v);
+            } else {
+              epi_store8(a, a.act, m, n, v);   // leaves the stored (pre-rounding) values in v
+            }
             gn_lane_add<8>(v, split, s);
           }
         }
@@ -342,7 +384,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
       return;
     }
   }
-  if (!GN && wide) {
+  if (!GN && !PF && wide) {   // the register-lean order (conv kernels): row fragment outer, everything fetched at its use
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
       const int64_t m = mw + mf * 16 + j;
@@ -352,7 +394,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
 #pragma unroll
         for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
         const int n = nw + (nf + (g & 1)) * 16 + (g >> 1) * 8;
-        if (m < a.M && n < a.N) {
+        if (FULL || (m < a.M && n < a.N)) {
           float v[8];
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -365,6 +407,93 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
       }
       if constexpr ((NF & 1) != 0) {
         const int n = nw + (NF - 1) * 16 + g * 4;
+        if (m < a.M && n < a.N) {
+          float v[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = acc[NF - 1][mf][r];
+          epi_terms3(a, m, n, v);
+          epi_store3(a, a.act, m, n, a.N, v);
+        }
+      }
+    }
+    return;
+  }
+  if (!GN && wide) {
+    // column pair outer, row fragment inner: the bias of a column group is loaded once, and the residual tile -- the one
+    // operand of this epilogue that comes from HBM -- is fetched one column pair (MF 16-byte loads per lane) AHEAD of its use,
+    // so its latency hides behind the previous pair's arithmetic and stores instead of stalling every fragment
+    constexpr int NP = NF / 2;
+    const bool has_res = a.residual != nullptr;
+    auto ncol = [&](int pr) { return nw + (2 * pr + (g & 1)) * 16 + (g >> 1) * 8; };
+    u16x8 rnext[MF];
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) rnext[mf] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (has_res && NP > 0) {
+      const int n0 = ncol(0);
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = mw + mf * 16 + j;
+        if ((FULL || m < a.M) && (FULL || n0 < a.N)) rnext[mf] = *(const u16x8*)(a.residual + m * a.ldr + n0);
+      }
+    }
+#pragma unroll
+    for (int pr = 0; pr < NP; ++pr) {
+      const int nf = 2 * pr;
+      const int n = ncol(pr);
+      const bool nok = FULL || n < a.N;
+      float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (a.bias && nok) {
+        const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+        b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
+      }
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = mw + mf * 16 + j;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
+        const bool ok = (FULL || m < a.M) && nok;
+        const u16x8 rcur = rnext[mf];
+        if (has_res && pr + 1 < NP) {   // this row's residual chunk of the NEXT column pair
+          const int n1 = ncol(pr + 1);
+          if ((FULL || m < a.M) && (FULL || n1 < a.N)) rnext[mf] = *(const u16x8*)(a.residual + m * a.ldr + n1);
+        }
+        if (ok) {
+          float v[8];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            v[r] = fmaf(acc[nf][mf][r], a.alpha, b8[r]);
+            v[4 + r] = fmaf(acc[nf + 1][mf][r], a.alpha, b8[4 + r]);
+          }
+          if (a.rowvec) {
+            const u16x8 rv = *(const u16x8*)(a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
+          }
+          if (has_res) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] += bf2f(rcur[r]);
+          }
+          if (a.act == ACT_SILU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+          }
+          if (a.out_f32) {
+            float* c = (float*)a.C + m * a.ldc + n;
+            *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+            *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+          } else {
+            uint4 pk;
+            pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+            *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
+          }
+        }
+      }
+    }
+    if constexpr ((NF & 1) != 0) {
+      const int n = nw + (NF - 1) * 16 + g * 4;
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = mw + mf * 16 + j;
         if (m < a.M && n < a.N) {
           float v[4];
 #pragma unroll
