@@ -19,14 +19,10 @@ sys.path.insert(0, ROOT)
 
 VARIANTS = {
     "base": ({}, {}),
-    "k14": ({14: 1}, {}),
-    "k15": ({15: 1}, {}),
-    "k16": ({16: 1}, {}),
-    "k14_15_16": ({14: 1, 15: 1, 16: 1}, {}),
-    "tloop": ({}, {"FDMI_TEACHER_LOOP": "1"}),
-    "dedup": ({}, {"FDMI_CFG_DEDUP": "1"}),
-    "tloop_dedup": ({13: 1}, {"FDMI_TEACHER_LOOP": "1"}),
-    "all": ({13: 1, 14: 1, 15: 1, 16: 1}, {"FDMI_TEACHER_LOOP": "1"}),
+    "unfused_qkv": ({17: 1}, {}),
+    "no_gn_epilogue": ({14: 1}, {}),
+    "no_dedup": ({13: 1}, {"FDMI_CFG_DEDUP": "0"}),
+    "no_tloop": ({}, {"FDMI_TEACHER_LOOP": "0"}),
 }
 
 
@@ -34,7 +30,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--variants", default=",".join(VARIANTS))
+    ap.add_argument("--variants", default="base,unfused_qkv")
     ap.add_argument("--legs", action="store_true")
     ap.add_argument("--extra", default="", help="extra variants: name:knob=val+knob=val;...")
     args = ap.parse_args()
