@@ -127,6 +127,7 @@ _SIGS = {
     "fdmi_batch_colsum_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, vp]),
     "fdmi_im2col_f32": (i32, [vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
     "fdmi_colsum_f32": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, vp]),
+    "fdmi_timestep_embed_f32": (i32, [vp, vp, i32, i32, i32, f32, vp]),
     "fdmi_pad_cols_f32": (i32, [vp, i32, vp, i32, i64, vp]),
 }
 # extended lazily by unet.py for the plan API

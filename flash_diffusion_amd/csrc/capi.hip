@@ -348,6 +348,9 @@ int fdmi_colsum_f32(const float* dy, const float* x, const float* stats, float* 
                     void* stream) {
   return launch_colsum32(dy, x, stats, out0, out1, rows, C, HW, G, (hipStream_t)stream);
 }
+int fdmi_timestep_embed_f32(const float* t, float* out, int B, int dim, int flip, float shift, void* stream) {
+  return launch_timestep_embed32(t, out, B, dim, flip, shift, (hipStream_t)stream);
+}
 int fdmi_pad_cols_f32(const float* src, int cols, float* dst, int cols_pad, int64_t rows, void* stream) {
   return launch_pad_cols32(src, cols, dst, cols_pad, rows, (hipStream_t)stream);
 }

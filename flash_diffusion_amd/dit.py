@@ -26,6 +26,9 @@ import torch.nn as nn
 from . import ops
 
 BF16 = torch.bfloat16
+F32 = torch.float32
+# precision: every activation tensor of a model is of ONE dtype -- bf16 (the measured MFMA path) or fp32 (the validation
+# kernels of csrc/ref32.hip, `precision="fp32"`: the parity gate against the fp32 oracle).  ops.py dispatches on it.
 PIXART_LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0", "proj_in", "proj_out", "ff.net.0.proj", "ff.net.2", "proj",
                        "linear", "linear_1", "linear_2")      # examples/train_flash_pixart.py:240-253
 
@@ -40,13 +43,13 @@ class _LinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, residual, lin, out_f32, need_bwd, A, B):
-        wb, wtb = lin.base16()
+        wb, wtb = lin.base16(x.dtype)
         M = x.shape[0]
         t = None
         if A is None:
             y = ops.gemm(x, wb, bias=lin.bias, residual=residual, out_f32=out_f32)
         else:
-            ab, _, bb, _ = lin.lora16()
+            ab, _, bb, _ = lin.lora16(x.dtype)
             t = ops.gemm(x, ab)
             y0 = ops.gemm(x, wb, bias=lin.bias, residual=residual)
             y = ops.gemm(t, bb, residual=y0, out_f32=out_f32)
@@ -63,14 +66,14 @@ class _LinearFn(torch.autograd.Function):
         lin = ctx.lin
         x, t = ctx.saved_tensors
         dy = dy.contiguous()
-        if ctx.out_f32:
+        if ctx.out_f32 and x.dtype == BF16:
             dy = ops.f32_to_bf16(dy)
         M = x.shape[0]
         dx = dA = dB = None
-        _, wtb = lin.base16()
+        _, wtb = lin.base16(x.dtype)
         flops = 0.0
         if ctx.lora:
-            _, abt, _, bbt = lin.lora16()
+            _, abt, _, bbt = lin.lora16(x.dtype)
             u = ops.gemm(dy, bbt)                                       # dL/d(A x)            [M, r]
             gv = lin._gviews           # views into the model's flat LoRA gradient (set by _reflatten_lora) or None
             # weight gradients by the TN kernel on the row-major operands (wgrad.hip): no transposed copies
@@ -95,7 +98,7 @@ class _LinearFn(torch.autograd.Function):
             dx = ops.gemm(dy, wtb)
             flops += 2.0 * M * lin.out_features * lin.in_features
             if ctx.lora:
-                _, abt, _, _ = lin.lora16()
+                _, abt, _, _ = lin.lora16(dy.dtype)
                 dx = ops.gemm(u, abt, residual=dx)
                 flops += 2.0 * M * lin.rank * lin.in_features
         lin.count(flops)
@@ -122,7 +125,7 @@ class _LnModFn(torch.autograd.Function):
         dshift = dscale = None
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
             dscale, dshift = ops.batch_colsum(dy, x, stats, rows_per_batch=ctx.rpb)
-            dscale, dshift = dscale.to(BF16), dshift.to(BF16)
+            dscale, dshift = dscale.to(x.dtype), dshift.to(x.dtype)
         return dx, dshift, dscale, None, None, None
 
 
@@ -143,7 +146,7 @@ class _GateResFn(torch.autograd.Function):
         dx = ops.gate_residual(dy, gate, None, ctx.rpb) if ctx.needs_input_grad[0] else None
         dgate = None
         if ctx.needs_input_grad[1]:
-            dgate = ops.batch_colsum(dy, x, None, rows_per_batch=ctx.rpb, want_sum=False)[0].to(BF16)
+            dgate = ops.batch_colsum(dy, x, None, rows_per_batch=ctx.rpb, want_sum=False)[0].to(x.dtype)
         return dx, dgate, (dy if ctx.needs_input_grad[2] else None), None, None
 
 
@@ -236,22 +239,30 @@ class MiLinear(nn.Module):
         if self._owner[0] is not None:
             self._owner[0].count(flops)
 
-    def base16(self):
+    @staticmethod
+    def _pair(w2d, dtype):
+        """(W, W^T) GEMM operands: bf16 copies by the cast + transpose kernel; in fp32 validation mode the master itself and
+        a transposed copy (pure data movement)"""
+        if dtype == F32:
+            return w2d.contiguous(), w2d.t().contiguous()
+        return tuple(ops.cast_transpose(w2d))
+
+    def base16(self, dtype=BF16):
         w = self.weight
-        key = (w.data_ptr(), w._version)
+        key = (w.data_ptr(), w._version, dtype)
         if self._b16 is None or self._b16[0] != key:
             assert ops._dev(w).dtype == torch.float32, "parameters must be fp32 on the GPU"
-            self._b16 = (key,) + tuple(ops.cast_transpose(w.detach().reshape(self.out_features, self.in_features)))
+            self._b16 = (key,) + self._pair(w.detach().reshape(self.out_features, self.in_features), dtype)
         return self._b16[1], self._b16[2]
 
-    def lora16(self):
-        """bf16 (A, A^T, B, B^T); re-cast once per model forward (in-place optimizer kernels do not bump ._version)"""
+    def lora16(self, dtype=BF16):
+        """(A, A^T, B, B^T) operands; re-made once per model forward (in-place optimizer kernels do not bump ._version)"""
         epoch = self._owner[0]._lora_epoch if self._owner[0] is not None else -1
         A, B = self.lora_A.default.weight, self.lora_B.default.weight
-        key = (epoch, A.data_ptr(), B.data_ptr(), A._version, B._version)
+        key = (epoch, A.data_ptr(), B.data_ptr(), A._version, B._version, dtype)
         if self._l16 is None or self._l16[0] != key:
-            ab, abt = ops.cast_transpose(A.detach().reshape(self.rank, self.in_features))
-            bb, bbt = ops.cast_transpose(B.detach().reshape(self.out_features, self.rank))
+            ab, abt = self._pair(A.detach().reshape(self.rank, self.in_features), dtype)
+            bb, bbt = self._pair(B.detach().reshape(self.out_features, self.rank), dtype)
             self._l16 = (key, ab, abt, bb, bbt)
         return self._l16[1:]
 
@@ -266,7 +277,7 @@ class MiLinear(nn.Module):
         self.rank = r
 
     def forward(self, x, residual=None, out_f32=False):
-        assert x.dtype == BF16 and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == self.in_features
+        assert x.dtype in (BF16, F32) and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == self.in_features
         need_bwd = torch.is_grad_enabled() and (x.requires_grad or self.rank > 0
                                                 or (residual is not None and residual.requires_grad))
         A = self.lora_A.default.weight if self.rank else None
@@ -455,8 +466,10 @@ class MiTransformer2DModel(_DenoiserBase):
                  attention_head_dim=88, in_channels=None, out_channels=None, num_layers=1, cross_attention_dim=None,
                  attention_bias=False, sample_size=None, patch_size=None, activation_fn="geglu", num_embeds_ada_norm=None,
                  norm_type="layer_norm", norm_elementwise_affine=True, norm_eps=1e-5, caption_channels=None,
-                 interpolation_scale=None, **unused):
+                 interpolation_scale=None, precision="bf16", **unused):
         super().__init__()
+        assert precision in ("bf16", "fp32")
+        self.dt = F32 if precision == "fp32" else BF16
         if not (patch_size is not None and norm_type == "ada_norm_single" and activation_fn == "gelu-approximate"
                 and not norm_elementwise_affine):
             raise NotImplementedError("only the PixArt-alpha configuration (patched input, ada_norm_single, gelu-approximate, "
@@ -510,7 +523,7 @@ class MiTransformer2DModel(_DenoiserBase):
             c = self.config_dict
             base = c["sample_size"] // c["patch_size"]
             pe = sincos_pos_embed(c["inner_dim"], h, w, base, c["interpolation_scale"])
-            pe = torch.from_numpy(pe).float().to(device).to(BF16)
+            pe = torch.from_numpy(pe).float().to(device).to(self.dt)
             self._pos_cache[key] = pe.unsqueeze(0).expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
         return self._pos_cache[key]
 
@@ -562,9 +575,9 @@ class MiTransformer2DModel(_DenoiserBase):
         if not torch.is_tensor(timestep):
             timestep = torch.full((B,), float(timestep), device=dev)
         ada = self.adaln_single
-        emb = ada.timestep_embedder(ops.timestep_embed(timestep.reshape(-1).to(dev), c["tdim"], True, 0.0))
+        emb = ada.timestep_embedder(ops.timestep_embed(timestep.reshape(-1).to(dev), c["tdim"], True, 0.0, self.dt))
         if self.vdim is not None:
-            vb = vector.to(BF16)
+            vb = vector.to(self.dt)
             if isinstance(ada.add_embedding, nn.ModuleList):
                 chunks = torch.chunk(vb, self.n_vec, dim=1)
                 emb = emb + torch.cat([ada.add_embedding[i](chunks[i].contiguous())
@@ -575,11 +588,11 @@ class MiTransformer2DModel(_DenoiserBase):
 
         # patch embedding: fold p x p patches (c, py, px order = the convolution weight's), one GEMM + positions
         patches = sample.float().reshape(B, c["in_channels"], h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T, -1)
-        hid = self.pos_embed.proj(patches.to(BF16).contiguous(), residual=self._pos(h, w, B, dev))
+        hid = self.pos_embed.proj(patches.to(self.dt).contiguous(), residual=self._pos(h, w, B, dev))
 
         # caption projection
         L = crossattn.shape[1]
-        ctx = crossattn.to(BF16).reshape(B * L, -1).contiguous()
+        ctx = crossattn.to(self.dt).reshape(B * L, -1).contiguous()
         if self.caption_projection is not None:
             t1 = self.caption_projection.linear_1(ctx)
             ctx = self.caption_projection.linear_2(_GeluTanhFn.apply(t1, grad and t1.requires_grad))
@@ -587,7 +600,7 @@ class MiTransformer2DModel(_DenoiserBase):
 
         eps = c["norm_eps"]
         for blk in self.transformer_blocks:
-            mod = (blk.scale_shift_table[None] + mod6).to(BF16)        # shift_msa, scale_msa, gate_msa, shift_mlp, ...
+            mod = (blk.scale_shift_table[None] + mod6).to(self.dt)     # shift_msa, scale_msa, gate_msa, shift_mlp, ...
             nb = grad and (hid.requires_grad or mod.requires_grad)
             n1 = _LnModFn.apply(hid, mod[:, 0], mod[:, 1], T, eps, nb)
             a1 = self._attn(blk.attn1, n1, n1, B, T, T, None)
@@ -599,7 +612,7 @@ class MiTransformer2DModel(_DenoiserBase):
             f = blk.ff.net[2](_GeluTanhFn.apply(f, grad and f.requires_grad))
             hid = _GateResFn.apply(f, mod[:, 5], hid, T, grad and (f.requires_grad or mod.requires_grad or hid.requires_grad))
 
-        fin = (self.scale_shift_table[None] + emb.float()[:, None]).to(BF16)                       # shift, scale
+        fin = (self.scale_shift_table[None] + emb.float()[:, None]).to(self.dt)                    # shift, scale
         n = _LnModFn.apply(hid, fin[:, 0], fin[:, 1], T, 1e-6, grad and (hid.requires_grad or fin.requires_grad))
         y = self.proj_out(n, out_f32=True)                                                       # [B*T, p*p*out]
         oc = c["out_channels"]
@@ -666,8 +679,10 @@ class MiSD3Transformer2DModel(_DenoiserBase):
 
     def __init__(self, sample_size=128, patch_size=2, in_channels=16, num_layers=18, attention_head_dim=64,
                  num_attention_heads=18, joint_attention_dim=4096, caption_projection_dim=1152, pooled_projection_dim=2048,
-                 out_channels=16, pos_embed_max_size=96, **unused):
+                 out_channels=16, pos_embed_max_size=96, precision="bf16", **unused):
         super().__init__()
+        assert precision in ("bf16", "fp32")
+        self.dt = F32 if precision == "fp32" else BF16
         for k, v in unused.items():
             if v not in (None, False, 0, 0.0, "default"):
                 raise NotImplementedError(f"{k}={v!r} is outside the reference's configurations")
@@ -703,7 +718,7 @@ class MiSD3Transformer2DModel(_DenoiserBase):
             assert h <= m and w <= m, "input larger than pos_embed_max_size"
             top, left = (m - h) // 2, (m - w) // 2
             pe = buf.reshape(1, m, m, -1)[:, top:top + h, left:left + w, :].reshape(1, h * w, -1)
-            self._pos_cache[key] = pe.to(device).to(BF16).expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
+            self._pos_cache[key] = pe.to(device).to(self.dt).expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
         return self._pos_cache[key]
 
     def _ff(self, ff: _FF, n, grad):
@@ -737,13 +752,13 @@ class MiSD3Transformer2DModel(_DenoiserBase):
         if not torch.is_tensor(timestep):
             timestep = torch.full((B,), float(timestep), device=dev)
         tte = self.time_text_embed
-        temb = tte.timestep_embedder(ops.timestep_embed(timestep.reshape(-1).to(dev), 256, True, 0.0)) \
-            + tte.text_embedder(vector.to(BF16).contiguous())
+        temb = tte.timestep_embedder(ops.timestep_embed(timestep.reshape(-1).to(dev), 256, True, 0.0, self.dt)) \
+            + tte.text_embedder(vector.to(self.dt).contiguous())
         st = _silu(temb)
 
         patches = sample.float().reshape(B, c["in_channels"], h, p, w, p).permute(0, 2, 4, 1, 3, 5).reshape(B * T, -1)
-        x = self.pos_embed.proj(patches.to(BF16).contiguous(), residual=self._pos(h, w, B, dev))
-        ctx = self.context_embedder(crossattn.to(BF16).reshape(B * L, -1).contiguous())
+        x = self.pos_embed.proj(patches.to(self.dt).contiguous(), residual=self._pos(h, w, B, dev))
+        ctx = self.context_embedder(crossattn.to(self.dt).reshape(B * L, -1).contiguous())
 
         def need(*ts):
             return grad and any(t.requires_grad for t in ts)

@@ -270,10 +270,10 @@ def nhwc_to_nchw(x, Cc):
     return y
 
 
-def timestep_embed(t, dim, flip=True, shift=0.0):
-    out = torch.empty(t.shape[0], dim, dtype=BF16, device=t.device)
-    check(lib().fdmi_timestep_embed(ptr(t.float().contiguous()), ptr(out), t.shape[0], dim, int(flip), shift,
-                                    stream_ptr()))
+def timestep_embed(t, dim, flip=True, shift=0.0, dtype=BF16):
+    out = torch.empty(t.shape[0], dim, dtype=dtype, device=t.device)
+    fn = lib().fdmi_timestep_embed_f32 if dtype == F32 else lib().fdmi_timestep_embed
+    check(fn(ptr(t.float().contiguous()), ptr(out), t.shape[0], dim, int(flip), shift, stream_ptr()))
     return out
 
 
@@ -315,6 +315,7 @@ def transpose2d_pad(x, rows_pad):
 
 
 def f32_to_bf16(x):
+    """fp32 -> the bf16 storage of the measured path"""
     y = torch.empty(x.shape, dtype=BF16, device=x.device)
     check(lib().fdmi_f32_to_bf16(ptr(x), ptr(y), x.numel(), stream_ptr()))
     return y
@@ -358,8 +359,9 @@ def pad_cols(x, cols_pad):
 
 # ---- adaLN-single DiT element-wise ops (csrc/dit.hip) --------------------------------------------------------------
 def _mod_ld(v, Cc):
-    """per-sample vector operand [B, C] bf16, possibly a column-slice view (e.g. mod[:, i] of a [B, n, C] table)"""
-    assert v.dtype == BF16 and v.dim() == 2 and v.shape[1] == Cc and v.stride(1) == 1
+    """per-sample vector operand [B, C] (bf16; fp32 in validation mode), possibly a column-slice view (e.g. mod[:, i] of a
+    [B, n, C] table)"""
+    assert v.dtype in (BF16, F32) and v.dim() == 2 and v.shape[1] == Cc and v.stride(1) == 1
     return v.stride(0)
 
 
@@ -370,6 +372,11 @@ def layernorm_mod_fwd(x, shift, scale, rows_per_batch, eps, need_stats=False):
     assert _mod_ld(shift, Cc) == ld
     y = torch.empty_like(x)
     stats = torch.empty(rows, 2, dtype=torch.float32, device=x.device) if need_stats else None
+    if _f32(x):
+        assert shift.dtype == F32 and scale.dtype == F32
+        check(lib().fdmi_layernorm_fwd_f32(ptr(x), None, None, ptr(shift), ptr(scale), ld, rows_per_batch, ptr(y), ptr(stats), rows,
+                                           Cc, eps, stream_ptr()))
+        return y, stats
     check(lib().fdmi_layernorm_mod_fwd(ptr(x), ptr(shift), ptr(scale), ld, rows_per_batch, ptr(y), ptr(stats), rows, Cc,
                                        eps, stream_ptr()))
     return y, stats
@@ -378,6 +385,10 @@ def layernorm_mod_fwd(x, shift, scale, rows_per_batch, eps, need_stats=False):
 def layernorm_mod_bwd(x, dy, scale, rows_per_batch, eps):
     rows, Cc = x.shape
     dx = torch.empty_like(x)
+    if _f32(x):
+        check(lib().fdmi_layernorm_bwd_f32(ptr(x), ptr(dy), None, ptr(scale), _mod_ld(scale, Cc), rows_per_batch, ptr(dx), rows, Cc,
+                                           eps, 0, stream_ptr()))
+        return dx
     check(lib().fdmi_layernorm_mod_bwd(ptr(x), ptr(dy), ptr(scale), _mod_ld(scale, Cc), rows_per_batch, ptr(dx), rows, Cc,
                                        eps, 0, stream_ptr()))
     return dx
@@ -387,6 +398,10 @@ def gate_residual(x, gate, res, rows_per_batch):
     """res + gate[b] * x (res None: gate[b] * x)"""
     rows, Cc = x.shape
     y = torch.empty_like(x)
+    if _f32(x):
+        check(lib().fdmi_gate_residual_f32(ptr(x), ptr(gate), _mod_ld(gate, Cc), ptr(res), ptr(y), rows, Cc, rows_per_batch,
+                                           stream_ptr()))
+        return y
     check(lib().fdmi_gate_residual(ptr(x), ptr(gate), _mod_ld(gate, Cc), ptr(res), ptr(y), rows, Cc, rows_per_batch,
                                    stream_ptr()))
     return y
@@ -394,13 +409,13 @@ def gate_residual(x, gate, res, rows_per_batch):
 
 def gelu_tanh(x):
     y = torch.empty_like(x)
-    check(lib().fdmi_gelu_tanh(ptr(x), ptr(y), x.numel(), stream_ptr()))
+    check((lib().fdmi_gelu_tanh_f32 if _f32(x) else lib().fdmi_gelu_tanh)(ptr(x), ptr(y), x.numel(), stream_ptr()))
     return y
 
 
 def gelu_tanh_bwd(x, dy):
     dx = torch.empty_like(x)
-    check(lib().fdmi_gelu_tanh_bwd(ptr(x), ptr(dy), ptr(dx), x.numel(), stream_ptr()))
+    check((lib().fdmi_gelu_tanh_bwd_f32 if _f32(x) else lib().fdmi_gelu_tanh_bwd)(ptr(x), ptr(dy), ptr(dx), x.numel(), stream_ptr()))
     return dx
 
 
@@ -411,7 +426,8 @@ def batch_colsum(dy, x=None, stats=None, *, rows_per_batch, want_mul=True, want_
     B = rows // rows_per_batch
     o0 = torch.empty(B, Cc, dtype=torch.float32, device=dy.device) if want_mul else None
     o1 = torch.empty(B, Cc, dtype=torch.float32, device=dy.device) if want_sum else None
-    check(lib().fdmi_batch_colsum(ptr(dy), ptr(x), ptr(stats), ptr(o0), ptr(o1), B, rows_per_batch, Cc, stream_ptr()))
+    fn = lib().fdmi_batch_colsum_f32 if _f32(dy) else lib().fdmi_batch_colsum
+    check(fn(ptr(dy), ptr(x), ptr(stats), ptr(o0), ptr(o1), B, rows_per_batch, Cc, stream_ptr()))
     return o0, o1
 
 

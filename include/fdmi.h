@@ -202,6 +202,7 @@ int fdmi_im2col_f32(const float* x, float* out, int B, int H, int W, int C, int 
                     void* stream);
 int fdmi_colsum_f32(const float* dy, const float* x, const float* stats, float* out0, float* out1, int64_t rows, int C, int HW, int G,
                     void* stream);
+int fdmi_timestep_embed_f32(const float* t, float* out, int B, int dim, int flip, float shift, void* stream);
 int fdmi_pad_cols_f32(const float* src, int cols, float* dst, int cols_pad, int64_t rows, void* stream);
 
 /* ---------------- UNet2DCondition plan: forward + input/LoRA-gradient backward -------------------

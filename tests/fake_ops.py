@@ -86,12 +86,12 @@ def silu_bwd(x, dy):
     return (dy.float() * (s * (1 + xf * (1 - s)))).to(BF16)
 
 
-def timestep_embed(t, dim, flip=True, shift=0.0):
+def timestep_embed(t, dim, flip=True, shift=0.0, dtype=BF16):
     half = dim // 2
     freq = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / (half - shift))
     arg = t.float()[:, None] * freq[None]
     sn, cs = torch.sin(arg), torch.cos(arg)
-    return (torch.cat([cs, sn], 1) if flip else torch.cat([sn, cs], 1)).to(BF16)
+    return (torch.cat([cs, sn], 1) if flip else torch.cat([sn, cs], 1)).to(dtype)
 
 
 def _heads(x, H):

@@ -318,3 +318,99 @@ def test_c1_full_size_step_at_1e3():
     log(f"step c1_sd15_full: {k} gradient tensors, worst |norm| rel {worst_n:.2e}, worst projection error / norm {worst_p:.2e}, "
         f"worst rel of the 4 tensors stored in full {full:.2e}")
     assert k >= 250 and worst_n <= 1e-2 and worst_p <= 1e-2 and full <= 1e-2, (k, worst_n, worst_p, full)
+
+
+# ---- the transformer denoisers in validation mode ------------------------------------------------------
+def _dit_product(cfg, ora, lora_r):
+    from flash_diffusion_amd.dit import MiSD3Transformer2DModel, MiTransformer2DModel
+    m = (MiSD3Transformer2DModel if "pos_embed_max_size" in cfg else MiTransformer2DModel)(**cfg, precision="fp32")
+    if lora_r:
+        m.add_adapter(lora_r)
+    m.load_state_dict({k.replace(".base_layer.", "."): v for k, v in ora.state_dict().items()})
+    return m.cuda()
+
+
+def _dit_cases():
+    from oracle.golden_cases import DIT_CASES, MMDIT_CASES
+    return list(DIT_CASES) + list(MMDIT_CASES)
+
+
+@pytest.mark.parametrize("name", _dit_cases())
+def test_transformer_denoiser_fp32_matches_reference_golden(name):
+    """PixArt DiT (adaLN-single, masked cross-attention) and SD3 MMDiT (joint attention) in fp32 validation mode against the
+    fixtures of the reference's REAL wrapper classes: frozen forward, LoRA forward, every LoRA gradient"""
+    from oracle.golden_cases import DIT_CASES, build_dit, build_mmdit
+    build = build_dit if name in DIT_CASES else build_mmdit
+    g = load_case(name)
+    cfg, ora, (x, t, cond), _ = build(name)
+    m = _dit_product(cfg, ora, 0)
+    m.freeze()
+    cc = {"cond": {k: v.cuda() for k, v in cond["cond"].items()}}
+    with torch.no_grad():
+        out = m(x.cuda(), t.cuda(), cc)
+    e0 = rel_err(out, g["out"]["frozen"])
+    cfg, ora, (x, t, cond), w = build(name, lora_r=8)
+    m = _dit_product(cfg, ora, 8)
+    out = m(x.cuda(), t.cuda(), cc)
+    e1 = rel_err(out, g["out"]["lora"])
+    (out * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    worst, n = 0.0, 0
+    for k, p in m.named_parameters():
+        if ".lora_" in k:
+            worst = max(worst, rel_err(p.grad, g["grads"][k]))
+            n += 1
+    log(f"denoiser {name} fp32: frozen {e0:.2e} lora {e1:.2e} worst of {n} LoRA grads {worst:.2e}")
+    assert e0 <= 1e-4 and e1 <= 1e-4 and n == len(g["grads"]) and worst <= 1e-3, (e0, e1, n, worst)
+
+
+def _sd3_cases():
+    from oracle.golden_cases import SD3_MMDIT_CASES
+    return list(SD3_MMDIT_CASES)
+
+
+@pytest.mark.parametrize("name", _sd3_cases())
+def test_sd3_step_over_the_mmdit_at_1e3(name):
+    """the flow-matching step (FlashDiffusionSD3: Euler teacher loop, DMD, lsgan GAN on the full-model backbone) with the MMDiT
+    and the PatchGAN head in fp32 validation mode, against the real FlashDiffusionSD3 over its real wrapper"""
+    from flash_diffusion_amd.dit import MiSD3Transformer2DModel
+    from flash_diffusion_amd.flash import Draws
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    from oracle.flash_sd3_ref import EmbeddingPipeline
+    from oracle.golden_cases import SD3_MMDIT_CASES, build_sd3_mmdit_inputs
+    kw, case, step, _ = SD3_MMDIT_CASES[name]
+    g = load_case(name)
+    cfg, t_o, s_o, head, pipe, batch = build_sd3_mmdit_inputs(case)
+    teacher = _dit_product(cfg, t_o, 0)
+    teacher.freeze()
+    student = _dit_product(cfg, s_o, 8)
+    pipe = EmbeddingPipeline(pipe.e[0].cuda(), pipe.e[2].cuda(), pipe.e[1].cuda(), pipe.e[3].cuda())
+    disc = copy.deepcopy(head).cuda()
+    m = FlashDiffusionSD3(FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), discriminator=disc, pipeline=pipe)
+    m.discriminator.precision = "fp32"
+    m.draws = Draws(g["draws"])
+    out = m({"image": batch["image"].cuda(), "text": batch["text"]}, step=step)
+    assert abs(out["start_timestep"] - g["start_timestep"]) < 1e-3
+    errs = {k: rel_err(out[k], g["out"][k]) for k in ("teacher_output", "student_output", "noisy_sample")}
+    lerr = []
+    for i in (0, 1):
+        ref, got = g["loss"][i], float(out["loss"][i])
+        lerr.append(abs(got - ref) / abs(ref) if ref != 0 else abs(got))
+    assert errs["noisy_sample"] < 1e-6 and errs["teacher_output"] <= 1e-4 and errs["student_output"] <= 1e-4, errs
+    assert lerr[0] <= 1e-3 and lerr[1] <= 1e-3, lerr
+    out["loss"][step].backward()
+    torch.cuda.synchronize()
+    worst, n = 0.0, 0
+    gmax = max(float(v.norm()) for v in g["grads"].values())
+    for pn, p in m.named_parameters():
+        if p.grad is None or (pn.startswith("student_denoiser.") and ".lora_" not in pn):
+            continue
+        ref = g["grads"][pn]
+        if float(ref.norm()) < 1e-6 * gmax:
+            continue
+        worst = max(worst, rel_err(p.grad, ref))
+        n += 1
+    log(f"step {name} (fp32 MMDiT): " + " ".join(f"{k}={v:.2e}" for k, v in errs.items()) +
+        f" loss_rel={lerr[0]:.2e},{lerr[1]:.2e}; {n} gradient tensors, worst rel {worst:.2e}")
+    assert n > 0 and worst <= 1e-2, (n, worst)
