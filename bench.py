@@ -24,7 +24,8 @@ BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<6
            "gemm_kernel<128,128,conv>", "gemm_kernel<128,64,conv>", "gemm_kernel<64,128,conv>", "gemm_kernel<64,64,conv>",
            "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
            "gemm3_kernel<256x160,row>", "gemm3_kernel<256x128,row>", "gemm3_kernel<256x160,conv>", "gemm3_kernel<256x128,conv>",
-           "gemm4_kernel<256x320,row>", "gemm4_kernel<256x320,conv>"]
+           "gemm4_kernel<256x320,row>", "gemm4_kernel<256x320,conv>", "gemm4_kernel<256x192,row>", "gemm4_kernel<256x192,conv>",
+           "wgrad_tn_kernel"]
 
 
 def _physical_cores():

@@ -39,7 +39,7 @@ int fdmi_tune_set(int key, int value) {
 int fdmi_tune_value(int key) { return fdmi_tune_get(key); }
 int fdmi_prof_enable(int on) { g_prof = on != 0; return 0; }
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches) {
-  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (17) buckets");
+  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (20) buckets");
   for (int i = 0; i < nbuckets; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   for (auto& r : g_recs) {
     FDMI_HIP(hipEventSynchronize(r.b));

@@ -290,6 +290,43 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
 #pragma unroll
     for (int q = 0; q < NF / 2; ++q) {
       if (wide && q < QW) continue;
+      if (FULL && wide) {   // whole tiles, aligned rows: the odd (value, gate) pair of the wave tile, 4 columns per lane
+        const int n = nw + q * 32 + g * 4;
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f), bg = bv;
+        if (a.bias) { bv = *(const float4*)(a.bias + n); bg = *(const float4*)(a.bias + n + 16); }
+#pragma unroll
+        for (int mf = 0; mf < MF; ++mf) {
+          const int64_t m = mw + mf * 16 + j;
+          float val[4], gate[4];
+          val[0] = fmaf(acc[2 * q][mf][0], a.alpha, bv.x); val[1] = fmaf(acc[2 * q][mf][1], a.alpha, bv.y);
+          val[2] = fmaf(acc[2 * q][mf][2], a.alpha, bv.z); val[3] = fmaf(acc[2 * q][mf][3], a.alpha, bv.w);
+          gate[0] = fmaf(acc[2 * q + 1][mf][0], a.alpha, bg.x); gate[1] = fmaf(acc[2 * q + 1][mf][1], a.alpha, bg.y);
+          gate[2] = fmaf(acc[2 * q + 1][mf][2], a.alpha, bg.z); gate[3] = fmaf(acc[2 * q + 1][mf][3], a.alpha, bg.w);
+          if (a.rowvec) {
+            const bf16_t* rvp = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
+            const u16x4 r0 = *(const u16x4*)rvp, r1 = *(const u16x4*)(rvp + 16);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { val[r] += bf2f(r0[r]); gate[r] += bf2f(r1[r]); }
+          }
+          if (a.preact) {
+            save_preact3(a, m, n, val);
+            save_preact3(a, m, n + 16, gate);
+          }
+          const int no = (nw >> 1) + q * 16 + g * 4;
+          float o[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
+          if (a.out_f32) {
+            *(float4*)((float*)a.C + m * a.ldc + no) = make_float4(o[0], o[1], o[2], o[3]);
+          } else {
+            uint2 pk;
+            pk.x = pack2bf(o[0], o[1]);
+            pk.y = pack2bf(o[2], o[3]);
+            *(uint2*)((bf16_t*)a.C + m * a.ldc + no) = pk;
+          }
+        }
+        continue;
+      }
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) {
         const int64_t m = mw + mf * 16 + j;
