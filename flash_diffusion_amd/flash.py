@@ -448,6 +448,17 @@ class FlashDiffusion(nn.Module):
                      f"_{teacher_guidance_scale}_cfg/teacher"] = samples_ref
         return logs
 
+    def _teacher_stream(self, like):
+        """side stream for the teacher loop (one per model and device); None off the GPU"""
+        if not (torch.is_tensor(like) and like.is_cuda):
+            return None
+        st = getattr(self, "_side_streams", None)
+        if st is None:
+            st = self._side_streams = {}
+        if like.device not in st:
+            st[like.device] = torch.cuda.Stream(device=like.device)
+        return st[like.device]
+
     def _teacher_cfg(self, x, tt, cond, uncond, cfg_cond, *args, ctx_cache=None, res=None, **kwargs):
         """The reference evaluates the frozen teacher twice per step, once per conditioning (FD:297-313).
         Every layer of the UNet is per-sample (GroupNorm included), so ONE call on the 2B batch
@@ -526,28 +537,42 @@ class FlashDiffusion(nn.Module):
             g = float(d.rand1("guidance")) * (g_max - g_min) + g_min
 
         # ---- teacher: n = K - start_idx CFG denoising steps, no grad (FD:288-324) ----
-        with torch.no_grad():
-            x = x_init
-            fused = hasattr(sch, "fused_cfg_step")
-            cfg_cond = self._cat_cond(conditioning, uncond)
-            one_call = (os.environ.get("FDMI_TEACHER_LOOP", "1") == "1" and cfg_cond is not None
-                        and getattr(self, "batch_cfg", True) and hasattr(sch, "loop_coefficients")
-                        and hasattr(self.teacher_denoiser, "teacher_loop") and not args and set(kwargs) <= {"device"}
-                        and set(cfg_cond["cond"]) <= {"crossattn", "vector"} and res is None)
-            if one_call:   # the whole loop inside the library (fdmi_teacher_loop; A/B switch: FDMI_TEACHER_LOOP=0)
-                x = self.teacher_denoiser.teacher_loop(x, [float(t) for t in sch.timesteps[si:]],
-                                                       cfg_cond["cond"]["crossattn"], cfg_cond["cond"].get("vector"),
-                                                       sch.loop_coefficients(si, g))
-            for it, t in enumerate(sch.timesteps[si:] if not one_call else []):
-                x_ = sch.scale_model_input(x, t)
-                e_c, e_u = self._teacher_cfg(x_, torch.full((B,), float(t), device=z.device), conditioning, uncond,
-                                             cfg_cond, *args, ctx_cache="fill" if it == 0 else "reuse", res=res, **kwargs)
-                if fused:
-                    x = sch.fused_cfg_step(e_c, e_u, g, t, x)
-                else:
-                    e = ops.axpby(e_c, g, e_u, 1.0 - g)
-                    x = sch.step(e, t, x, return_dict=False)[0]
-            teacher_output = x
+        def run_teacher():
+            with torch.no_grad():
+                x = x_init
+                fused = hasattr(sch, "fused_cfg_step")
+                cfg_cond = self._cat_cond(conditioning, uncond)
+                one_call = (os.environ.get("FDMI_TEACHER_LOOP", "1") == "1" and cfg_cond is not None
+                            and getattr(self, "batch_cfg", True) and hasattr(sch, "loop_coefficients")
+                            and hasattr(self.teacher_denoiser, "teacher_loop") and not args and set(kwargs) <= {"device"}
+                            and set(cfg_cond["cond"]) <= {"crossattn", "vector"} and res is None)
+                if one_call:   # the whole loop inside the library (fdmi_teacher_loop; A/B switch: FDMI_TEACHER_LOOP=0)
+                    x = self.teacher_denoiser.teacher_loop(x, [float(t) for t in sch.timesteps[si:]],
+                                                           cfg_cond["cond"]["crossattn"], cfg_cond["cond"].get("vector"),
+                                                           sch.loop_coefficients(si, g))
+                for it, t in enumerate(sch.timesteps[si:] if not one_call else []):
+                    x_ = sch.scale_model_input(x, t)
+                    e_c, e_u = self._teacher_cfg(x_, torch.full((B,), float(t), device=z.device), conditioning, uncond,
+                                                 cfg_cond, *args, ctx_cache="fill" if it == 0 else "reuse", res=res, **kwargs)
+                    if fused:
+                        x = sch.fused_cfg_step(e_c, e_u, g, t, x)
+                    else:
+                        e = ops.axpby(e_c, g, e_u, 1.0 - g)
+                        x = sch.step(e, t, x, return_dict=False)[0]
+                return x
+
+        # The teacher loop and the student's forward are independent (the teacher is frozen, both start from x_init): the loop
+        # is issued on a SIDE HIP stream and the student's forward on the current one, so the many launches of the B-row
+        # student that under-fill the chip (deep UNet levels, rank-r LoRA GEMMs) run beside the teacher's 2B-row kernels instead
+        # of after them; the streams join before the first loss that needs both.  (A/B switch: FDMI_TEACHER_STREAM=0.)
+        side = self._teacher_stream(z) if os.environ.get("FDMI_TEACHER_STREAM", "1") == "1" else None
+        if side is not None:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                teacher_output = run_teacher()
+        else:
+            teacher_output = run_teacher()
 
         # ---- student: one step with grad (FD:255-280, 328) ----
         hook = getattr(self, "before_student", None)
@@ -561,6 +586,9 @@ class FlashDiffusion(nn.Module):
         ca = (c_skip + c_out * inv_a).float().contiguous()
         cb = (c_out * ms_a).float().contiguous()
         student_output = _PerSampleAffine.apply(eps_s, x_init, ca, cb)
+        if side is not None:   # join: everything below reads the teacher's result on the current stream
+            cur.wait_stream(side)
+            teacher_output.record_stream(cur)
 
         l_distill = self._distill_loss(student_output, teacher_output)
         loss = l_distill * self.distill_loss_scale[K_step]

@@ -23,6 +23,7 @@ VARIANTS = {
     "no_gn_epilogue": ({14: 1}, {}),
     "no_dedup": ({13: 1}, {"FDMI_CFG_DEDUP": "0"}),
     "no_tloop": ({}, {"FDMI_TEACHER_LOOP": "0"}),
+    "no_side_stream": ({}, {"FDMI_TEACHER_STREAM": "0"}),
 }
 
 
