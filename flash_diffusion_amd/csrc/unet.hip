@@ -417,7 +417,11 @@ template <typename Tp>
 int dmalloc(fdmi_unet* U, Tp** p, size_t n) {
   void* q = nullptr;
   FDMI_HIP(hipMalloc(&q, n * sizeof(Tp)));
+  // The clear runs on the NULL stream, which does not order itself against the caller's (non-blocking) streams: without the
+  // wait below it can land AFTER the first kernels that fill the buffer on the caller's stream -- seen once the teacher loop
+  // and the student's forward ran on two streams (a cross-attention K/V cache zeroed behind the GEMM that had just written it).
   FDMI_HIP(hipMemset(q, 0, n * sizeof(Tp)));
+  FDMI_HIP(hipStreamSynchronize(nullptr));
   U->owned.push_back(q);
   *p = (Tp*)q;
   return 0;

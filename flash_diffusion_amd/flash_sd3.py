@@ -16,6 +16,7 @@ Same constructor and return contract as the reference class, including the scala
 from __future__ import annotations
 
 import copy
+import os
 from dataclasses import dataclass, field
 from types import SimpleNamespace
 from typing import Any, Dict, List, Optional
@@ -26,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .flash import Draws, _DistillLoss, _DmdLoss, _PerSampleAffine, gaussian_mixture_pmf
+from .flash import Draws, FlashDiffusion, _DistillLoss, _DmdLoss, _PerSampleAffine, gaussian_mixture_pmf
 
 
 # the reference's fixed unconditional prompt (FD3:207-209 in forward, 726-728 in sample): a value of its recipe, not code
@@ -358,14 +359,32 @@ class FlashDiffusionSD3(nn.Module):
             g = float(self.fixed_guidance)
         else:
             g = float(d.rand1("guidance")) * (g_max - g_min) + g_min
-        with torch.no_grad():                                            # FD3:282-314: Euler steps with CFG
-            x = self._euler_cfg(self.teacher_denoiser, sch, sch.timesteps[si:], x_init, cond, uncond, g, *args, **kwargs)
-            teacher_output = x
-        hook = getattr(self, "before_student", None)
-        if hook is not None:
-            hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
-        v_s = self.student_denoiser(sample=x_init, timestep=start_t, conditioning=cond)
-        student_output = _PerSampleAffine.apply(v_s.float(), x_init, torch.ones_like(sig), (-sig).contiguous())   # FD3:325
+        def run_teacher():
+            with torch.no_grad():                                        # FD3:282-314: Euler steps with CFG
+                return self._euler_cfg(self.teacher_denoiser, sch, sch.timesteps[si:], x_init, cond, uncond, g, *args, **kwargs)
+
+        def run_student():
+            hook = getattr(self, "before_student", None)
+            if hook is not None:
+                hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
+            v_s = self.student_denoiser(sample=x_init, timestep=start_t, conditioning=cond)
+            return _PerSampleAffine.apply(v_s.float(), x_init, torch.ones_like(sig), (-sig).contiguous())         # FD3:325
+
+        # the frozen teacher's loop and the student's forward are independent: two HIP streams, joined before the first loss
+        # (flash.py does the same; A/B switch FDMI_TEACHER_STREAM=0).  The student is ISSUED first: this denoiser is launched
+        # op by op from the host, and the B-row student is a ninth of the launches -- the GPU then has both queues from the start.
+        side = FlashDiffusion._teacher_stream(self, z) if os.environ.get("FDMI_TEACHER_STREAM", "1") == "1" else None
+        if side is None:
+            teacher_output = run_teacher()
+            student_output = run_student()
+        else:
+            cur = torch.cuda.current_stream()
+            side.wait_stream(cur)
+            student_output = run_student()
+            with torch.cuda.stream(side):
+                teacher_output = run_teacher()
+            cur.wait_stream(side)
+            teacher_output.record_stream(cur)
         if self.distill_loss_type == "lpips":     # FD3:391-411 (clamped crop bounds); the caller's VAE / LPIPS torch modules
             so, to = student_output, teacher_output.detach()
             crop_h = max((so.shape[2] - 64) // 2, 0)
