@@ -43,8 +43,9 @@ def cpu_baseline(n_teacher_steps, budget_s=75.0):
     """The oracle (CPU fp32 restatement of the reference step, oracle/flash_ref.py -- kind "port") timed on this box's host
     cores on a bounded sample of the SAME workload (SD1.5, r128 LoRA, 64x64 latents, n teacher steps): whole generator
     iterations (forward + backward + AdamW) at B=1 -- one warm-up UNet forward, then the median of up to 3 timed
-    iterations -- and, if the time budget allows, one iteration at B=2 (the batch-scaling point).  Threads = physical
-    cores (FDMI_CPU_THREADS overrides)."""
+    iterations -- and, if the time budget allows, one iteration at B=2 (the batch-scaling point).  Threads: the fastest of a
+    short sweep (physical cores / 8 ... physical cores) of one UNet forward -- the GPU box's 128 cores are slower at 128
+    torch threads than at 32 (profiles/r2_cpu_thread_sweep.txt); FDMI_CPU_THREADS pins a count."""
     import copy
     import statistics
     import torch
@@ -238,6 +239,9 @@ def main():
     t0 = time.perf_counter()
     run(args.steps, flops)
     pipe.finish()
+    # the last iteration's backward is issued by finish() (deferred backward, trainer.py): its FLOPs are counted here
+    flops[0] += model.student_denoiser.step_flops + model.teacher_denoiser.step_flops
+    model.student_denoiser.step_flops = model.teacher_denoiser.step_flops = 0.0
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -253,17 +257,45 @@ def main():
     # records events ----
     roofline = None
     L = _lib.lib()
+    # The profiled step runs SERIALLY (no side stream for the teacher, backward not deferred): a kernel's duration is then its
+    # own, not its share of a chip it splits with the other stream's kernels.  Each profiled launch carries its own start /
+    # stop events (hipExtLaunchKernelGGL = the dispatch's timestamps, as in rocprofv3's kernel trace); if the runtime
+    # returns no valid elapsed time for them the leg is repeated with events recorded around the launches (knob 20).
+    serial_env = {"FDMI_TEACHER_STREAM": "0", "FDMI_DEFER_BACKWARD": "0"}
+    saved_env = {k: os.environ.get(k) for k in serial_env}
+    os.environ.update(serial_env)
+    nb = 24
+    ms = (C.c_double * nb)()
+    fl = (C.c_double * nb)()
+    ln = (C.c_int64 * nb)()
+    timing = "per-dispatch start/stop events (hipExtLaunchKernelGGL)"
+    for attempt in (0, 1):
+        if rank == 0:
+            L.fdmi_tune_set(20, max(attempt, L.fdmi_tune_value(20)))
+            L.fdmi_prof_enable(1)
+        run(1)
+        pipe.finish()
+        if rank == 0:
+            L.fdmi_prof_enable(0)
+            rc = L.fdmi_prof_collect(nb, ms, fl, ln)
+            ok = rc == 0 and sum(ln) > 0 and sum(ms) > 0
+            if L.fdmi_tune_value(20):
+                timing = "events recorded around each launch (includes dispatch latency)"
+                _lib.check(rc)
+        else:
+            ok = True
+        if world > 1:
+            t = torch.tensor([1.0 if ok else 0.0], device="cuda")
+            dist.broadcast(t, 0)
+            ok = bool(t.item() > 0)
+        if ok:
+            break
+    for k, v in saved_env.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
     if rank == 0:
-        L.fdmi_prof_enable(1)
-    run(1)
-    pipe.finish()
-    if rank == 0:
-        L.fdmi_prof_enable(0)
-        nb = 24
-        ms = (C.c_double * nb)()
-        fl = (C.c_double * nb)()
-        ln = (C.c_int64 * nb)()
-        _lib.check(L.fdmi_prof_collect(nb, ms, fl, ln))
         rows = [(BUCKETS[i], ms[i], fl[i], ln[i]) for i in range(len(BUCKETS)) if ln[i] > 0]
         rows.sort(key=lambda r: -r[1])
         name, tms, tfl, tln = rows[0]
@@ -290,6 +322,8 @@ def main():
         roofline = {"bound": "mfma", "kernel": name, "achieved": ach, "peak": PEAK_BF16 / 1e12, "unit": "TFLOP/s",
                     "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic, "traffic_source": traffic_src, "launches_per_step": int(tln),
                     "avg_launch_us": tms * 1e3 / tln, "algorithmic_gflop_per_launch": tfl / tln / 1e9,
+                    "timing": timing + "; profiled step issued serially (teacher loop on the main stream, backward not "
+                              "deferred) so that a launch's duration is its own",
                     "all_mfma_kernels": {r[0]: {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),
                                                 "launches": int(r[3])} for r in rows},
                     "whole_step": {"algorithmic_tflop_per_step_per_gpu": step_flops / 1e12,

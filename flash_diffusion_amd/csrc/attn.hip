@@ -851,13 +851,13 @@ int fwd_t(const AttnArgs& a, hipStream_t st) {
   const bool ones = a.vt_ones && a.d < DV;
   if constexpr (CAN_DMA) {
     if (dma) {
-      if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, true, true>), grid, dim3(256), smem, st, a);
-      else hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, false, true>), grid, dim3(256), smem, st, a);
+      if (ones) FDMI_KLAUNCH(prof, (attn_fwd_kernel<DK, DV, NF, true, true>), grid, dim3(256), smem, st, a);
+      else FDMI_KLAUNCH(prof, (attn_fwd_kernel<DK, DV, NF, false, true>), grid, dim3(256), smem, st, a);
     }
   }
   if (!dma) {
-    if (ones) hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, true, false>), grid, dim3(256), smem, st, a);
-    else hipLaunchKernelGGL((attn_fwd_kernel<DK, DV, NF, false, false>), grid, dim3(256), smem, st, a);
+    if (ones) FDMI_KLAUNCH(prof, (attn_fwd_kernel<DK, DV, NF, true, false>), grid, dim3(256), smem, st, a);
+    else FDMI_KLAUNCH(prof, (attn_fwd_kernel<DK, DV, NF, false, false>), grid, dim3(256), smem, st, a);
   }
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
@@ -871,7 +871,7 @@ int dq_t(const AttnArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_ATTN_DQ, 6.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
-  hipLaunchKernelGGL((attn_bwd_dq_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  FDMI_KLAUNCH(prof, (attn_bwd_dq_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -884,7 +884,7 @@ int dkv_t(const AttnArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.Skv, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_ATTN_DKV, 8.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
-  hipLaunchKernelGGL((attn_bwd_dkv_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
+  FDMI_KLAUNCH(prof, (attn_bwd_dkv_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;

@@ -22,12 +22,25 @@ hipEvent_t prof_event() {
 static int g_tune[32] = {0};
 int fdmi_tune_get(int key) { return (key >= 0 && key < 32) ? g_tune[key] : 0; }
 bool fdmi_prof_on() { return g_prof; }
+// tune 20 = 0 (default): the launch that follows takes the record's two events as its own start / stop events
+// (FDMI_KLAUNCH -> hipExtLaunchKernelGGL); 1: the events are recorded on the stream around the launch
+static bool g_take = false;
 void fdmi_prof_begin(hipStream_t st, int bucket, double flops) {
   ProfRec r{prof_event(), prof_event(), flops, bucket};
-  (void)hipEventRecord(r.a, st);
+  if (fdmi_tune_get(20)) (void)hipEventRecord(r.a, st);
+  else g_take = true;
   g_recs.push_back(r);
 }
-void fdmi_prof_end(hipStream_t st) { (void)hipEventRecord(g_recs.back().b, st); }
+bool fdmi_prof_take(hipEvent_t* a, hipEvent_t* b) {
+  if (!g_take) return false;
+  g_take = false;
+  *a = g_recs.back().a; *b = g_recs.back().b;
+  return true;
+}
+void fdmi_prof_end(hipStream_t st) {
+  if (fdmi_tune_get(20)) (void)hipEventRecord(g_recs.back().b, st);
+  else if (g_take) { g_take = false; g_pool.push_back(g_recs.back().a); g_pool.push_back(g_recs.back().b); g_recs.pop_back(); }  // no launch took them
+}
 
 extern "C" {
 
@@ -41,14 +54,20 @@ int fdmi_prof_enable(int on) { g_prof = on != 0; return 0; }
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches) {
   FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (20) buckets");
   for (int i = 0; i < nbuckets; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  FDMI_HIP(hipDeviceSynchronize());
+  int bad = 0;
   for (auto& r : g_recs) {
-    FDMI_HIP(hipEventSynchronize(r.b));
     float t = 0;
-    FDMI_HIP(hipEventElapsedTime(&t, r.a, r.b));
-    ms[r.bucket] += t; flops[r.bucket] += r.flops; launches[r.bucket] += 1;
+    if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && t >= 0.f) {
+      ms[r.bucket] += t; flops[r.bucket] += r.flops; launches[r.bucket] += 1;
+    } else {
+      ++bad;
+    }
     g_pool.push_back(r.a); g_pool.push_back(r.b);
   }
   g_recs.clear();
+  (void)hipGetLastError();
+  FDMI_CHECK(bad == 0, "prof_collect: " + std::to_string(bad) + " launch records without a valid elapsed time");
   return 0;
 }
 

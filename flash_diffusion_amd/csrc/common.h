@@ -1,6 +1,7 @@
 // Shared device/host helpers for the fdmi kernels (gfx950 / CDNA4 only).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <string>
 
@@ -85,5 +86,17 @@ int fdmi_tune_get(int key);   // developer tuning knobs (fdmi_tune_set)
 bool fdmi_prof_on();
 void fdmi_prof_begin(hipStream_t st, int bucket, double flops);
 void fdmi_prof_end(hipStream_t st);
+bool fdmi_prof_take(hipEvent_t* a, hipEvent_t* b);
+// A profiled launch carries its own start / stop events (hipExtLaunchKernelGGL: the timestamps of the dispatch itself -- what
+// rocprofv3's kernel trace reports) instead of two event packets around it, whose elapsed time also holds the dispatch latency
+// on either side (several us per launch; developer knob 20 = 1 goes back to the brackets).  `prof` false: the plain launch.
+#define FDMI_KLAUNCH(prof, kernel, grid, block, smem, st, ...)                                              \
+  do {                                                                                                      \
+    hipEvent_t pa_ = nullptr, pb_ = nullptr;                                                                \
+    if ((prof) && fdmi_prof_take(&pa_, &pb_))                                                               \
+      hipExtLaunchKernelGGL(kernel, grid, block, smem, st, pa_, pb_, 0, __VA_ARGS__);                       \
+    else                                                                                                    \
+      hipLaunchKernelGGL(kernel, grid, block, smem, st, __VA_ARGS__);                                       \
+  } while (0)
 
 static inline int cdiv(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }

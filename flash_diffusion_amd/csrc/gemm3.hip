@@ -279,7 +279,7 @@ int launch3_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);   // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, PROF_GEMM3 + MODE * 2 + (BN == 160 ? 0 : 1), gemm_flops(a));
-  hipLaunchKernelGGL((gemm3_kernel<BN, MODE, GN>), grid, dim3(512), smem, stream, a);
+  FDMI_KLAUNCH(prof, (gemm3_kernel<BN, MODE, GN>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;

@@ -274,7 +274,7 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a));
-  hipLaunchKernelGGL((gemm4_kernel<MODE, GEGLU, BN, GN>), grid, dim3(512), smem, stream, a);
+  FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;

@@ -132,7 +132,7 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
   const int nz = (int)((M + a.rows_per_split - 1) / a.rows_per_split);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_WGRAD_TN, 2.0 * (double)M * N1 * N2);
-  hipLaunchKernelGGL(wgrad_tn_kernel, dim3(t2, t1, nz), dim3(256), 0, st, a);
+  FDMI_KLAUNCH(prof, wgrad_tn_kernel, dim3(t2, t1, nz), dim3(256), 0, st, a);
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;

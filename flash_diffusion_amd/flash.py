@@ -266,6 +266,7 @@ class FlashDiffusion(nn.Module):
         ac = teacher_noise_scheduler.alphas_cumprod
         self.register_buffer("sqrt_alpha_cumprod", torch.sqrt(ac))
         self.register_buffer("sigmas", torch.sqrt(1 - ac))
+        self._alpha_all_positive = bool((ac > 0).all())   # checked once on the host table (no per-step device round trip)
         self.draws: Optional[Draws] = None
         self.last_draws: Optional[Draws] = None
         self.terms: Dict[str, Any] = {}
@@ -306,6 +307,7 @@ class FlashDiffusion(nn.Module):
         else:
             start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
         t0 = self.teacher_noise_scheduler.timesteps[start_idx]
+        self._start_t_host = int(t0.reshape(-1)[0])   # forward() reports it without a device round trip
         return start_idx, t0.to(device).repeat(num_samples)
 
     @staticmethod
@@ -486,7 +488,8 @@ class FlashDiffusion(nn.Module):
         """per-sample (1/alpha_t, -sigma_t/alpha_t) of the epsilon-branch of _predicted_x_0 (FD:731-742)."""
         al = self.sqrt_alpha_cumprod[t]
         sg = self.sigmas[t]
-        assert bool((al > 0).all()), "alpha_t == 0 never occurs on the trailing schedules of the reference configs"
+        assert self._alpha_all_positive or bool((al > 0).all()), \
+            "alpha_t == 0 never occurs on the trailing schedules of the reference configs"
         return 1.0 / al, -sg / al
 
     # ---- forward (FD:179-366) ------------------------------------------------------------------------
@@ -519,6 +522,8 @@ class FlashDiffusion(nn.Module):
         if K != self.K_prev:
             self.K_prev = K
             if getattr(self, "switch_teacher", False):  # the reference reads an attribute it never sets (FD:230)
+                if getattr(self, "before_student", None) is not None:
+                    self.before_student()   # the copy reads the student: outstanding backward / AdamW first
                 self.teacher_denoiser = deepcopy(self.student_denoiser)
                 self.teacher_denoiser.freeze()
 
@@ -605,7 +610,7 @@ class FlashDiffusion(nn.Module):
         self.terms["gan_D"] = gan[1].detach() if torch.is_tensor(gan[1]) else gan[1]
         loss = loss + self.adversarial_loss_scale[K_step] * gan[0]
         return {"loss": [loss, gan[1]], "teacher_output": teacher_output, "student_output": student_output,
-                "noisy_sample": x_init, "start_timestep": int(start_t[0].item())}
+                "noisy_sample": x_init, "start_timestep": self._start_t_host}
 
     # ---- losses --------------------------------------------------------------------------------------
     def _distill_loss(self, s, t):

@@ -337,6 +337,8 @@ class FlashDiffusionSD3(nn.Module):
         if K != self.K_prev:                                             # FD3:243-249
             self.K_prev = K
             if getattr(self, "switch_teacher", False):  # the reference reads an attribute it never sets (FD3:245)
+                if getattr(self, "before_student", None) is not None:
+                    self.before_student()   # the copy reads the student: outstanding backward / AdamW first
                 self.teacher_denoiser = copy.deepcopy(self.student_denoiser)
                 self.teacher_denoiser.freeze()
         noise = d.randn_like("noise", z)
@@ -346,8 +348,9 @@ class FlashDiffusionSD3(nn.Module):
         else:
             start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
         si = int(start_idx)
-        start_t = sch.timesteps[si].to(z.device).repeat(B)
-        sig = get_sigmas(sch, start_t).to(z.device)                      # [B]
+        t_host = sch.timesteps[si].reshape(1).repeat(B)                  # host values: no device round trip in the step
+        start_t = t_host.to(z.device)
+        sig = get_sigmas(sch, t_host).to(z.device)                       # [B]
         if si == 0:                                                      # FD3:264-268: start from pure noise
             x_init = noise
             if hasattr(sch, "init_noise_sigma"):
@@ -404,9 +407,9 @@ class FlashDiffusionSD3(nn.Module):
             gan = self._gan_loss(d, z, student_output, teacher_output, cond, step)
             loss = loss + self.adversarial_loss_scale[K_step] * gan[0]
             return {"loss": [loss, gan[1]], "teacher_output": teacher_output, "student_output": student_output,
-                    "noisy_sample": x_init, "start_timestep": float(start_t[0].item())}
+                    "noisy_sample": x_init, "start_timestep": float(t_host[0])}
         return {"loss": loss.mean(), "teacher_output": teacher_output, "student_output": student_output,
-                "noisy_sample": x_init, "start_timestep": float(start_t[0].item())}
+                "noisy_sample": x_init, "start_timestep": float(t_host[0])}
 
     def _noised(self, x, noise, sig):
         """sigma eps + (1 - sigma) x, differentiable w.r.t. x (gradient (1 - sigma) g)"""
@@ -418,8 +421,9 @@ class FlashDiffusionSD3(nn.Module):
         B = s.shape[0]
         noise = d.randn_like("dmd_noise", s)
         ti = d.randint("dmd_t", 0, self.teacher_noise_scheduler.config.num_train_timesteps, (B,), "cpu")
-        t = sc.timesteps[ti.cpu()].to(s.device)
-        sig = get_sigmas(sc, t).to(s.device)
+        t_host = sc.timesteps[ti.cpu()]
+        t = t_host.to(s.device)
+        sig = get_sigmas(sc, t_host).to(s.device)
         noisy = self._noised(s, noise.contiguous(), sig)
         with torch.no_grad():
             r_c = self.teacher_denoiser(sample=noisy.detach(), timestep=t, conditioning=cond)
@@ -441,8 +445,9 @@ class FlashDiffusionSD3(nn.Module):
         real = teacher_output if self.use_teacher_as_real else z
         sel = [float(sc.timesteps[-10]), float(sc.timesteps[-250]), float(sc.timesteps[-500]), float(sc.timesteps[-750])]
         idx = d.multinomial("gan_t", torch.tensor([0.25, 0.25, 0.25, 0.25]), B, replacement=True)
-        ts = torch.tensor(sel)[idx.cpu()].to(s.device)
-        sig = get_sigmas(sc, ts).to(s.device)
+        ts_host = torch.tensor(sel)[idx.cpu()]
+        ts = ts_host.to(s.device)
+        sig = get_sigmas(sc, ts_host).to(s.device)
         gen = step % 2 == 0
         noisy_fake = self._noised(s if gen else s.detach(), noise.contiguous(), sig)
         with torch.no_grad():

@@ -8,11 +8,19 @@
     summed with ONE RCCL all-reduce per optimizer on a flat buffer (the reference gets bucketed NCCL
     all-reduces from Lightning's DDP strategy, examples/train_flash_sd.py:386).  Because the teacher is
     frozen, the all-reduce + AdamW of iteration i run on a side stream concurrently with the teacher
-    loop of iteration i+1; the student forward waits on that stream (FlashDiffusion.before_student).
+    loop of iteration i+1; the student forward waits on that stream (FlashDiffusion.before_student);
+  * deferred backward (single-optimizer mode without a discriminator, GPU only; A/B switch FDMI_DEFER_BACKWARD=0): the
+    student's backward + all-reduce + AdamW of iteration i are ISSUED from the before_student hook of iteration i+1, i.e.
+    after that iteration's teacher loop has been handed to its side stream and before its student forward.  The teacher
+    is frozen and reads nothing the backward writes, so its 2B-row kernels run beside the backward's many small launches
+    (rank-r LoRA products, split-K tails, deep UNet levels) instead of after them; the order of every read and write of
+    the trainable tensors is the reference's (backward i, step i, forward i+1).  finish() -- and every reader of the
+    parameters on this class -- drains the outstanding backward.
 AdamW itself is the fused HIP kernel fdmi_adamw (torch.optim.AdamW semantics)."""
 from __future__ import annotations
 
 import logging
+import os
 import re
 import time
 from dataclasses import dataclass, field
@@ -116,6 +124,7 @@ class TrainingPipeline(nn.Module):
         self.overlap = overlap
         self._comm_stream = None
         self._pending = None      # event recorded on the comm stream after the deferred optimizer step
+        self._deferred = None     # (loss, optimizer index) whose backward + step the next before_student hook issues
         self.global_rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
         self.world = torch.distributed.get_world_size() if torch.distributed.is_initialized() else 1
         # a process group of ONE rank still runs the collective (a no-op exchange): the RCCL path of a single-GPU box is
@@ -163,7 +172,7 @@ class TrainingPipeline(nn.Module):
                      sum(p.numel() for p in self.model.parameters() if p.requires_grad))
         if self.overlap and torch.cuda.is_available():
             self._comm_stream = torch.cuda.Stream()
-            self.model.before_student = self._wait_pending
+            self.model.before_student = self._before_student
         if any(sc is not None for sc in self.lr_schedulers):
             return optimizers, [sc for sc in self.lr_schedulers]
         return optimizers
@@ -207,6 +216,31 @@ class TrainingPipeline(nn.Module):
         if self._pending is not None and torch.cuda.is_available():
             torch.cuda.current_stream().wait_event(self._pending)
             self._pending = None
+
+    def _defer_ok(self):
+        """backward of this iteration may wait for the next iteration's hook: GPU, overlap on, a model that calls the hook
+        right before its student forward, and no discriminator (the GAN generator term back-propagates through the frozen
+        teacher's plan, which the next teacher loop is already using on the side stream)"""
+        return (self._comm_stream is not None and getattr(self.model, "calls_before_student", False)
+                and getattr(self.model, "discriminator", None) is None and not getattr(self.model, "use_adversarial_loss", False)
+                and os.environ.get("FDMI_DEFER_BACKWARD", "1") == "1")
+
+    def _backward_and_step(self, loss, i):
+        opt = self.optims[i]
+        # zero_grad may only run once the deferred step has consumed the previous gradients
+        self._zero_grad(opt)
+        loss.backward()
+        self._reduce_and_step(opt)
+        self._lr_step(i, "step")
+
+    def _run_deferred(self):
+        if self._deferred is not None:
+            (loss, i), self._deferred = self._deferred, None
+            self._backward_and_step(loss, i)
+
+    def _before_student(self):
+        self._run_deferred()
+        self._wait_pending()
 
     def _reduce_and_step(self, opt):
         """All-reduce (sum) the optimizer's gradients over the data-parallel ranks, then step.  Runs on
@@ -253,18 +287,17 @@ class TrainingPipeline(nn.Module):
         if not getattr(self.model, "calls_before_student", False):
             # a model whose forward never calls the before_student hook would read parameters the deferred step is
             # still writing: wait here instead (FlashDiffusion / FlashDiffusionSD3 call the hook after their teacher loop)
-            self._wait_pending()
+            self._before_student()
         if self.automatic_optimization:
-            opt = self.optims[0]
-            out = self.model(train_batch, device=self.device)
+            out = self.model(train_batch, device=self.device)   # its before_student hook issued the previous backward
+            self._run_deferred()                                # (a forward that never reached the hook)
             loss = out["loss"][0] if isinstance(out["loss"], (list, tuple)) else out["loss"]
-            # zero_grad may only run once the deferred step has consumed the previous gradients;
-            # model.before_student already waited for it.
-            self._zero_grad(opt)
-            loss.backward()
-            self._reduce_and_step(opt)
-            self._lr_step(0, "step")
+            if self._defer_ok():
+                self._deferred = (loss, 0)
+            else:
+                self._backward_and_step(loss, 0)
             return {"loss": loss.detach(), "batch_idx": batch_idx, "start_timestep": out.get("start_timestep")}
+        self._run_deferred()
         outputs = {"batch_idx": batch_idx}
         for i, opt in enumerate(self.optims):
             model_output = self.model(train_batch, device=self.device, step=i, batch_idx=batch_idx)
@@ -299,7 +332,8 @@ class TrainingPipeline(nn.Module):
         self._toggled = []
 
     def finish(self):
-        """Drain the deferred optimizer step (end of training / before reading parameters)."""
+        """Drain the deferred backward and optimizer step (end of training / before reading parameters)."""
+        self._run_deferred()
         self._wait_pending()
         if torch.cuda.is_available():
             torch.cuda.synchronize()

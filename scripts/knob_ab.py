@@ -24,6 +24,8 @@ VARIANTS = {
     "no_dedup": ({13: 1}, {"FDMI_CFG_DEDUP": "0"}),
     "no_tloop": ({}, {"FDMI_TEACHER_LOOP": "0"}),
     "no_side_stream": ({}, {"FDMI_TEACHER_STREAM": "0"}),
+    "no_defer": ({}, {"FDMI_DEFER_BACKWARD": "0"}),
+    "serial": ({}, {"FDMI_DEFER_BACKWARD": "0", "FDMI_TEACHER_STREAM": "0"}),
 }
 
 
@@ -62,11 +64,18 @@ def main():
             else:
                 os.environ.pop(k, None)
 
-    def run(n):
+    host_ms = {}
+
+    def run(n, tag=None):
+        h = []
         for i in range(n):
+            t = time.perf_counter()
             pipe.training_step(batches[i % 4], i)
+            h.append((time.perf_counter() - t) * 1e3)   # host time to ISSUE the step (no device wait inside = it runs ahead)
         pipe.finish()
         torch.cuda.synchronize()
+        if tag is not None:
+            host_ms.setdefault(tag, []).extend(h)
 
     res = {n: [] for n in names}
     for n in names:   # warm every variant once (allocations, first-launch attribute calls)
@@ -81,13 +90,15 @@ def main():
             apply(n)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            run(args.steps)
+            run(args.steps, n)
             res[n].append((time.perf_counter() - t0) / args.steps * 1e3)
     apply("base")
     out = {n: {"median_ms": round(statistics.median(v), 2), "min_ms": round(min(v), 2), "all": [round(x, 2) for x in v]}
            for n, v in res.items()}
     for n, v in out.items():
-        print(f"{n:14s} median {v['median_ms']:8.2f}  min {v['min_ms']:8.2f}  {v['all']}", flush=True)
+        v["host_issue_ms_median"] = round(statistics.median(host_ms[n]), 2)
+    for n, v in out.items():
+        print(f"{n:14s} host-issue {v['host_issue_ms_median']:7.2f}  median {v['median_ms']:8.2f}  min {v['min_ms']:8.2f}  {v['all']}", flush=True)
     if args.legs:
         b = batches[0]
         cond = {"cond": {"crossattn": torch.cat([b["crossattn"], torch.zeros_like(b["crossattn"])], 0)}}

@@ -240,3 +240,75 @@ def test_fused_adamw_refuses_keywords_it_does_not_implement():
             FusedAdamW(p, lr=1e-3, **kw)
     with pytest.raises(TypeError):
         FusedAdamW(p, lr=1e-3, nesterov=True)
+
+
+class _ToyHook(nn.Module):
+    """a model that calls the trainer's before_student hook like FlashDiffusion.forward: after the (frozen) teacher, before
+    the student reads its parameters"""
+    calls_before_student = True
+
+    def __init__(self):
+        super().__init__()
+        self.student_denoiser = nn.Linear(4, 4)
+        self.teacher_denoiser = nn.Linear(4, 4)
+        self.discriminator = None
+        self.order = []
+        for p in self.teacher_denoiser.parameters():
+            p.requires_grad = False
+
+    def forward(self, batch, **kw):
+        t = self.teacher_denoiser(batch["x"]).detach()
+        self.order.append("teacher")
+        hook = getattr(self, "before_student", None)
+        if hook is not None:
+            hook()
+        self.order.append("student")
+        s = self.student_denoiser(batch["x"])
+        return {"loss": [((s - t) ** 2).mean(), 0], "start_timestep": 1}
+
+
+def test_deferred_backward_is_the_same_training_run():
+    """the backward + AdamW of iteration i issued from the hook of iteration i+1 (what the GPU path does to run it beside the
+    next teacher loop): parameters after N steps + finish() equal the immediate schedule bit for bit, the step happens
+    before the next student forward reads the parameters, and finish() / state_dict() drain the outstanding one"""
+    xs = [torch.randn(8, 4, generator=torch.Generator().manual_seed(i)) for i in range(4)]
+
+    def train(defer):
+        torch.manual_seed(0)
+        m = _ToyHook()
+        pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-2],
+                                                  lr_schedulers_name=["StepLR"], lr_schedulers_kwargs=[{"step_size": 2, "gamma": 0.5}],
+                                                  trainable_params=[["student_denoiser"]]), overlap=False)
+        pipe.configure_optimizers()
+        if defer:   # what configure_optimizers sets up on a GPU (no streams on this box: the comm stream is a placeholder)
+            pipe._comm_stream = object()
+            m.before_student = pipe._before_student
+            assert pipe._defer_ok()
+        snaps = []
+        for i, x in enumerate(xs):
+            w0 = m.student_denoiser.weight.detach().clone()
+            pipe.training_step({"x": x}, i)
+            snaps.append((w0, m.student_denoiser.weight.detach().clone(), pipe._deferred is not None))
+        sd = pipe.state_dict()   # drains
+        assert pipe._deferred is None
+        return m, snaps, {k: v.clone() for k, v in sd.items()}, pipe.optims[0].param_groups[0]["lr"]
+
+    m0, s0, sd0, lr0 = train(False)
+    m1, s1, sd1, lr1 = train(True)
+    assert all(torch.equal(sd0[k], sd1[k]) for k in sd0) and lr0 == lr1
+    assert all(not pend for _, _, pend in s0) and all(pend for _, _, pend in s1)
+    # deferred: training_step(i) returns with the parameters of step i-1 applied (its own update is outstanding) ...
+    assert torch.equal(s1[0][0], s1[0][1]) and torch.equal(s1[1][1], s0[0][1]) and torch.equal(s1[3][1], s0[2][1])
+    # ... and the student forward of step i+1 saw them updated: same losses means same trajectory (checked through sd above)
+    assert m1.order == ["teacher", "student"] * 4
+    os.environ["FDMI_DEFER_BACKWARD"] = "0"
+    try:
+        torch.manual_seed(0)
+        m = _ToyHook()
+        pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-2],
+                                                  trainable_params=[["student_denoiser"]]), overlap=False)
+        pipe.configure_optimizers()
+        pipe._comm_stream = object()
+        assert not pipe._defer_ok()
+    finally:
+        del os.environ["FDMI_DEFER_BACKWARD"]
