@@ -98,11 +98,29 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_b
       const u16x8 dv = BWD ? *(const u16x8*)(a.dy + off) : xv;
       consume(xv, dv);
     }
+    if (cpg >= 8) {
+      // a chunk of 8 channels touches at most two groups when a group is >= 8 channels wide: the thread folds its 8 partial
+      // sums into those two before the LDS atomics (4 instead of 16 same-address `ds_add_f32` per thread: -2 ms of the C2 step)
+      const int g0 = c0 / cpg, split = (g0 + 1) * cpg - c0;   // elements e < split belong to g0, the rest to g0 + 1
+      float a0 = 0.f, a1 = 0.f, b0 = 0.f, b1 = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int gi = (c0 + e) / cpg;
-      atomicAdd(&sred[gi][0], s0[e]);
-      atomicAdd(&sred[gi][1], s1[e]);
+      for (int e = 0; e < 8; ++e) {
+        if (e < split) { a0 += s0[e]; a1 += s1[e]; }
+        else { b0 += s0[e]; b1 += s1[e]; }
+      }
+      atomicAdd(&sred[g0][0], a0);
+      atomicAdd(&sred[g0][1], a1);
+      if (split < 8) {
+        atomicAdd(&sred[g0 + 1][0], b0);
+        atomicAdd(&sred[g0 + 1][1], b1);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int gi = (c0 + e) / cpg;
+        atomicAdd(&sred[gi][0], s0[e]);
+        atomicAdd(&sred[gi][1], s1[e]);
+      }
     }
   }
   __syncthreads();

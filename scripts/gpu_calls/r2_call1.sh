@@ -4,7 +4,7 @@
 set -u
 out=gpurun_out/r2c1
 mkdir -p "$out"
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 echo "== pytest -m gpu with FDMI_RUN_DEV_KNOBS=1"
 FDMI_RUN_DEV_KNOBS=1 timeout 900 python -m pytest tests -m gpu -q -rxXsf -p no:cacheprovider > "$out/pytest.txt" 2>&1

@@ -4,7 +4,7 @@
 set -u
 out=gpurun_out/r2c2
 mkdir -p "$out"
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 run() { name=$1; shift; echo "== $name: $*"; ( "$@" ) > "$out/$name.log" 2>&1; echo "   exit $? ($(tail -1 "$out/$name.log" | cut -c1-300))"; }
 run 01_pytest_new timeout 900 python -m pytest tests/test_multiproc_gpu.py tests/test_unet_gpu.py "tests/test_zz_dit_gpu.py::test_step_with_vae_and_lpips_matches_reference_golden" -q -rxXsf -p no:cacheprovider

@@ -3,7 +3,7 @@
 set -u
 out=gpurun_out/r2c3
 mkdir -p "$out"
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 echo "== pytest fp32 gate"
 timeout 1200 python -m pytest tests/test_fp32_gate_gpu.py -q -rxXsf -p no:cacheprovider > "$out/pytest_fp32.txt" 2>&1

@@ -2,7 +2,7 @@
 set -u
 out=gpurun_out/r2c4
 mkdir -p "$out"
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 run() { name=$1; shift; echo "== $name: $*"; ( "$@" ) > "$out/$name.log" 2>&1; echo "   exit $? ($(tail -1 "$out/$name.log" | cut -c1-240))"; }
 run 01_pytest timeout 1500 python -m pytest tests/test_fp32_gate_gpu.py tests/test_sd3_mmdit_step_gpu.py tests/test_multiproc_gpu.py tests/test_flash_gpu.py "tests/test_zz_dit_gpu.py::test_step_with_vae_and_lpips_matches_reference_golden" -q -rxXsf -p no:cacheprovider

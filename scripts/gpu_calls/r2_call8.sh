@@ -2,7 +2,7 @@
 set -u
 out=gpurun_out/r2c8
 mkdir -p "$out"
-cd "$(dirname "$0")/.." || exit 1
+cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp
 run() { name=$1; shift; echo "== $name: $*"; ( "$@" ) > "$out/$name.log" 2>&1; echo "   exit $? ($(tail -1 "$out/$name.log" | cut -c1-300))"; }
 run 01_pytest_a timeout 900 python -m pytest tests/test_flash_gpu.py tests/test_sd3_mmdit_step_gpu.py tests/test_flash_sd3_gpu.py tests/test_fullsize_gpu.py -q -rxXsf -p no:cacheprovider

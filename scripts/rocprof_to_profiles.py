@@ -112,6 +112,7 @@ def main():
     ap.add_argument("--stats-dir", required=True)
     ap.add_argument("--fetch-dir")
     ap.add_argument("--write-dir")
+    ap.add_argument("--tcc-dir", help="a --pmc TCC_HIT_sum TCC_MISS_sum pass: per-kernel L2 hit rate -> rN_l2_hit_rate.csv")
     ap.add_argument("--tag", default="", help="file-name suffix, e.g. _gn for a knob run")
     ap.add_argument("--command", default="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary")
     a = ap.parse_args()
@@ -122,6 +123,19 @@ def main():
     print("top kernels (ms per step):")
     for n, (calls, ns) in rows[:12]:
         print(f"  {ns / a.steps / 1e6:8.3f}  {calls / a.steps:7.1f} x {ns / calls / 1e3:8.1f} us  {n}")
+    if a.tcc_dir:   # L2 (TCC) hit rate per kernel: TCC_HIT_sum / (TCC_HIT_sum + TCC_MISS_sum)  (MI355X_MICROARCH.md, L2 section)
+        hit, miss = counter(a.tcc_dir, "TCC_HIT_sum"), counter(a.tcc_dir, "TCC_MISS_sum")
+        with open(f"{pre}_l2_hit_rate{a.tag}.csv", "w") as fh:
+            fh.write("# rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace (own pass); requests per launch, "
+                     "hit rate = hit / (hit + miss).  FETCH_SIZE counts the misses' traffic to the fabric, Infinity-Cache hits "
+                     "included -- a low rate here with FETCH far above the algorithmic bytes is re-reads the 4 MiB per-XCD L2 "
+                     "did not hold\n")
+            fh.write("kernel,launches,tcc_hit_per_launch,tcc_miss_per_launch,l2_hit_rate\n")
+            for n, (c, h) in sorted(hit.items(), key=lambda kv: -kv[1][0] * (kv[1][1] + miss.get(kv[0], (0, 0.0))[1])):
+                m = miss.get(n, (0, 0.0))[1]
+                if h + m > 0:
+                    fh.write(f"\"{n}\",{c},{h:.0f},{m:.0f},{h / (h + m):.4f}\n")
+        print("wrote", f"{pre}_l2_hit_rate{a.tag}.csv")
     if not (a.fetch_dir and a.write_dir):
         return
     # FETCH_SIZE / WRITE_SIZE are reported in KB (MI355X_MICROARCH.md, HBM section); FETCH_SIZE x 2 on gfx950

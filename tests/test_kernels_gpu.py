@@ -143,6 +143,28 @@ def test_gemm_splitk_and_atomic():
     close("gemm_atomic", acc, 1.0 + 2.0 * ref, tol_el=1e-4, tol_fro=1e-4)
 
 
+@pytest.mark.parametrize("N", [320, 328, 324])   # whole 320-wide tiles, a ragged last tile, N % 8 != 0
+@pytest.mark.parametrize("sk", [2, 3, 5])
+def test_gemm_splitk_finalize_epilogues(N, sk):
+    """slab split-K + finalize with every epilogue term: equals the reference and -- the slabs are summed in a fixed order --
+    is bit-identical between two runs"""
+    ops = _ops()
+    M, K, rpb = 512, 2560, 128
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    rowvec = b16(rnd(M // rpb, N, seed=4))
+    res = b16(rnd(M, N, seed=5))
+    pre = 0.5 * (A.float() @ W.float().t()) + bias + rowvec.float().repeat_interleave(rpb, 0)
+    kw = dict(bias=bias.cuda(), rowvec=rowvec.cuda(), rows_per_batch=rpb, residual=res.cuda(), alpha=0.5, splitk=sk)
+    out = ops.gemm(A.cuda(), W.cuda(), **kw)
+    close(f"splitk_fin_{N}_{sk}", out, pre + res.float())
+    assert torch.equal(out, ops.gemm(A.cuda(), W.cuda(), **kw))
+    out = ops.gemm(A.cuda(), W.cuda(), act=ops.ACT_SILU, **kw)
+    close(f"splitk_fin_silu_{N}_{sk}", out, F.silu(pre + res.float()))
+    out = ops.gemm(A.cuda(), W.cuda(), out_f32=True, **kw)
+    close(f"splitk_fin_f32_{N}_{sk}", out, pre + res.float(), tol_el=1e-4, tol_fro=1e-4)
+
+
 CONVS = [
     # (B, H, W, Cin, Cout, k, stride, pad, ups)
     (2, 8, 8, 32, 64, 3, 1, 1, 0),

@@ -11,7 +11,7 @@ K = "void (anonymous namespace)::gemm4_kernel<1, false, 320, false>(GemmArgs)"
 
 
 def test_converter_reproduces_the_round1_figures(tmp_path):
-    for d in ("stats/h", "f/h", "w/h"):
+    for d in ("stats/h", "f/h", "w/h", "t/h"):
         os.makedirs(tmp_path / d)
     (tmp_path / "stats/h/1_kernel_stats.csv").write_text(
         '"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs","StdDev"\n'
@@ -22,10 +22,13 @@ def test_converter_reproduces_the_round1_figures(tmp_path):
     row = '{i},{i},4,1,10,10,131072,5,"' + K + '",512,147456,0,128,128,112,"{c}",{v},1,2\n'
     (tmp_path / "f/h/1_counter_collection.csv").write_text(head + "".join(row.format(i=i, c="FETCH_SIZE", v=298397.2) for i in (1, 2)))
     (tmp_path / "w/h/1_counter_collection.csv").write_text(head + "".join(row.format(i=i, c="WRITE_SIZE", v=74512.0) for i in (1, 2)))
+    (tmp_path / "t/h/1_counter_collection.csv").write_text(
+        head + "".join(row.format(i=i, c=c, v=v) for i in (1, 2) for c, v in (("TCC_HIT_sum", 3.0e6), ("TCC_MISS_sum", 1.0e6))))
     pre = os.path.join(ROOT, "profiles", "r987")
     try:
         subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "rocprof_to_profiles.py"), "--round", "987", "--steps", "4",
-                        "--stats-dir", str(tmp_path / "stats"), "--fetch-dir", str(tmp_path / "f"), "--write-dir", str(tmp_path / "w")],
+                        "--stats-dir", str(tmp_path / "stats"), "--fetch-dir", str(tmp_path / "f"), "--write-dir", str(tmp_path / "w"),
+                        "--tcc-dir", str(tmp_path / "t")],
                        check=True, capture_output=True)
         stats = open(pre + "_kernel_stats.csv").read().splitlines()
         assert stats[2] == '"void gemm4_kernel<1, false, 320, false>",190.0,44.997,236.8'
@@ -33,7 +36,9 @@ def test_converter_reproduces_the_round1_figures(tmp_path):
         t = json.load(open(pre + "_traffic.json"))["kernels"]["gemm4_kernel<256x320,conv>"]
         assert t["fetch_MB_corrected"] == 611.12 and t["write_MB"] == 76.3 and t["launches_sampled"] == 2
         assert abs(t["hbm_bytes_per_launch"] - 687.42e6) < 0.01e6
+        l2 = open(pre + "_l2_hit_rate.csv").read().splitlines()
+        assert l2[2] == '"void gemm4_kernel<1, false, 320, false>",2,3000000,1000000,0.7500'
     finally:
-        for suf in ("_kernel_stats.csv", "_pmc_hbm_traffic.csv", "_traffic.json"):
+        for suf in ("_kernel_stats.csv", "_pmc_hbm_traffic.csv", "_traffic.json", "_l2_hit_rate.csv"):
             if os.path.exists(pre + suf):
                 os.remove(pre + suf)
