@@ -395,7 +395,8 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world,
                        # opt-in developer switches in effect for this line (none = the default, judged configuration)
                        "dev_switches": {k: os.environ[k] for k in ("FDMI_TUNE", "FDMI_TEACHER_LOOP", "FDMI_CFG_DEDUP",
-                                                                   "FDMI_NO_CTX_CACHE") if os.environ.get(k)}},
+                                                                   "FDMI_NO_CTX_CACHE", "FDMI_TEACHER_STREAM",
+                                                                   "FDMI_DEFER_BACKWARD") if os.environ.get(k)}},
             "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler, "two_optimizer_step": two_opt},
         }
         print(json.dumps(line))

@@ -9,13 +9,16 @@
     all-reduces from Lightning's DDP strategy, examples/train_flash_sd.py:386).  Because the teacher is
     frozen, the all-reduce + AdamW of iteration i run on a side stream concurrently with the teacher
     loop of iteration i+1; the student forward waits on that stream (FlashDiffusion.before_student);
-  * deferred backward (single-optimizer mode without a discriminator, GPU only; A/B switch FDMI_DEFER_BACKWARD=0): the
-    student's backward + all-reduce + AdamW of iteration i are ISSUED from the before_student hook of iteration i+1, i.e.
-    after that iteration's teacher loop has been handed to its side stream and before its student forward.  The teacher
-    is frozen and reads nothing the backward writes, so its 2B-row kernels run beside the backward's many small launches
-    (rank-r LoRA products, split-K tails, deep UNet levels) instead of after them; the order of every read and write of
-    the trainable tensors is the reference's (backward i, step i, forward i+1).  finish() -- and every reader of the
-    parameters on this class -- drains the outstanding backward.
+  * deferred backward (GPU only; A/B switch FDMI_DEFER_BACKWARD=0): the backward + all-reduce + AdamW of a forward are
+    ISSUED from the before_student hook of the NEXT forward (the next iteration's, or -- with several optimizers -- the
+    next optimizer's forward of the same batch), i.e. after that forward's teacher loop has been handed to its side
+    stream and before its student call.  The teacher is frozen and reads nothing the backward writes, so its 2B-row
+    kernels run beside the backward's many small launches (rank-r LoRA products, split-K tails, deep UNet levels)
+    instead of after them; the order of every read and write of the trainable tensors is the reference's (backward i,
+    step i, forward i+1).  With a discriminator the generator loss also back-propagates through the frozen teacher's
+    plan (GAN backbone) while the next teacher loop runs on it: the two runs live in different slots of the plan (own
+    workspace, own statistics pool; a SAVE run never touches the plan-owned context K/V cache), so they share only
+    read-only weights.  finish() -- and every reader of the parameters on this class -- drains the outstanding backward.
 AdamW itself is the fused HIP kernel fdmi_adamw (torch.optim.AdamW semantics)."""
 from __future__ import annotations
 
@@ -218,25 +221,29 @@ class TrainingPipeline(nn.Module):
             self._pending = None
 
     def _defer_ok(self):
-        """backward of this iteration may wait for the next iteration's hook: GPU, overlap on, a model that calls the hook
-        right before its student forward, and no discriminator (the GAN generator term back-propagates through the frozen
-        teacher's plan, which the next teacher loop is already using on the side stream)"""
+        """the backward of a forward may wait for the next forward's hook: GPU, overlap on, a model that calls the hook
+        right before its student call"""
         return (self._comm_stream is not None and getattr(self.model, "calls_before_student", False)
-                and getattr(self.model, "discriminator", None) is None and not getattr(self.model, "use_adversarial_loss", False)
                 and os.environ.get("FDMI_DEFER_BACKWARD", "1") == "1")
 
-    def _backward_and_step(self, loss, i):
+    def _backward_and_step(self, loss, i, manual=False):
         opt = self.optims[i]
+        if manual:   # TR:199-216: only optimizer i's parameters accumulate during its backward
+            self._toggle(i)
         # zero_grad may only run once the deferred step has consumed the previous gradients
         self._zero_grad(opt)
-        loss.backward()
-        self._reduce_and_step(opt)
-        self._lr_step(i, "step")
+        if torch.is_tensor(loss) and loss.requires_grad:
+            loss.backward()
+            self._reduce_and_step(opt)
+        if manual:
+            self._untoggle()
+        else:
+            self._lr_step(i, "step")
 
     def _run_deferred(self):
         if self._deferred is not None:
-            (loss, i), self._deferred = self._deferred, None
-            self._backward_and_step(loss, i)
+            (loss, i, manual), self._deferred = self._deferred, None
+            self._backward_and_step(loss, i, manual)
 
     def _before_student(self):
         self._run_deferred()
@@ -293,24 +300,24 @@ class TrainingPipeline(nn.Module):
             self._run_deferred()                                # (a forward that never reached the hook)
             loss = out["loss"][0] if isinstance(out["loss"], (list, tuple)) else out["loss"]
             if self._defer_ok():
-                self._deferred = (loss, 0)
+                self._deferred = (loss, 0, False)
             else:
                 self._backward_and_step(loss, 0)
             return {"loss": loss.detach(), "batch_idx": batch_idx, "start_timestep": out.get("start_timestep")}
-        self._run_deferred()
         outputs = {"batch_idx": batch_idx}
         for i, opt in enumerate(self.optims):
+            # (the forward's before_student hook issues the previous forward's backward: optimizer i-1's, or the last
+            # optimizer's of the previous batch -- before anything of this forward reads a trainable parameter)
             model_output = self.model(train_batch, device=self.device, step=i, batch_idx=batch_idx)
+            self._run_deferred()                                # (a forward that never reached the hook)
             loss = model_output["loss"]
             if "start_timestep" in model_output:
                 outputs["start_timestep"] = model_output["start_timestep"]
             outputs[f"loss_optimizer_{i}"] = loss[i].detach() if torch.is_tensor(loss[i]) else loss[i]
-            self._toggle(i)
-            self._zero_grad(opt)
-            if torch.is_tensor(loss[i]) and loss[i].requires_grad:
-                loss[i].backward()
-                self._reduce_and_step(opt)
-            self._untoggle()
+            if self._defer_ok() and torch.is_tensor(loss[i]) and loss[i].requires_grad:
+                self._deferred = (loss[i], i, True)
+            else:
+                self._backward_and_step(loss[i], i, manual=True)
         return outputs
 
     def _toggle(self, i):

@@ -144,3 +144,49 @@ def test_reference_invariants_optimizers(distill_scale):
     stu = changed("student_denoiser.")
     assert stu and all(".lora_" in k for k in stu), "only LoRA tensors of the student may change"
     assert changed("discriminator."), "discriminator must be updated by the D-step"
+
+
+@pytest.mark.parametrize("optimizers", [1, 2])
+def test_deferred_backward_equals_the_immediate_schedule(optimizers):
+    """trainer.py's deferred backward (each forward's backward + AdamW issued from the NEXT forward's before_student hook,
+    beside that forward's teacher loop on its side stream): 3 batches with DMD + a GAN term -- the generator loss back-propagates
+    through the frozen teacher's plan while the next teacher loop runs on the same plan -- end at the parameters of the immediate
+    schedule (FDMI_DEFER_BACKWARD=0).  The step is not bit-reproducible (float atomics in GroupNorm sums and weight gradients; AdamW
+    turns a sign flip of a near-zero gradient into a +-lr move), so the yardstick is the distance between two immediate runs."""
+    import os
+    from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
+    kw = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="gaussian", gan_loss_type="lsgan", use_dmd_loss=True)
+
+    def run(defer):
+        os.environ["FDMI_DEFER_BACKWARD"] = "1" if defer else "0"
+        try:
+            torch.manual_seed(0)
+            m = build_product(kw)
+            m.fixed_start_idx = 1
+            names = ["AdamW", "AdamW"][:optimizers]
+            pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=names, learning_rates=[1e-3, 1e-3][:optimizers],
+                                                      trainable_params=[["student_denoiser"], ["discriminator."]][:optimizers]))
+            pipe.configure_optimizers()
+            for i in range(3):
+                g = torch.Generator().manual_seed(100 + i)
+                batch = {"image": torch.randn(2, 4, 32, 32, generator=g).cuda(), "crossattn": torch.randn(2, 77, 64, generator=g).cuda(),
+                         "text": ["x", "y"]}
+                torch.manual_seed(1000 + i)   # the step's own draws (noise, DMD / GAN timesteps)
+                pipe.training_step(batch, i)
+                assert (pipe._deferred is not None) == defer
+            pipe.finish()
+            assert pipe._deferred is None
+            sd = m.state_dict()
+            return {k: v.detach().double().cpu().clone() for k, v in sd.items() if ".lora_" in k or k.startswith("discriminator.")}
+        finally:
+            os.environ.pop("FDMI_DEFER_BACKWARD", None)
+
+    a, a2, b = run(False), run(False), run(True)
+    dist = lambda x, y: max(float((x[k] - y[k]).abs().max()) for k in x)
+    moved = max(float(v.abs().max()) for v in a.values())
+    noise = dist(a, a2)
+    assert all(torch.isfinite(v).all() for v in b.values()) and moved > 0
+    # (a run without a single sign flip between a and a2 must not make one flip in b a failure: then the bulk decides)
+    n_all = sum(v.numel() for v in a.values())
+    n_off = sum(int(((a[k] - b[k]).abs() > 1e-5).sum()) for k in a)
+    assert dist(a, b) <= 3 * noise + 1e-6 or n_off <= 0.005 * n_all, (dist(a, b), noise, n_off, n_all)

@@ -312,3 +312,52 @@ def test_deferred_backward_is_the_same_training_run():
         assert not pipe._defer_ok()
     finally:
         del os.environ["FDMI_DEFER_BACKWARD"]
+
+
+class _ToyHook2(_ToyHook):
+    """+ a discriminator and the reference's step-selected losses: loss[0] (generator: distillation + a term through the
+    discriminator) at step 0, loss[1] (discriminator) at step 1"""
+
+    def __init__(self):
+        super().__init__()
+        self.discriminator = nn.Sequential(nn.Linear(4, 1))
+
+    def forward(self, batch, step=0, **kw):
+        t = self.teacher_denoiser(batch["x"]).detach()
+        hook = getattr(self, "before_student", None)
+        if hook is not None:
+            hook()
+        s = self.student_denoiser(batch["x"])
+        if step % 2 == 0:
+            return {"loss": [((s - t) ** 2).mean() - self.discriminator(s).mean(), 0], "start_timestep": 1}
+        return {"loss": [0, self.discriminator(s.detach()).mean() - self.discriminator(t).mean()], "start_timestep": 1}
+
+
+def test_deferred_backward_two_optimizers_is_the_same_training_run():
+    """manual (two-optimizer) loop: each forward's backward issued from the NEXT forward's hook, with the optimizer toggle applied
+    around it -- same parameters (student and discriminator) as the immediate schedule after 3 batches, bit for bit; the
+    generator's backward leaves the discriminator's gradients untouched"""
+    xs = [torch.randn(8, 4, generator=torch.Generator().manual_seed(10 + i)) for i in range(3)]
+
+    def train(defer):
+        torch.manual_seed(0)
+        m = _ToyHook2()
+        pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-2, 3e-2],
+                                                  trainable_params=[["student_denoiser"], ["discriminator."]]), overlap=False)
+        pipe.configure_optimizers()
+        assert not pipe.automatic_optimization
+        if defer:
+            pipe._comm_stream = object()
+            m.before_student = pipe._before_student
+        for i, x in enumerate(xs):
+            out = pipe.training_step({"x": x}, i)
+            assert "loss_optimizer_0" in out and "loss_optimizer_1" in out
+            assert (pipe._deferred is not None) == defer
+        pipe.finish()
+        assert pipe._deferred is None and not pipe._toggled
+        assert all(p.requires_grad for p in m.discriminator.parameters())
+        return {k: v.clone() for k, v in m.state_dict().items()}
+
+    a, b = train(False), train(True)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert any(k.startswith("discriminator") for k in a)
