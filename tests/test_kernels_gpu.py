@@ -257,6 +257,8 @@ ATTN = [
     (2, 2, 64, 64, 16), (1, 2, 128, 128, 32), (2, 8, 256, 256, 40), (1, 3, 100, 100, 64), (2, 8, 256, 77, 40),
     (1, 8, 64, 77, 160), (1, 8, 256, 256, 80), (1, 2, 1024, 1024, 40), (1, 4, 200, 120, 72), (1, 2, 64, 64, 160),
     (1, 2, 130, 70, 8),
+    # the software-pipelined forward (d in 33..64): one tile, one ragged tile, odd / even tile counts, ragged last tile
+    (1, 2, 64, 64, 40), (1, 2, 96, 50, 64), (1, 4, 128, 192, 40), (1, 2, 70, 150, 64), (1, 2, 128, 320, 40), (1, 2, 200, 448, 56),
 ]
 
 
