@@ -259,6 +259,10 @@ ATTN = [
     (1, 2, 130, 70, 8),
     # the software-pipelined forward (d in 33..64): one tile, one ragged tile, odd / even tile counts, ragged last tile
     (1, 2, 64, 64, 40), (1, 2, 96, 50, 64), (1, 4, 128, 192, 40), (1, 2, 70, 150, 64), (1, 2, 128, 320, 40), (1, 2, 200, 448, 56),
+    # whole tiles at every (padded head dim, ones-row) instantiation of the forward: the exits of its tile loop (round 2: the
+    # compiler placed accumulator copies right behind the last asynchronous MFMAs for head dims 56 and 64)
+    (1, 2, 128, 128, 64), (1, 2, 256, 192, 64), (1, 2, 64, 1024, 64), (1, 2, 128, 128, 56), (2, 4, 128, 256, 48), (1, 2, 128, 256, 24),
+    (1, 2, 128, 192, 96), (1, 2, 128, 192, 88), (1, 2, 64, 192, 128), (1, 2, 64, 128, 120), (1, 2, 64, 192, 160), (1, 2, 64, 128, 16),
 ]
 
 
