@@ -229,4 +229,6 @@ def test_two_saved_forwards_and_a_stale_graph_keep_their_slots():
     b = m(xs[1], t.cuda(), c)            # must NOT be given a's slot
     (a.square().mean() + b.square().mean()).backward()
     both = grads()
-    assert rel_err(both, sep[0] + sep[1]) < 2e-2, rel_err(both, sep[0] + sep[1])
+    # bf16 activations + fp32 atomics: the joint and the two separate backward passes differ by ~2e-2 (2.0e-2 measured, run to
+    # run); a slot handed out twice overwrites saved activations and gives an error of order one
+    assert rel_err(both, sep[0] + sep[1]) < 4e-2, rel_err(both, sep[0] + sep[1])
