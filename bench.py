@@ -393,7 +393,7 @@ def main():
                                    f"{args.hw}x{args.hw} latents, {args.teacher_steps} teacher CFG steps (K={args.teacher_steps}, "
                                    "start_idx=0), l2 distill, generator iteration fwd+bwd+fused AdamW",
                        "global_batch": B * world, "parallelism": f"dp{world}", "images_per_sec_per_gpu": value / world,
-                       # opt-in developer switches in effect for this line (none = the default, judged configuration)
+                       # developer / A-B switches in effect for this line (none = the default, judged configuration)
                        "dev_switches": {k: os.environ[k] for k in ("FDMI_TUNE", "FDMI_TEACHER_LOOP", "FDMI_CFG_DEDUP",
                                                                    "FDMI_NO_CTX_CACHE", "FDMI_TEACHER_STREAM",
                                                                    "FDMI_DEFER_BACKWARD") if os.environ.get(k)}},

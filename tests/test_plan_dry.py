@@ -88,7 +88,7 @@ def test_odd_batch_ignores_cfg_halves_and_bad_sizes_fail():
     assert _query(plan, 3, 32, 77, FDMI_UNET_CFG_HALVES)[1] == _query(plan, 3, 32, 77, 0)[1]
 
 
-# ---- GroupNorm statistics in the producing GEMM's epilogue (developer knob 14; GPU numerics in tests/test_zz_dit_gpu.py) ----
+# ---- GroupNorm statistics in the producing GEMM's epilogue (default; A/B switch 14 turns it off; GPU numerics in tests/test_zz_dit_gpu.py) ----
 def _gn_plan(B, H, Ci, Co, kind):
     import ctypes as C
     from flash_diffusion_amd import ops
