@@ -239,6 +239,15 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
     for (int df = 0; df < DF; ++df) acc_o[df][f] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  // The zeros are materialised HERE: left alone, hipcc sinks each accumulator's `v_mov` to just in front of the first inline-asm
+  // MFMA that takes it as C -- with one wait state in the d = 40 instantiation and none in the 64 x 64 ones-row one (head dims
+  // 49..63: the first query fragment's denominators came out ~5 % low), and a VALU write needs two before an MFMA reads it
+  // (scripts/asm_hazard_audit.py finds these statically; guide section 5.7 item 2).
+#pragma unroll
+  for (int f = 0; f < QF; ++f)
+#pragma unroll
+    for (int df = 0; df < DF; ++df) pv_pin(acc_o[df][f]);
+  asm volatile("s_nop 1");
 
   // one KV tile for query fragments [f0, f0+QP); TAIL masks keys >= Skv (last tile only)
   // DMA layout: this lane's swizzled fragment offsets inside a tile (loop invariant; fragments 16 rows = 2048 B apart)
@@ -870,10 +879,7 @@ int fwd_t(const AttnArgs& a, hipStream_t st) {
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
-  // denominator from the ones row of V^T -- not for the 64 x 64 tile pair (head dims 49..63): that instantiation returned the
-  // first query fragment's denominators ~5 % low (round 2, tests at d = 56; not root-caused, no model of the reference has such a
-  // head dim), so those heads take the VALU row sum like d = 64 does
-  const bool ones = a.vt_ones && a.d < DV && !(DK == 64 && DV == 64);
+  const bool ones = a.vt_ones && a.d < DV;
   if constexpr (CAN_DMA) {
     if (dma) {
       if (ones) FDMI_KLAUNCH(prof, (attn_fwd_kernel<DK, DV, NF, true, true>), grid, dim3(256), smem, st, a);
