@@ -316,6 +316,11 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
           float o[4];
 #pragma unroll
           for (int r = 0; r < 4; ++r) o[r] = val[r] * gelu_f(gate[r]);
+          if (a.residual) {   // (as epi_store8 does for the 8-wide pairs of the same tile; `wide`: ldr % 8 == 0)
+            const u16x4 t = *(const u16x4*)(a.residual + m * a.ldr + no);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += bf2f(t[r]);
+          }
           if (a.out_f32) {
             *(float4*)((float*)a.C + m * a.ldc + no) = make_float4(o[0], o[1], o[2], o[3]);
           } else {

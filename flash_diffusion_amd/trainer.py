@@ -59,18 +59,35 @@ class TrainingConfig:
             self.trainable_params = [[".*"] for _ in self.optimizers_name]
         assert len(self.optimizers_name) == len(self.trainable_params)
         assert len(self.optimizers_name) == len(self.learning_rates)
-        # training_config.py:96-136: one scheduler entry per optimizer, defaults broadcast
-        n = len(self.optimizers_name)
-        if self.lr_schedulers_name == [None]:
-            self.lr_schedulers_name = [None] * n
-        if self.lr_schedulers_kwargs == [{}]:
+        # training_config.py:108-131: the scheduler lists are sized by len(lr_schedulers_name) -- NOT by the optimizer count
+        # (a 2-optimizer config with lr_schedulers_name=["StepLR"] is valid upstream: only optimizer 0 gets a scheduler);
+        # defaults are recognised by VALUE as upstream does (`!= [{}]`, `!= [1]`, `!= ["step"]`) and broadcast to that length
+        n = len(self.lr_schedulers_name)
+        if self.lr_schedulers_kwargs != [{}]:
+            assert n == len(self.lr_schedulers_kwargs), (
+                f"The length of lr_schedulers_name ({n}) must be equal to the length of lr_schedulers_kwargs "
+                f"({len(self.lr_schedulers_kwargs)})")
+            if self.lr_schedulers_frequency != [1]:
+                assert n == len(self.lr_schedulers_frequency), (
+                    f"The length of lr_schedulers_name ({n}) must be equal to the length of lr_schedulers_frequency "
+                    f"({len(self.lr_schedulers_frequency)})")
+            else:
+                self.lr_schedulers_frequency = [1 for _ in range(n)]
+            if self.lr_schedulers_interval != ["step"]:
+                assert n == len(self.lr_schedulers_interval), (
+                    f"The length of lr_schedulers_name ({n}) must be equal to the length of lr_schedulers_interval "
+                    f"({len(self.lr_schedulers_interval)})")
+            else:
+                self.lr_schedulers_interval = ["step" for _ in range(n)]
+        else:
             self.lr_schedulers_kwargs = [{} for _ in range(n)]
-        if self.lr_schedulers_interval == ["step"]:
-            self.lr_schedulers_interval = ["step"] * n
-        if self.lr_schedulers_frequency == [1]:
-            self.lr_schedulers_frequency = [1] * n
-        for f in (self.lr_schedulers_name, self.lr_schedulers_kwargs, self.lr_schedulers_interval, self.lr_schedulers_frequency):
-            assert len(f) == n, "one lr-scheduler entry per optimizer"
+            # (upstream leaves frequency / interval at their one-entry defaults on this branch and would raise IndexError for
+            # a second named scheduler without kwargs; broadcasting them is the one deliberate superset here)
+            if len(self.lr_schedulers_frequency) < n:
+                self.lr_schedulers_frequency = list(self.lr_schedulers_frequency) + [1] * (n - len(self.lr_schedulers_frequency))
+            if len(self.lr_schedulers_interval) < n:
+                self.lr_schedulers_interval = list(self.lr_schedulers_interval) + ["step"] * (n - len(self.lr_schedulers_interval))
+        assert n <= len(self.optimizers_name), "more lr schedulers than optimizers (TR:140-166 indexes self.optims[i])"
 
 
 class FusedAdamW(torch.optim.Optimizer):
@@ -90,6 +107,24 @@ class FusedAdamW(torch.optim.Optimizer):
         self.grad_scale = 1.0
         self._flat_state = None
         self.step_count = 0
+
+    def state_dict(self):
+        sd = super().state_dict()   # (TrainingPipeline's pre-hook has drained a deferred step by now)
+        # the moments of the flat (LoRA) buffer live outside torch's per-parameter state
+        if self._flat_state is not None:
+            sd["flat_state"] = {"m": self._flat_state[0], "v": self._flat_state[1], "step_count": self.step_count}
+        else:
+            sd["flat_state"] = {"step_count": self.step_count}
+        return sd
+
+    def load_state_dict(self, sd):
+        sd = dict(sd)
+        fs = sd.pop("flat_state", None)
+        super().load_state_dict(sd)
+        if fs is not None:
+            self.step_count = int(fs.get("step_count", 0))
+            if "m" in fs and self.flat is not None:
+                self._flat_state = (fs["m"].to(self.flat).clone(), fs["v"].to(self.flat).clone())
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -166,6 +201,8 @@ class TrainingPipeline(nn.Module):
         if len(optimizers) > 1:
             self.automatic_optimization = False
         self.optims = optimizers
+        for opt in optimizers:   # optimizer.state_dict() (checkpoint callbacks) first drains a deferred backward / step
+            opt.register_state_dict_pre_hook(lambda optimizer: self.drain())
         self.lr_schedulers = self.configure_lr_schedulers()
         for pname, p in self.model.named_parameters():
             keep = any(re.match(re.compile(rx), pname) for rxs in cfg.trainable_params for rx in rxs) and p.requires_grad
@@ -176,6 +213,10 @@ class TrainingPipeline(nn.Module):
         if self.overlap and torch.cuda.is_available():
             self._comm_stream = torch.cuda.Stream()
             self.model.before_student = self._before_student
+        # readers that bypass this class (pipe.model.state_dict(), EMA / checkpoint callbacks walking the model) must not
+        # see parameters one optimizer step stale: drain before the model serialises itself
+        if not getattr(self, "_sd_hook", None):
+            self._sd_hook = self.model.register_state_dict_pre_hook(lambda module, prefix, keep_vars: self.drain())
         if any(sc is not None for sc in self.lr_schedulers):
             return optimizers, [sc for sc in self.lr_schedulers]
         return optimizers
@@ -208,11 +249,23 @@ class TrainingPipeline(nn.Module):
             sc["scheduler"].step()
 
     def on_train_epoch_end(self):
+        # the last training_step's backward + optimizer step may still be deferred: it must run with THIS epoch's lr, as in
+        # the immediate schedule and in the reference (Lightning steps epoch-interval schedulers after the last optimizer step)
+        self.drain()
         for i in range(len(self.optims)):
             self._lr_step(i, "epoch")
 
     def optimizers(self):
+        """Lightning's accessor.  A caller that reads optimizer state (checkpointing) must see the step of the last
+        training_step: drain the deferred backward first."""
+        self.drain()
         return self.optims
+
+    def drain(self):
+        """Issue the deferred backward + optimizer step (if any) and make the current stream wait for it -- without a device
+        synchronisation.  Every reader of trainable parameters / optimizer state outside training_step goes through here."""
+        self._run_deferred()
+        self._wait_pending()
 
     # ---- gradient exchange + optimizer step ---------------------------------------------------------
     def _wait_pending(self):

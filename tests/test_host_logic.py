@@ -361,3 +361,76 @@ def test_deferred_backward_two_optimizers_is_the_same_training_run():
     a, b = train(False), train(True)
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert any(k.startswith("discriminator") for k in a)
+
+
+def test_epoch_interval_scheduler_steps_after_the_deferred_optimizer_step():
+    """with the deferred backward the last optimizer step of an epoch is still outstanding when
+    on_train_epoch_end() runs -- it must be issued with THIS epoch's lr before an interval="epoch" scheduler advances, and
+    readers that bypass the pipeline (optimizers(), optimizer.state_dict(), model.state_dict()) must drain it as well:
+    parameters, lr trajectory and optimizer state equal the immediate schedule bit for bit."""
+    xs = [torch.randn(8, 4, generator=torch.Generator().manual_seed(40 + i)) for i in range(6)]
+
+    def train(defer, reader):
+        torch.manual_seed(0)
+        m = _ToyHook()
+        pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-1],
+                                                  lr_schedulers_name=["StepLR"], lr_schedulers_kwargs=[{"step_size": 1, "gamma": 0.1}],
+                                                  lr_schedulers_interval=["epoch"], trainable_params=[["student_denoiser"]]),
+                                overlap=False)
+        pipe.configure_optimizers()
+        if defer:
+            pipe._comm_stream = object()
+            m.before_student = pipe._before_student
+        lrs, seen = [], None
+        for epoch in range(2):
+            for i in range(3):
+                pipe.training_step({"x": xs[epoch * 3 + i]}, i)
+                lrs.append(pipe.optims[0].param_groups[0]["lr"])
+            if epoch == 0:
+                assert (pipe._deferred is not None) == defer
+            pipe.on_train_epoch_end()
+            assert pipe._deferred is None                   # drained BEFORE the scheduler moved the lr
+        pipe.training_step({"x": xs[0]}, 0)
+        if reader == "optimizers":
+            seen = pipe.optimizers()[0].state_dict()
+        elif reader == "opt_state":
+            seen = pipe.optims[0].state_dict()
+        else:
+            seen = m.state_dict()
+        assert pipe._deferred is None
+        return {k: v.clone() for k, v in m.state_dict().items()}, lrs, seen
+
+    for reader in ("optimizers", "opt_state", "model_state"):
+        (a, la, sa), (b, lb, sb) = train(False, reader), train(True, reader)
+        assert la == lb and all(torch.equal(a[k], b[k]) for k in a), reader
+        if reader != "model_state":
+            ea, eb = sa["state"], sb["state"]      # (torch.optim.AdamW on this CPU box: exp_avg / exp_avg_sq / step)
+            assert ea.keys() == eb.keys() and len(ea) > 0, reader
+            for k in ea:
+                assert all(torch.equal(torch.as_tensor(ea[k][n]), torch.as_tensor(eb[k][n])) for n in ea[k]), reader
+                assert float(ea[k]["step"]) == 7.0
+
+
+def test_scheduler_lists_are_sized_by_lr_schedulers_name_like_the_reference():
+    """training_config.py:108-131 sizes the scheduler lists by len(lr_schedulers_name), TR:140-166 iterates
+    over that: two optimizers with ONE named scheduler is a valid reference config (optimizer 1 gets none)."""
+    cfg = TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-2, 1e-2],
+                         trainable_params=[["student_denoiser"], ["discriminator."]],
+                         lr_schedulers_name=["StepLR"], lr_schedulers_kwargs=[dict(step_size=1, gamma=0.5)])
+    assert cfg.lr_schedulers_interval == ["step"] and cfg.lr_schedulers_frequency == [1]
+    pipe = TrainingPipeline(_ToyHook2(), cfg, overlap=False)
+    pipe.configure_optimizers()
+    assert len(pipe.lr_schedulers) == 1 and pipe.lr_schedulers[0]["scheduler"].optimizer is pipe.optims[0]
+    pipe.training_step({"x": torch.randn(8, 4)}, 0)        # the manual loop: index 1 has no scheduler entry
+    pipe.on_train_epoch_end()
+    # mismatched explicit lists are refused with the reference's message
+    with pytest.raises(AssertionError, match="lr_schedulers_kwargs"):
+        TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-2], lr_schedulers_name=["StepLR", None],
+                       lr_schedulers_kwargs=[dict(step_size=1)])
+    with pytest.raises(AssertionError, match="lr_schedulers_frequency"):
+        TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-2, 1e-2], lr_schedulers_name=["StepLR", None],
+                       lr_schedulers_kwargs=[dict(step_size=1), {}], lr_schedulers_frequency=[2])
+    # explicit values equal to nothing special are kept as given (no silent broadcast of a user's [2])
+    c2 = TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-2, 1e-2], lr_schedulers_name=["StepLR", "StepLR"],
+                        lr_schedulers_kwargs=[dict(step_size=1), dict(step_size=2)], lr_schedulers_frequency=[2, 3])
+    assert c2.lr_schedulers_frequency == [2, 3] and c2.lr_schedulers_interval == ["step", "step"]

@@ -429,6 +429,24 @@ def test_gemm4_geglu():
     close("gemm4_geglu_preact", pre, h[:, perm])
 
 
+@pytest.mark.parametrize("Fh", [320, 640])
+def test_gemm4_geglu_with_residual(Fh):
+    """GEGLU + residual on the 256 x 320 tile (N = 2 Fh = 640 / 1280: NF = 10 fragments per wave, the odd (value,
+    gate) pair q = 4 takes the 4-column path) -- every output column carries the residual"""
+    ops = _ops()
+    M, K = 512, 128
+    A = b16(rnd(M, K, seed=1))
+    W = b16(rnd(2 * Fh, K, seed=2, scale=K ** -0.5))
+    bias = rnd(2 * Fh, seed=3)
+    res = b16(rnd(M, Fh, seed=4, scale=3.0))
+    perm = ops.geglu_perm(Fh)
+    h = A.float() @ W.float().t() + bias
+    ref = h[:, :Fh] * F.gelu(h[:, Fh:]) + res.float()
+    out = ops.gemm(A.cuda(), W[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), act=ops.ACT_GEGLU,
+                   residual=res.cuda(), force_tile=T4)
+    close(f"gemm4_geglu_residual{Fh}", out, ref)
+
+
 def test_gemm4_many_items_per_block():
     """more (tile, split) items than CUs: the persistent loop crosses item boundaries with tiles in flight"""
     ops = _ops()
