@@ -133,6 +133,18 @@ class TensorConditioner(nn.Module):
 
 
 # ----------------------------------------------------------------------------------------------------
+def _tensors_of(obj):
+    """every tensor inside nested dicts / lists / tuples"""
+    if torch.is_tensor(obj):
+        yield obj
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            yield from _tensors_of(v)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            yield from _tensors_of(v)
+
+
 class _PerSampleAffine(torch.autograd.Function):
     """out[b] = ca[b] * x[b] + cb[b] * eps[b]  (fused; gradient flows to eps only)."""
 
@@ -571,28 +583,39 @@ class FlashDiffusion(nn.Module):
         # student that under-fill the chip (deep UNet levels, rank-r LoRA GEMMs) run beside the teacher's 2B-row kernels instead
         # of after them; the streams join before the first loss that needs both.  (A/B switch: FDMI_TEACHER_STREAM=0.)
         side = self._teacher_stream(z) if os.environ.get("FDMI_TEACHER_STREAM", "1") == "1" else None
+        cur = torch.cuda.current_stream() if side is not None else None
         if side is not None:
-            cur = torch.cuda.current_stream()
             side.wait_stream(cur)
-            with torch.cuda.stream(side):
+            # tensors allocated on the current stream and read by the side stream: the caching allocator must not hand their
+            # blocks to a later current-stream allocation before the side stream is done with them
+            for t_ in _tensors_of((x_init, conditioning, uncond, res)):
+                if t_.is_cuda:
+                    t_.record_stream(side)
+        try:
+            if side is not None:
+                with torch.cuda.stream(side):
+                    teacher_output = run_teacher()
+            else:
                 teacher_output = run_teacher()
-        else:
-            teacher_output = run_teacher()
 
-        # ---- student: one step with grad (FD:255-280, 328) ----
-        hook = getattr(self, "before_student", None)
-        if hook is not None:
-            hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
-        eps_s = self.student_denoiser(sample=x_in, timestep=start_t, conditioning=student_conditioning,
-                                      down_intrablock_additional_residuals=res)
-        c_skip, c_out = self._scalings_for_boundary_conditions(start_t.float())
-        inv_a, ms_a = self._x0_coeffs(start_t.long())
-        # student_output = c_skip x + c_out (x - sigma eps)/alpha
-        ca = (c_skip + c_out * inv_a).float().contiguous()
-        cb = (c_out * ms_a).float().contiguous()
-        student_output = _PerSampleAffine.apply(eps_s, x_init, ca, cb)
-        if side is not None:   # join: everything below reads the teacher's result on the current stream
-            cur.wait_stream(side)
+            # ---- student: one step with grad (FD:255-280, 328) ----
+            hook = getattr(self, "before_student", None)
+            if hook is not None:
+                hook()  # data-parallel trainer: wait for the deferred all-reduce + AdamW of the previous step
+            eps_s = self.student_denoiser(sample=x_in, timestep=start_t, conditioning=student_conditioning,
+                                          down_intrablock_additional_residuals=res)
+            c_skip, c_out = self._scalings_for_boundary_conditions(start_t.float())
+            inv_a, ms_a = self._x0_coeffs(start_t.long())
+            # student_output = c_skip x + c_out (x - sigma eps)/alpha
+            ca = (c_skip + c_out * inv_a).float().contiguous()
+            cb = (c_out * ms_a).float().contiguous()
+            student_output = _PerSampleAffine.apply(eps_s, x_init, ca, cb)
+        finally:
+            # join -- also when the student raised: the teacher's plan slot / workspace may not be reused (a later no-grad
+            # teacher call of the DMD / GAN branches, the next forward) while the side stream still runs in it
+            if side is not None:
+                cur.wait_stream(side)
+        if side is not None:   # everything below reads the teacher's result on the current stream
             teacher_output.record_stream(cur)
 
         l_distill = self._distill_loss(student_output, teacher_output)

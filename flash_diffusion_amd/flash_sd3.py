@@ -27,7 +27,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .flash import Draws, FlashDiffusion, _DistillLoss, _DmdLoss, _PerSampleAffine, gaussian_mixture_pmf
+from .flash import Draws, FlashDiffusion, _DistillLoss, _DmdLoss, _PerSampleAffine, _tensors_of, gaussian_mixture_pmf
 
 
 # the reference's fixed unconditional prompt (FD3:207-209 in forward, 726-728 in sample): a value of its recipe, not code
@@ -383,10 +383,15 @@ class FlashDiffusionSD3(nn.Module):
         else:
             cur = torch.cuda.current_stream()
             side.wait_stream(cur)
-            student_output = run_student()
-            with torch.cuda.stream(side):
-                teacher_output = run_teacher()
-            cur.wait_stream(side)
+            for t_ in _tensors_of((x_init, cond, uncond)):   # read on the side stream, allocated on the current one
+                if t_.is_cuda:
+                    t_.record_stream(side)
+            try:
+                student_output = run_student()
+                with torch.cuda.stream(side):
+                    teacher_output = run_teacher()
+            finally:
+                cur.wait_stream(side)   # (also on an exception: nothing may reuse the teacher's buffers under the side stream)
             teacher_output.record_stream(cur)
         if self.distill_loss_type == "lpips":     # FD3:391-411 (clamped crop bounds); the caller's VAE / LPIPS torch modules
             so, to = student_output, teacher_output.detach()

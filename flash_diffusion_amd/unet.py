@@ -135,6 +135,23 @@ class _Plan:
         self.next_slot = 1
         self.busy = set()
         self.gen: Dict[int, int] = {}   # per-slot generation: a stale finalizer / backward must not free a re-acquired slot
+        self.last_use: Dict[int, tuple] = {}   # slot -> (stream, event after its last launch): cross-stream reuse waits on it
+
+    def enter(self, slot):
+        """A run slot (workspace + tape + statistics pool) is used from one stream at a time.  The teacher loop runs slot 0 on a
+        side stream while no-grad calls of the DMD / GAN branches use the same slot from the caller's stream after the join:
+        instead of relying on every caller to have joined, a use from a DIFFERENT stream than the previous one first waits for
+        an event recorded behind that previous use (same-stream reuse is ordered by the stream itself: no event wait)."""
+        cur = torch.cuda.current_stream()
+        last = self.last_use.get(slot)
+        if last is not None and last[0] != cur:
+            cur.wait_event(last[1])
+
+    def leave(self, slot):
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self.last_use[slot] = (cur, ev)
 
     def release(self, slot, gen):
         if self.gen.get(slot) == gen:
@@ -502,8 +519,12 @@ class MiUNet2DConditionModel(nn.Module):
         if res is not None:
             arr = (C.c_void_p * len(res))(*[r.data_ptr() for r in res])
             check(L.fdmi_unet_set_down_residuals(plan.handle, arr, len(res), 1.0))
-        check(L.fdmi_unet_forward(plan.handle, slot, ptr(sample), ptr(t), ptr(enc), ptr(vec), ptr(out), B, H, W, Lc,
-                                  ptr(ws), ws.numel(), flags, stream_ptr()))
+        plan.enter(slot)
+        try:
+            check(L.fdmi_unet_forward(plan.handle, slot, ptr(sample), ptr(t), ptr(enc), ptr(vec), ptr(out), B, H, W, Lc,
+                                      ptr(ws), ws.numel(), flags, stream_ptr()))
+        finally:
+            plan.leave(slot)
         self.last_flops = L.fdmi_unet_last_flops(plan.handle)
         self.step_flops += self.last_flops
         return out, slot
@@ -540,8 +561,12 @@ class MiUNet2DConditionModel(nn.Module):
             plan.workspaces["teacher_loop"] = sc
         ts = (C.c_float * n)(*[float(t) for t in timesteps])
         cf = (C.c_float * (6 * n))(*[float(v) for r in coeffs for v in r])
-        check(L.fdmi_teacher_loop(plan.handle, 0, ptr(x), ts, n, ptr(enc), ptr(vec), cf, B, H, W, Lc, ptr(ws), ws.numel(),
-                                  ptr(sc), sc.numel(), stream_ptr()))
+        plan.enter(0)
+        try:
+            check(L.fdmi_teacher_loop(plan.handle, 0, ptr(x), ts, n, ptr(enc), ptr(vec), cf, B, H, W, Lc, ptr(ws), ws.numel(),
+                                      ptr(sc), sc.numel(), stream_ptr()))
+        finally:
+            plan.leave(0)
         self.last_flops = L.fdmi_unet_last_flops(plan.handle)
         self.step_flops += self.last_flops
         return x
@@ -553,9 +578,11 @@ class MiUNet2DConditionModel(nn.Module):
             self._attach_lora_grads()
         g = grad_out.float().contiguous()
         gx = torch.empty(xshape, dtype=torch.float32, device=g.device) if needs_x else None
+        plan.enter(slot)
         try:
             check(L.fdmi_unet_backward(plan.handle, slot, ptr(g), ptr(gx), stream_ptr()))
         finally:
+            plan.leave(slot)
             if gen is None:
                 plan.busy.discard(slot)
             else:
