@@ -172,6 +172,29 @@ def source_hash():
     return h.hexdigest()[:16]
 
 
+# the sources that define each MFMA kernel family (bench.py's bucket names): PMC traffic measured for a family stays valid for
+# as long as THESE files are unchanged -- an edit to another kernel's file no longer voids it
+_KERNEL_SOURCES = {"gemm4_kernel": ("gemm4.hip", "gemm_tile.h", "gemm.h", "common.h"),
+                   "gemm3_kernel": ("gemm3.hip", "gemm_tile.h", "gemm.h", "common.h"),
+                   "gemm_kernel": ("gemm.hip", "gemm.h", "common.h"),
+                   "attn_": ("attn.hip", "ops.h", "common.h"),
+                   "wgrad_tn_kernel": ("wgrad.hip", "gemm_tile.h", "gemm.h", "common.h")}
+
+
+def kernel_source_hash(bucket: str):
+    """sha256 (first 16 hex digits) over the source files of one kernel family ("gemm4_kernel<256x320,row>" -> gemm4.hip +
+    the headers it includes); None for an unknown family"""
+    import hashlib
+    for prefix, files in _KERNEL_SOURCES.items():
+        if bucket.startswith(prefix):
+            h = hashlib.sha256()
+            for f in files:
+                with open(os.path.join(_HERE, "csrc", f), "rb") as fh:
+                    h.update(f.encode() + b"\0" + fh.read())
+            return h.hexdigest()[:16]
+    return None
+
+
 def check(rc):
     if rc != 0:
         raise RuntimeError("fdmi: " + lib().fdmi_last_error().decode())

@@ -246,3 +246,172 @@ def build_sd3_mmdit_inputs(case="mmdit_tiny"):
     batch = {"image": torch.randn(2, 16, 16, 16, generator=gb), "text": ["a", "b"]}
     return cfg, teacher, student, sd3_mmdit_head(), pipe, batch
 
+
+
+# ---- FlashDiffusion (epsilon-prediction step) over the PixArt DiT wrapper: BASELINE.json configs[3] ("C4") in miniature --------
+# The reference's REAL FlashDiffusion on the reference's REAL DiffusersTransformer2DWrapper (TW:9-100; restated diffusers base)
+# with the example's discriminator recipe (examples/train_flash_pixart.py:277-325: strided 4x4 convs without bias, GroupNorm(4),
+# SiLU, a final valid 4x4 conv, on the epsilon prediction itself -- the DiT wrapper ignores `return_intermediate`) and the
+# example's loss configuration (configs/flash_pixart.yaml: mixture timesteps, DMD, lsgan, USE_EMPTY_PROMPT).
+PIXART_STEP_CASES = {
+    # name: (config kwargs, step, seed)
+    "pixart_g_dmd_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="mixture", mixture_num_components=4,
+                                mixture_var=0.5, mode_probs=[[0.1, 0.3, 0.3, 0.3]], distill_loss_type="l2",
+                                gan_loss_type="lsgan", use_dmd_loss=True, guidance_scale_min=2.0, guidance_scale_max=9.0,
+                                dmd_loss_scale=0.3, adversarial_loss_scale=0.1, ucg_keys=["text"], use_empty_prompt=True), 0, 51),
+    "pixart_d_lsgan": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="mixture", mixture_num_components=4,
+                            mixture_var=0.5, mode_probs=[[0.25, 0.25, 0.25, 0.25]], gan_loss_type="lsgan",
+                            ucg_keys=["text"], use_empty_prompt=True), 1, 52),
+}
+PIXART_STEP_DIT = dict(sample_size=32, num_layers=2, attention_head_dim=8, num_attention_heads=4, cross_attention_dim=32,
+                       time_embed_dim=32, caption_channels=48, num_vector_conditionings=2)
+
+
+class PromptTableConditioner(torch.nn.Module):
+    """Stand-in for the T5 conditioner of the PixArt recipe (embedders/conditioners_wrapper.py:39-91) that DOES look at the
+    prompts: a batch whose prompts are all "" (what FD:194-199 builds under `use_empty_prompt`) gets the `*_empty` embeddings
+    and key mask, any other batch the regular ones -- so the unconditional branch really differs, as with a text encoder."""
+
+    def __init__(self, input_key="text"):
+        super().__init__()
+        self.input_key = input_key
+
+    def forward(self, batch, ucg_keys=None, set_ucg_rate_zero=False, *args, **kwargs):
+        empty = all(t == "" for t in batch[self.input_key])
+        sfx = "_empty" if empty else ""
+        return {"cond": {"crossattn": batch["crossattn" + sfx], "attention_mask": batch["attention_mask" + sfx],
+                         "vector": batch["vector"]}}
+
+
+def pixart_step_head(in_ch=4, feat=16):
+    """examples/train_flash_pixart.py:277-325 with three strided stages instead of five (32x32 latents instead of 128x128)"""
+    nn = torch.nn
+    d = nn.Sequential(nn.Conv2d(in_ch, feat, 4, 2, 1, bias=False), nn.SiLU(True),
+                      nn.Conv2d(feat, feat * 2, 4, 2, 1, bias=False), nn.GroupNorm(4, feat * 2), nn.SiLU(True),
+                      nn.Conv2d(feat * 2, feat * 4, 4, 2, 1, bias=False), nn.GroupNorm(4, feat * 4), nn.SiLU(True),
+                      nn.Conv2d(feat * 4, 1, 4, 1, 0, bias=False), nn.Flatten())
+    g3 = torch.Generator().manual_seed(3)
+    for n_, p in d.named_parameters():
+        gn_w = p.dim() == 1 and n_.endswith("weight")
+        p.data.copy_(torch.randn(p.shape, generator=g3) * (0.1 if p.dim() == 1 else (p[0].numel() ** -0.5)) + (1.0 if gn_w else 0.0))
+    return d
+
+
+def build_pixart_step_inputs():
+    """(cfg, seeded teacher oracle module, student oracle module with LoRA r=8, head, batch) for PIXART_STEP_CASES"""
+    from . import dit_cpu
+    cfg = {**dit_cpu.TINY_DIT, **PIXART_STEP_DIT}
+    teacher = dit_cpu.seeded_init_(dit_cpu.PixartTransformerRef(**cfg), 3)
+    student = dit_cpu.seeded_init_(dit_cpu.PixartTransformerRef(**cfg), 3)
+    dit_cpu.add_lora_(student, 8, seed=4, b_std=0.05)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    teacher.eval()
+    g = torch.Generator().manual_seed(61)
+    B, L = 2, 7
+    nv = cfg["num_vector_conditionings"] * cfg["projection_class_embeddings_input_dim"]
+    batch = {"image": torch.randn(B, 4, 32, 32, generator=g), "text": ["a", "b"],
+             "crossattn": torch.randn(B, L, cfg["caption_channels"], generator=g),
+             "crossattn_empty": torch.randn(1, L, cfg["caption_channels"], generator=g).repeat(B, 1, 1),
+             "attention_mask": torch.tensor([[1, 1, 1, 1, 0, 0, 0], [1, 1, 1, 1, 1, 1, 1]]),
+             "attention_mask_empty": torch.tensor([[1, 0, 0, 0, 0, 0, 0], [1, 0, 0, 0, 0, 0, 0]]),
+             "vector": torch.randn(B, nv, generator=g)}
+    return cfg, teacher, student, pixart_step_head(), batch
+
+
+# ---- full-size B = 1 forwards of the C3 / C4 / C5 denoisers (VERDICT r2 item 1d): SDXL UNet (examples/train_flash_sdxl.py:66-118),
+# PixArt-alpha XL/2 (train_flash_pixart.py:65-86), SD3-medium (train_flash_sd3.py:65-77) at 128x128 latents.  Weights and inputs
+# come from oracle/hash_init.py (bit-identical on host and GPU), the fixture holds the fp32 oracle's output only. ---------------
+FULL_SEED = 1
+
+
+def _hu(shape, stream, device, scale=1.0):
+    from .hash_init import hash_uniform
+    n = 1
+    for s in shape:
+        n *= int(s)
+    return (hash_uniform(n, 77, stream, device) * scale).to(torch.float32).reshape(shape)
+
+
+def full_inputs(name, device="cpu"):
+    """(sample, timestep, conditioning) of a FULL_CASES entry: unit-variance hashed values on `device`"""
+    if name == "full_sdxl":
+        cond = {"crossattn": _hu((1, 77, 2048), 2, device), "vector": _hu((1, 2816), 3, device)}
+        return _hu((1, 4, 128, 128), 1, device), torch.tensor([749.0], device=device), {"cond": cond}
+    if name == "full_pixart":
+        mask = torch.ones(1, 120, dtype=torch.long, device=device)
+        mask[:, 100:] = 0                                   # a ragged T5 key mask (TW:75)
+        cond = {"crossattn": _hu((1, 120, 4096), 2, device), "vector": _hu((1, 768), 3, device), "attention_mask": mask}
+        return _hu((1, 4, 128, 128), 1, device), torch.tensor([749.0], device=device), {"cond": cond}
+    if name == "full_sd3":
+        cond = {"crossattn": _hu((1, 333, 4096), 2, device), "vector": _hu((1, 2048), 3, device)}
+        return _hu((1, 16, 128, 128), 1, device), torch.tensor([749.0], device=device), {"cond": cond}
+    raise KeyError(name)
+
+
+def full_arch(name):
+    """constructor keywords shared by the oracle restatement and the HIP module (flash_diffusion_amd.workloads mirrors them;
+    restated here so that the oracle package does not import the product)"""
+    if name == "full_pixart":
+        return dict(sample_size=128, num_layers=28, attention_head_dim=72, in_channels=4, out_channels=8, patch_size=2,
+                    attention_bias=True, num_attention_heads=16, cross_attention_dim=1152, activation_fn="gelu-approximate",
+                    num_embeds_ada_norm=1000, norm_type="ada_norm_single", norm_elementwise_affine=False, norm_eps=1e-6,
+                    caption_channels=4096, projection_class_embeddings_input_dim=256, time_embed_dim=1152,
+                    timesteps_embedding_num_channels=256, use_concat_vector_conditioning=True, num_vector_conditionings=3)
+    if name == "full_sd3":
+        return dict(sample_size=128, patch_size=2, in_channels=16, num_layers=24, attention_head_dim=64, num_attention_heads=24,
+                    joint_attention_dim=4096, caption_projection_dim=1536, pooled_projection_dim=2048, out_channels=16,
+                    pos_embed_max_size=192)
+    raise KeyError(name)
+
+
+FULL_CASES = ("full_sdxl", "full_pixart", "full_sd3")
+
+
+def build_full_oracle(name):
+    from . import dit_cpu, mmdit_cpu
+    from .hash_init import hash_init_
+    from .unet_cpu import sdxl_config
+    if name == "full_sdxl":
+        m = UNet2DConditionRef(sdxl_config())
+    elif name == "full_pixart":
+        m = dit_cpu.PixartTransformerRef(**full_arch(name))
+    else:
+        m = mmdit_cpu.SD3TransformerRef(**full_arch(name))
+    return hash_init_(m, FULL_SEED).eval()
+
+
+# ---- a C2-SHAPED step (BASELINE.json configs[1], the headline): full-size SD1.5, LoRA r128, FOUR teacher CFG steps (K = [4],
+# start index 0), B = 2, l2 distillation + the lsgan term the reference's forward always runs (FD:347-358) ---------------------
+C2_LORA_RANK = 128
+C2_KW = dict(K=[4], num_iterations_per_K=[10], timestep_distribution="mixture", mixture_num_components=4, mixture_var=0.5,
+             mode_probs=[[1.0, 0.0, 0.0, 0.0]], distill_loss_type="l2", gan_loss_type="lsgan", use_dmd_loss=False,
+             guidance_scale_min=3.0, guidance_scale_max=13.0, adversarial_loss_scale=0.1)
+
+
+def build_c2_models(device="cpu", make=None):
+    """teacher / student (r128 LoRA, non-zero B) / SD1.5 PatchGAN head with hashed weights.  `make(lora_rank)` builds an empty
+    denoiser module with the oracle's parameter names (default: the oracle restatement; the GPU tests pass the HIP module)."""
+    from .hash_init import hash_init_
+    from .unet_cpu import sd15_config
+
+    def oracle(lora_rank):
+        m = UNet2DConditionRef(sd15_config())
+        if lora_rank:
+            m.add_adapter(lora_rank)
+        return m
+    make = make or oracle
+    strip = lambda n: n.replace(".base_layer.", ".")
+    teacher = hash_init_(make(0).to(device), 1, rename=strip)
+    student = hash_init_(make(C2_LORA_RANK).to(device), 2, rename=strip)
+    base = {strip(k): v for k, v in teacher.state_dict().items()}
+    with torch.no_grad():
+        for n, p in student.named_parameters():
+            if ".lora_" not in n:
+                p.copy_(base[strip(n)])
+    disc = hash_init_(make_discriminator(kind="sd15", color_dim=1280, feat=64, last_k=4).to(device), 3)
+    return teacher, student, disc
+
+
+def c2_batch(device="cpu", B=2):
+    return {"image": _hu((B, 4, 64, 64), 11, device), "crossattn": _hu((B, 77, 768), 12, device), "text": ["a"] * B}

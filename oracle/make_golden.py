@@ -249,7 +249,133 @@ def make_sd3_mmdit_golden():
               os.path.getsize(path) // 1024, "KiB")
 
 
+def make_pixart_step_golden():
+    """FlashDiffusion (the REAL class) over the REAL DiffusersTransformer2DWrapper (TW:9-100) with the PixArt example's head and
+    loss recipe: fixtures tests/golden/pixart_*.npz for the epsilon-prediction step over the HIP DiT (BASELINE C4's workload)."""
+    from . import dit_cpu
+    from .flash_ref import FlashConfigRef, FlashDiffusionRef
+    from .golden_cases import PIXART_STEP_CASES, PromptTableConditioner, build_pixart_step_inputs
+    FD, FDC = shim_import.import_reference()
+    Wrapper, _ = shim_import.import_reference_dit()
+    for name, (kw, step, seed) in PIXART_STEP_CASES.items():
+        def models():
+            cfg, t_o, s_o, head, batch = build_pixart_step_inputs()
+            teacher = Wrapper(**cfg)
+            teacher.load_state_dict(t_o.state_dict())
+            teacher.freeze()
+            student = Wrapper(**cfg)
+            dit_cpu.add_lora_(student, 8, seed=4, b_std=0.05)
+            student.load_state_dict(s_o.state_dict())
+            return teacher, student, head, batch
+        teacher, student, head, batch = models()
+        ref = FD(FDC(**kw), student_denoiser=student, teacher_denoiser=teacher, teacher_noise_scheduler=SCHEDS["dpm"](),
+                 conditioner=PromptTableConditioner(), discriminator=head)
+        torch.manual_seed(seed)
+        out = ref(batch, step=step, device="cpu")
+        out["loss"][step].backward()
+        grads = {n.replace(".base_layer.", "."): p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+        teacher, student, head, batch2 = models()
+        ora = FlashDiffusionRef(FlashConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                                teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=PromptTableConditioner(), discriminator=head)
+        torch.manual_seed(seed)
+        out2 = ora(batch2, step=step, device="cpu")
+        for k in ("teacher_output", "student_output", "noisy_sample"):
+            assert torch.equal(out[k], out2[k]), (name, k)
+        assert float(out["loss"][step]) == float(out2["loss"][step])
+        blob = {"z": batch["image"].numpy(), "step": np.int64(step), "start_timestep": np.int64(out["start_timestep"])}
+        for k, v in ora.last_draws.values.items():
+            blob["draw:" + k] = v.numpy()
+        for k in ("teacher_output", "student_output", "noisy_sample"):
+            blob["out:" + k] = out[k].detach().numpy()
+        for i in (0, 1):
+            blob[f"loss:{i}"] = np.float64(float(out["loss"][i]))
+        for k, v in ora.terms.items():
+            blob["term:" + k] = np.float64(float(v))
+        for n, g in grads.items():
+            blob["grad:" + n] = g.numpy()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, "loss", blob["loss:0"], blob["loss:1"], "ngrads", len(grads), "start_t", out["start_timestep"],
+              {k: float(blob[k]) for k in blob if k.startswith("term:")}, os.path.getsize(path) // 1024, "KiB")
+
+
+def make_fullsize_golden(names=None):
+    """fp32 oracle output of one full-size B = 1 forward per C3 / C4 / C5 denoiser (tests/golden/full_*.npz); the weights and
+    inputs are rebuilt from oracle/hash_init.py wherever the fixture is replayed"""
+    from .golden_cases import FULL_CASES, build_full_oracle, full_inputs
+    import time
+    for name in (names or FULL_CASES):
+        t0 = time.time()
+        m = build_full_oracle(name)
+        x, t, cond = full_inputs(name)
+        t1 = time.time()
+        with torch.no_grad():
+            out = m(x, t, cond)
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, out=out.numpy(), nparams=np.int64(sum(p.numel() for p in m.parameters())),
+                            psum=np.float64(sum(float(p.double().sum()) for p in m.parameters())))
+        print(name, tuple(out.shape), "mean |out|", float(out.abs().mean()), "std", float(out.std()),
+              f"init {t1 - t0:.0f} s fwd {time.time() - t1:.0f} s", os.path.getsize(path) // 1024, "KiB")
+        del m
+
+
 from .golden_cases import C1_KW, C1_SEED, build_c1_models, c1_grad_probe  # noqa: E402
+
+
+def make_c2_golden():
+    """One C2-shaped step (fixture tests/golden/c2_sd15_r128_n4.npz): the REAL reference class, full-size SD1.5, r128, all four
+    teacher CFG steps, B = 2; stored like the C1 fixture (outputs, losses, per-tensor gradient norm + seeded projection, four
+    LoRA tensors in full)."""
+    from .flash_ref import FlashConfigRef, FlashDiffusionRef, timestep_pmf
+    from .golden_cases import C2_KW, build_c2_models, c2_batch
+    FD, FDC = shim_import.import_reference()
+    batch = c2_batch()
+    # the reference draws the start index from the pmf (FD:167): pick the seed whose draw is index 0 (= all four teacher steps)
+    pmf = timestep_pmf(FlashConfigRef(**C2_KW), 4, 0)
+    seed = None
+    for s in range(100, 200):
+        torch.manual_seed(s)
+        torch.randn_like(batch["image"])
+        if int(torch.multinomial(pmf, 1)) == 0:
+            seed = s
+            break
+    teacher, student, disc = build_c2_models()
+    ref = FD(FDC(**C2_KW), student_denoiser=student, teacher_denoiser=teacher,
+             teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=TensorConditioner(), discriminator=disc)
+    torch.manual_seed(seed)
+    out = ref(batch, step=0, device="cpu")
+    out["loss"][0].backward()
+    grads = {n: p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+    del ref
+    teacher, student, disc = build_c2_models()
+    ora = FlashDiffusionRef(FlashConfigRef(**C2_KW), student_denoiser=student, teacher_denoiser=teacher,
+                            teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=TensorConditioner(), discriminator=disc)
+    torch.manual_seed(seed)
+    out2 = ora(c2_batch(), step=0, device="cpu")
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert torch.equal(out[k], out2[k]), k
+    assert int(out["start_timestep"]) == 999, out["start_timestep"]    # start index 0 of the trailing K = 4 schedule: 4 teacher steps
+    blob = {"step": np.int64(0), "start_timestep": np.int64(out["start_timestep"]), "seed": np.int64(seed)}
+    for k, v in ora.last_draws.values.items():
+        blob["draw:" + k] = v.numpy()
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        blob["out:" + k] = out[k].detach().numpy()
+    for i in (0, 1):
+        blob[f"loss:{i}"] = np.float64(float(out["loss"][i]))
+    for k, v in ora.terms.items():
+        blob["term:" + k] = np.float64(float(v))
+    names = sorted(grads)
+    blob["gradnames"] = np.array(names)
+    blob["gradnorm"] = np.array([float(grads[n].double().norm()) for n in names])
+    blob["gradproj"] = np.array([float(grads[n].double().flatten() @ c1_grad_probe(grads[n].numel(), 1000 + i).double())
+                                 for i, n in enumerate(names)])
+    lora = [n for n in names if ".lora_" in n]
+    for n in lora[:2] + lora[-2:]:
+        blob["grad:" + n] = grads[n].numpy()
+    path = os.path.join(OUT, "c2_sd15_r128_n4.npz")
+    np.savez_compressed(path, **blob)
+    print("c2_sd15_r128_n4 seed", seed, "loss", blob["loss:0"], "terms", {k: float(blob[k]) for k in blob if k.startswith("term:")},
+          "ngrads", len(names), os.path.getsize(path) // 1024, "KiB")
 
 
 def make_c1_golden():
@@ -303,6 +429,15 @@ if __name__ == "__main__":
         make_c1_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "sd3_mmdit":
         make_sd3_mmdit_golden()
+        make_pixart_step_golden()
+        make_fullsize_golden()
+        make_c2_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "pixart_step":
+        make_pixart_step_golden()
+    elif len(sys.argv) > 1 and sys.argv[1] == "full":
+        make_fullsize_golden(sys.argv[2:] or None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "c2":
+        make_c2_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "gan":
         from .golden_cases import CASES as _C
         want = sys.argv[2:] or ("g_wgan", "d_wgan", "d_lsgan", "d_vanilla", "d_nonsat")
@@ -329,3 +464,6 @@ if __name__ == "__main__":
         make_dit_golden()
         make_c1_golden()
         make_sd3_mmdit_golden()
+        make_pixart_step_golden()
+        make_fullsize_golden()
+        make_c2_golden()

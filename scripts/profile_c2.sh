@@ -24,11 +24,14 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d "$out/pmc_write" -o r${round
 echo "== rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum (own pass: L2 hit rate per kernel)"
 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -f csv -d "$out/pmc_tcc" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/pmc_tcc_bench.json" 2> "$out/pmc_tcc.err"
+echo "== rocprofv3 --pmc GRBM_GUI_ACTIVE (own pass: effective clock per kernel)"
+rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -f csv -d "$out/pmc_grbm" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
+  > "$out/pmc_grbm_bench.json" 2> "$out/pmc_grbm.err"
 python scripts/rocprof_to_profiles.py --round "$round" --steps 4 --stats-dir "$out/stats" --fetch-dir "$out/pmc_fetch" \
-  --write-dir "$out/pmc_write" --tcc-dir "$out/pmc_tcc" > "$out/summary.txt" 2>&1
+  --write-dir "$out/pmc_write" --tcc-dir "$out/pmc_tcc" --grbm-dir "$out/pmc_grbm" > "$out/summary.txt" 2>&1
 # the per-dispatch traces are large: keep only the summaries (gpurun_out/ merges back <= 64 MiB)
 find "$out" -name '*kernel_trace.csv' -delete; find "$out" -name '*counter_collection.csv' -delete
-mkdir -p "$out/profiles" && cp profiles/r${round}_kernel_stats.csv profiles/r${round}_pmc_hbm_traffic.csv profiles/r${round}_traffic.json profiles/r${round}_l2_hit_rate.csv "$out/profiles/" 2>/dev/null
+mkdir -p "$out/profiles" && cp profiles/r${round}_kernel_stats.csv profiles/r${round}_pmc_hbm_traffic.csv profiles/r${round}_traffic.json profiles/r${round}_l2_hit_rate.csv profiles/r${round}_clock.csv "$out/profiles/" 2>/dev/null
 echo "== register-only MFMA rate under full-chip load (scripts/ubench/mfma_rate.hip)"
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_rate scripts/ubench/mfma_rate.hip && /tmp/mfma_rate > "$out/profiles/r${round}_mfma_rate.txt" 2>&1
 cat "$out/profiles/r${round}_mfma_rate.txt"

@@ -58,9 +58,11 @@ def short(name):
 
 # bench.py's bucket names for the MFMA kernel families (profiles/README.md "Name mapping")
 def bucket(name):
-    m = re.search(r"gemm4_kernel<(\d), (?:false|true)(?:, (\d+))?", name)
+    m = re.search(r"gemm4_kernel<(\d), (false|true)(?:, (\d+))?(?:, (?:false|true))?(?:, (\d+))?", name)
     if m:
-        return f"gemm4_kernel<256x{m.group(2) or '320'},{'conv' if m.group(1) == '1' else 'row'}>"
+        if m.group(4) == "128":   # the 128 x 160 geometry (two blocks per CU): bench.py buckets it by epilogue
+            return f"gemm4_kernel<128x{m.group(3)},{'geglu' if m.group(2) == 'true' else 'row'}>"
+        return f"gemm4_kernel<256x{m.group(3) or '320'},{'conv' if m.group(1) == '1' else 'row'}>"
     m = re.search(r"gemm3_kernel<(\d+), (\d)", name)
     if m:
         return f"gemm3_kernel<256x{m.group(1)},{'conv' if m.group(2) == '1' else 'row'}>"
@@ -113,6 +115,7 @@ def main():
     ap.add_argument("--fetch-dir")
     ap.add_argument("--write-dir")
     ap.add_argument("--tcc-dir", help="a --pmc TCC_HIT_sum TCC_MISS_sum pass: per-kernel L2 hit rate -> rN_l2_hit_rate.csv")
+    ap.add_argument("--grbm-dir", help="a --pmc GRBM_GUI_ACTIVE pass: effective shader clock per kernel -> rN_clock.csv")
     ap.add_argument("--tag", default="", help="file-name suffix, e.g. _gn for a knob run")
     ap.add_argument("--command", default="python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary")
     a = ap.parse_args()
@@ -136,6 +139,30 @@ def main():
                 if h + m > 0:
                     fh.write(f"\"{n}\",{c},{h:.0f},{m:.0f},{h / (h + m):.4f}\n")
         print("wrote", f"{pre}_l2_hit_rate{a.tag}.csv")
+    if a.grbm_dir:   # effective clock = GRBM_GUI_ACTIVE / kernel wall time (MI355X_MICROARCH.md, "DVFS give-back")
+        agg = defaultdict(lambda: [0, 0.0, 0.0])
+        for f in _files(a.grbm_dir, "counter_collection.csv"):
+            with open(f, newline="") as fh:
+                for row in csv.DictReader(fh):
+                    if row[_col(row, "Counter_Name", "CounterName")] != "GRBM_GUI_ACTIVE":
+                        continue
+                    try:
+                        dur = float(row[_col(row, "End_Timestamp", "EndTimestamp")]) - float(row[_col(row, "Start_Timestamp", "StartTimestamp")])
+                    except KeyError:
+                        dur = 0.0
+                    n = short(row[_col(row, "Kernel_Name", "KernelName", "Name")])
+                    agg[n][0] += 1
+                    agg[n][1] += float(row[_col(row, "Counter_Value", "CounterValue", "Value")])
+                    agg[n][2] += dur
+        with open(f"{pre}_clock{a.tag}.csv", "w") as fh:
+            fh.write("# rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace (own pass): busy cycles per launch as reported and the dispatch's "
+                     "duration from the same rows; GHz = cycles / ns.  The counter is summed over the chip's 8 XCDs when the value "
+                     "is ~8x a plausible clock: ghz_per_xcd = GHz / 8 is then the shader clock the kernel ran at\n")
+            fh.write("kernel,launches,avg_us,grbm_gui_active_per_launch,ghz_raw,ghz_per_xcd\n")
+            for n, (c, cyc, ns) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
+                if ns > 0:
+                    fh.write(f"\"{n}\",{c},{ns / c / 1e3:.1f},{cyc / c:.0f},{cyc / ns:.3f},{cyc / ns / 8:.3f}\n")
+        print("wrote", f"{pre}_clock{a.tag}.csv")
     if not (a.fetch_dir and a.write_dir):
         return
     # FETCH_SIZE / WRITE_SIZE are reported in KB (MI355X_MICROARCH.md, HBM section); FETCH_SIZE x 2 on gfx950
@@ -161,7 +188,9 @@ def main():
                              "write_MB": round(w / c, 2), "launches_sampled": c}
     sys.path.insert(0, ROOT)
     from flash_diffusion_amd import _lib
-    out["csrc_sha"] = _lib.source_hash()   # bench.py reports this traffic only for the build it was measured on
+    out["csrc_sha"] = _lib.source_hash()   # the whole build, for the record
+    for b in out["kernels"]:               # bench.py reports a family's traffic only while ITS sources are the measured ones
+        out["kernels"][b]["src_sha"] = _lib.kernel_source_hash(b)
     with open(f"{pre}_traffic{a.tag}.json", "w") as fh:
         json.dump(out, fh, indent=1)
     print("wrote", f"{pre}_traffic{a.tag}.json")

@@ -29,6 +29,15 @@ def load_case(name):
     return g
 
 
+def parity_log(msg, fname="flash_parity.txt"):
+    """append a measured-parity line to gpurun_out/<fname> (copied to profiles/ at the end of a round) and print it"""
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, fname), "a") as f:
+        f.write(msg + "\n")
+    print(msg, flush=True)
+
+
 def rel_err(a, b):
     a = a.detach().double().cpu()
     b = b.detach().double().cpu()

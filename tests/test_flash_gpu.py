@@ -3,12 +3,13 @@ the fixtures the REAL reference produced (tests/golden/*.npz, oracle/make_golden
 latents (every random draw injected), plus the reference's own invariants
 (tests/test_flash/test_flash_diffusion.py:146-222) re-expressed on the new path.
 
-Tolerance (stated): bf16 activations vs the reference's fp32 CPU run: student/teacher outputs rel.
-Frobenius < 4e-2, each loss term |rel| < 6e-2 (north_star asks 1e-3 for an fp32-equivalent path; the
-bf16 figure is what precision="bf16-mixed" gives -- measured values in gpurun_out/flash_parity.txt),
-LoRA / discriminator gradients: cosine similarity of the CONCATENATED gradient > 0.99, every tensor
-> 0.95 with its norm within 12 % (the DMD direction is a difference of two nearly equal bf16 UNet
-outputs, FD:474-478, so individual small tensors carry visible rounding noise)."""
+Tolerance (stated): bf16 activations vs the reference's fp32 CPU run.  north_star's 1e-3 is asserted in the fp32 validation
+mode (tests/test_fp32_gate_gpu.py); here every bound is ~2x what the production bf16 path MEASURED on these fixtures in round 2
+(profiles/r2_parity_flash.txt, table MEASURED below): teacher output rel. Frobenius < 4e-2 (measured <= 1.94e-2), student
+output < 1e-2 (<= 4.96e-3), each loss |rel| < 2x its measured value (floor 6e-3; worst case d_vanilla 1.83e-2 -> 3.7e-2),
+LoRA / discriminator gradients: cosine of the CONCATENATED gradient > 0.995 (measured >= 0.9970), every tensor > 0.98
+(>= 0.9865; the DMD direction is a difference of two nearly equal bf16 UNet outputs, FD:474-478, so individual small tensors
+carry visible rounding noise), norm of every tensor carrying >= 5 % of the largest gradient norm within 9 % (<= 4.2 %)."""
 import copy
 import os
 
@@ -27,6 +28,12 @@ def log(msg):
     os.makedirs(os.path.dirname(LOG), exist_ok=True)
     with open(LOG, "a") as f:
         f.write(msg + "\n")
+
+
+# round-2 measurements of the bf16 path on these fixtures (profiles/r2_parity_flash.txt): (loss[0] rel, loss[1] rel)
+MEASURED = {"g_dmd_lsgan": (2.3e-3, 0.0), "d_hinge": (2.8e-4, 4.8e-3), "g_nonsat_teacher_real": (3.4e-3, 0.0),
+            "g_noreg_vanilla": (3.2e-3, 0.0), "g_wgan": (8.3e-3, 0.0), "d_wgan": (7.0e-3, 2.9e-3), "d_lsgan": (8.2e-3, 2.7e-3),
+            "d_vanilla": (1.83e-2, 2.7e-5), "d_nonsat": (4.1e-3, 2.8e-3)}
 
 
 def build_product(kw, sched="dpm"):
@@ -68,8 +75,9 @@ def test_step_matches_reference_golden(name):
     log(f"{name}: " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + f" loss_rel={lerr[0]:.3e},{lerr[1]:.3e}"
         + f" terms={ {k: (float(v) if torch.is_tensor(v) else v) for k, v in m.terms.items()} } ref_terms={g['terms']}")
     assert errs["noisy_sample"] < 1e-6
-    assert errs["teacher_output"] < 4e-2 and errs["student_output"] < 4e-2
-    assert lerr[0] < 6e-2 and lerr[1] < 6e-2
+    assert errs["teacher_output"] < 4e-2 and errs["student_output"] < 1e-2, errs
+    for i in (0, 1):
+        assert lerr[i] < max(2.0 * MEASURED[name][i], 6e-3), (i, lerr, MEASURED[name])
     out["loss"][step].backward()
     torch.cuda.synchronize()
     n, worst_cos, worst_ratio = 0, 1.0, 0.0
@@ -101,7 +109,7 @@ def test_step_matches_reference_golden(name):
     gcos = cos(torch.cat(flat_a), torch.cat(flat_b))
     log(f"{name}: {n} grad tensors, global cosine {gcos:.4f}, worst cosine {worst_cos:.4f}, worst |norm ratio - 1| {worst_ratio:.3e}"
         + (" " + " ".join(detail) if n <= 8 else ""))
-    assert n > 0 and gcos > 0.99 and worst_cos > 0.95 and worst_ratio < 0.12
+    assert n > 0 and gcos > 0.995 and worst_cos > 0.98 and worst_ratio < 0.09, (n, gcos, worst_cos, worst_ratio)
 
 
 def test_reference_invariants_forward_signs():

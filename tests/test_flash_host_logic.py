@@ -255,3 +255,34 @@ def test_teacher_loop_route_is_taken_only_when_asked(monkeypatch):
     assert u0 == [] and len(u1) == 1 and u1[0][1][0] == 2 * g["z"].shape[0] and u1[0][2] == len(u1[0][0])
     assert rel_err(o1["teacher_output"], o0["teacher_output"]) < 1e-5
     assert rel_err(o1["teacher_output"], g["out"]["teacher_output"]) < 1e-4
+
+
+@pytest.mark.parametrize("name", ["pixart_g_dmd_lsgan", "pixart_d_lsgan"])
+def test_pixart_step_orchestration_matches_reference_golden(monkeypatch, name):
+    """BASELINE C4's workload in miniature on the host: the PRODUCT FlashDiffusion over the oracle's PixArt DiT (key mask,
+    vector conditioning, `use_empty_prompt` unconditional embeddings, the six-conv-recipe head on the epsilon prediction --
+    the DiT ignores return_intermediate) against the fixture of the REAL reference class over its REAL DiT wrapper"""
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import PIXART_STEP_CASES, PromptTableConditioner, build_pixart_step_inputs
+    _patch(monkeypatch)
+    kw, step, _ = PIXART_STEP_CASES[name]
+    g = load_case(name)
+    cfg, teacher, student, head, batch = build_pixart_step_inputs()
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=PromptTableConditioner(),
+                       discriminator=_Head(head))
+    m.draws = Draws(g["draws"])
+    calls = []
+    orig = type(teacher).forward
+    monkeypatch.setattr(type(teacher), "forward",
+                        lambda self, *a, **k: (calls.append((k["sample"] if "sample" in k else a[0]).shape[0]), orig(self, *a, **k))[1])
+    out = m(batch, step=step, device="cpu")
+    assert 4 in calls                                       # [cond | uncond] (with their key masks) as ONE 2B call
+    assert out["start_timestep"] == g["start_timestep"]
+    for k in ("teacher_output", "student_output", "noisy_sample"):
+        assert rel_err(out[k], g["out"][k]) < 1e-4, (k, rel_err(out[k], g["out"][k]))
+    for i in (0, 1):
+        assert abs(float(out["loss"][i]) - g["loss"][i]) <= 1e-4 * max(1.0, abs(g["loss"][i])), i
+    out["loss"][step].backward()
+    _check_grads(m, g, lambda k: k.replace("discriminator.seq.", "discriminator.").replace(".base_layer.", "."))

@@ -1,0 +1,199 @@
+"""Full-size parity on the GPU, every body in its own interpreter:
+
+* one B = 1 forward of each of the C3 / C4 / C5 denoisers at its real width -- SDXL UNet (examples/train_flash_sdxl.py:66-118: 10-layer
+  transformer blocks, class embedding, 128x128), PixArt-alpha XL/2 (train_flash_pixart.py:65-86: 28 blocks, d = 1152, 4096 tokens,
+  ragged key mask), SD3-medium (train_flash_sd3.py:65-77: 24 joint blocks, 4096 + 333 tokens) -- bf16 production kernels against
+  the fp32 CPU oracle's output stored in tests/golden/full_*.npz (`python -m oracle.make_golden full`);
+* a C2-SHAPED training step (BASELINE.json configs[1]: full-size SD1.5, LoRA r128, all four teacher CFG steps, B = 2, l2 + lsgan)
+  against the fixture of the REAL reference class (tests/golden/c2_sd15_r128_n4.npz, `python -m oracle.make_golden c2`), in the
+  bf16 production mode AND in the fp32 validation mode;
+* the full-size C1 fixture (tests/golden/c1_sd15_full.npz) in the bf16 production mode as well (the fp32 run lives in
+  tests/test_fp32_gate_gpu.py) -- the full-width bf16 BACKWARD against the oracle.
+
+Weights and inputs of the hashed fixtures are rebuilt on the GPU by oracle/hash_init.py (bit-identical to the host's).
+Tolerances (stated): bf16 forwards rel. Frobenius < 3e-2 (the bar of tests/test_unet_gpu.py::test_sd15_full_size_forward_B1);
+bf16 steps: teacher / student output 4e-2 / 1e-2, losses 4e-2, per-tensor gradient norm within 10 % and projection on a seeded
+direction within 15 % of the tensor's norm (tensors carrying >= 5 % of the largest norm), the tensors stored in full: cosine
+> 0.98; fp32 steps: north_star's 1e-3 on every loss term, 1e-4 on the outputs, 1e-2 on the gradient norms / projections."""
+import copy
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from tests.golden_util import GOLDEN_DIR, load_case, rel_err
+from tests.isolate import run_isolated
+
+pytestmark = pytest.mark.gpu
+LOG = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "fullsize_parity.txt")
+
+
+def log(msg):
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(msg + "\n")
+    print(msg, flush=True)
+
+
+def _cos(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+# ---- 1d: full-size forwards ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["full_sdxl", "full_pixart", "full_sd3"])
+def test_full_size_forward_B1_matches_the_fp32_oracle(name):
+    run_isolated(__name__, "_forward_body", (name,), timeout=900)
+
+
+def _product(name):
+    from flash_diffusion_amd import workloads
+    from flash_diffusion_amd.dit import MiSD3Transformer2DModel, MiTransformer2DModel
+    from flash_diffusion_amd.unet import MiUNet2DConditionModel
+    cls, arch = {"full_sdxl": (MiUNet2DConditionModel, workloads.SDXL), "full_pixart": (MiTransformer2DModel, workloads.PIXART),
+                 "full_sd3": (MiSD3Transformer2DModel, workloads.SD3)}[name]
+    with torch.device("cuda"):          # (the constructor's placeholder init runs on the GPU: seconds instead of a minute)
+        m = cls(**arch)
+    return m.cuda()
+
+
+def _forward_body(name):
+    from oracle.golden_cases import FULL_SEED, full_arch, full_inputs
+    from oracle.hash_init import hash_init_
+    from flash_diffusion_amd import workloads
+    if name != "full_sdxl":             # the oracle package restates the architecture keywords: they must be the product's
+        assert full_arch(name) == {"full_pixart": workloads.PIXART, "full_sd3": workloads.SD3}[name]
+    blob = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    m = _product(name)
+    hash_init_(m, FULL_SEED)
+    m.freeze()
+    n = sum(p.numel() for p in m.parameters())
+    psum = sum(float(p.double().sum()) for p in m.parameters())
+    assert n == int(blob["nparams"]) and abs(psum - float(blob["psum"])) <= 1e-6 * max(1.0, abs(float(blob["psum"]))), \
+        (n, int(blob["nparams"]), psum, float(blob["psum"]))           # same weights as the host's oracle
+    x, t, cond = full_inputs(name, "cuda")
+    with torch.no_grad():
+        out = m(x, t, cond)
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(blob["out"])
+    e = rel_err(out, ref)
+    log(f"{name} B=1 forward (bf16 vs fp32 oracle): rel {e:.3e}, cosine {_cos(out, ref):.6f}, {n / 1e9:.2f} B parameters, "
+        f"flops {getattr(m, 'last_flops', 0.0):.4e}")
+    assert torch.isfinite(out).all() and e < 3e-2, e
+
+
+# ---- 1c / 1b: full-size steps ----------------------------------------------------------------------------------------------------
+def _check_projected_grads(tag, m, blob, g, fp32):
+    from oracle.golden_cases import c1_grad_probe
+    names = [str(n) for n in blob["gradnames"]]
+    params = {pn: p for pn, p in m.named_parameters()}
+    nmax = float(blob["gradnorm"].max())
+    worst_n = worst_p = worst_n_big = worst_p_big = 0.0
+    k = 0
+    for i, n in enumerate(names):
+        pn = n.replace(".base_layer.", ".")
+        gr = params[pn].grad
+        assert gr is not None, pn
+        rn, rp = float(blob["gradnorm"][i]), float(blob["gradproj"][i])
+        if rn < 1e-6 * nmax:
+            continue
+        gn = float(gr.double().norm())
+        gp = float(gr.detach().double().cpu().flatten() @ c1_grad_probe(gr.numel(), 1000 + i).double())
+        en, ep = abs(gn - rn) / rn, abs(gp - rp) / rn
+        worst_n, worst_p = max(worst_n, en), max(worst_p, ep)
+        if rn >= 0.05 * nmax:
+            worst_n_big, worst_p_big = max(worst_n_big, en), max(worst_p_big, ep)
+        k += 1
+    full = {pn: (rel_err(params[pn.replace(".base_layer.", ".")].grad, ref), _cos(params[pn.replace(".base_layer.", ".")].grad, ref))
+            for pn, ref in g["grads"].items()}
+    log(f"step {tag}: {k} gradient tensors; |norm| rel worst {worst_n:.2e} (tensors >= 5 % of the largest: {worst_n_big:.2e}); "
+        f"projection error / norm worst {worst_p:.2e} (large tensors {worst_p_big:.2e}); stored in full: "
+        + " ".join(f"rel={r:.2e},cos={c:.4f}" for r, c in full.values()))
+    assert k >= 250
+    if fp32:
+        assert worst_n <= 1e-2 and worst_p <= 1e-2 and all(r <= 1e-2 for r, _ in full.values()), (worst_n, worst_p, full)
+    else:
+        assert worst_n_big <= 0.10 and worst_p_big <= 0.15 and all(c > 0.98 for _, c in full.values()), \
+            (worst_n_big, worst_p_big, full)
+
+
+def _check_outputs(tag, m, g, out, fp32):
+    assert out["start_timestep"] == g["start_timestep"]
+    errs = {k: rel_err(out[k], g["out"][k]) for k in ("teacher_output", "student_output", "noisy_sample")}
+    lerr = []
+    for i in (0, 1):
+        ref, got = g["loss"][i], float(out["loss"][i])
+        lerr.append(abs(got - ref) / abs(ref) if ref != 0 else abs(got))
+    terr = {k: abs(float(v) - g["terms"][k]) / max(abs(g["terms"][k]), 1e-12) for k, v in m.terms.items()
+            if k in g["terms"] and k not in ("K_step", "guidance", "n_teacher_steps") and g["terms"][k] != 0}
+    log(f"step {tag}: " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + f" loss_rel={lerr[0]:.3e},{lerr[1]:.3e} "
+        f"terms={ {k: f'{v:.1e}' for k, v in terr.items()} }")
+    o_t, o_s, l_tol = (1e-4, 1e-4, 1e-3) if fp32 else (4e-2, 1e-2, 4e-2)
+    assert errs["noisy_sample"] < 1e-6 and errs["teacher_output"] <= o_t and errs["student_output"] <= o_s, errs
+    assert lerr[0] <= l_tol and lerr[1] <= l_tol, lerr
+    assert all(v <= l_tol for v in terr.values()), terr
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_c2_shaped_step_matches_reference_golden(precision):
+    run_isolated(__name__, "_c2_body", (precision,), timeout=900)
+
+
+def _c2_body(precision):
+    from flash_diffusion_amd import workloads
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from flash_diffusion_amd.unet import MiUNet2DConditionModel
+    from oracle.golden_cases import C2_KW, C2_LORA_RANK, build_c2_models, c2_batch
+    g = load_case("c2_sd15_r128_n4")
+    blob = np.load(os.path.join(GOLDEN_DIR, "c2_sd15_r128_n4.npz"))
+
+    def make(lora_rank):
+        with torch.device("cuda"):
+            m = MiUNet2DConditionModel(**workloads.SD15, precision=precision)
+        m = m.cuda()
+        if lora_rank:
+            m.add_adapter(lora_rank)
+        return m
+    teacher, student, disc = build_c2_models("cuda", make)
+    teacher.freeze()
+    assert student.lora_rank == C2_LORA_RANK
+    m = FlashDiffusion(FlashDiffusionConfig(**C2_KW), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                       discriminator=disc).cuda()
+    assert type(m.discriminator).__name__ == "MiDiscriminator" and m.discriminator.precision == precision
+    m.draws = Draws(g["draws"])
+    out = m(c2_batch("cuda"), step=0, device="cuda")
+    assert m.terms["n_teacher_steps"] == 4                  # the headline's four teacher CFG steps
+    _check_outputs(f"c2_sd15_r128_n4 [{precision}]", m, g, out, precision == "fp32")
+    out["loss"][0].backward()
+    torch.cuda.synchronize()
+    _check_projected_grads(f"c2_sd15_r128_n4 [{precision}]", m, blob, g, precision == "fp32")
+
+
+def test_c1_full_size_step_bf16():
+    run_isolated(__name__, "_c1_bf16_body", (), timeout=900)
+
+
+def _c1_bf16_body():
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import C1_KW, C1_LORA_RANK, build_c1_models
+    from tests.unet_util import mi_from_oracle
+    g = load_case("c1_sd15_full")
+    blob = np.load(os.path.join(GOLDEN_DIR, "c1_sd15_full.npz"))
+    teacher_o, student_o, disc_o = build_c1_models()
+    teacher = mi_from_oracle(teacher_o)
+    teacher.freeze()
+    student = mi_from_oracle(student_o, lora_rank=C1_LORA_RANK)
+    del teacher_o, student_o
+    m = FlashDiffusion(FlashDiffusionConfig(**C1_KW), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                       discriminator=copy.deepcopy(disc_o).cuda()).cuda()
+    m.draws = Draws(g["draws"])
+    out = m({"image": g["z"].cuda(), "crossattn": g["crossattn"].cuda(), "text": ["a"]}, step=0, device="cuda")
+    _check_outputs("c1_sd15_full [bf16]", m, g, out, False)
+    out["loss"][0].backward()
+    torch.cuda.synchronize()
+    _check_projected_grads("c1_sd15_full [bf16]", m, blob, g, False)

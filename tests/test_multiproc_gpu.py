@@ -72,3 +72,96 @@ def test_bench_launches_its_own_ranks():
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["config"]["parallelism"] == "dp2" and j["config"]["global_batch"] == 2 * 16
     assert j["value"] > 0 and abs(j["config"]["images_per_sec_per_gpu"] * 2 - j["value"]) < 1e-6 * j["value"]
+
+
+# ---- two ranks of the REAL data-parallel path -------------------------------------------------------------------
+def _tiny_pipe(seed=0):
+    import torch
+    from flash_diffusion_amd.trainer import TrainingConfig, TrainingPipeline
+    from flash_diffusion_amd.workloads import TINY, build_flash
+    m = build_flash(TINY, lora_rank=8, n_teacher_steps=2, device="cuda", seed=seed)
+    with torch.no_grad():   # peft's B = 0 would make the first update invisible in the output
+        for p in m.student_denoiser.lora_parameters()[1::2]:
+            p.normal_(0, 0.02, generator=torch.Generator(device="cuda").manual_seed(3))
+    pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-3],
+                                              trainable_params=[["student_denoiser"]]), overlap=True)
+    pipe.configure_optimizers()
+    return m, pipe
+
+
+def _shard(step, rank):
+    from flash_diffusion_amd.workloads import synthetic_batch
+    return synthetic_batch(2, 16, 64, seed=500 + 10 * step + rank)
+
+
+N_STEPS = 3
+
+
+def _body_two_rank(rank, port, out_path):
+    """one rank of a 2-rank job on the box's single GPU (gloo moves the CUDA gradient through the host; RCCL cannot put two
+    ranks on one device): the product's flat LoRA buffer, deferred backward, comm stream -- everything but the transport"""
+    import torch
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=2)
+    m, pipe = _tiny_pipe()
+    assert pipe.distributed and pipe.world == 2 and pipe._comm_stream is not None and pipe._defer_ok()
+    calls = []
+    orig = dist.all_reduce
+    dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), orig(*a, **k))[1]
+    for i in range(N_STEPS):
+        torch.manual_seed(9000 + 10 * i + rank)        # this rank's own draws (noise, guidance) -- different per rank
+        pipe.training_step(_shard(i, rank), i)
+        assert pipe._deferred is not None               # the backward of step i waits for step i+1's hook (or finish())
+    pipe.finish()
+    flat = m.student_denoiser.lora_flat().detach().cpu()
+    assert len(calls) == N_STEPS and all(n == flat.numel() for n in calls), calls   # ONE collective on the flat gradient per step
+    torch.save(flat, out_path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _body_two_rank_reference(out_path):
+    """ONE process fed both shards: per step the two backwards accumulate into the flat gradient, AdamW applies their mean --
+    the arithmetic of _reduce_and_step (sum over ranks, 1/world folded into the fused AdamW).  Run twice for the yardstick."""
+    import torch
+
+    def run():
+        m, pipe = _tiny_pipe()
+        opt = pipe.optims[0]
+        for i in range(N_STEPS):
+            opt.flat_grad.zero_()
+            for rank in (0, 1):
+                torch.manual_seed(9000 + 10 * i + rank)
+                out = m(_shard(i, rank), device="cuda")
+                out["loss"][0].backward()
+            opt.grad_scale = 0.5
+            opt.step()
+        torch.cuda.synchronize()
+        return m.student_denoiser.lora_flat().detach().cpu()
+    torch.save({"a": run(), "b": run()}, out_path)
+
+
+def test_two_rank_replicas_are_identical_and_equal_the_averaged_single_process(tmp_path):
+    import torch
+    port = 29700 + os.getpid() % 200
+    outs = [str(tmp_path / f"rank{r}.pt") for r in range(2)]
+    code = ("import sys; sys.path.insert(0, {root!r}); from tests.test_multiproc_gpu import _body_two_rank; "
+            "_body_two_rank({rank}, {port}, {out!r}); print('RANK-OK')")
+    procs = [subprocess.Popen([sys.executable, "-c", code.format(root=ROOT, rank=r, port=port, out=outs[r])], cwd=ROOT,
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(2)]
+    res = [p.communicate(timeout=600) for p in procs]
+    for p, (so, se) in zip(procs, res):
+        assert p.returncode == 0 and "RANK-OK" in so, se[-4000:]
+    ref_path = str(tmp_path / "ref.pt")
+    run_isolated(__name__, "_body_two_rank_reference", (ref_path,))
+    r0, r1 = torch.load(outs[0]), torch.load(outs[1])
+    ref = torch.load(ref_path)
+    assert torch.isfinite(r0).all() and torch.equal(r0, r1), "the two replicas diverged"
+    # not bit-reproducible across runs (float atomics; AdamW turns a sign flip of a ~0 gradient into a +-lr move): the
+    # yardstick is the distance between two single-process runs, with the bulk rule of test_flash_gpu.py as the fallback
+    noise = float((ref["a"] - ref["b"]).abs().max())
+    dist_ = float((r0 - ref["a"]).abs().max())
+    n_off = int(((r0 - ref["a"]).abs() > 1e-5).sum())
+    assert dist_ <= 3 * noise + 1e-6 or n_off <= 0.005 * r0.numel(), (dist_, noise, n_off, r0.numel())
+    assert float((r0 - ref["a"]).abs().mean()) < 1e-5       # and the two trajectories moved together

@@ -9,7 +9,7 @@ import pytest
 import torch
 
 from oracle.golden_cases import SD3_MMDIT_CASES, build_sd3_mmdit_inputs
-from tests.golden_util import load_case, rel_err
+from tests.golden_util import load_case, parity_log, rel_err
 from tests.isolate import run_isolated
 
 pytestmark = pytest.mark.gpu
@@ -54,7 +54,7 @@ def _body(name):
     for i in (0, 1):
         ref, got = g["loss"][i], float(out["loss"][i])
         lerr.append(abs(got - ref) / abs(ref) if ref != 0 else abs(got))
-    print(f"{name}: " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + f" loss_rel={lerr[0]:.3e},{lerr[1]:.3e}", flush=True)
+    parity_log(f"{name}: " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + f" loss_rel={lerr[0]:.3e},{lerr[1]:.3e}")
     assert errs["noisy_sample"] < 1e-6 and errs["teacher_output"] < 4e-2 and errs["student_output"] < 4e-2, errs
     assert lerr[0] < 6e-2 and lerr[1] < 6e-2, lerr
     out["loss"][step].backward()
@@ -73,5 +73,5 @@ def _body(name):
         fa.append(p.grad.detach().float().cpu().flatten())
         fb.append(ref.float().flatten())
     gc = _cos(torch.cat(fa), torch.cat(fb))
-    print(f"{name}: {len(fa)} gradient tensors, global cosine {gc:.4f}", flush=True)
+    parity_log(f"{name}: {len(fa)} gradient tensors, global cosine {gc:.4f}")
     assert len(fa) > 0 and gc > 0.99, (len(fa), gc)
