@@ -28,6 +28,7 @@ class GemmDesc(C.Structure):
         ("alpha", f32),
         ("splitk", i32), ("ws", vp),
         ("accum_atomic", i32), ("force_tile", i32), ("use_glds", i32),
+        ("A2", vp), ("lda2", i64), ("K1", i32),
     ]
 
 
@@ -67,12 +68,15 @@ _SIGS = {
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "fdmi_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
+    "fdmi_gemm_a2_ok": (i32, [C.POINTER(GemmDesc)]),
     "fdmi_wgrad_tn": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]),
     "fdmi_gemm_gn_ok": (i32, [C.POINTER(GemmDesc), i32, i32]),
     "fdmi_gemm_gn": (i32, [C.POINTER(GemmDesc), vp, i32, i32, vp]),
     "fdmi_groupnorm_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "fdmi_groupnorm_fwd": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
     "fdmi_groupnorm_bwd": (i32, [vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
+    "fdmi_groupnorm_cat_fwd": (i32, [vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),
+    "fdmi_groupnorm_cat_bwd": (i32, [vp, vp, i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, i32, vp]),
     "fdmi_layernorm_fwd": (i32, [vp, vp, vp, vp, i64, i32, f32, vp]),
     "fdmi_layernorm_bwd": (i32, [vp, vp, vp, vp, i64, i32, f32, i32, vp]),
     "fdmi_layernorm_mod_fwd": (i32, [vp, vp, vp, i64, i32, vp, vp, i64, i32, f32, vp]),

@@ -93,8 +93,10 @@ static GemmArgs gemm_args_from(const fdmi_gemm_desc* d) {
   a.accum_atomic = d->accum_atomic;
   a.force_tile = d->force_tile;
   a.use_glds = d->use_glds;
+  a.A2 = (const bf16_t*)d->A2; a.lda2 = d->lda2; a.K1 = d->K1;
   return a;
 }
+int fdmi_gemm_a2_ok(const fdmi_gemm_desc* d) { return d != nullptr && gemm_a2_ok(gemm_args_from(d)) ? 1 : 0; }
 int fdmi_gemm(const fdmi_gemm_desc* d, void* stream) {
   FDMI_CHECK(d != nullptr, "null descriptor");
   return launch_gemm(gemm_args_from(d), (hipStream_t)stream);
@@ -142,6 +144,17 @@ int fdmi_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const 
                        int silu, int accumulate, void* stream) {
   return launch_groupnorm_bwd((const bf16_t*)x, (const bf16_t*)dy, gamma, beta, stats, bstats, (bf16_t*)dx, B,
                               HW, C, G, eps, silu, accumulate, (hipStream_t)stream);
+}
+int fdmi_groupnorm_cat_fwd(const void* x1, const void* x2, int C1, const float* gamma, const float* beta, float* stats, void* y,
+                           int B, int HW, int C, int G, float eps, int silu, void* stream) {
+  return launch_groupnorm_fwd((const bf16_t*)x1, gamma, beta, stats, (bf16_t*)y, B, HW, C, G, eps, silu, (hipStream_t)stream,
+                              false, false, (const bf16_t*)x2, C1);
+}
+int fdmi_groupnorm_cat_bwd(const void* x1, const void* x2, int C1, const void* dy, const float* gamma, const float* beta,
+                           const float* stats, float* bstats, void* dx, int B, int HW, int C, int G, float eps, int silu,
+                           int accumulate, void* stream) {
+  return launch_groupnorm_bwd((const bf16_t*)x1, (const bf16_t*)dy, gamma, beta, stats, bstats, (bf16_t*)dx, B, HW, C, G, eps,
+                              silu, accumulate, (hipStream_t)stream, false, (const bf16_t*)x2, C1);
 }
 int fdmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int C,
                        float eps, void* stream) {

@@ -227,13 +227,17 @@ __global__ __launch_bounds__(256) void cast_transpose_jobs_kernel(const CastJob*
     if (r0 + r < rows && c0 + c < cols) {
       v = f2bf(jb.src[(int64_t)(r0 + r) * cols + c0 + c]);
       jb.dst[(int64_t)(r0 + r) * cols + c0 + c] = v;
+      if (jb.dst2) jb.dst2[(int64_t)(r0 + r) * jb.ld2 + c0 + c] = v;
     }
     tile[r][c] = v;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < 64 * 64; i += 256) {
     const int c = i >> 6, r = i & 63;
-    if (c0 + c < cols && r0 + r < rows) jb.dstT[(int64_t)(c0 + c) * (jb.ldT ? jb.ldT : rows) + r0 + r] = tile[r][c];
+    if (c0 + c < cols && r0 + r < rows) {
+      jb.dstT[(int64_t)(c0 + c) * (jb.ldT ? jb.ldT : rows) + r0 + r] = tile[r][c];
+      if (jb.dstT2) jb.dstT2[(int64_t)(c0 + c) * jb.ldT2 + r0 + r] = tile[r][c];
+    }
   }
 }
 

@@ -8,6 +8,11 @@ enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2 };
 struct GemmArgs {
   int M = 0, N = 0, K = 0;
   const bf16_t* A = nullptr; int64_t lda = 0;   // ROW: A[M][lda]; CONV: NHWC activation base
+  // ROW only: a second segment of the reduction index -- columns k >= K1 of the (virtual) [M][K] operand are A2[m][k - K1]
+  // (row stride lda2), columns k < K1 are A[m][k].  K1 % 64 == 0: a 64-deep K tile never straddles the seam.  This is how a
+  // channel concatenation [h | skip] feeds a GEMM without being materialised, and how a LoRA up-projection rides along as extra
+  // K tiles of the base GEMM: y = [x | t] [W | B]^T.  Only the 256-row / 128-row LDS-DMA kernels implement it (gemm_a2_ok).
+  const bf16_t* A2 = nullptr; int64_t lda2 = 0; int K1 = 0;
   const bf16_t* W = nullptr; int64_t ldw = 0;   // W[N][ldw], reduction index contiguous
   int mode = GEMM_ROW;
   // CONV geometry.  forward: X[B,Hin,Win,Cin] (virtually 2x nearest-upsampled when ups) ->
@@ -53,6 +58,9 @@ int gemm3_pick_bn(const GemmArgs& a);
 int launch_gemm3(const GemmArgs& a, int BN, hipStream_t stream);
 bool gemm4_eligible(const GemmArgs& a, int BN = 320);   // 256 x {320, 192} tile (gemm4.hip)
 int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN = 320);
+// true when launch_gemm can run this problem with a two-segment A operand (GemmArgs::A2): a kernel that implements it is
+// eligible (row GEMM, M >= 256, N >= 128, K and K1 multiples of 64)
+bool gemm_a2_ok(const GemmArgs& a);
 bool gemm5_eligible(const GemmArgs& a);                 // 128 x 160 tile, two persistent blocks per CU (gemm4.hip): short-K row GEMMs
 int launch_gemm5(const GemmArgs& a, hipStream_t stream);
 // true when launch_gemm will run this problem on a kernel whose epilogue accumulates GemmArgs::gn_stats (a 256-row tile

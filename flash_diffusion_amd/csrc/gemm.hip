@@ -513,12 +513,19 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   // 256 x 128 ring kernel it displaces (profiles/r2_knob12_c4.txt); A/B switch 12 = 1 takes it out of the planner
   if (!fdmi_tune_get(12) && gemm4_eligible(a, 192)) consider(2, 256, 192, 256, 3.9);
   const bool geglu = a.act == ACT_GEGLU;
+  if (a.A2) return p;   // a two-segment A operand: only the LDS-DMA kernels above read it (gemm_a2_ok)
   consider(0, 128, 128, 512, 1.05);
   consider(0, 128, 64, 768, 0.60);
   consider(0, 64, 128, 768, 0.50);
   if (a.N <= 64 || a.M <= 64) consider(0, 64, 64, 1280, 0.22);
   (void)geglu;
   return p;
+}
+
+bool gemm_a2_ok(const GemmArgs& a) {
+  if (a.f32 || a.mode != GEMM_ROW || !a.A2) return false;
+  if (a.K1 <= 0 || a.K1 >= a.K || (a.K1 & 63) || (a.K & 63) || (a.lda2 & 7) || ((uintptr_t)a.A2 & 15)) return false;
+  return gemm3_eligible(a);   // (whenever gemm4 / gemm5 are eligible, so is the 256-row ring kernel)
 }
 
 bool gemm_gn_ok(const GemmArgs& a, bool ws_available) {
@@ -572,9 +579,11 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     FDMI_CHECK(a.stride == 1 || a.stride == 2, "conv: stride must be 1 or 2");
     FDMI_CHECK(!(a.ups && a.dgrad), "conv: ups+dgrad unsupported (dgrad at the upsampled size, then pool)");
   }
+  if (a.A2) FDMI_CHECK(gemm_a2_ok(a), "gemm: a second A segment needs a row GEMM with M >= 256, N >= 128, K1 % 64 == 0, K % 64 == 0");
   if (a.act == ACT_GEGLU) FDMI_CHECK((a.N % 32) == 0, "geglu: N must be a multiple of 32");
   if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic);
+  if (a.A2) FDMI_CHECK(p.big != 0, "gemm: a second A segment is read by the LDS-DMA kernels only (forced tile?)");
   if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
   if (p.big == 2) FDMI_CHECK(gemm4_eligible(a, p.BN), "gemm: 256x320 / 256x192 tile not applicable to this problem");
   if (p.big == 3) FDMI_CHECK(gemm5_eligible(a) && p.splitk <= 1 && !a.accum_atomic, "gemm: 128x160 tile not applicable to this problem");

@@ -107,7 +107,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
       ainc[i] = ok ? 64 : 0;
     }
   };
+  int akpos = 0, am0 = 0;   // ROW with a second A segment: k of the tile to issue next, the item's first row
   auto setup_issue = [&](const Item& it) {
+    akpos = it.kbeg;
+    am0 = it.m0;
     if (MODE == GEMM_CONV) {
       const int tap = it.kbeg / a.Cin;
       cc = it.kbeg - tap * a.Cin;
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
       const int m = it.m0 + lr + 64 * i;
       aval[i] = m < a.M;
       if (MODE == GEMM_ROW) {
-        ap[i] = aval[i] ? a.A + (int64_t)m * a.lda + it.kbeg + c8 : zero;
+        if (a.A2 && it.kbeg >= a.K1) ap[i] = aval[i] ? a.A2 + (int64_t)m * a.lda2 + (it.kbeg - a.K1) + c8 : zero;
+        else ap[i] = aval[i] ? a.A + (int64_t)m * a.lda + it.kbeg + c8 : zero;
         ainc[i] = aval[i] ? 64 : 0;
         aby[i] = abx[i] = apix[i] = 0;
       } else {
@@ -158,6 +162,14 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
       if (wave < 4) {
         glds16m(wp[WR - 1], sa + BM * 128 + 512 * 16 * (WR - 1));
         wp[WR - 1] += winc[WR - 1];
+      }
+    }
+    if (MODE == GEMM_ROW) {
+      akpos += 64;
+      if (a.A2 && akpos == a.K1) {   // the next tile is the first of the second A segment (GemmArgs::A2; uniform)
+#pragma unroll
+        for (int i = 0; i < AR; ++i)
+          if (ainc[i]) ap[i] = a.A2 + (int64_t)(am0 + lr + 64 * i) * a.lda2 + c8;
       }
     }
     if (MODE == GEMM_CONV) {

@@ -82,8 +82,9 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
   unsigned aok = 0;          // CONV: bit i = row i reads real data (advances along Cin)
   int ayx[AR], apix[AR];     // CONV: (y << 16 | x) window origin (biased by +256), batch pixel base
   int ky = 0, kx = 0, cc = 0;
-  const bf16_t* abase = zero;  // ROW: row m0+lr; piece i is 64*i rows further
+  const bf16_t* abase = zero;  // ROW: row m0+lr; piece i is PR*i rows further
   int64_t astep = 0;
+  int akpos = 0, arow = 0;     // ROW with a second A segment (GemmArgs::A2): k of the tile to issue next, this thread's row
   const bf16_t* wbase = zero;  // W row n0+lr; piece i is 64*i rows further
   int64_t wstep = 0;
   auto retap = [&]() {
@@ -116,8 +117,15 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
   };
   auto setup_issue = [&](const Item& it) {
     if (MODE == GEMM_ROW) {
-      abase = a.A + (int64_t)(it.m0 + lr) * a.lda + it.kbeg + c8;
-      astep = PR * a.lda;
+      if (a.A2 && it.kbeg >= a.K1) {   // (a k-split that starts behind the seam)
+        abase = a.A2 + (int64_t)(it.m0 + lr) * a.lda2 + (it.kbeg - a.K1) + c8;
+        astep = PR * a.lda2;
+      } else {
+        abase = a.A + (int64_t)(it.m0 + lr) * a.lda + it.kbeg + c8;
+        astep = PR * a.lda;
+      }
+      akpos = it.kbeg;
+      arow = it.m0 + lr;
     } else {
       const int tap = it.kbeg / a.Cin;
       cc = it.kbeg - tap * a.Cin;
@@ -181,6 +189,11 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
   auto issue_finish = [&]() {
     if (MODE == GEMM_ROW) {
       abase += astep ? 64 : 0;
+      akpos += 64;
+      if (a.A2 && akpos == a.K1 && astep) {   // the next tile is the first of the second segment (uniform)
+        abase = a.A2 + (int64_t)arow * a.lda2 + c8;
+        astep = PR * a.lda2;
+      }
     } else {
       cc += 64;
       if (cc >= a.Cin) {  // next tile starts a new filter tap (uniform: Cin % 64 == 0)

@@ -15,7 +15,17 @@ struct GnArgs {
   float* bstats;       // [B][G][2] backward sums
   bf16_t* y;           // forward output / dx output
   int B, HW, C, G; float eps; int silu; int accumulate;
+  // x as a channel concatenation that was never materialised (the UNet's up-path [h | skip]): channels c < C1 are read from
+  // x[row][C1], channels c >= C1 from x2[row][C - C1] (x2 == nullptr: one tensor of C channels).  C1 % 8 == 0; a thread's
+  // channel chunk is fixed, so the choice is made once per thread.  dy / y always span all C channels.
+  const bf16_t* x2; int C1;
 };
+// this thread's x source for channel chunk c0: pointer to (row 0, channel c0) and the row stride
+__device__ __forceinline__ const bf16_t* gn_xsrc(const GnArgs& a, int c0, int64_t& xld) {
+  if (a.x2 && c0 >= a.C1) { xld = a.C - a.C1; return a.x2 + (c0 - a.C1); }
+  xld = a.x2 ? a.C1 : a.C;
+  return a.x + c0;
+}
 
 // UNR: rows fetched per loop trip before any of them is consumed (UNR 16-byte loads in flight per thread instead of one; a
 // plain loop waits for each load before issuing the next: round 1 measured that at 1.6 TB/s, 20 % of the HBM roofline).
@@ -44,6 +54,8 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_b
       if (chunk >= CPR) continue;
     }
     const int c0 = chunk * 8;
+    int64_t xld;
+    const bf16_t* xp = gn_xsrc(a, c0, xld);
     float s0[8], s1[8], mean[8], rstd[8], gm[8], bt[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -84,18 +96,18 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_b
         u16x8 xv[UNR], dv[UNR];
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
-          const int64_t off = ((int64_t)b * a.HW + r + u * R) * a.C + c0;
-          xv[u] = *(const u16x8*)(a.x + off);
-          if (BWD) dv[u] = *(const u16x8*)(a.dy + off);
+          const int64_t row = (int64_t)b * a.HW + r + u * R;
+          xv[u] = *(const u16x8*)(xp + row * xld);
+          if (BWD) dv[u] = *(const u16x8*)(a.dy + row * a.C + c0);
         }
 #pragma unroll
         for (int u = 0; u < UNR; ++u) consume(xv[u], BWD ? dv[u] : xv[u]);
       }
     }
     for (; r < row1; r += R) {
-      const int64_t off = ((int64_t)b * a.HW + r) * a.C + c0;
-      const u16x8 xv = *(const u16x8*)(a.x + off);
-      const u16x8 dv = BWD ? *(const u16x8*)(a.dy + off) : xv;
+      const int64_t row = (int64_t)b * a.HW + r;
+      const u16x8 xv = *(const u16x8*)(xp + row * xld);
+      const u16x8 dv = BWD ? *(const u16x8*)(a.dy + row * a.C + c0) : xv;
       consume(xv, dv);
     }
     if (cpg >= 8) {
@@ -155,6 +167,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a, int rows_per_bl
       if (chunk >= CPR) continue;
     }
     const int c0 = chunk * 8;
+    int64_t xld;
+    const bf16_t* xp = gn_xsrc(a, c0, xld);
     float ca[8], cb[8], gm[8], bt[8], m1[8], m2[8], mean[8], rstd[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -177,7 +191,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a, int rows_per_bl
       for (; r + (UNR - 1) * R < row1; r += UNR * R) {
         u16x8 xu[UNR];
 #pragma unroll
-        for (int u = 0; u < UNR; ++u) xu[u] = *(const u16x8*)(a.x + ((int64_t)b * a.HW + r + u * R) * a.C + c0);
+        for (int u = 0; u < UNR; ++u) xu[u] = *(const u16x8*)(xp + ((int64_t)b * a.HW + r + u * R) * xld);
 #pragma unroll
         for (int u = 0; u < UNR; ++u) {
           u16x8 ov;
@@ -193,7 +207,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(GnArgs a, int rows_per_bl
     }
     for (; r < row1; r += R) {
       const int64_t off = ((int64_t)b * a.HW + r) * a.C + c0;
-      const u16x8 xv = *(const u16x8*)(a.x + off);
+      const u16x8 xv = *(const u16x8*)(xp + ((int64_t)b * a.HW + r) * xld);
       u16x8 ov;
       if (!BWD) {
 #pragma unroll
@@ -232,9 +246,10 @@ static int gn_rows_per_block(int B, int HW) {
 
 int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta, float* stats,
                          bf16_t* y, int B, int HW, int C, int G, float eps, int silu,
-                         hipStream_t st, bool stats_zeroed, bool stats_ready) {
+                         hipStream_t st, bool stats_zeroed, bool stats_ready, const bf16_t* x2, int C1) {
   FDMI_CHECK(C % 8 == 0 && C % G == 0 && G <= 32 && C <= 4096, "groupnorm: unsupported C/G");
-  GnArgs a{x, nullptr, gamma, beta, stats, nullptr, y, B, HW, C, G, eps, silu, 0};
+  FDMI_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % 8 == 0), "groupnorm: a two-part input needs 0 < C1 < C, C1 % 8 == 0");
+  GnArgs a{x, nullptr, gamma, beta, stats, nullptr, y, B, HW, C, G, eps, silu, 0, x2, x2 ? C1 : 0};
   const int rpb = gn_rows_per_block(B, HW);
   if (!stats_ready) {
     if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
@@ -247,9 +262,10 @@ int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
 
 int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta,
                          const float* stats, float* bstats, bf16_t* dx, int B, int HW, int C, int G,
-                         float eps, int silu, int accumulate, hipStream_t st, bool stats_zeroed) {
+                         float eps, int silu, int accumulate, hipStream_t st, bool stats_zeroed, const bf16_t* x2, int C1) {
   FDMI_CHECK(C % 8 == 0 && C % G == 0 && G <= 32 && C <= 4096, "groupnorm: unsupported C/G");
-  GnArgs a{x, dy, gamma, beta, (float*)stats, bstats, dx, B, HW, C, G, eps, silu, accumulate};
+  FDMI_CHECK(!x2 || (C1 > 0 && C1 < C && C1 % 8 == 0), "groupnorm: a two-part input needs 0 < C1 < C, C1 % 8 == 0");
+  GnArgs a{x, dy, gamma, beta, (float*)stats, bstats, dx, B, HW, C, G, eps, silu, accumulate, x2, x2 ? C1 : 0};
   if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(bstats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
   hipLaunchKernelGGL(gn_reduce_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);

@@ -11,10 +11,12 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
 int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta, float* stats,
                          bf16_t* y, int B, int HW, int C, int G, float eps, int silu, hipStream_t st,
                          bool stats_zeroed = false,   // stats_zeroed: caller already cleared the accumulators
-                         bool stats_ready = false);   // stats_ready: they already hold the sums (producer's GEMM epilogue)
+                         bool stats_ready = false,    // stats_ready: they already hold the sums (producer's GEMM epilogue)
+                         const bf16_t* x2 = nullptr, int C1 = 0);   // x = [x[.][C1] | x2[.][C - C1]], never materialised
 int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const float* beta,
                          const float* stats, float* bstats, bf16_t* dx, int B, int HW, int C, int G,
-                         float eps, int silu, int accumulate, hipStream_t st, bool stats_zeroed = false);
+                         float eps, int silu, int accumulate, hipStream_t st, bool stats_zeroed = false,
+                         const bf16_t* x2 = nullptr, int C1 = 0);
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, const bf16_t* shift,
                          const bf16_t* scale, int64_t mod_ld, int rows_per_batch, bf16_t* y,
                          int64_t rows, int C, float eps, hipStream_t st, float* stats = nullptr);
@@ -78,7 +80,11 @@ int launch_pad_cols(const bf16_t* src, int cols, bf16_t* dst, int cols_pad, int6
 // LoRA refresh: f32 master W[rows][cols] -> bf16 copy and bf16 transpose
 int launch_cast_transpose(const float* w, bf16_t* wb, bf16_t* wtb, int rows, int cols, hipStream_t st);
 // one 64x64 tile of an f32 [rows][cols] -> bf16 copy + bf16 transposed copy (LoRA refresh of a whole plan in one launch)
-struct CastJob { const float* src; bf16_t* dst; bf16_t* dstT; int rows, cols, r0, c0; int ldT; /* row stride of dstT (0: rows) */ };
+struct CastJob {
+  const float* src; bf16_t* dst; bf16_t* dstT; int rows, cols, r0, c0; int ldT; /* row stride of dstT (0: rows) */
+  // optional second pair of destinations with their own row strides (the LoRA halves of the fused [W | B] / [W^T | A^T] operands)
+  bf16_t* dst2; int ld2; bf16_t* dstT2; int ldT2;
+};
 int launch_cast_transpose_jobs(const CastJob* jobs, int njobs, hipStream_t st);
 // fused AdamW on a flat f32 buffer
 int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2,

@@ -52,6 +52,11 @@ struct T {  // NHWC / token-major bf16 activation [rows][cols] (+ lazily allocat
   int col0 = 0;
   int64_t ldv = 0;
   int64_t ld() const { return ldv ? ldv : cols; }
+  // a channel concatenation that is never materialised (Exec::cat): columns [0, c1) live at p (row stride c1), columns
+  // [c1, cols) at p2 (row stride cols - c1).  Only groupnorm() and linear_w() (the ResNet block's norm1 and 1x1 shortcut, the two
+  // readers of the up path's [h | skip]) accept such a tensor; its gradient buffer g is an ordinary [rows][cols] one.
+  bf16_t* p2 = nullptr;
+  int c1 = 0;
 };
 
 struct Weight {
@@ -78,6 +83,10 @@ struct Lora {
   int AT_ld = 0;
   int r = 0, in = 0, out = 0;
   bool on = false;
+  // LoRA up-projection as extra K tiles of the base GEMM (round 3): Wc [out][in + r] = [W | B] so that y = [x | t] Wc^T is ONE
+  // launch (no read-modify-write pass over y), and Wtc [in][out + r] = [W^T | A^T] so that dx = [dy | dt] Wtc^T is one launch as
+  // well.  The base halves are copied from the packed weight when it changes, the LoRA halves by the per-forward refresh.
+  bf16_t *Wc = nullptr, *Wtc = nullptr;
 };
 struct LinearW {
   Weight w;
@@ -99,6 +108,9 @@ struct TBlockW {
   Weight qkv;
   bf16_t *A3 = nullptr, *AT3 = nullptr;
   int fused_r = 0;
+  // ... and, with the LoRA up-projections folded in: Wc3 [3C][C + 3r] = [Wqkv | blockdiag(B_q, B_k, B_v)], Wtc3 [C][3C + 3r] =
+  // [Wqkv^T | A_q^T A_k^T A_v^T]
+  bf16_t *Wc3 = nullptr, *Wtc3 = nullptr;
   // cross-attention K / V / V^T of a fixed context (FDMI_UNET_CTX_FILL / _REUSE), plan-owned
   bf16_t *ck = nullptr, *cv = nullptr, *cvt = nullptr;
   int64_t c_rows = 0, c_vt = 0;
@@ -537,9 +549,35 @@ static bool qkv_fusable(const fdmi_unet* U, const TBlockW& b) {
   if (!q.on && !k.on && !v.on) return true;
   return q.on && k.on && v.on && q.r == k.r && q.r == v.r;
 }
+// LoRA up-projection folded into the base GEMM as extra K tiles (bf16 plans; A/B switch 31 = 1 keeps the separate launches):
+// the seam of the two-segment operands sits at in (forward) / out (dgrad), so both and the rank must be multiples of 64
+static bool lora_foldable(const fdmi_unet* U, const Lora& l) {
+  return !U->f32 && !fdmi_tune_get(31) && l.on && (l.r % 64) == 0 && (l.in % 64) == 0 && (l.out % 64) == 0 && l.out >= 128;
+}
+static int copy2d_dev(bf16_t* dst, int64_t ldd, const bf16_t* src, int64_t lds, int rows, int cols, hipStream_t st) {
+  FDMI_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * 2, src, (size_t)lds * 2, (size_t)cols * 2, rows, hipMemcpyDeviceToDevice, st));
+  return 0;
+}
+// base halves of the folded LoRA operands: Wc [out][in + r] <- W, Wtc [in][out + r] <- W^T (the packed copies)
+int build_lora_folded(fdmi_unet* U, hipStream_t st) {
+  for (auto& kv : U->lora_targets) {
+    LinearW& L = *kv.second;
+    Lora& l = L.lora;
+    if (!lora_foldable(U, l) || !L.w.w || !L.w.wt) continue;
+    if (!l.Wc) {
+      RET_IF(dmalloc(U, &l.Wc, (size_t)l.out * (l.in + l.r)));
+      RET_IF(dmalloc(U, &l.Wtc, (size_t)l.in * (l.out + l.r)));
+      U->cast_dirty = true;   // the refresh table gains the second destinations
+    }
+    RET_IF(copy2d_dev(l.Wc, l.in + l.r, L.w.w, l.in, l.out, l.in, st));
+    RET_IF(copy2d_dev(l.Wtc, l.out + l.r, L.w.wt, l.out, l.in, l.out, st));
+  }
+  return 0;
+}
 // (re)build the concatenated operands of every fusable block from the packed per-projection weights
 int build_fused_operands(fdmi_unet* U, hipStream_t st) {
-  int rc = 0;
+  int rc = build_lora_folded(U, st);
+  if (rc) return rc;
   for_each_tblock(U, [&](TransformerW& t, TBlockW& b) {
     if (rc || U->f32) return;
     const int C = t.C;
@@ -557,6 +595,17 @@ int build_fused_operands(fdmi_unet* U, hipStream_t st) {
         fdmi_set_error("unet: copying the fused q/k/v operands failed");
         rc = -2;
       }
+    }
+    // ... and with the three LoRA up-projections folded in (zero blocks off the diagonal: dmalloc clears)
+    const Lora& lq = b.a1.q.lora;
+    if (!rc && qkv_fusable(U, b) && lq.on && lora_foldable(U, lq) && lora_foldable(U, b.a1.k.lora) && lora_foldable(U, b.a1.v.lora)) {
+      const int r = lq.r, ldc = C + 3 * r, ldt = 3 * C + 3 * r;
+      if (!b.Wc3) {
+        if ((rc = dmalloc(U, &b.Wc3, (size_t)3 * C * ldc)) || (rc = dmalloc(U, &b.Wtc3, (size_t)C * ldt))) return;
+        U->cast_dirty = true;
+      }
+      if ((rc = copy2d_dev(b.Wc3, ldc, b.qkv.w, C, 3 * C, C, st))) return;
+      if ((rc = copy2d_dev(b.Wtc3, ldt, b.qkv.wt, 3 * C, C, 3 * C, st))) return;
     }
   });
   if (!rc) U->fused_dirty = false;
@@ -666,9 +715,11 @@ struct Exec {
     if (U->cast_dirty) {
       U->cast_mode = fdmi_tune_get(17);  // (re)build the tile table of the one-launch refresh
       std::vector<CastJob> jobs;
-      auto add = [&](const float* src, bf16_t* dst, bf16_t* dstT, int rows, int cols, int ldT) {
+      auto add = [&](const float* src, bf16_t* dst, bf16_t* dstT, int rows, int cols, int ldT, bf16_t* dst2 = nullptr, int ld2 = 0,
+                     bf16_t* dstT2 = nullptr, int ldT2 = 0) {
         for (int r0 = 0; r0 < rows; r0 += 64)
-          for (int c0 = 0; c0 < cols; c0 += 64) jobs.push_back(CastJob{src, dst, dstT, rows, cols, r0, c0, ldT});
+          for (int c0 = 0; c0 < cols; c0 += 64)
+            jobs.push_back(CastJob{src, dst, dstT, rows, cols, r0, c0, ldT, dst2, ld2, dstT2, ldT2});
       };
       for (Lora* l : U->loras) { l->A_dst = l->A; l->AT_dst = l->AT; l->AT_ld = 0; }
       // blocks whose attn1 projections run fused: the three A copies land in one [3r][in] / [in][3r] pair
@@ -688,9 +739,29 @@ struct Exec {
         }
       });
       RET_IF(rc);
+      // the LoRA halves of the folded operands ride along as second destinations: A^T [in][r] -> Wtc[:, out:], B [out][r] ->
+      // Wc[:, in:]; for a fused q / k / v block slice s lands at Wtc3[:, 3C + s r :] and Wc3[s C :, C + s r :]
+      std::map<const Lora*, std::pair<TBlockW*, int>> in_qkv;
+      for_each_tblock(U, [&](TransformerW& t, TBlockW& b) {
+        if (!b.Wc3 || !qkv_fusable(U, b)) return;
+        Lora* l3[3] = {&b.a1.q.lora, &b.a1.k.lora, &b.a1.v.lora};
+        for (int sI = 0; sI < 3; ++sI) in_qkv[l3[sI]] = {&b, sI};
+      });
       for (Lora* l : U->loras) {
-        add(l->A_master, l->A_dst, l->AT_dst, l->r, l->in, l->AT_ld);
-        add(l->B_master, l->B, l->BT, l->out, l->r, 0);
+        bf16_t *a2 = nullptr, *b2 = nullptr;
+        int a2ld = 0, b2ld = 0;
+        auto q = in_qkv.find(l);
+        if (q != in_qkv.end()) {
+          TBlockW& b = *q->second.first;
+          const int sI = q->second.second, C = l->in, r = l->r;
+          a2 = b.Wtc3 + 3 * C + sI * r; a2ld = 3 * C + 3 * r;
+          b2 = b.Wc3 + (size_t)sI * C * (C + 3 * r) + C + sI * r; b2ld = C + 3 * r;
+        } else if (l->Wc) {
+          a2 = l->Wtc + l->out; a2ld = l->out + l->r;
+          b2 = l->Wc + l->in; b2ld = l->in + l->r;
+        }
+        add(l->A_master, l->A_dst, l->AT_dst, l->r, l->in, l->AT_ld, nullptr, 0, a2, a2ld);
+        add(l->B_master, l->B, l->BT, l->out, l->r, 0, b2, b2ld, nullptr, 0);
       }
       if (U->cast_jobs) FDMI_HIP(hipFree(U->cast_jobs));
       U->cast_jobs = nullptr;
@@ -708,27 +779,39 @@ struct Exec {
   T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true, int gn_rows = 0) {
     T* y = R.mk(x->rows, w.N, x->B, x->H, x->W);
     if (!y) return nullptr;
-    {
-      GemmArgs a = rows_args(x->p, x->cols, x->rows, w.w, w.N, w.K, w.bias, y->p, w.N, residual ? residual->p : nullptr,
-                             residual ? residual->cols : 0);
-      if (gn_rows > 0 && !lo) want_gn(a, gn_rows);   // (a LoRA delta is added to y afterwards: the sums would be stale)
-      NULL_IF(gemm(a));
-      y->gn = a.gn_stats;
-    }
+    // LoRA up-projection folded into the base GEMM: y = [x | t] [W | B]^T (+ bias, residual) -- needs the folded operands
+    // (lora_foldable, built by build_lora_folded) and a problem the two-segment loaders take (M >= 256)
+    const bool fold = lo && (R.dry() ? lora_foldable(U, *lo) : lo->Wc != nullptr) && x->rows >= 256 && !x->p2;
     T* t = nullptr;
     if (lo) {
       t = R.mk(x->rows, lo->r);
       if (!t) return nullptr;
       const bf16_t* LA = f32() ? (const bf16_t*)lo->A_master : lo->A;
-      const bf16_t* LB = f32() ? (const bf16_t*)lo->B_master : lo->B;
       NULL_IF(gemm_rows(x->p, x->cols, x->rows, LA, lo->r, lo->in, nullptr, t->p, lo->r, nullptr, 0));
+    }
+    {
+      GemmArgs a = rows_args(x->p, x->cols, x->rows, w.w, w.N, w.K, w.bias, y->p, w.N, residual ? residual->p : nullptr,
+                             residual ? residual->cols : 0);
+      if (x->p2) {   // x = [h | skip], never materialised (cat)
+        a.lda = x->c1; a.A2 = x->p2; a.lda2 = x->cols - x->c1; a.K1 = x->c1;
+      }
+      if (fold) {
+        a.W = lo->Wc; a.K = w.K + lo->r; a.ldw = a.K;
+        a.A2 = t->p; a.lda2 = lo->r; a.K1 = w.K;
+      }
+      if (gn_rows > 0 && !lo) want_gn(a, gn_rows);   // (a LoRA delta is added to y afterwards: the sums would be stale)
+      NULL_IF(gemm(a));
+      y->gn = a.gn_stats;
+    }
+    if (lo && !fold) {
+      const bf16_t* LB = f32() ? (const bf16_t*)lo->B_master : lo->B;
       NULL_IF(gemm_rows(t->p, lo->r, x->rows, LB, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N));
     }
     if (R.save) {
-      R.tape.push_back([x, y, residual, lo, t, need_dx, &w](Exec& E) -> int {
+      R.tape.push_back([x, y, residual, lo, t, need_dx, fold, &w](Exec& E) -> int {
         if (!y->g) return 0;  // no gradient reached this output
         if (residual) RET_IF(E.add_grad(residual, y->g, y->cols, 0, y->cols));
-        if (need_dx) {
+        if (need_dx && !fold) {
           bf16_t* dx = E.grad_of(x);
           FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
           if (E.f32())   // dx = dy W: the one [N][K] copy read k-strided
@@ -757,7 +840,15 @@ struct Exec {
               RET_IF(launch_wgrad_tn(dt->p, lo->r, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
             }
           }
-          if (need_dx) {
+          if (need_dx && fold) {   // dx (+)= [dy | dt] [W^T | A^T]^T: the base input gradient and the LoRA one in ONE launch
+            bf16_t* dx = E.grad_of(x);
+            FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
+            GemmArgs d = rows_args(y->g, w.N, x->rows, lo->Wtc, w.K, w.N + lo->r, nullptr, dx, x->cols, x->ginit ? dx : nullptr,
+                                   x->cols);
+            d.ldw = w.N + lo->r; d.A2 = dt->p; d.lda2 = lo->r; d.K1 = w.N;
+            RET_IF(E.gemm(d));
+            x->ginit = true;
+          } else if (need_dx) {
             bf16_t* dx = E.grad_of(x);
             if (E.f32())
               RET_IF(E.gemm_rows_strided(dt->p, lo->r, x->rows, lo->A_master, lo->in, lo->r, 1, lo->in, dx, x->cols, dx, x->cols));
@@ -779,23 +870,36 @@ struct Exec {
     const int r = lora ? l3[0]->r : 0;
     T* y = R.mk(x->rows, 3 * C, x->B, x->H, x->W);
     if (!y) return nullptr;
-    NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.qkv.w, 3 * C, C, nullptr, y->p, 3 * C, nullptr, 0));
+    // the three LoRA up-projections folded in: y = [x | t_q t_k t_v] [Wqkv | blockdiag(B_q, B_k, B_v)]^T, one launch
+    const bool fold = lora && x->rows >= 256 &&
+                      (R.dry() ? (lora_foldable(U, *l3[0]) && lora_foldable(U, *l3[1]) && lora_foldable(U, *l3[2])) : b.Wc3 != nullptr);
     T* t3 = nullptr;
     if (lora) {
       t3 = R.mk(x->rows, 3 * r);
       if (!t3) return nullptr;
       NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.A3, 3 * r, C, nullptr, t3->p, 3 * r, nullptr, 0));
-      for (int s = 0; s < 3; ++s)
-        NULL_IF(gemm_rows(t3->p + s * r, 3 * r, x->rows, l3[s]->B, C, r, nullptr, y->p + s * C, 3 * C, y->p + s * C, 3 * C));
+    }
+    if (fold) {
+      GemmArgs a = rows_args(x->p, x->cols, x->rows, b.Wc3, 3 * C, C + 3 * r, nullptr, y->p, 3 * C, nullptr, 0);
+      a.ldw = C + 3 * r; a.A2 = t3->p; a.lda2 = 3 * r; a.K1 = C;
+      NULL_IF(gemm(a));
+      flops -= 2.0 * x->rows * (3.0 * C) * (2.0 * r);   // (the zero blocks off the diagonal are not algorithmic work)
+    } else {
+      NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.qkv.w, 3 * C, C, nullptr, y->p, 3 * C, nullptr, 0));
+      if (lora)
+        for (int s = 0; s < 3; ++s)
+          NULL_IF(gemm_rows(t3->p + s * r, 3 * r, x->rows, l3[s]->B, C, r, nullptr, y->p + s * C, 3 * C, y->p + s * C, 3 * C));
     }
     if (R.save) {
-      R.tape.push_back([x, y, t3, &b, C, r, lora](Exec& E) -> int {
+      R.tape.push_back([x, y, t3, &b, C, r, lora, fold](Exec& E) -> int {
         if (!y->g) return 0;
         Lora* l3[3] = {&b.a1.q.lora, &b.a1.k.lora, &b.a1.v.lora};
         bf16_t* dx = E.grad_of(x);
         FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
-        RET_IF(E.gemm_rows(y->g, 3 * C, x->rows, b.qkv.wt, C, 3 * C, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
-        x->ginit = true;
+        if (!fold) {
+          RET_IF(E.gemm_rows(y->g, 3 * C, x->rows, b.qkv.wt, C, 3 * C, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols));
+          x->ginit = true;
+        }
         if (lora) {   // per slice s: dt_s = dy_s B_s ; dB_s += dy_s^T t_s ; dA_s += dt_s^T x ; then dx += [dt_q | dt_k | dt_v] A3
           T* dt3 = E.R.mk(x->rows, 3 * r);
           FDMI_CHECK(dt3, "unet: workspace exhausted (lora)");
@@ -808,7 +912,14 @@ struct Exec {
               RET_IF(launch_wgrad_tn(dt3->p + s * r, 3 * r, x->p, x->cols, x->rows, r, C, l3[s]->A_grad, C, E.st));
             }
           }
-          RET_IF(E.gemm_rows(dt3->p, 3 * r, x->rows, b.AT3, C, 3 * r, nullptr, dx, x->cols, dx, x->cols));
+          if (fold) {   // dx (+)= [dy_q dy_k dy_v | dt_q dt_k dt_v] [Wqkv^T | A_q^T A_k^T A_v^T]^T, one launch
+            GemmArgs d = rows_args(y->g, 3 * C, x->rows, b.Wtc3, C, 3 * C + 3 * r, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols);
+            d.ldw = 3 * C + 3 * r; d.A2 = dt3->p; d.lda2 = 3 * r; d.K1 = 3 * C;
+            RET_IF(E.gemm(d));
+            x->ginit = true;
+          } else {
+            RET_IF(E.gemm_rows(dt3->p, 3 * r, x->rows, b.AT3, C, 3 * r, nullptr, dx, x->cols, dx, x->cols));
+          }
         }
         return 0;
       });
@@ -910,7 +1021,8 @@ struct Exec {
     const int HW = x->H * x->W, G = U->cfg.groups;
     if (!R.dry())
       NULL_IF(f32() ? launch_groupnorm32_fwd(F(x->p), n.gamma, n.beta, stats, F(y->p), x->B, HW, x->cols, G, eps, silu, st)
-                    : launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st, zeroed, ready));
+                    : launch_groupnorm_fwd(x->p, n.gamma, n.beta, stats, y->p, x->B, HW, x->cols, G, eps, silu, st, zeroed, ready,
+                                           x->p2, x->c1));
     if (R.save) {
       R.tape.push_back([x, y, &n, stats, HW, G, eps, silu](Exec& E) -> int {
         if (!y->g) return 0;
@@ -925,7 +1037,7 @@ struct Exec {
           RET_IF(E.f32() ? launch_groupnorm32_bwd(F(x->p), F(y->g), n.gamma, n.beta, stats, F(dx), x->B, HW, x->cols, G, silu,
                                                   x->ginit ? 1 : 0, E.st)
                          : launch_groupnorm_bwd(x->p, y->g, n.gamma, n.beta, stats, bst, dx, x->B, HW, x->cols, G, eps, silu,
-                                                x->ginit ? 1 : 0, E.st, bzeroed));
+                                                x->ginit ? 1 : 0, E.st, bzeroed, x->p2, x->c1));
         x->ginit = true;
         return 0;
       });
@@ -1064,13 +1176,25 @@ struct Exec {
     return y;
   }
 
-  T* cat(T* a, T* b) {
-    T* y = R.mk(a->rows, a->cols + b->cols, a->B, a->H, a->W);
-    if (!y) return nullptr;
-    U->hbm[HBM_COPY2D] += 4.0 * y->rows * y->cols;
-    if (!R.dry()) {
-      NULL_IF(l_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0));
-      NULL_IF(l_copy2d(b->p, b->cols, 0, y->p, y->cols, a->cols, b->rows, b->cols, 0));
+  // virt: the result is only read by readers that take a two-part operand (groupnorm / linear_w: the ResNet block's norm1 and
+  // its 1x1 shortcut): no copy, the tensor header points at both parts (A/B switch 30 = 1: always copy)
+  T* cat(T* a, T* b, bool virt = false) {
+    virt = virt && !f32() && !fdmi_tune_get(30) && (a->cols % 64) == 0 && (b->cols % 64) == 0 && a->rows >= 256 &&
+           !a->parent && !b->parent && !a->p2 && !b->p2;
+    T* y;
+    if (virt) {
+      R.tensors.emplace_back();
+      y = &R.tensors.back();
+      y->rows = a->rows; y->cols = a->cols + b->cols; y->B = a->B; y->H = a->H; y->W = a->W;
+      y->p = a->p; y->p2 = b->p; y->c1 = a->cols;
+    } else {
+      y = R.mk(a->rows, a->cols + b->cols, a->B, a->H, a->W);
+      if (!y) return nullptr;
+      U->hbm[HBM_COPY2D] += 4.0 * y->rows * y->cols;
+      if (!R.dry()) {
+        NULL_IF(l_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0));
+        NULL_IF(l_copy2d(b->p, b->cols, 0, y->p, y->cols, a->cols, b->rows, b->cols, 0));
+      }
     }
     if (R.save) {
       R.tape.push_back([y, a, b](Exec& E) -> int {
@@ -1342,7 +1466,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
       for (size_t j = 0; j < s.res.size(); ++j) {
         T* sk = skips.back();
         skips.pop_back();
-        T* hc = E.cat(h, sk);
+        T* hc = E.cat(h, sk, s.res[j]->has_sc);   // (a block without a shortcut conv would read the concat as a residual)
         FAIL_IF_NULL(hc);
         // the up path's block outputs are concatenated with a skip before the next norm (no statistics to pass on), except
         // the very last one, which conv_norm_out reads
@@ -1465,6 +1589,7 @@ int fdmi_unet_set_lora(fdmi_unet* U, const char* target, const float* A, const f
     RET_IF(dmalloc(U, &l.BT, (size_t)rank * l.out));
     l.on = true;
     U->loras.push_back(&l);
+    U->fused_dirty = true;   // the folded [W | B] / [W^T | A^T] operands of this linear are built at the next forward
   }
   FDMI_CHECK(l.r == rank, "unet: LoRA rank changed");
   return 0;

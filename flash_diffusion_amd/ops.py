@@ -54,7 +54,7 @@ def geglu_perm(n_half, device=None):
 # ---- GEMM / conv -------------------------------------------------------------------------------
 def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows_per_batch=1, residual=None,
          act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1, ws=None, accum_atomic=False,
-         force_tile=0, use_glds=True, conv=None, gn=None):
+         force_tile=0, use_glds=True, conv=None, gn=None, A2=None):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue).  conv: dict(Hin,Win,Cin,Hout,Wout,KH,KW,stride,pad,ups,dgrad)
     with A the NHWC activation.  gn=(stats [B,G,2] f32 zeroed, rows_per_sample): the epilogue also accumulates the GroupNorm
     sums of the output (fdmi_gemm_gn; raises when the problem's kernel cannot -- ask gemm_gn_ok first)."""
@@ -72,6 +72,10 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
             setattr(d, k, int(conv.get(k, 0)))
         assert M is not None
     d.M, d.N, d.K = M, N, K
+    if A2 is not None:   # second segment of the reduction index: the operand is [A | A2] (never materialised)
+        assert conv is None and A2.dtype == BF16 and A2.shape[0] == A.shape[0]
+        d.A2, d.lda2, d.K1 = ptr(A2), A2.stride(0), A.shape[1]
+        assert K == A.shape[1] + A2.shape[1], "W must span both segments"
     d.A, d.W, d.ldw = ptr(A), ptr(W), W.stride(0)
     d.bias = ptr(bias)
     d.rowvec, d.rowvec_ld, d.rows_per_batch = ptr(rowvec), (rowvec.stride(0) if rowvec is not None else 0), rows_per_batch
@@ -179,6 +183,29 @@ def groupnorm_fwd(x, gamma, beta, G, eps, silu):
     check(lib().fdmi_groupnorm_fwd(ptr(x), ptr(gamma), ptr(beta), ptr(stats), ptr(y), B, HW, Cc, G, eps,
                                    int(silu), stream_ptr()))
     return y, stats
+
+
+def groupnorm_cat_fwd(x1, x2, gamma, beta, G, eps, silu):
+    """GroupNorm of [x1 | x2] along channels without materialising the concatenation: x1 [B,HW,C1], x2 [B,HW,C2] bf16 ->
+    (y [B,HW,C1+C2], stats [B,G,2])"""
+    B, HW, C1 = x1.shape
+    Cc = C1 + x2.shape[2]
+    y = torch.empty(B, HW, Cc, dtype=x1.dtype, device=x1.device)
+    stats = torch.empty(B, G, 2, dtype=torch.float32, device=x1.device)
+    check(lib().fdmi_groupnorm_cat_fwd(ptr(x1), ptr(x2), C1, ptr(gamma), ptr(beta), ptr(stats), ptr(y), B, HW, Cc, G, eps,
+                                       int(silu), stream_ptr()))
+    return y, stats
+
+
+def groupnorm_cat_bwd(x1, x2, dy, gamma, beta, stats, G, eps, silu):
+    """input gradient of groupnorm_cat_fwd as ONE [B,HW,C1+C2] tensor (the caller splits it)"""
+    B, HW, C1 = x1.shape
+    Cc = C1 + x2.shape[2]
+    dx = torch.empty(B, HW, Cc, dtype=x1.dtype, device=x1.device)
+    bstats = torch.zeros(B, G, 2, dtype=torch.float32, device=x1.device)
+    check(lib().fdmi_groupnorm_cat_bwd(ptr(x1), ptr(x2), C1, ptr(dy), ptr(gamma), ptr(beta), ptr(stats), ptr(bstats), ptr(dx), B, HW,
+                                       Cc, G, eps, int(silu), 0, stream_ptr()))
+    return dx
 
 
 def groupnorm_apply(x, gamma, beta, stats, eps, silu):

@@ -60,10 +60,18 @@ typedef struct fdmi_gemm_desc {
   int32_t accum_atomic;
   int32_t force_tile;
   int32_t use_glds;
+  /* mode 0 only, optional (A2 == NULL: absent): a second segment of the reduction index -- columns k >= K1 of the [M][K]
+   * operand are A2[m][k - K1] (row stride lda2), columns k < K1 are A[m][k]; K1 % 64 == 0, M >= 256, N >= 128.  Feeds a channel
+   * concatenation (the UNet's up-path [h | skip], diffusers UNet2DConditionModel up blocks) or a LoRA up-projection
+   * (y = [x | t] [W | B]^T, peft's y = W x + B A x, examples/train_flash_sd.py:191-200) through ONE GEMM without materialising
+   * the concatenated operand.  fdmi_gemm_a2_ok (host only) says whether the problem qualifies.                          */
+  const void* A2; int64_t lda2; int32_t K1;
 } fdmi_gemm_desc;
+int fdmi_gemm_a2_ok(const fdmi_gemm_desc* d);
 int fdmi_gemm(const fdmi_gemm_desc* d, void* stream);
 /* host-only planner query: kernel 0 = 128/64-row tiles (gemm.hip), 1 = 256 x {128,160} LDS-DMA ring (gemm3.hip),
- * 2 = 256 x 320 (gemm4.hip); the tile and the split-K factor that fdmi_gemm would use (splitk <= 0 in the descriptor
+ * 2 = 256 x 320 / 256 x 192 (gemm4.hip), 3 = 128 x 160 with two persistent blocks per CU (gemm4.hip, short-K row GEMMs);
+ * the tile and the split-K factor that fdmi_gemm would use (splitk <= 0 in the descriptor
  * = let the planner split).  No device work, no GPU needed.                                       */
 int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_t* BN, int32_t* splitk);
 /* The GEMM / conv above whose epilogue ALSO accumulates the GroupNorm statistics of its output for the consumer:
@@ -88,6 +96,14 @@ int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, flo
 int fdmi_groupnorm_bwd(const void* x, const void* dy, const float* gamma, const float* beta,
                        const float* stats, float* bstats, void* dx, int B, int HW, int C, int G, float eps,
                        int silu, int accumulate, void* stream);
+/* GroupNorm of a channel concatenation that is never materialised: x = [x1[B*HW][C1] | x2[B*HW][C - C1]] (the up path of
+ * diffusers' UNet2DConditionModel concatenates the hidden state with a skip tensor in front of every ResNet block's norm1);
+ * y / dy / dx span all C channels.  C1 % 8 == 0.                                                                       */
+int fdmi_groupnorm_cat_fwd(const void* x1, const void* x2, int C1, const float* gamma, const float* beta, float* stats, void* y,
+                           int B, int HW, int C, int G, float eps, int silu, void* stream);
+int fdmi_groupnorm_cat_bwd(const void* x1, const void* x2, int C1, const void* dy, const float* gamma, const float* beta,
+                           const float* stats, float* bstats, void* dx, int B, int HW, int C, int G, float eps, int silu,
+                           int accumulate, void* stream);
 int fdmi_layernorm_fwd(const void* x, const float* gamma, const float* beta, void* y, int64_t rows, int C,
                        float eps, void* stream);
 int fdmi_layernorm_bwd(const void* x, const void* dy, const float* gamma, void* dx, int64_t rows, int C,

@@ -516,6 +516,72 @@ def test_gemm5_is_the_planners_choice_for_short_k_rows():
     assert torch.equal(ops.gemm(A, W), ops.gemm(A, W, force_tile=T5))
 
 
+# ---- two-segment A operand (GemmArgs::A2): [A | A2] W^T without materialising the concatenation ---------------------------------
+@pytest.mark.parametrize("tile", [T4, T5, (256 << 16) | 160, (256 << 16) | 128, (256 << 16) | 192, 0])
+@pytest.mark.parametrize("shape", [(512, 640, 320, 128), (1024, 1920, 1280, 640), (768, 320, 64, 64), (2048, 960, 320, 384)])
+def test_gemm_two_segment_a(tile, shape):
+    """every LDS-DMA kernel reads a two-part A operand: the seam at K1 (a multiple of 64) inside an item, at an item's first tile
+    (split-K slices that start behind the seam) and across persistent items; tile 0 = the planner's choice"""
+    ops = _ops()
+    M, N, K1, K2 = shape
+    if tile and N % (tile & 0xffff):
+        pytest.skip("N is not a multiple of this tile's width")
+    A1, A2 = b16(rnd(M, K1, seed=1)), b16(rnd(M, K2, seed=2))
+    W = b16(rnd(N, K1 + K2, seed=3, scale=(K1 + K2) ** -0.5))
+    bias, res = rnd(N, seed=4), b16(rnd(M, N, seed=5))
+    ref = torch.cat([A1, A2], 1).float() @ W.float().t() + bias + res.float()
+    out = ops.gemm(A1.cuda(), W.cuda(), A2=A2.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=tile)
+    close(f"gemm_a2{shape}@{tile:x}", out, ref)
+    # the same product from the materialised concatenation, same kernel: bit-identical (same tiles, same order)
+    if tile:
+        cat = torch.cat([A1, A2], 1).contiguous().cuda()
+        assert torch.equal(out, ops.gemm(cat, W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=tile))
+    if tile and (K1 + K2) // 64 >= 4:   # split-K: some slices start behind the seam
+        sk = 3 if (K1 + K2) // 64 >= 6 else 2
+        out = ops.gemm(A1.cuda(), W.cuda(), A2=A2.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=tile, splitk=sk)
+        close(f"gemm_a2_splitk{shape}@{tile:x}", out, ref)
+    # A2 as a column slice of a wider buffer (the LoRA t of a fused q / k / v projection: row stride 3r)
+    wide = b16(rnd(M, 3 * K2, seed=6)).cuda()
+    sl = wide[:, K2:2 * K2]
+    ref2 = torch.cat([A1, sl.cpu()], 1).float() @ W.float().t()
+    close(f"gemm_a2_strided{shape}@{tile:x}", ops.gemm(A1.cuda(), W.cuda(), A2=sl, force_tile=tile), ref2)
+
+
+def test_gemm_two_segment_a_is_refused_where_no_kernel_reads_it():
+    ops = _ops()
+    A1, A2 = b16(rnd(128, 64, seed=1)).cuda(), b16(rnd(128, 64, seed=2)).cuda()      # M < 256: only the small tiles could run it
+    W = b16(rnd(128, 128, seed=3)).cuda()
+    with pytest.raises(RuntimeError, match="second A segment"):
+        ops.gemm(A1, W, A2=A2)
+    A1, A2 = b16(rnd(512, 96, seed=1)).cuda(), b16(rnd(512, 32, seed=2)).cuda()      # seam not on a 64-deep K tile
+    with pytest.raises(RuntimeError, match="second A segment"):
+        ops.gemm(A1, W, A2=A2)
+
+
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 320, 320, 32), (1, 32, 32, 1280, 640, 32), (3, 8, 8, 64, 128, 8), (2, 16, 16, 640, 320, 32)])
+@pytest.mark.parametrize("silu", [0, 1])
+def test_groupnorm_of_a_concatenation(cfg, silu):
+    """GroupNorm(+SiLU) forward and input gradient of [x1 | x2] read from the two tensors (groups straddle the seam when C1 is not
+    a multiple of the group width: 1280 + 640 channels in 32 groups of 60) against the same kernels on the materialised tensor"""
+    ops = _ops()
+    B, H, W_, C1, C2, G = cfg
+    x1, x2 = b16(rnd(B, H * W_, C1, seed=1)).cuda(), b16(rnd(B, H * W_, C2, seed=2, scale=2.0)).cuda()
+    gamma, beta = (rnd(C1 + C2, seed=3) * 0.2 + 1).cuda(), rnd(C1 + C2, seed=4).cuda()
+    cat = torch.cat([x1, x2], 2).contiguous()
+    y, st = ops.groupnorm_cat_fwd(x1, x2, gamma, beta, G, 1e-5, silu)
+    y0, st0 = ops.groupnorm_fwd(cat, gamma, beta, G, 1e-5, silu)
+    close(f"gn_cat_stats{cfg}", st, st0, tol_el=1e-5, tol_fro=1e-5)       # (float atomics: equal up to summation order)
+    close(f"gn_cat_fwd{cfg}{silu}", y, y0.float(), tol_el=2 ** -7, tol_fro=1e-3)
+    xf = cat.float().cpu().view(B, H * W_, G, -1)
+    mean, var = xf.mean((1, 3), keepdim=True), xf.var((1, 3), unbiased=False, keepdim=True)
+    ref = ((xf - mean) / (var + 1e-5).sqrt()).view(B, H * W_, C1 + C2) * gamma.cpu() + beta.cpu()
+    close(f"gn_cat_ref{cfg}{silu}", y, F.silu(ref) if silu else ref)
+    dy = b16(rnd(B, H * W_, C1 + C2, seed=5)).cuda()
+    dx = ops.groupnorm_cat_bwd(x1, x2, dy, gamma, beta, st, G, 1e-5, silu)
+    dx0 = ops.groupnorm_bwd(cat, dy, gamma, beta, st0, G, 1e-5, silu)
+    close(f"gn_cat_bwd{cfg}{silu}", dx, dx0.float(), tol_el=2 ** -7, tol_fro=2e-3)
+
+
 CONVS4 = [
     (4, 8, 8, 320, 320, 3, 1, 1, 0), (2, 16, 16, 64, 640, 3, 1, 1, 0), (4, 16, 16, 128, 320, 3, 2, 1, 0),
     (4, 8, 8, 64, 320, 3, 1, 1, 1), (2, 16, 16, 192, 320, 1, 1, 0, 0), (1, 32, 32, 640, 320, 3, 1, 1, 0),

@@ -187,7 +187,15 @@ def test_hbm_byte_counters_of_the_memory_bound_families():
     f16, f32 = fam(16, 0), fam(32, 0)
     assert all(abs(b - 2 * a) <= 1e-9 * max(b, 1.0) for a, b in zip(f16[:8], f32[:8]))   # (split-K choices depend on the row count)
     assert f16[0] > 0 and abs(f16[1] - 2 * f16[0]) < 1e-9 * f16[1]            # forward: reduce reads x, apply reads x + writes y
-    assert f16[2] > 0 and f16[4] > 0 and f16[5] > 0 and f16[6] == 0 and f16[7] == 0   # (GEGLU backward / pooling: backward only)
+    assert f16[2] > 0 and f16[4] > 0 and f16[6] == 0 and f16[7] == 0   # (GEGLU backward / pooling: backward only)
+    # round 3: the up path's [h | skip] concatenations are never materialised (two-part operands of GroupNorm and of the 1x1
+    # shortcut GEMM): a forward moves no copy2d bytes at all; A/B switch 30 = 1 brings the copies back
+    assert f16[5] == 0
+    lib.fdmi_tune_set(30, 1)
+    try:
+        assert fam(16, 0)[5] > 0
+    finally:
+        lib.fdmi_tune_set(30, 0)
     assert lib.fdmi_unet_last_hbm_bytes(plan.handle, 9) == -1.0 and f16[8] > 0      # (the deep levels run split-K)
     sv = fam(16, FDMI_UNET_SAVE)
     lib.fdmi_tune_set(14, 0)
