@@ -781,7 +781,7 @@ struct Exec {
     if (!y) return nullptr;
     // LoRA up-projection folded into the base GEMM: y = [x | t] [W | B]^T (+ bias, residual) -- needs the folded operands
     // (lora_foldable, built by build_lora_folded) and a problem the two-segment loaders take (M >= 256)
-    const bool fold = lo && (R.dry() ? lora_foldable(U, *lo) : lo->Wc != nullptr) && x->rows >= 256 && !x->p2;
+    const bool fold = lo && lora_foldable(U, *lo) && (R.dry() || lo->Wc != nullptr) && x->rows >= 256 && !x->p2;
     T* t = nullptr;
     if (lo) {
       t = R.mk(x->rows, lo->r);
@@ -871,8 +871,8 @@ struct Exec {
     T* y = R.mk(x->rows, 3 * C, x->B, x->H, x->W);
     if (!y) return nullptr;
     // the three LoRA up-projections folded in: y = [x | t_q t_k t_v] [Wqkv | blockdiag(B_q, B_k, B_v)]^T, one launch
-    const bool fold = lora && x->rows >= 256 &&
-                      (R.dry() ? (lora_foldable(U, *l3[0]) && lora_foldable(U, *l3[1]) && lora_foldable(U, *l3[2])) : b.Wc3 != nullptr);
+    const bool fold = lora && x->rows >= 256 && lora_foldable(U, *l3[0]) && lora_foldable(U, *l3[1]) && lora_foldable(U, *l3[2]) &&
+                      (R.dry() || b.Wc3 != nullptr);
     T* t3 = nullptr;
     if (lora) {
       t3 = R.mk(x->rows, 3 * r);
