@@ -25,7 +25,7 @@ BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<6
            "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
            "gemm3_kernel<256x160,row>", "gemm3_kernel<256x128,row>", "gemm3_kernel<256x160,conv>", "gemm3_kernel<256x128,conv>",
            "gemm4_kernel<256x320,row>", "gemm4_kernel<256x320,conv>", "gemm4_kernel<256x192,row>", "gemm4_kernel<256x192,conv>",
-           "wgrad_tn_kernel", "gemm4_kernel<128x160,row>", "gemm4_kernel<128x160,geglu>"]
+           "wgrad_tn_kernel"]
 
 
 def _physical_cores():
@@ -439,6 +439,35 @@ def main():
         two_opt = {"metric": "literal 2-optimizer training_step (G + D iteration, lsgan, SD1.5 PatchGAN head on the "
                              "teacher's mid-block features)", "ms_per_step": dq * 1e3, "value": B / dq, "unit": "images/s"}
         del p2, m2
+    # ---- secondary: the generator iteration with the loss every shipped YAML trains with -- LPIPS on the VAE
+    # decode of both outputs' 64x64 crops (FD:383-397): SD1.5 AutoencoderKL decoder + VGG16 on the HIP path, student side taped ----
+    lpips_leg = None
+    if world == 1 and args.arch == "sd15" and not args.no_secondary:
+        from flash_diffusion_amd.workloads import sd_vae
+        try:
+            del pipe
+        except NameError:
+            pass
+        m3 = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0,
+                         distill_loss_type="lpips", vae=sd_vae())
+        p3 = TrainingPipeline(m3, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-5],
+                                                 trainable_params=[["student_denoiser"]]), overlap=not args.no_overlap)
+        p3.configure_optimizers()
+        p3.training_step(batches[0], 0)
+        p3.finish()
+        torch.cuda.synchronize()
+        tq = time.perf_counter()
+        nrep = 2
+        for i in range(nrep):
+            p3.training_step(batches[i % len(batches)], i)
+        p3.finish()
+        torch.cuda.synchronize()
+        dq = (time.perf_counter() - tq) / nrep
+        lpips_leg = {"metric": "generator iteration with distill_loss_type='lpips' (SD1.5 VAE decoder to 512 px + LPIPS-VGG16 of both "
+                               "outputs, student side back-propagated; random-init VAE / VGG weights)", "ms_per_step": dq * 1e3,
+                     "value": B / dq, "unit": "images/s",
+                     "vae_decode_tflop_per_call": m3.vae.vae_model.last_flops / 1e12}
+        del p3, m3
     if world > 1:
         dist.barrier()
     cpu = None
@@ -462,7 +491,7 @@ def main():
                        "dev_switches": {k: os.environ[k] for k in ("FDMI_TUNE", "FDMI_TEACHER_LOOP", "FDMI_CFG_DEDUP",
                                                                    "FDMI_NO_CTX_CACHE", "FDMI_TEACHER_STREAM",
                                                                    "FDMI_DEFER_BACKWARD") if os.environ.get(k)}},
-            "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler, "two_optimizer_step": two_opt},
+            "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler, "two_optimizer_step": two_opt, "lpips_step": lpips_leg},
         }
         print(json.dumps(line))
     if world > 1:

@@ -39,6 +39,12 @@ class UNetCfg(C.Structure):
                 ("flip_sin_to_cos", i32), ("freq_shift", f32), ("precision", i32)]
 
 
+class NetCfg(C.Structure):
+    _fields_ = [("kind", i32), ("in_channels", i32), ("out_channels", i32), ("n_levels", i32), ("block_out", i32 * 4),
+                ("layers_per_block", i32), ("groups", i32), ("eps", f32), ("precision", i32), ("lpips_shift", f32 * 3),
+                ("lpips_scale", f32 * 3), ("adapter_downscale", i32), ("adapter_xl", i32)]
+
+
 _SIGS = {
     "fdmi_unet_create": (vp, [C.POINTER(UNetCfg)]),
     "fdmi_unet_destroy": (None, [vp]),
@@ -54,6 +60,12 @@ _SIGS = {
     "fdmi_unet_last_gn_epilogue": (i32, [vp, C.POINTER(i32)]),
     "fdmi_unet_last_hbm_bytes": (C.c_double, [vp, i32]),
     "fdmi_unet_set_down_residuals": (i32, [vp, vp, i32, f32]),
+    "fdmi_net_create": (vp, [C.POINTER(NetCfg)]),
+    "fdmi_net_workspace_bytes": (i64, [vp, i32, i32, i32, i32]),
+    "fdmi_net_forward": (i32, [vp, i32, vp, vp, vp, i32, i32, i32, vp, i64, i32, vp]),
+    "fdmi_net_backward": (i32, [vp, i32, vp, vp, vp]),
+    "fdmi_adapter_out_shape": (i32, [vp, i32, i32, i32, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+    "fdmi_adapter_forward": (i32, [vp, i32, vp, vp, i32, i32, i32, i32, vp, i64, vp]),
     "fdmi_teacher_loop_scratch_bytes": (i64, [vp, i32, i32, i32]),
     "fdmi_teacher_loop": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, vp]),
     "fdmi_version": (i32, []),

@@ -52,7 +52,7 @@ int fdmi_tune_set(int key, int value) {
 int fdmi_tune_value(int key) { return fdmi_tune_get(key); }
 int fdmi_prof_enable(int on) { g_prof = on != 0; return 0; }
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches) {
-  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (22) buckets");
+  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (20) buckets");
   for (int i = 0; i < nbuckets; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
   FDMI_HIP(hipDeviceSynchronize());
   int bad = 0;
@@ -106,7 +106,7 @@ int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_
   FDMI_CHECK(d != nullptr && kernel && BM && BN && splitk, "gemm_plan: null argument");
   const GemmArgs a = gemm_args_from(d);
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic || a.splitk <= 0);
-  *kernel = p.big; *BM = p.big == 3 ? 128 : (p.big ? 256 : p.BM); *BN = p.BN; *splitk = p.splitk;
+  *kernel = p.big; *BM = p.big ? 256 : p.BM; *BN = p.BN; *splitk = p.splitk;
   return 0;
 }
 

@@ -81,7 +81,7 @@ void fdmi_set_error(const std::string& msg);
 // optional per-launch HIP-event profiling (bench.py roofline leg); see capi.hip
 enum { PROF_GEMM0 = 0 /* +mode*4 + tile */, PROF_ATTN_FWD = 8, PROF_ATTN_DQ = 9, PROF_ATTN_DKV = 10,
        PROF_GEMM3 = 11 /* + mode*2 + (BN==128) */, PROF_GEMM4 = 15 /* + mode (256x320) */, PROF_GEMM4_192 = 17 /* + mode */,
-       PROF_WGRAD_TN = 19, PROF_GEMM5 = 20 /* 128x160 row tile, + GEGLU */, PROF_NBUCKETS = 22 };
+       PROF_WGRAD_TN = 19, PROF_NBUCKETS = 20 };
 int fdmi_tune_get(int key);   // developer tuning knobs (fdmi_tune_set)
 bool fdmi_prof_on();
 void fdmi_prof_begin(hipStream_t st, int bucket, double flops);

@@ -3,7 +3,7 @@
 #include "common.h"
 
 enum { GEMM_ROW = 0, GEMM_CONV = 1 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2 };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2, ACT_RELU = 3 /* conv + ReLU of the VGG16 feature stack (LPIPS) */ };
 
 struct GemmArgs {
   int M = 0, N = 0, K = 0;
@@ -49,7 +49,7 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm32(const GemmArgs& a, hipStream_t stream);   // a.f32 == 1 (launch_gemm forwards to it)
 // kernel / tile / split-K selection (shared by the launcher and by callers that must size `ws`)
-struct GemmPlan { int big = 0;  /* 0: gemm.hip tiles, 1: gemm3 (256 x BN), 2: gemm4 (256 x BN, BN = 320 | 192), 3: gemm5 (128 x 160, two blocks per CU) */ int BM = 128, BN = 128, splitk = 1; };
+struct GemmPlan { int big = 0;  /* 0: gemm.hip tiles, 1: gemm3 (256 x BN), 2: gemm4 (256 x BN, BN = 320 | 192) */ int BM = 128, BN = 128, splitk = 1; };
 GemmPlan plan_gemm(const GemmArgs& a, bool ws_available);
 // bytes of fp32 workspace the auto split-K plan wants for this problem (0 = no split)
 size_t gemm_ws_bytes(const GemmArgs& a);
@@ -61,8 +61,6 @@ int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN = 320);
 // true when launch_gemm can run this problem with a two-segment A operand (GemmArgs::A2): a kernel that implements it is
 // eligible (row GEMM, M >= 256, N >= 128, K and K1 multiples of 64)
 bool gemm_a2_ok(const GemmArgs& a);
-bool gemm5_eligible(const GemmArgs& a);                 // 128 x 160 tile, two persistent blocks per CU (gemm4.hip): short-K row GEMMs
-int launch_gemm5(const GemmArgs& a, hipStream_t stream);
 // true when launch_gemm will run this problem on a kernel whose epilogue accumulates GemmArgs::gn_stats (a 256-row tile
 // without split-K, full tiles inside one sample, 8-column-aligned operands); a.gn_* and a.ws-availability as at launch
 bool gemm_gn_ok(const GemmArgs& a, bool ws_available);

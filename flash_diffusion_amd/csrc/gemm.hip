@@ -59,6 +59,9 @@ __device__ __forceinline__ void epi_store(const GemmArgs& a, int act, int64_t m,
   if (act == ACT_SILU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+  } else if (act == ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -476,7 +479,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   if (a.force_tile) {
     p.BM = a.force_tile >> 16;
     p.BN = a.force_tile & 0xffff;
-    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : ((p.BM == 128 && p.BN == 160) ? 3 : 0);
+    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : 0;
     p.splitk = a.splitk > 0 ? a.splitk : 1;
     return p;
   }
@@ -499,15 +502,6 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
     // the other column width may quantise better (e.g. M=4096, N=1280: 128 tiles of 256x160 vs 160 of 256x128)
     if (a.act != ACT_GEGLU && gemm3_pick_bn(a) == 160 && (a.N % 128) == 0) consider(1, 256, 128, 256, 3.4);
   }
-  // 128 x 160, two persistent blocks per CU (gemm4.hip, round 3): the short-K row GEMMs -- K = 320 / 640 linears and GEGLU
-  // projections -- whose epilogue (store + residual read + GELU) is a third to a half of an item: with two blocks per CU it runs
-  // under the other block's main loop.  An explicit rule, not a rate: these problems are HBM- / epilogue-bound and the cost model
-  // below prices MFMA time only.  A/B switch 28 = 1 takes the tile out of the planner; switch 29 = K limit (default 640).
-  if (!fdmi_tune_get(28) && gemm5_eligible(a) && !a.accum_atomic && a.splitk <= 1 &&
-      a.K <= (fdmi_tune_get(29) > 0 ? fdmi_tune_get(29) : 640) && (int64_t)(a.M / 128) * (a.N / 160) >= 512) {
-    p.big = 3; p.BM = 128; p.BN = 160; p.splitk = 1;
-    return p;
-  }
   if (gemm4_eligible(a)) consider(2, 256, 320, 256, 4.8);
   // 256 x 192 (the widths of the transformer denoisers, which 320 does not divide): measured -6.6 % on the C4 step against the
   // 256 x 128 ring kernel it displaces (profiles/r2_knob12_c4.txt); A/B switch 12 = 1 takes it out of the planner
@@ -525,7 +519,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
 bool gemm_a2_ok(const GemmArgs& a) {
   if (a.f32 || a.mode != GEMM_ROW || !a.A2) return false;
   if (a.K1 <= 0 || a.K1 >= a.K || (a.K1 & 63) || (a.K & 63) || (a.lda2 & 7) || ((uintptr_t)a.A2 & 15)) return false;
-  return gemm3_eligible(a);   // (whenever gemm4 / gemm5 are eligible, so is the 256-row ring kernel)
+  return gemm3_eligible(a);   // (whenever the 256 x 320 / 256 x 192 kernel is eligible, so is the 256-row ring kernel)
 }
 
 bool gemm_gn_ok(const GemmArgs& a, bool ws_available) {
@@ -535,7 +529,7 @@ bool gemm_gn_ok(const GemmArgs& a, bool ws_available) {
   if (a.out_f32 || a.accum_atomic || a.act == ACT_GEGLU || a.preact || a.force_tile || a.splitk > 1) return false;
   if ((a.N & 7) || (a.ldc & 7) || (a.residual && (a.ldr & 7)) || (a.rowvec && (a.rowvec_ld & 7))) return false;
   const GemmPlan p = plan_gemm(a, ws_available);
-  return p.big != 0 && p.splitk == 1 && (p.big != 2 || p.BN == 320) && (a.N % p.BN) == 0;   // (gemm3, gemm4 256x320, gemm5)
+  return p.big != 0 && p.splitk == 1 && (p.big != 2 || p.BN == 320) && (a.N % p.BN) == 0;
 }
 
 size_t gemm_ws_bytes(const GemmArgs& a) {
@@ -586,7 +580,6 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.A2) FDMI_CHECK(p.big != 0, "gemm: a second A segment is read by the LDS-DMA kernels only (forced tile?)");
   if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
   if (p.big == 2) FDMI_CHECK(gemm4_eligible(a, p.BN), "gemm: 256x320 / 256x192 tile not applicable to this problem");
-  if (p.big == 3) FDMI_CHECK(gemm5_eligible(a) && p.splitk <= 1 && !a.accum_atomic, "gemm: 128x160 tile not applicable to this problem");
   a.splitk = p.splitk;
   {  // every split must own at least one K tile (slabs of empty splits would stay uninitialised)
     const int kt = cdiv(a.K, 64);
@@ -600,9 +593,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     ++g_gemm_log.n[std::make_tuple(a.mode, a.M, a.N, a.K, a.act, (a.residual ? 1 : 0) | (a.preact ? 2 : 0) | (a.accum_atomic ? 4 : 0) | (a.out_f32 ? 8 : 0) | (a.dgrad ? 16 : 0),
                                    p.big ? p.big * 1000 + p.BN : p.BM * 1000 + p.BN, a.splitk)];
   int rc;
-  if (p.big == 3)
-    rc = launch_gemm5(a, stream);
-  else if (p.big == 2)
+  if (p.big == 2)
     rc = launch_gemm4(a, stream, p.BN);
   else if (p.big)
     rc = launch_gemm3(a, p.BN, stream);

@@ -14,15 +14,6 @@
 // tile; one `s_waitcnt vmcnt(0) lgkmcnt(0)` + `s_barrier` per tile hands the slots over.  W fragments
 // are streamed through a 4-deep register ring (10 W fragments per k-step would not fit beside 160
 // accumulator registers at 2 waves per SIMD); both k-steps' A fragments stay resident.
-//
-// Round 3: the same pipeline as a SECOND geometry, 128 x 160 x 64 with 256 threads (4 waves as 4(M) x 1(N), wave tile
-// 32 x 160 = 2 x 10 accumulator fragments, 2 x 36 KB of LDS) that runs TWO persistent blocks per CU.  It exists for the
-// short-K row GEMMs (K = 320 / 640 linears and GEGLU projections of the 64x64 / 32x32 levels): with five or ten K tiles per
-// item the store / residual-read / GELU epilogue of the one-block-per-CU kernel is a third to a half of an item and nothing
-// runs under it (the K = 320 linears sat at 3.25 TB/s = 41 % of HBM peak); with two blocks per CU one
-// block's epilogue runs under the other's main loop.  The piece counts are the 256 x 320 kernel's (4 A + 5 W pieces per thread
-// per tile, 20 MFMA groups), so the instruction stream of the main loop is the same shape; at 71 flop per L1 byte the tile is
-// fill-bound at ~0.7 of the MFMA peak, which is why the planner only picks it where HBM, not MFMA, is the bound.
 #include "gemm_tile.h"
 
 namespace {
@@ -31,23 +22,18 @@ namespace {
 // the transformer denoisers' 1152 / 1536 / 4608 / 6144 (PixArt, SD3): 56 KB per tile, 110 flop/B, wave tile 64 x 96.
 // GN: the epilogue also accumulates the consumer's GroupNorm statistics (GemmArgs::gn_stats); a separate instantiation, so the
 // default kernels are instruction-identical with and without the feature
-// BM = 256: 8 waves as 4(M) x 2(N), one block per CU.  BM = 128: 4 waves as 4(M) x 1(N), two blocks per CU.
-template <int MODE, bool GEGLU, int BN, bool GN = false, int BM = 256>
-__global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
+template <int MODE, bool GEGLU, int BN, bool GN = false>
+__global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  static_assert(BM == 256 || BM == 128, "tile heights");
-  constexpr int NT = BM * 2;                 // threads
-  constexpr int WN = BM == 256 ? 2 : 1;      // waves along N (always 4 along M)
-  constexpr int PR = NT / 8;                 // rows one LDS-DMA piece group covers (8 threads per 128-B row)
-  static_assert(BN % (16 * WN) == 0 && (BN * 8) % NT == 0 && BN >= 128, "16-wide fragments, whole LDS-DMA pieces");
+  constexpr int BM = 256;
+  static_assert(BN % 64 == 0 && BN >= 128, "two waves along N, 16-wide fragments in pairs, 64-row LDS-DMA pieces");
   constexpr int STAGE = (BM + BN) * 128;
-  constexpr int AR = BM * 8 / NT, WR = BN * 8 / NT, NP = AR + WR;  // LDS-DMA pieces (1 KiB per wave) per thread per tile
-  constexpr int MF = BM / 64, NF = BN / (16 * WN), NQ = 2 * NF;    // NQ MFMA groups (k-step, W fragment) per tile
+  constexpr int AR = 4, WR = BN / 64, NP = AR + WR;  // LDS-DMA pieces (1 KiB per wave) per thread per tile
+  constexpr int MF = 4, NF = BN / 32, NQ = 2 * NF;   // NQ MFMA groups (k-step, W fragment) per tile
   static_assert(NP <= NQ && NQ >= 8, "one piece per MFMA group; the W ring runs 3 groups ahead");
-  static_assert(!GEGLU || NF % 2 == 0, "(value, gate) fragment pairs inside one wave");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+  const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, j = lane & 15;
 
   // ---- persistent work loop: item = (tile, k-split); block b takes items b, b+G, b+2G, ... ----
@@ -82,7 +68,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
   unsigned aok = 0;          // CONV: bit i = row i reads real data (advances along Cin)
   int ayx[AR], apix[AR];     // CONV: (y << 16 | x) window origin (biased by +256), batch pixel base
   int ky = 0, kx = 0, cc = 0;
-  const bf16_t* abase = zero;  // ROW: row m0+lr; piece i is PR*i rows further
+  const bf16_t* abase = zero;  // ROW: row m0+lr; piece i is 64*i rows further
   int64_t astep = 0;
   int akpos = 0, arow = 0;     // ROW with a second A segment (GemmArgs::A2): k of the tile to issue next, this thread's row
   const bf16_t* wbase = zero;  // W row n0+lr; piece i is 64*i rows further
@@ -119,10 +105,10 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
     if (MODE == GEMM_ROW) {
       if (a.A2 && it.kbeg >= a.K1) {   // (a k-split that starts behind the seam)
         abase = a.A2 + (int64_t)(it.m0 + lr) * a.lda2 + (it.kbeg - a.K1) + c8;
-        astep = PR * a.lda2;
+        astep = 64 * a.lda2;
       } else {
         abase = a.A + (int64_t)(it.m0 + lr) * a.lda + it.kbeg + c8;
-        astep = PR * a.lda;
+        astep = 64 * a.lda;
       }
       akpos = it.kbeg;
       arow = it.m0 + lr;
@@ -134,7 +120,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
       const int hw = a.Hout * a.Wout;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        const int m = it.m0 + lr + PR * i;
+        const int m = it.m0 + lr + 64 * i;
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         apix[i] = b * a.Hin * a.Win;
@@ -145,7 +131,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
       retap();
     }
     wbase = a.W + (int64_t)(it.n0 + lr) * a.ldw + it.kbeg + c8;
-    wstep = PR * a.ldw;
+    wstep = 64 * a.ldw;
   };
   const unsigned lds0 = (unsigned)(uintptr_t)((LDS_AS char*)smem);
   int iv = blockIdx.x, ikt = 0, ink = 0, islot = 0;
@@ -177,13 +163,13 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
   auto piece = [&](int i, unsigned sa) {
     if (i < AR) {
       if (MODE == GEMM_ROW) {
-        glds16(abase + i * astep, sa + NT * 16 * i);
+        glds16(abase + i * astep, sa + 512 * 16 * i);
       } else {
-        glds16(ap[i], sa + NT * 16 * i);
+        glds16(ap[i], sa + 512 * 16 * i);
         ap[i] += ((aok >> i) & 1u) << 6;
       }
     } else {
-      glds16(wbase + (i - AR) * wstep, sa + BM * 128 + NT * 16 * (i - AR));
+      glds16(wbase + (i - AR) * wstep, sa + BM * 128 + 512 * 16 * (i - AR));
     }
   };
   auto issue_finish = [&]() {
@@ -192,7 +178,7 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
       akpos += 64;
       if (a.A2 && akpos == a.K1 && astep) {   // the next tile is the first of the second segment (uniform)
         abase = a.A2 + (int64_t)arow * a.lda2 + c8;
-        astep = PR * a.lda2;
+        astep = 64 * a.lda2;
       }
     } else {
       cc += 64;
@@ -215,12 +201,12 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
   bf16x8 af[2][MF], wq[4];
   auto lds_a = [&](int ks, int mf, int slot) -> bf16x8 {
     const int pc = (ks * 4 + g) ^ (j >> 1);
-    return *(const bf16x8*)(smem + slot * STAGE + ((wm * (16 * MF) + mf * 16 + j) * 8 + pc) * 16);
+    return *(const bf16x8*)(smem + slot * STAGE + ((wm * 64 + mf * 16 + j) * 8 + pc) * 16);
   };
   auto lds_w = [&](int q, int slot) -> bf16x8 {  // q = ks * NF + nf
     const int ks = q / NF, nf = q - ks * NF;
     const int pc = (ks * 4 + g) ^ (j >> 1);
-    return *(const bf16x8*)(smem + slot * STAGE + BM * 128 + ((wn * (BN / WN) + nf * 16 + j) * 8 + pc) * 16);
+    return *(const bf16x8*)(smem + slot * STAGE + BM * 128 + ((wn * (BN / 2) + nf * 16 + j) * 8 + pc) * 16);
   };
 
   // prologue: tile 0 -> slot 0
@@ -275,20 +261,20 @@ __global__ __launch_bounds__(BM * 2, 2) void gemm4_kernel(const GemmArgs a) {
       cslot ^= 1;
     }
     // the next item's first tile is landing meanwhile
-    tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN, true, MODE == GEMM_ROW>(a, it.m0 + wm * (16 * MF), it.n0 + wn * (BN / WN), it.z, acc, g, j);   // (whole tiles only)
+    tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN, true, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);   // (whole tiles only)
   }
   wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
 }
 
-template <int MODE, bool GEGLU, int BN, bool GN = false, int BM = 256>
+template <int MODE, bool GEGLU, int BN, bool GN = false>
 int launch4_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
-  constexpr int smem = 2 * (BM + BN) * 128;
+  constexpr int smem = 2 * (256 + BN) * 128;
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN, BM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
-  const int items = (a.M / BM) * (a.N / BN) * (a.splitk > 1 ? a.splitk : 1);
+  const int items = (a.M / 256) * (a.N / BN) * (a.splitk > 1 ? a.splitk : 1);
   static int ncu = 0;
   if (!ncu) {
     int dev = 0;
@@ -298,11 +284,10 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
     ncu = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount & ~7) : 256;
     if (ncu < 8) ncu = 8;
   }
-  const int slots = ncu * (BM == 256 ? 1 : 2);   // persistent: one 8-wave block per CU, or two 4-wave blocks (128-row tile)
-  dim3 grid(items < slots ? items : slots, 1, 1);
+  dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(stream, BM == 128 ? PROF_GEMM5 + (GEGLU ? 1 : 0) : (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a));
-  FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN, BM>), grid, dim3(BM * 2), smem, stream, a);
+  if (prof) fdmi_prof_begin(stream, (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a));
+  FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -317,21 +302,6 @@ bool gemm4_eligible(const GemmArgs& a, int BN) {
   if (a.mode == GEMM_CONV && ((a.Cin & 63) != 0 || a.Hout > 2048 || a.Wout > 2048)) return false;
   if (a.act == ACT_GEGLU && (a.mode != GEMM_ROW || a.accum_atomic || fdmi_tune_get(9))) return false;
   return true;
-}
-// ---- 128 x 160 tile, two blocks per CU: short-K row GEMMs (plain, GEGLU, GroupNorm-sum epilogues) ----
-bool gemm5_eligible(const GemmArgs& a) {
-  if (a.mode != GEMM_ROW || (a.K & 63) != 0 || (a.M & 127) != 0 || (a.N % 160) != 0) return false;
-  if (a.act == ACT_GEGLU && (a.accum_atomic || fdmi_tune_get(9))) return false;
-  return true;
-}
-int launch_gemm5(const GemmArgs& a, hipStream_t stream) {
-  FDMI_CHECK(gemm5_eligible(a), "gemm5: whole 128 x 160 x 64 tiles of a row GEMM only (its epilogue has no bounds checks)");
-  if (a.act == ACT_GEGLU) {
-    FDMI_CHECK(a.splitk <= 1 && !a.accum_atomic, "gemm5: GEGLU needs a plain row GEMM");
-    return launch4_t<GEMM_ROW, true, 160, false, 128>(a, stream);
-  }
-  if (a.gn_stats) return launch4_t<GEMM_ROW, false, 160, true, 128>(a, stream);
-  return launch4_t<GEMM_ROW, false, 160, false, 128>(a, stream);
 }
 int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
   FDMI_CHECK((a.M & 255) == 0 && (a.N % BN) == 0 && (a.K & 63) == 0, "gemm4: whole 256 x BN x 64 tiles only (its epilogue has no bounds checks)");

@@ -48,6 +48,9 @@ __device__ __forceinline__ void epi_store3(const GemmArgs& a, int act, int64_t m
   if (act == ACT_SILU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
+  } else if (act == ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -117,6 +120,9 @@ __device__ __forceinline__ void epi_finish8(const GemmArgs& a, int act, int64_t 
   if (act == ACT_SILU) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+  } else if (act == ACT_RELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -518,6 +524,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
           if (a.act == ACT_SILU) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = silu_f(v[r]);
+          } else if (a.act == ACT_RELU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
           }
           if (a.out_f32) {
             float* c = (float*)a.C + m * a.ldc + n;

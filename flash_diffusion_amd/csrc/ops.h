@@ -118,6 +118,33 @@ int launch_add_noise(const float* z, const float* noise, const float* sa, const 
 int launch_axpby4(const float* x0, float c0, const float* x1, float c1, const float* x2, float c2,
                   const float* x3, float c3, float* out, int64_t n, hipStream_t st);
 
+// ---- netops.hip: the frozen convolutional nets beside the denoiser (VGG16 / LPIPS, VAE, T2I adapter); `32` = fp32 plans ----
+int launch_relu_mask(const bf16_t* y, bf16_t* dy, int64_t n, hipStream_t st);                 // dy *= (y > 0)
+int launch_relu_mask32(const float* y, float* dy, int64_t n, hipStream_t st);
+int launch_maxpool2_fwd(const bf16_t* x, bf16_t* y, int B, int H, int W, int C, hipStream_t st);
+int launch_maxpool2_fwd32(const float* x, float* y, int B, int H, int W, int C, hipStream_t st);
+int launch_maxpool2_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int B, int H, int W, int C, int accumulate, hipStream_t st);
+int launch_maxpool2_bwd32(const float* x, const float* dy, float* dx, int B, int H, int W, int C, int accumulate, hipStream_t st);
+int launch_avgpool2_fwd(const bf16_t* x, bf16_t* y, int B, int H, int W, int C, hipStream_t st);
+int launch_avgpool2_fwd32(const float* x, float* y, int B, int H, int W, int C, hipStream_t st);
+int launch_pixel_unshuffle(const float* x, bf16_t* y, int B, int C, int H, int W, int f, int Cpad, hipStream_t st);
+int launch_pixel_unshuffle32(const float* x, float* y, int B, int C, int H, int W, int f, int Cpad, hipStream_t st);
+int launch_nhwc_to_nchw_any(const bf16_t* x, float* y, int B, int C, int HW, hipStream_t st);
+int launch_nhwc_to_nchw_any32(const float* x, float* y, int B, int C, int HW, hipStream_t st);
+int launch_bf16_to_f32(const bf16_t* x, float* y, int64_t n, hipStream_t st);
+// out[b] += mean over the sample's pixels of sum_c w[c] (f0 / (|f0| + 1e-10) - f1 / (|f1| + 1e-10))^2 ; rows = B * HW pixel rows
+int launch_lpips_level_fwd(const bf16_t* f0, const bf16_t* f1, const float* w, float* out, int64_t rows, int HW, int C, hipStream_t st);
+int launch_lpips_level_fwd32(const float* f0, const float* f1, const float* w, float* out, int64_t rows, int HW, int C, hipStream_t st);
+int launch_lpips_level_bwd(const bf16_t* f0, const bf16_t* f1, const float* w, const float* gout, bf16_t* df0, int64_t rows, int HW,
+                           int C, int accumulate, hipStream_t st);
+int launch_lpips_level_bwd32(const float* f0, const float* f1, const float* w, const float* gout, float* df0, int64_t rows, int HW,
+                             int C, int accumulate, hipStream_t st);
+// LPIPS ScalingLayer + layout: NCHW f32 [B,3,HW] -> NHWC [B*HW][Cpad]; shift / scale: 3 HOST floats each
+int launch_lpips_input(const float* x, bf16_t* y, int B, int HW, int Cpad, const float* shift, const float* scale, hipStream_t st);
+int launch_lpips_input32(const float* x, float* y, int B, int HW, int Cpad, const float* shift, const float* scale, hipStream_t st);
+int launch_lpips_input_bwd(const bf16_t* dy, float* dx, int B, int HW, int Cpad, const float* scale, hipStream_t st);
+int launch_lpips_input_bwd32(const float* dy, float* dx, int B, int HW, int Cpad, const float* scale, hipStream_t st);
+
 // ---- ref32.hip: fp32 validation mode (exact-f32 MFMA contractions, fp32 storage, fp64 statistics) ----
 int launch_wgrad_tn32(const float* X, int64_t ldx, const float* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
                       hipStream_t st);

@@ -176,6 +176,7 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmArgs a, int kspli
     if (rowvec) v += rowvec[(m / a.rows_per_batch) * a.rowvec_ld + n];
     if (residual) v += residual[m * a.ldr + n];
     if (a.act == ACT_SILU) v = silu32(v);
+    else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
     C[m * a.ldc + n] = v;
   }
 }

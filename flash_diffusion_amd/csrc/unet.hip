@@ -129,13 +129,37 @@ struct StageW {
   Weight resample;  // downsample (stride 2) or upsample conv
 };
 
-enum SlotKind { S_CONV_W, S_LIN_W, S_BIAS, S_GAMMA, S_BETA, S_TEMB_W, S_TEMB_B };
+enum SlotKind { S_CONV_W, S_LIN_W, S_BIAS, S_GAMMA, S_BETA, S_TEMB_W, S_TEMB_B, S_VEC };
 struct Slot {
   SlotKind kind;
   Weight* w = nullptr;
   Norm* n = nullptr;
   int64_t numel = 0;
   int row_off = 0, rows = 0;  // S_TEMB_*
+  float** vec = nullptr;      // S_VEC: a plain fp32 device vector (the LPIPS 1x1 "lin" weights)
+};
+
+// ---- the frozen convolutional networks that sit beside the denoiser in the step, on the same executor ----
+enum { NET_UNET = 0, NET_VAE_DECODER = 1, NET_VGG_LPIPS = 3, NET_T2I_ADAPTER = 4 };
+struct NetVae {   // diffusers AutoencoderKL: post_quant_conv + Decoder (vae/autoencoderKL.py:63-128 calls .decode)
+  Weight post_quant, conv_in, conv_out;
+  Norm norm_out, mid_gn;
+  std::unique_ptr<ResnetW> mid_r0, mid_r1;
+  Weight q, k, v, o;
+  std::vector<std::unique_ptr<StageW>> up;
+};
+struct NetVgg {   // lpips.LPIPS(net="vgg"): torchvision VGG16 features up to relu5_3 + five non-negative 1x1 "lin" layers
+  Weight conv[13];
+  float* lin[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+};
+struct AdapterBlockW {   // diffusers AdapterBlock: [AvgPool2d(2)] [1x1 in_conv] + num_res x (conv3x3, ReLU, conv1x1, + x)
+  bool down = false, has_in = false;
+  Weight in_conv;
+  std::vector<std::unique_ptr<std::pair<Weight, Weight>>> res;
+};
+struct NetAdapter {
+  Weight conv_in;
+  std::vector<std::unique_ptr<AdapterBlockW>> body;
 };
 
 struct Exec;
@@ -184,11 +208,18 @@ struct Run {
     return t;
   }
   bool dry() const { return arena.dry; }
+  const float* gvec = nullptr;   // NET_VGG_LPIPS backward: d loss / d distance [B] (device, fp32)
+  std::vector<T*> outs;          // NET_T2I_ADAPTER: the feature maps of the last forward
 };
 
 }  // namespace
 
 struct fdmi_unet {
+  int kind = NET_UNET;
+  fdmi_net_config ncfg{};
+  std::unique_ptr<NetVae> vae;
+  std::unique_ptr<NetVgg> vgg;
+  std::unique_ptr<NetAdapter> adp;
   // T2I-adapter residuals for the NEXT forward (one f32 NCHW tensor per down block, consumed once): UW:100-106
   std::vector<const float*> down_res;
   float down_res_scale = 1.f;
@@ -294,10 +325,11 @@ static inline int gridfor(int64_t n) {
 // ---------------------------------------------------------------------------------------------
 struct Builder {
   fdmi_unet* U;
-  void conv(const std::string& name, Weight& w, int cout, int cin, int k, bool bias = true) {
+  // pad_out: the GEMM produces Cout_pad columns (zero weights / bias in the pad) so that the result can feed another conv
+  void conv(const std::string& name, Weight& w, int cout, int cin, int k, bool bias = true, bool pad_out = false) {
     w.Cin = cin; w.Cout = cout; w.KH = w.KW = k;
     w.Cin_pad = (cin + 7) & ~7; w.Cout_pad = (cout + 7) & ~7;
-    w.N = cout; w.K = k * k * w.Cin_pad; w.has_bias = bias;
+    w.N = pad_out ? w.Cout_pad : cout; w.K = k * k * w.Cin_pad; w.has_bias = bias;
     U->slots[name + ".weight"] = Slot{S_CONV_W, &w, nullptr, (int64_t)cout * cin * k * k};
     if (bias) U->slots[name + ".bias"] = Slot{S_BIAS, &w, nullptr, cout};
   }
@@ -333,6 +365,23 @@ struct Builder {
     r->has_sc = cin != cout;
     if (r->has_sc) conv(name + ".conv_shortcut", r->sc, cout, cin, 1);
     return r;
+  }
+  // ResnetBlock2D without a time embedding (AutoencoderKL: temb_channels=None)
+  std::unique_ptr<ResnetW> resnet_plain(const std::string& name, int cin, int cout) {
+    auto r = std::make_unique<ResnetW>();
+    r->cin = cin; r->cout = cout; r->temb_off = -1;
+    norm(name + ".norm1", r->n1, cin);
+    conv(name + ".conv1", r->c1, cout, cin, 3);
+    norm(name + ".norm2", r->n2, cout);
+    conv(name + ".conv2", r->c2, cout, cout, 3);
+    r->has_sc = cin != cout;
+    if (r->has_sc) conv(name + ".conv_shortcut", r->sc, cout, cin, 1);
+    return r;
+  }
+  void vec(const std::string& name, float** dst, int n) {
+    Slot sl{S_VEC, nullptr, nullptr, n};
+    sl.vec = dst;
+    U->slots[name] = sl;
   }
   std::unique_ptr<TransformerW> transformer(const std::string& name, int C, int heads, int layers) {
     auto t = std::make_unique<TransformerW>();
@@ -450,7 +499,7 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
       Weight& w = *s.w;
       const size_t k = U->f32 ? 2 : 1;   // (dmalloc counts bf16 elements: an fp32 plan takes twice as many)
       if (!w.w) {
-        RET_IF(dmalloc(U, &w.w, k * w.Cout * w.KH * w.KW * w.Cin_pad));
+        RET_IF(dmalloc(U, &w.w, k * (w.N > w.Cout ? w.N : w.Cout) * w.KH * w.KW * w.Cin_pad));   // (pad_out: zero rows)
         RET_IF(dmalloc(U, &w.wt, k * w.Cin * w.KH * w.KW * w.Cout_pad));
       }
       const int g1 = gridfor((int64_t)w.Cout * w.K), g2 = gridfor((int64_t)w.Cin * w.KH * w.KW * w.Cout_pad);
@@ -483,7 +532,8 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
     case S_BIAS: {
       Weight& w = *s.w;
       if (!w.bias) RET_IF(dmalloc(U, &w.bias, (size_t)w.N));
-      hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(w.N)), dim3(256), 0, st, src, w.bias, w.N, w.geglu ? 1 : 0);
+      const int nb = (w.Cout > 0 && w.Cout < w.N) ? w.Cout : w.N;   // (a conv with padded output columns: the pad stays zero)
+      hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(nb)), dim3(256), 0, st, src, w.bias, nb, w.geglu ? 1 : 0);
       w.set |= 2;
       break;
     }
@@ -494,6 +544,11 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
       if (!*dst) RET_IF(dmalloc(U, dst, (size_t)n.C));
       hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(n.C)), dim3(256), 0, st, src, *dst, n.C, 0);
       n.set |= s.kind == S_GAMMA ? 1 : 2;
+      break;
+    }
+    case S_VEC: {
+      if (!*s.vec) RET_IF(dmalloc(U, s.vec, (size_t)s.numel));
+      hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor((int)s.numel)), dim3(256), 0, st, src, *s.vec, (int)s.numel, 0);
       break;
     }
     case S_TEMB_W:
@@ -667,7 +722,7 @@ struct Exec {
       if (!q.accum_atomic && q.splitk == 1 && gemm_ws_bytes(q)) q.splitk = 0;
       const GemmPlan p = plan_gemm(q, true);
       fprintf(stderr, "PLANGEMM mode=%d M=%d N=%d K=%d act=%d res=%d dgrad=%d atomic=%d kernel=%d BM=%d BN=%d splitk=%d\n", a.mode, a.M, a.N,
-              a.K, a.act, a.residual ? 1 : 0, a.dgrad, a.accum_atomic, p.big, p.big == 3 ? 128 : (p.big ? 256 : p.BM), p.BN, p.splitk);
+              a.K, a.act, a.residual ? 1 : 0, a.dgrad, a.accum_atomic, p.big, p.big ? 256 : p.BM, p.BN, p.splitk);
     }
     if (!a.accum_atomic && a.splitk == 1) {  // let the launcher split K when the tile grid under-fills the chip
       const size_t wsb = gemm_ws_bytes(a);
@@ -942,7 +997,9 @@ struct Exec {
   }
 
   // 3x3 (or kxk) convolution on NHWC; stride 1|2, optional fused nearest-2x upsample of the input
-  T* conv(T* x, Weight& w, int stride, int ups, const bf16_t* rowvec, int64_t rowvec_ld, T* residual, bool gn_next = false) {
+  // act: ACT_NONE | ACT_RELU (fused into the epilogue; the backward masks dY with the stored output first)
+  T* conv(T* x, Weight& w, int stride, int ups, const bf16_t* rowvec, int64_t rowvec_ld, T* residual, bool gn_next = false,
+          int act = ACT_NONE) {
     const int pad = w.KH / 2;
     const int Hv = x->H << ups, Wv = x->W << ups;
     const int Ho = (Hv + 2 * pad - w.KH) / stride + 1, Wo = (Wv + 2 * pad - w.KW) / stride + 1;
@@ -955,13 +1012,16 @@ struct Exec {
     a.stride = stride; a.pad = pad; a.ups = ups; a.bias = w.bias;
     a.rowvec = rowvec; a.rowvec_ld = rowvec_ld; a.rows_per_batch = Ho * Wo;
     a.residual = residual ? residual->p : nullptr; a.ldr = residual ? residual->cols : 0;
-    a.C = y->p; a.ldc = w.N;
+    a.C = y->p; a.ldc = w.N; a.act = act;
     if (gn_next) want_gn(a, Ho * Wo);
     NULL_IF(gemm(a));
     y->gn = a.gn_stats;
     if (R.save) {
-      R.tape.push_back([x, y, residual, &w, stride, ups, pad, Hv, Wv, Ho, Wo](Exec& E) -> int {
+      R.tape.push_back([x, y, residual, &w, stride, ups, pad, Hv, Wv, Ho, Wo, act](Exec& E) -> int {
         if (!y->g) return 0;
+        if (act == ACT_RELU && !E.R.dry())   // every consumer of y has added its gradient by now (reverse tape order)
+          RET_IF(E.f32() ? launch_relu_mask32(F(y->p), F(y->g), y->rows * y->cols, E.st)
+                         : launch_relu_mask(y->p, y->g, y->rows * y->cols, E.st));
         if (residual) RET_IF(E.add_grad(residual, y->g, y->cols, 0, y->cols));
         // dgrad: gather form of the transposed conv over dY (channels padded to 8)
         const bf16_t* dy = y->g;
@@ -1219,13 +1279,122 @@ struct Exec {
     return y;
   }
 
+  // ---- ops of the frozen nets beside the denoiser (VGG16 / LPIPS, VAE decoder, T2I adapter) ----
+  T* maxpool2(T* x) {
+    T* y = R.mk((int64_t)x->B * (x->H / 2) * (x->W / 2), x->cols, x->B, x->H / 2, x->W / 2);
+    if (!y) return nullptr;
+    if (!R.dry())
+      NULL_IF(f32() ? launch_maxpool2_fwd32(F(x->p), F(y->p), x->B, x->H, x->W, x->cols, st)
+                    : launch_maxpool2_fwd(x->p, y->p, x->B, x->H, x->W, x->cols, st));
+    if (R.save) {
+      R.tape.push_back([x, y](Exec& E) -> int {
+        if (!y->g) return 0;
+        bf16_t* dx = E.grad_of(x);
+        FDMI_CHECK(dx, "net: workspace exhausted (grad)");
+        if (!E.R.dry())
+          RET_IF(E.f32() ? launch_maxpool2_bwd32(F(x->p), F(y->g), F(dx), x->B, x->H, x->W, x->cols, x->ginit ? 1 : 0, E.st)
+                         : launch_maxpool2_bwd(x->p, y->g, dx, x->B, x->H, x->W, x->cols, x->ginit ? 1 : 0, E.st));
+        x->ginit = true;
+        return 0;
+      });
+    }
+    return y;
+  }
+  T* avgpool2(T* x) {   // forward only (the adapter is frozen and its input carries no gradient)
+    T* y = R.mk((int64_t)x->B * (x->H / 2) * (x->W / 2), x->cols, x->B, x->H / 2, x->W / 2);
+    if (!y) return nullptr;
+    if (!R.dry())
+      NULL_IF(f32() ? launch_avgpool2_fwd32(F(x->p), F(y->p), x->B, x->H, x->W, x->cols, st)
+                    : launch_avgpool2_fwd(x->p, y->p, x->B, x->H, x->W, x->cols, st));
+    return y;
+  }
+  // y = a + b (element-wise; forward only: the adapter's ResNet skip)
+  T* add(T* a, T* b) {
+    T* y = R.mk(a->rows, a->cols, a->B, a->H, a->W);
+    if (!y) return nullptr;
+    if (!R.dry()) {
+      NULL_IF(l_copy2d(a->p, a->cols, 0, y->p, y->cols, 0, a->rows, a->cols, 0));
+      NULL_IF(l_copy2d(b->p, b->cols, 0, y->p, y->cols, 0, b->rows, b->cols, 1));
+    }
+    return y;
+  }
+  // single- or few-head attention whose head dim exceeds the flash kernels' (the VAE mid block: one head of 512): scores are
+  // materialised by the exact-f32 kernels of the validation family (ref32.hip) in BOTH precisions -- a bf16 plan stages its
+  // operands through fp32 copies.  One layer per decode; the FLOPs are 4 B S^2 d like any attention.
+  T* attention_wide(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv) {
+    const int d = q->cols / H;
+    if (f32()) return attention32(q, k, v, Bn, H, Sq, Skv, d);
+    T* o = R.mk(q->rows, q->cols, q->B, q->H, q->W);
+    const int64_t nq = q->rows * q->cols, nk = k->rows * k->cols;
+    float* qf = (float*)R.arena.alloc((size_t)nq * 4);
+    float* kf = (float*)R.arena.alloc((size_t)nk * 4);
+    float* vf = (float*)R.arena.alloc((size_t)nk * 4);
+    float* of = (float*)R.arena.alloc((size_t)nq * 4);
+    float* sc = attn_scratch(Bn, H, Sq, Skv, 0);
+    if (!o || !qf || !kf || !vf || !of || !sc) return nullptr;
+    const float scale = 1.f / sqrtf((float)d);
+    flops += 4.0 * Bn * H * (double)Sq * Skv * d;
+    if (!R.dry()) {
+      NULL_IF(launch_bf16_to_f32(q->p, qf, nq, st));
+      NULL_IF(launch_bf16_to_f32(k->p, kf, nk, st));
+      NULL_IF(launch_bf16_to_f32(v->p, vf, nk, st));
+      NULL_IF(launch_attn32_fwd(qf, q->cols, kf, k->cols, vf, v->cols, of, q->cols, Bn, H, Sq, Skv, d, scale, sc, R.sc32_elems, st));
+      NULL_IF(launch_f32_to_bf16(of, o->p, nq, st));
+    }
+    if (R.save) {
+      R.tape.push_back([o, q, k, v, qf, kf, vf, of, Bn, H, Sq, Skv, d, scale, nq, nk](Exec& E) -> int {
+        if (!o->g) return 0;
+        float* sc2 = E.attn_scratch(Bn, H, Sq, Skv, 1);
+        float* dqf = (float*)E.R.arena.alloc((size_t)nq * 4);
+        float* dkf = (float*)E.R.arena.alloc((size_t)nk * 4);
+        float* dvf = (float*)E.R.arena.alloc((size_t)nk * 4);
+        bf16_t *dq = E.grad_of(q), *dk = E.grad_of(k), *dv = E.grad_of(v);
+        FDMI_CHECK(sc2 && dqf && dkf && dvf && dq && dk && dv, "net: workspace exhausted (attn bwd)");
+        FDMI_CHECK(!q->ginit && !k->ginit && !v->ginit, "attention_wide: q / k / v must have no other consumer");
+        E.flops += 2.0 * 4.0 * Bn * H * (double)Sq * Skv * d;
+        if (!E.R.dry()) {
+          RET_IF(launch_bf16_to_f32(o->g, of, nq, E.st));   // (of is free: the forward's output was converted already)
+          RET_IF(launch_attn32_bwd(qf, q->cols, kf, k->cols, vf, v->cols, of, q->cols, dqf, q->cols, dkf, k->cols, dvf, v->cols, Bn, H,
+                                   Sq, Skv, d, scale, sc2, E.R.sc32_elems, E.st));
+          RET_IF(launch_f32_to_bf16(dqf, dq, nq, E.st));
+          RET_IF(launch_f32_to_bf16(dkf, dk, nk, E.st));
+          RET_IF(launch_f32_to_bf16(dvf, dv, nk, E.st));
+        }
+        q->ginit = k->ginit = v->ginit = true;
+        return 0;
+      });
+    }
+    return o;
+  }
+  // one LPIPS level: out[b] += mean_pixels sum_c w[c] (unit(f0) - unit(f1))^2 ; gradient to f0 only (f1 = the no-grad side)
+  int lpips_level(T* f0, T* f1, const float* w, float* out) {
+    const int HW = f0->H * f0->W;
+    if (!R.dry())
+      RET_IF(f32() ? launch_lpips_level_fwd32(F(f0->p), F(f1->p), w, out, f0->rows, HW, f0->cols, st)
+                   : launch_lpips_level_fwd(f0->p, f1->p, w, out, f0->rows, HW, f0->cols, st));
+    if (R.save) {
+      R.tape.push_back([f0, f1, w, HW](Exec& E) -> int {
+        bf16_t* d0 = E.grad_of(f0);
+        FDMI_CHECK(d0 && (E.R.dry() || E.R.gvec), "lpips: workspace exhausted / no output gradient");
+        if (!E.R.dry())
+          RET_IF(E.f32() ? launch_lpips_level_bwd32(F(f0->p), F(f1->p), w, E.R.gvec, F(d0), f0->rows, HW, f0->cols, f0->ginit ? 1 : 0, E.st)
+                         : launch_lpips_level_bwd(f0->p, f1->p, w, E.R.gvec, d0, f0->rows, HW, f0->cols, f0->ginit ? 1 : 0, E.st));
+        f0->ginit = true;
+        return 0;
+      });
+    }
+    return 0;
+  }
+
   // ---- blocks ----------------------------------------------------------------------------------
   // gn_next: the block's output goes straight into a GroupNorm (the next ResNet block's or a transformer's)
   T* resnet(T* x, ResnetW& r, T* temb_all, bool gn_next = false) {
     const fdmi_unet_config& c = U->cfg;
     T* a = groupnorm(x, r.n1, c.eps, 1);
     if (!a) return nullptr;
-    T* h = conv(a, r.c1, 1, 0, off(temb_all->p, r.temb_off), temb_all->cols, nullptr, true);
+    // (temb_all == nullptr: a ResnetBlock2D without time embedding -- the VAE's)
+    T* h = temb_all ? conv(a, r.c1, 1, 0, off(temb_all->p, r.temb_off), temb_all->cols, nullptr, true)
+                    : conv(a, r.c1, 1, 0, nullptr, 0, nullptr, true);
     if (!h) return nullptr;
     T* a2 = groupnorm(h, r.n2, c.eps, 1);
     if (!a2) return nullptr;
@@ -1466,7 +1635,9 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
       for (size_t j = 0; j < s.res.size(); ++j) {
         T* sk = skips.back();
         skips.pop_back();
-        T* hc = E.cat(h, sk, s.res[j]->has_sc);   // (a block without a shortcut conv would read the concat as a residual)
+        // virtual only when both readers take a two-part operand: the 1x1 shortcut GEMM exists and is wide enough for the LDS-DMA
+        // kernels (N >= 128; a block without a shortcut conv would read the concat as a residual)
+        T* hc = E.cat(h, sk, s.res[j]->has_sc && s.res[j]->cout >= 128);
         FAIL_IF_NULL(hc);
         // the up path's block outputs are concatenated with a skip before the next norm (no statistics to pass on), except
         // the very last one, which conv_norm_out reads
@@ -1521,6 +1692,291 @@ int run_backward(fdmi_unet* U, Run& R, const float* grad_out, float* grad_x) {
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// plan construction + forward graphs of the frozen nets beside the denoiser
+// ---------------------------------------------------------------------------------------------
+int build_net(fdmi_unet* U) {
+  const fdmi_net_config& c = U->ncfg;
+  Builder b{U};
+  if (U->kind == NET_VAE_DECODER) {
+    FDMI_CHECK(c.n_levels >= 1 && c.n_levels <= 4, "vae: n_levels must be 1..4");
+    auto v = std::make_unique<NetVae>();
+    const int top = c.block_out[c.n_levels - 1];
+    b.conv("post_quant_conv", v->post_quant, c.in_channels, c.in_channels, 1, true, /*pad_out=*/true);
+    b.conv("decoder.conv_in", v->conv_in, top, c.in_channels, 3);
+    v->mid_r0 = b.resnet_plain("decoder.mid_block.resnets.0", top, top);
+    b.norm("decoder.mid_block.attentions.0.group_norm", v->mid_gn, top);
+    b.linear("decoder.mid_block.attentions.0.to_q", v->q, top, top, true);
+    b.linear("decoder.mid_block.attentions.0.to_k", v->k, top, top, true);
+    b.linear("decoder.mid_block.attentions.0.to_v", v->v, top, top, true);
+    b.linear("decoder.mid_block.attentions.0.to_out.0", v->o, top, top, true);
+    v->mid_r1 = b.resnet_plain("decoder.mid_block.resnets.1", top, top);
+    int prev = top;
+    for (int i = 0; i < c.n_levels; ++i) {   // decoder levels run over reversed(block_out_channels)
+      auto st = std::make_unique<StageW>();
+      const int out = c.block_out[c.n_levels - 1 - i];
+      const std::string bn = "decoder.up_blocks." + std::to_string(i);
+      for (int j = 0; j < c.layers_per_block + 1; ++j)
+        st->res.push_back(b.resnet_plain(bn + ".resnets." + std::to_string(j), j == 0 ? prev : out, out));
+      st->has_resample = i != c.n_levels - 1;
+      if (st->has_resample) b.conv(bn + ".upsamplers.0.conv", st->resample, out, out, 3);
+      prev = out;
+      v->up.push_back(std::move(st));
+    }
+    b.norm("decoder.conv_norm_out", v->norm_out, prev);
+    b.conv("decoder.conv_out", v->conv_out, c.out_channels, prev, 3);
+    U->vae = std::move(v);
+  } else if (U->kind == NET_VGG_LPIPS) {
+    auto g = std::make_unique<NetVgg>();
+    // torchvision vgg16().features indices of the 13 convolutions, grouped into lpips' five slices (pretrained_networks.py)
+    static const int idx[13] = {0, 2, 5, 7, 10, 12, 14, 17, 19, 21, 24, 26, 28};
+    static const int slice[13] = {1, 1, 2, 2, 3, 3, 3, 4, 4, 4, 5, 5, 5};
+    static const int ch[13] = {64, 64, 128, 128, 256, 256, 256, 512, 512, 512, 512, 512, 512};
+    int cin = 3;
+    for (int i = 0; i < 13; ++i) {
+      b.conv("net.slice" + std::to_string(slice[i]) + "." + std::to_string(idx[i]), g->conv[i], ch[i], cin, 3);
+      cin = ch[i];
+    }
+    static const int lc[5] = {64, 128, 256, 512, 512};
+    for (int l = 0; l < 5; ++l) b.vec("lin" + std::to_string(l) + ".model.1.weight", &g->lin[l], lc[l]);
+    U->vgg = std::move(g);
+  } else if (U->kind == NET_T2I_ADAPTER) {
+    FDMI_CHECK(c.n_levels >= 1 && c.n_levels <= 4 && c.adapter_downscale > 0, "adapter: n_levels must be 1..4, downscale > 0");
+    auto a = std::make_unique<NetAdapter>();
+    const int f = c.adapter_downscale;
+    b.conv("adapter.conv_in", a->conv_in, c.block_out[0], c.in_channels * f * f, 3);
+    for (int i = 0; i < c.n_levels; ++i) {
+      auto blk = std::make_unique<AdapterBlockW>();
+      const int cin = i == 0 ? c.block_out[0] : c.block_out[i - 1], cout = c.block_out[i];
+      // FullAdapter: every block but the first downsamples; FullAdapterXL: only block 2 (diffusers adapter.py)
+      blk->down = c.adapter_xl ? (i == 2) : (i > 0);
+      blk->has_in = cin != cout;
+      const std::string bn = "adapter.body." + std::to_string(i);
+      if (blk->has_in) b.conv(bn + ".in_conv", blk->in_conv, cout, cin, 1);
+      for (int j = 0; j < c.layers_per_block; ++j) {
+        auto pr = std::make_unique<std::pair<Weight, Weight>>();
+        b.conv(bn + ".resnets." + std::to_string(j) + ".block1", pr->first, cout, cout, 3);
+        b.conv(bn + ".resnets." + std::to_string(j) + ".block2", pr->second, cout, cout, 1);
+        blk->res.push_back(std::move(pr));
+      }
+      a->body.push_back(std::move(blk));
+    }
+    U->adp = std::move(a);
+  } else {
+    FDMI_CHECK(false, "net: unknown kind");
+  }
+  return 0;
+}
+
+static void run_reset(fdmi_unet* U, Run& R, int flags) {
+  U->last_gn = U->last_gn_epi = 0;
+  for (double& b : U->hbm) b = 0;
+  R.tensors.clear();
+  R.tape.clear();
+  R.outs.clear();
+  R.arena.off = 0;
+  R.es = U->f32 ? 4 : 2;
+  R.sc32 = nullptr;
+  R.sc32_elems = 0;
+  R.gvec = nullptr;
+  R.save = (flags & FDMI_UNET_SAVE) != 0;
+}
+static int run_zpool(fdmi_unet* U, Run& R, int B, int n_norms) {   // accumulator pool of the GroupNorm statistics (fwd + bwd)
+  const size_t per = (((size_t)B * U->cfg.groups * 2 * sizeof(float)) + 255) & ~(size_t)255;
+  R.zcap = per * 2 * (size_t)(n_norms + 2);
+  R.zoff = 0;
+  R.zpool = (char*)R.arena.alloc(R.zcap);
+  FAIL_IF_NULL(R.zpool);
+  if (!R.dry()) FDMI_HIP(hipMemsetAsync(R.zpool, 0, R.zcap, R.st));
+  return 0;
+}
+
+// AutoencoderKL.decode(z).sample (diffusers; the wrapper divides by the scaling factor first, vae/autoencoderKL.py:63-128):
+// post_quant_conv 1x1 -> conv_in -> mid (ResNet, one-head attention over all H*W positions, ResNet) -> per level (layers + 1)
+// ResNets [+ nearest-2x upsample fused into the following 3x3 conv] -> GroupNorm + SiLU -> conv_out
+int run_vae_decoder(fdmi_unet* U, Run& R, const float* z, float* out, int B, int H, int W, int flags) {
+  NetVae& V = *U->vae;
+  const fdmi_net_config& c = U->ncfg;
+  Exec E{U, R, R.st};
+  E.gn_epi = fdmi_tune_get(14) == 0 && !U->f32;
+  run_reset(U, R, flags);
+  int n_norms = 2 * 2 + 1 + 1;
+  for (auto& st : V.up) n_norms += 2 * (int)st->res.size();
+  RET_IF(run_zpool(U, R, B, n_norms));
+  const int cin_pad = V.post_quant.Cin_pad;
+  T* x0 = R.mk((int64_t)B * H * W, cin_pad, B, H, W);
+  FAIL_IF_NULL(x0);
+  R.x0 = x0;
+  if (!R.dry())
+    RET_IF(U->f32 ? launch_nchw_to_nhwc32(z, Exec::F(x0->p), B, c.in_channels, H * W, cin_pad, R.st)
+                  : launch_nchw_to_nhwc(z, x0->p, B, c.in_channels, H * W, cin_pad, R.st));
+  T* h = E.conv(x0, V.post_quant, 1, 0, nullptr, 0, nullptr);
+  FAIL_IF_NULL(h);
+  h = E.conv(h, V.conv_in, 1, 0, nullptr, 0, nullptr, true);
+  FAIL_IF_NULL(h);
+  h = E.resnet(h, *V.mid_r0, nullptr, true);
+  FAIL_IF_NULL(h);
+  {   // Attention(heads = 1, residual_connection = True, norm_num_groups): x + to_out(softmax(q k^T / sqrt(C)) v) on GroupNorm(x)
+    T* hn = E.groupnorm(h, V.mid_gn, c.eps, 0);
+    FAIL_IF_NULL(hn);
+    T *q = E.linear_w(hn, V.q), *k = E.linear_w(hn, V.k), *v = E.linear_w(hn, V.v);
+    FAIL_IF_NULL(q); FAIL_IF_NULL(k); FAIL_IF_NULL(v);
+    T* o = E.attention_wide(q, k, v, B, 1, H * W, H * W);
+    FAIL_IF_NULL(o);
+    h = E.linear_w(o, V.o, h, nullptr, true, H * W);
+    FAIL_IF_NULL(h);
+  }
+  h = E.resnet(h, *V.mid_r1, nullptr, true);
+  FAIL_IF_NULL(h);
+  for (auto& sp : V.up) {
+    StageW& st = *sp;
+    for (size_t j = 0; j < st.res.size(); ++j) {
+      // the next reader is a GroupNorm (the next ResNet's norm1 / conv_norm_out) unless an upsampling conv comes first
+      const bool gn_next = j + 1 < st.res.size() || !st.has_resample;
+      h = E.resnet(h, *st.res[j], nullptr, gn_next);
+      FAIL_IF_NULL(h);
+    }
+    if (st.has_resample) {
+      h = E.conv(h, st.resample, 1, 1, nullptr, 0, nullptr, true);
+      FAIL_IF_NULL(h);
+    }
+  }
+  T* a = E.groupnorm(h, V.norm_out, c.eps, 1);
+  FAIL_IF_NULL(a);
+  h = E.conv(a, V.conv_out, 1, 0, nullptr, 0, nullptr);
+  FAIL_IF_NULL(h);
+  R.out = h;
+  R.outC = h->cols;
+  if (!R.dry())
+    RET_IF(U->f32 ? launch_nhwc_to_nchw32(Exec::F(h->p), h->cols, out, B, h->cols, h->H * h->W, 0, R.st)
+                  : launch_nhwc_to_nchw(h->p, h->cols, out, B, h->cols, h->H * h->W, 0, R.st));
+  U->last_flops = E.flops;
+  return 0;
+}
+
+// lpips.LPIPS(net="vgg", lpips=True, spatial=False).forward(in0, in1) (lpips 0.1.4): ScalingLayer, the VGG16 feature stack
+// (conv3x3 + ReLU x 13, max pooling in front of slices 2..5), per tap: channel-unit-normalise both, squared difference, the
+// non-negative 1x1 lin layer, spatial mean; the five levels are summed.  in1 is the no-grad side (the teacher's decode): its
+// features are computed without a tape.
+static int vgg_features(Exec& E, NetVgg& G, T* x, T* feats[5]) {
+  T* h = x;
+  int l = 0;
+  for (int i = 0; i < 13; ++i) {
+    if (i == 2 || i == 4 || i == 7 || i == 10) {
+      h = E.maxpool2(h);
+      FAIL_IF_NULL(h);
+    }
+    h = E.conv(h, G.conv[i], 1, 0, nullptr, 0, nullptr, false, ACT_RELU);
+    FAIL_IF_NULL(h);
+    if (i == 1 || i == 3 || i == 6 || i == 9 || i == 12) feats[l++] = h;
+  }
+  return 0;
+}
+int run_lpips(fdmi_unet* U, Run& R, const float* img0, const float* img1, float* out, int B, int H, int W, int flags) {
+  NetVgg& G = *U->vgg;
+  const fdmi_net_config& c = U->ncfg;
+  FDMI_CHECK(H % 16 == 0 && W % 16 == 0, "lpips: H, W must be multiples of 16 (four 2x2 poolings)");
+  Exec E{U, R, R.st};
+  run_reset(U, R, flags);
+  const bool save = R.save;
+  const int cpad = G.conv[0].Cin_pad;
+  T* x1 = R.mk((int64_t)B * H * W, cpad, B, H, W);
+  T* x0 = R.mk((int64_t)B * H * W, cpad, B, H, W);
+  FAIL_IF_NULL(x1); FAIL_IF_NULL(x0);
+  R.x0 = x0;
+  if (!R.dry()) {
+    FDMI_HIP(hipMemsetAsync(out, 0, (size_t)B * sizeof(float), R.st));
+    RET_IF(U->f32 ? launch_lpips_input32(img1, Exec::F(x1->p), B, H * W, cpad, c.lpips_shift, c.lpips_scale, R.st)
+                  : launch_lpips_input(img1, x1->p, B, H * W, cpad, c.lpips_shift, c.lpips_scale, R.st));
+    RET_IF(U->f32 ? launch_lpips_input32(img0, Exec::F(x0->p), B, H * W, cpad, c.lpips_shift, c.lpips_scale, R.st)
+                  : launch_lpips_input(img0, x0->p, B, H * W, cpad, c.lpips_shift, c.lpips_scale, R.st));
+  }
+  T *f1[5], *f0[5];
+  R.save = false;                       // the reference side: no tape
+  RET_IF(vgg_features(E, G, x1, f1));
+  R.save = save;
+  RET_IF(vgg_features(E, G, x0, f0));
+  for (int l = 0; l < 5; ++l) RET_IF(E.lpips_level(f0[l], f1[l], G.lin[l], out));
+  R.out = nullptr;
+  U->last_flops = E.flops;
+  return 0;
+}
+
+// diffusers T2IAdapter (full_adapter / full_adapter_xl), frozen: PixelUnshuffle -> conv_in -> per block [AvgPool2d(2)]
+// [1x1 in_conv] + resnets (x + conv1x1(relu(conv3x3(x)))); the output of every block is a feature map
+int run_adapter(fdmi_unet* U, Run& R, const float* x, float* const* outs, int n_outs, int B, int H, int W) {
+  NetAdapter& A = *U->adp;
+  const fdmi_net_config& c = U->ncfg;
+  const int f = c.adapter_downscale;
+  FDMI_CHECK(n_outs == (int)A.body.size(), "adapter: one output per block expected");
+  FDMI_CHECK(H % f == 0 && W % f == 0, "adapter: H, W must be multiples of the downscale factor");
+  Exec E{U, R, R.st};
+  run_reset(U, R, 0);
+  const int cpad = A.conv_in.Cin_pad;
+  T* h = R.mk((int64_t)B * (H / f) * (W / f), cpad, B, H / f, W / f);
+  FAIL_IF_NULL(h);
+  if (!R.dry())
+    RET_IF(U->f32 ? launch_pixel_unshuffle32(x, Exec::F(h->p), B, c.in_channels, H, W, f, cpad, R.st)
+                  : launch_pixel_unshuffle(x, h->p, B, c.in_channels, H, W, f, cpad, R.st));
+  h = E.conv(h, A.conv_in, 1, 0, nullptr, 0, nullptr);
+  FAIL_IF_NULL(h);
+  for (size_t i = 0; i < A.body.size(); ++i) {
+    AdapterBlockW& blk = *A.body[i];
+    if (blk.down) {
+      FDMI_CHECK(h->H % 2 == 0 && h->W % 2 == 0, "adapter: odd feature map in front of a downsampling block");
+      h = E.avgpool2(h);
+      FAIL_IF_NULL(h);
+    }
+    if (blk.has_in) {
+      h = E.conv(h, blk.in_conv, 1, 0, nullptr, 0, nullptr);
+      FAIL_IF_NULL(h);
+    }
+    for (auto& pr : blk.res) {
+      T* t = E.conv(h, pr->first, 1, 0, nullptr, 0, nullptr, false, ACT_RELU);
+      FAIL_IF_NULL(t);
+      h = E.conv(t, pr->second, 1, 0, nullptr, 0, h);   // + x as the epilogue's residual
+      FAIL_IF_NULL(h);
+    }
+    R.outs.push_back(h);
+    if (!R.dry())
+      RET_IF(U->f32 ? launch_nhwc_to_nchw_any32(Exec::F(h->p), outs[i], B, h->cols, h->H * h->W, R.st)
+                    : launch_nhwc_to_nchw_any(h->p, outs[i], B, h->cols, h->H * h->W, R.st));
+  }
+  U->last_flops = E.flops;
+  return 0;
+}
+
+int run_net_backward(fdmi_unet* U, Run& R, const float* grad_out, float* grad_x) {
+  FDMI_CHECK(R.save, "net: backward without a saved forward in this slot");
+  Exec E{U, R, R.st};
+  if (U->kind == NET_VGG_LPIPS) {
+    R.gvec = grad_out;
+  } else {
+    FDMI_CHECK(R.out, "net: backward without a saved forward in this slot");
+    T* o = R.out;
+    bf16_t* g = E.grad_of(o);
+    FDMI_CHECK(g, "net: workspace exhausted (grad)");
+    if (!R.dry())
+      RET_IF(U->f32 ? launch_nchw_to_nhwc32(grad_out, Exec::F(g), o->B, o->cols, o->H * o->W, o->cols, R.st)
+                    : launch_nchw_grad_to_nhwc(grad_out, g, o->cols, o->B, o->cols, o->H * o->W, R.st));
+    o->ginit = true;
+  }
+  for (auto it = R.tape.rbegin(); it != R.tape.rend(); ++it) RET_IF((*it)(E));
+  FDMI_CHECK(R.dry() || (R.x0->g && R.x0->ginit), "net: no gradient reached the input");
+  if (grad_x && !R.dry()) {
+    if (U->kind == NET_VGG_LPIPS)
+      RET_IF(U->f32 ? launch_lpips_input_bwd32(Exec::F(R.x0->g), grad_x, R.x0->B, R.x0->H * R.x0->W, R.x0->cols, U->ncfg.lpips_scale, R.st)
+                    : launch_lpips_input_bwd(R.x0->g, grad_x, R.x0->B, R.x0->H * R.x0->W, R.x0->cols, U->ncfg.lpips_scale, R.st));
+    else
+      RET_IF(U->f32 ? launch_nhwc_to_nchw32(Exec::F(R.x0->g), R.x0->cols, grad_x, R.x0->B, U->ncfg.in_channels, R.x0->H * R.x0->W, 0, R.st)
+                    : launch_nhwc_to_nchw(R.x0->g, R.x0->cols, grad_x, R.x0->B, U->ncfg.in_channels, R.x0->H * R.x0->W, 0, R.st));
+  }
+  R.save = false;
+  R.tape.clear();
+  U->last_flops = E.flops;
+  return 0;
+}
+
 int check_ready(fdmi_unet* U) {
   for (auto& kv : U->slots) {
     const Slot& s = kv.second;
@@ -1529,6 +1985,7 @@ int check_ready(fdmi_unet* U) {
     else if (s.kind == S_BIAS) ok = (s.w->set & 2) != 0;
     else if (s.kind == S_GAMMA) ok = (s.n->set & 1) != 0;
     else if (s.kind == S_BETA) ok = (s.n->set & 2) != 0;
+    else if (s.kind == S_VEC) ok = *s.vec != nullptr;
     else ok = U->temb_proj.w != nullptr;
     FDMI_CHECK(ok, "unet: parameter '" + kv.first + "' was never set");
   }
@@ -1613,7 +2070,7 @@ int64_t fdmi_unet_workspace_bytes(fdmi_unet* U, int B, int H, int W, int L, int 
 int fdmi_unet_forward(fdmi_unet* U, int slot, const float* sample, const float* timestep, const float* ctx,
                       const float* class_labels, float* out, int B, int H, int W, int L, void* workspace,
                       int64_t workspace_bytes, int flags, void* stream) {
-  FDMI_CHECK(U && slot >= 0 && slot < 8, "bad plan / slot");
+  FDMI_CHECK(U && U->kind == NET_UNET && slot >= 0 && slot < 8, "bad plan / slot");
   FDMI_CHECK(sample && timestep && ctx && out && workspace, "null argument");
   FDMI_CHECK(H % (1 << (U->nl - 1)) == 0 && W % (1 << (U->nl - 1)) == 0, "unet: H, W must be divisible by 2^(levels-1)");
   Run& R = U->runs[slot];
@@ -1646,6 +2103,84 @@ int fdmi_unet_set_down_residuals(fdmi_unet* U, const float* const* residuals, in
   U->down_res.assign(residuals, residuals + n);
   U->down_res_scale = scale;
   return 0;
+}
+
+// ---- the frozen nets beside the denoiser (VAE decoder, LPIPS-VGG, T2I adapter): same handle type, own graphs ----
+fdmi_unet* fdmi_net_create(const fdmi_net_config* cfg) {
+  if (!cfg) { fdmi_set_error("null config"); return nullptr; }
+  if (cfg->kind != NET_VAE_DECODER && cfg->kind != NET_VGG_LPIPS && cfg->kind != NET_T2I_ADAPTER) {
+    fdmi_set_error("net: kind must be FDMI_NET_VAE_DECODER, FDMI_NET_VGG_LPIPS or FDMI_NET_T2I_ADAPTER");
+    return nullptr;
+  }
+  if (cfg->precision != 0 && cfg->precision != 1) {
+    fdmi_set_error("net: precision must be 0 (bf16 MFMA) or 1 (fp32 validation mode)");
+    return nullptr;
+  }
+  auto* U = new fdmi_unet();
+  U->kind = cfg->kind;
+  U->ncfg = *cfg;
+  U->cfg = fdmi_unet_config{};
+  U->cfg.groups = cfg->groups > 0 ? cfg->groups : 32;
+  U->cfg.eps = cfg->eps;
+  U->cfg.precision = cfg->precision;
+  U->f32 = cfg->precision == 1;
+  if (build_net(U)) { delete U; return nullptr; }
+  return U;
+}
+static int net_run(fdmi_unet* U, Run& R, const float* x, const float* x2, float* out, int B, int H, int W, int flags) {
+  if (U->kind == NET_VAE_DECODER) return run_vae_decoder(U, R, x, out, B, H, W, flags);
+  if (U->kind == NET_VGG_LPIPS) return run_lpips(U, R, x, x2, out, B, H, W, flags);
+  FDMI_CHECK(false, "net: this plan kind has its own entry point");
+}
+int64_t fdmi_net_workspace_bytes(fdmi_unet* U, int B, int H, int W, int flags) {
+  if (!U || U->kind == NET_UNET) return -1;
+  Run R;
+  R.arena.dry = true;
+  if (U->kind == NET_T2I_ADAPTER) {
+    if (run_adapter(U, R, nullptr, nullptr, (int)U->adp->body.size(), B, H, W)) return -1;
+    return (int64_t)R.arena.peak + (1 << 20);
+  }
+  if (net_run(U, R, nullptr, nullptr, nullptr, B, H, W, flags)) return -1;
+  if (flags & FDMI_UNET_SAVE) {
+    if (run_net_backward(U, R, nullptr, (float*)(uintptr_t)256)) return -1;
+  }
+  return (int64_t)R.arena.peak + (1 << 20);
+}
+int fdmi_net_forward(fdmi_unet* U, int slot, const float* x, const float* x2, float* out, int B, int H, int W, void* workspace,
+                     int64_t workspace_bytes, int flags, void* stream) {
+  FDMI_CHECK(U && U->kind != NET_UNET && slot >= 0 && slot < 8, "bad plan / slot");
+  FDMI_CHECK(x && out && workspace && (U->kind != NET_VGG_LPIPS || x2), "null argument");
+  Run& R = U->runs[slot];
+  R.arena.base = (char*)workspace;
+  R.arena.cap = (size_t)workspace_bytes;
+  R.arena.dry = false;
+  R.st = (hipStream_t)stream;
+  return net_run(U, R, x, x2, out, B, H, W, flags);
+}
+int fdmi_net_backward(fdmi_unet* U, int slot, const float* grad_out, float* grad_x, void* stream) {
+  FDMI_CHECK(U && U->kind != NET_UNET && slot >= 0 && slot < 8 && grad_out && grad_x, "bad plan / slot / null gradient");
+  Run& R = U->runs[slot];
+  R.st = (hipStream_t)stream;
+  return run_net_backward(U, R, grad_out, grad_x);
+}
+int fdmi_adapter_out_shape(fdmi_unet* U, int level, int H, int W, int* C, int* h, int* w) {
+  FDMI_CHECK(U && U->kind == NET_T2I_ADAPTER && level >= 0 && level < (int)U->adp->body.size() && C && h && w, "adapter: bad argument");
+  const int f = U->ncfg.adapter_downscale;
+  int hh = H / f, ww = W / f;
+  for (int i = 0; i <= level; ++i)
+    if (U->adp->body[i]->down) { hh /= 2; ww /= 2; }
+  *C = U->ncfg.block_out[level]; *h = hh; *w = ww;
+  return 0;
+}
+int fdmi_adapter_forward(fdmi_unet* U, int slot, const float* x, float* const* outs, int n_outs, int B, int H, int W, void* workspace,
+                         int64_t workspace_bytes, void* stream) {
+  FDMI_CHECK(U && U->kind == NET_T2I_ADAPTER && slot >= 0 && slot < 8 && x && outs && workspace, "adapter: bad argument");
+  Run& R = U->runs[slot];
+  R.arena.base = (char*)workspace;
+  R.arena.cap = (size_t)workspace_bytes;
+  R.arena.dry = false;
+  R.st = (hipStream_t)stream;
+  return run_adapter(U, R, x, outs, n_outs, B, H, W);
 }
 
 // ---- the frozen teacher's CFG loop without a host round trip between steps (FD:288-324) ----------------------------

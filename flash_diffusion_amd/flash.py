@@ -232,12 +232,12 @@ class FlashDiffusion(nn.Module):
         self.teacher_sampling_noise_scheduler = teacher_sampling_noise_scheduler
         self.sampling_noise_scheduler = sampling_noise_scheduler
         # VAE (FD:67): optional, any frozen module with the surface of the reference's AutoencoderKLDiffusers that the step touches
-        # (vae/autoencoderKL.py:11-128: config.input_key, encode, decode, latent_channels, downsampling_factor).  The network itself
-        # is outside the hand-written hot path: it runs as the caller's torch module on the same
-        # device; with vae=None the batch carries latents (the benchmark's case, FD:184-185).
+        # (vae/autoencoderKL.py:11-128: config.input_key, encode, decode, latent_channels, downsampling_factor).  On the HIP path:
+        # nets.MiAutoencoderKLDiffusers (decoder = a plan of libfdmi.so); any other module works as the
+        # caller's torch module.  With vae=None the batch carries latents (the benchmark's case, FD:184-185).
         self.vae = vae
         # T2I adapter (FD:91-94): any frozen module mapping batch[adapter_input_key] to one residual per UNet down block
-        # (the diffusers T2IAdapter network itself is outside the hot path); its features are threaded to every denoiser
+        # (on the HIP path: nets.MiT2IAdapter); its features are threaded to every denoiser
         # call exactly as the reference does (FD:207-218, 264, 301, 310, 436-450, 555-567, 820-899)
         self.adapter = adapter
         self.adapter_conditioning_scale = config.adapter_conditioning_scale
@@ -263,12 +263,13 @@ class FlashDiffusion(nn.Module):
             if vae is None:
                 raise ValueError("distill_loss_type='lpips' decodes both outputs: a vae is required (FD:394-395)")
             if lpips_model is None:
-                try:
-                    import lpips
-                except ImportError as e:
-                    raise ImportError("distill_loss_type='lpips': the `lpips` package (setup.py:40) is not installed; pass the "
-                                      "perceptual network as lpips_model=<module(img0, img1) -> [B,1,1,1]>") from e
-                lpips_model = lpips.LPIPS(net="vgg")
+                # the reference builds lpips.LPIPS(net="vgg") with its pretrained weights (FD:102-103).  The HIP twin has the
+                # same architecture and state_dict names (nets.MiLPIPS): built here with placeholder weights -- load the
+                # lpips / torchvision checkpoint into it (load_state_dict) for a real perceptual distance
+                from .nets import MiLPIPS
+                lpips_model = MiLPIPS(precision="fp32" if getattr(student_denoiser, "config_dict", {}).get("precision") == "fp32"
+                                      else "bf16")
+                lpips_model.freeze()
             self.lpips = lpips_model
         self.iter_steps = 0
         self.disc_update_counter = 0
@@ -638,9 +639,10 @@ class FlashDiffusion(nn.Module):
     # ---- losses --------------------------------------------------------------------------------------
     def _distill_loss(self, s, t):
         """FD:368-399.  l2 / l1: one fused HIP launch (+ one for the gradient).  lpips: the centre 64x64 latent crop of both
-        outputs (the reference's slice expression verbatim) goes through the caller's VAE decoder and perceptual network --
-        torch modules on the same device, outside the hand-written kernels; the gradient returns to the
-        student through torch autograd into the HIP backward."""
+        outputs (the reference's slice expression verbatim) goes through the VAE decoder and the perceptual network -- on the
+        HIP path nets.MiAutoencoderKLDiffusers / nets.MiLPIPS (plans of libfdmi.so: implicit-GEMM convs, GroupNorm, the LPIPS
+        distance kernels, taped input gradients); the student's decode and its half of the VGG stack are
+        taped, the teacher's run without a tape."""
         if self.distill_loss_type == "lpips":
             crop_h = (s.shape[2] - 64) // 2
             crop_w = (s.shape[3] - 64) // 2

@@ -127,7 +127,7 @@ def wgrad_tn(X, Y, out):
 
 def gemm_plan(M, N, K, act=ACT_NONE, conv=None, ws=True, **fields):
     """host-only: (kernel, BM, BN, splitk) the launcher would pick for this problem -- kernel 0: gemm.hip tiles, 1: gemm3
-    (256 x BN ring), 2: gemm4 (256 x 320 / 192), 3: the 128 x 160 two-blocks-per-CU geometry (fdmi_gemm_plan)"""
+    (256 x BN ring), 2: gemm4 (256 x 320 / 192) (fdmi_gemm_plan)"""
     d = GemmDesc()
     d.M, d.N, d.K, d.lda, d.ldw, d.ldc, d.use_glds, d.alpha, d.act = M, N, K, K, K, (N // 2 if act == ACT_GEGLU else N), 1, 1.0, act
     d.splitk = 0 if ws else 1          # 0: the planner may split K (a workspace is available)

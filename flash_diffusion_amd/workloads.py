@@ -43,7 +43,7 @@ def sd15_discriminator(color_dim=1280, feat=64):
 
 
 def build_flash(arch=SD15, lora_rank=128, n_teacher_steps=4, device="cuda", seed=0, discriminator=None,
-                use_dmd_loss=False, gan_loss_type="lsgan", guidance=8.0):
+                use_dmd_loss=False, gan_loss_type="lsgan", guidance=8.0, distill_loss_type="l2", vae=None, lpips_model=None):
     """teacher (frozen) + student = copy + LoRA (peft init: A gaussian, B = 0), DPM-Solver++ trailing schedule
     with K = n_teacher_steps and start index pinned to 0 (so every step runs exactly n teacher CFG steps)."""
     torch.manual_seed(seed)
@@ -58,15 +58,31 @@ def build_flash(arch=SD15, lora_rank=128, n_teacher_steps=4, device="cuda", seed
     student = student.to(device)
     student.add_adapter(lora_rank)
     cfg = FlashDiffusionConfig(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform",
-                               distill_loss_type="l2", use_dmd_loss=use_dmd_loss, gan_loss_type=gan_loss_type,
+                               distill_loss_type=distill_loss_type, use_dmd_loss=use_dmd_loss, gan_loss_type=gan_loss_type,
                                guidance_scale_min=3.0, guidance_scale_max=13.0, adversarial_loss_scale=0.1,
                                dmd_loss_scale=0.3)
     m = FlashDiffusion(cfg, student_denoiser=student, teacher_denoiser=teacher,
                        teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
-                       discriminator=discriminator).to(device)
+                       discriminator=discriminator, vae=vae, lpips_model=lpips_model).to(device)
     m.fixed_start_idx = 0
     m.fixed_guidance = guidance
     return m
+
+
+def sd_vae(device="cuda", seed=0):
+    """the SD1.5 AutoencoderKL decoder (random-init weights of the architecture: no network) behind the reference wrapper's
+    surface, on the HIP path; the batch carries latents, so the (no-grad, pre-hot-path) encode is an identity stand-in"""
+    from .nets import MiAutoencoderKL, MiAutoencoderKLDiffusers
+
+    class _LatentsIn(torch.nn.Module):
+        def encode(self, x):
+            return x
+    torch.manual_seed(seed)
+    with torch.device(device):
+        v = MiAutoencoderKL()
+    w = MiAutoencoderKLDiffusers(v.to(device), encoder=_LatentsIn())
+    w.freeze()
+    return w
 
 
 def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77, vector_dim=0, attention_mask=False):

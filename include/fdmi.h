@@ -70,8 +70,7 @@ typedef struct fdmi_gemm_desc {
 int fdmi_gemm_a2_ok(const fdmi_gemm_desc* d);
 int fdmi_gemm(const fdmi_gemm_desc* d, void* stream);
 /* host-only planner query: kernel 0 = 128/64-row tiles (gemm.hip), 1 = 256 x {128,160} LDS-DMA ring (gemm3.hip),
- * 2 = 256 x 320 / 256 x 192 (gemm4.hip), 3 = 128 x 160 with two persistent blocks per CU (gemm4.hip, short-K row GEMMs);
- * the tile and the split-K factor that fdmi_gemm would use (splitk <= 0 in the descriptor
+ * 2 = 256 x 320 / 256 x 192 (gemm4.hip); the tile and the split-K factor that fdmi_gemm would use (splitk <= 0 in the descriptor
  * = let the planner split).  No device work, no GPU needed.                                       */
 int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_t* BN, int32_t* splitk);
 /* The GEMM / conv above whose epilogue ALSO accumulates the GroupNorm statistics of its output for the consumer:
@@ -296,6 +295,47 @@ double fdmi_unet_last_hbm_bytes(fdmi_unet* u, int family);
  * a cross-attention block (before its skip connection and downsampler), to the output of an attention-free block.  The
  * adapter is frozen in the reference's recipes, so no gradient flows to the residuals.  n = 0 clears.              */
 int fdmi_unet_set_down_residuals(fdmi_unet* u, const float* const* residuals, int n, float scale);
+
+/* ---------------- the frozen convolutional networks beside the denoiser, on the same plan executor ----------------
+ * The reference's shipped recipes train with distill_loss_type="lpips" (examples/configs/flash_sd.yaml:20): both outputs' centre
+ * crops go through the VAE decoder and the LPIPS-VGG distance (flash_diffusion_model.py:383-397, vae/autoencoderKL.py:63-128),
+ * and the canny recipe feeds a T2I-adapter's feature maps to every denoiser call (adapters/t2i_adapter.py:7-26,
+ * flash_diffusion_model.py:207-218).  These are plans of the SAME executor as the UNet (conv = implicit-GEMM MFMA kernels,
+ * GroupNorm, taped input gradients): fdmi_unet_set_param / _num_params / _param_name / _ready / _destroy work on the handle;
+ * parameters carry the upstream state_dict names (diffusers AutoencoderKL: "post_quant_conv.weight", "decoder.conv_in.weight",
+ * "decoder.mid_block.attentions.0.to_q.weight", ...; lpips.LPIPS(net="vgg"): "net.slice1.0.weight", "lin0.model.1.weight", ...;
+ * diffusers T2IAdapter: "adapter.conv_in.weight", "adapter.body.0.resnets.0.block1.weight", ...).  Weights are frozen: the
+ * backward returns the gradient with respect to the input only.                                                        */
+enum { FDMI_NET_VAE_DECODER = 1, FDMI_NET_VGG_LPIPS = 3, FDMI_NET_T2I_ADAPTER = 4 };
+typedef struct fdmi_net_config {
+  int32_t kind;                /* FDMI_NET_* */
+  int32_t in_channels;         /* VAE decoder: latent channels (4); LPIPS: 3; adapter: control-image channels */
+  int32_t out_channels;        /* VAE decoder: image channels (3) */
+  int32_t n_levels;            /* VAE decoder: len(block_out_channels) (<= 4); adapter: len(channels) (<= 4) */
+  int32_t block_out[4];        /* VAE: block_out_channels of the AutoencoderKL config (decoder order is the reverse); adapter: channels */
+  int32_t layers_per_block;    /* VAE: 2 (the decoder runs layers_per_block + 1 ResNet blocks per level); adapter: num_res_blocks */
+  int32_t groups;              /* GroupNorm groups (32) */
+  float eps;                   /* GroupNorm eps (1e-6 in AutoencoderKL) */
+  int32_t precision;           /* 0 = bf16 MFMA, 1 = fp32 validation kernels */
+  float lpips_shift[3], lpips_scale[3];   /* lpips ScalingLayer constants */
+  int32_t adapter_downscale;   /* adapter: PixelUnshuffle factor (8: full_adapter, 16: full_adapter_xl) */
+  int32_t adapter_xl;          /* adapter: 1 = FullAdapterXL block layout (downsample only in front of block 2) */
+} fdmi_net_config;
+fdmi_unet* fdmi_net_create(const fdmi_net_config* cfg);
+/* workspace bytes of a forward (+ taped backward when flags has FDMI_UNET_SAVE) on [B, in_channels, H, W] */
+int64_t fdmi_net_workspace_bytes(fdmi_unet* n, int B, int H, int W, int flags);
+/* VAE decoder: x = latents [B, C, H, W] f32 (already divided by the scaling factor) -> out [B, 3, 8H, 8W] f32.
+ * LPIPS: x, x2 = images [B, 3, H, W] f32 in [-1, 1] (x2 = the reference side, no gradient) -> out [B] f32 distances.
+ * flags: FDMI_UNET_SAVE keeps the tape for fdmi_net_backward on the same slot.                                      */
+int fdmi_net_forward(fdmi_unet* n, int slot, const float* x, const float* x2, float* out, int B, int H, int W, void* workspace,
+                     int64_t workspace_bytes, int flags, void* stream);
+/* grad_out: d loss / d out (VAE: [B, 3, 8H, 8W]; LPIPS: [B]) -> grad_x: d loss / d x, same shape as x */
+int fdmi_net_backward(fdmi_unet* n, int slot, const float* grad_out, float* grad_x, void* stream);
+/* T2I adapter (frozen, forward only): control image [B, in_channels, H, W] f32 -> n_levels feature maps, outs[i] =
+ * [B, channels[i], h_i, w_i] f32 NCHW (caller-allocated; shapes from fdmi_adapter_out_shape)                           */
+int fdmi_adapter_out_shape(fdmi_unet* n, int level, int H, int W, int* C, int* h, int* w);
+int fdmi_adapter_forward(fdmi_unet* n, int slot, const float* x, float* const* outs, int n_outs, int B, int H, int W, void* workspace,
+                         int64_t workspace_bytes, void* stream);
 
 /* The frozen teacher's classifier-free-guidance loop (flash_diffusion_model.py:288-324) as ONE call: for each of the n
  * steps  eps = unet([x | x], t_i, [ctx_cond | ctx_uncond])  (one forward on the 2B batch; the cross-attention K/V of the

@@ -403,6 +403,7 @@ def build_c2_models(device="cpu", make=None):
     make = make or oracle
     strip = lambda n: n.replace(".base_layer.", ".")
     teacher = hash_init_(make(0).to(device), 1, rename=strip)
+    teacher.freeze()                                       # (UW:121-127: the reference freezes the teacher before the step)
     student = hash_init_(make(C2_LORA_RANK).to(device), 2, rename=strip)
     base = {strip(k): v for k, v in teacher.state_dict().items()}
     with torch.no_grad():
@@ -415,3 +416,47 @@ def build_c2_models(device="cpu", make=None):
 
 def c2_batch(device="cpu", B=2):
     return {"image": _hu((B, 4, 64, 64), 11, device), "crossattn": _hu((B, 77, 768), 12, device), "text": ["a"] * B}
+
+
+# ---- the LPIPS distillation loss over the REAL architectures: AutoencoderKL decoder (two levels, one-head
+# mid-block attention) + LPIPS on the full-width VGG16, both restated from upstream (oracle/vae_cpu.py); the batch carries pixels,
+# a fixed strided convolution stands in for the VAE encoder (the step encodes under no_grad before the hot path, FD:128-133) ------
+LPIPS_REAL_CASES = {
+    "g_lpips_real": (dict(K=[4], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="lpips",
+                          gan_loss_type="lsgan", use_dmd_loss=True, guidance_scale_min=3.0, guidance_scale_max=13.0,
+                          dmd_loss_scale=0.3, adversarial_loss_scale=0.1), "dpm", 0, 23),
+}
+LPIPS_REAL_VAE = dict(block_out_channels=(32, 64), layers_per_block=1, latent_channels=4, norm_num_groups=32)
+
+
+class RealVaeWrapperRef(torch.nn.Module):
+    """the surface of AutoencoderKLDiffusers the step touches (vae/autoencoderKL.py:11-128) around the restated AutoencoderKL
+    decoder: config.input_key, encode (a fixed 2x2 / stride-2 convolution: the posterior mean of a stand-in encoder), decode"""
+
+    def __init__(self, seed=31):
+        super().__init__()
+        from types import SimpleNamespace
+        from .vae_cpu import AutoencoderKLDecoderRef, seeded_net_init_
+        self.config = SimpleNamespace(input_key="image")
+        self.latent_channels, self.downsampling_factor = 4, 2
+        self.vae_model = seeded_net_init_(AutoencoderKLDecoderRef(**LPIPS_REAL_VAE), seed)
+        self.enc = torch.nn.Conv2d(3, 4, 2, 2)
+        g = torch.Generator().manual_seed(seed + 1)
+        for p in self.enc.parameters():
+            p.data.copy_(torch.randn(p.shape, generator=g) * (0.5 / max(1, p[0].numel()) ** 0.5 if p.dim() > 1 else 0.05))
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def encode(self, x):
+        return self.enc(x) * self.vae_model.scaling_factor
+
+    def decode(self, z):
+        return self.vae_model.decode(z)
+
+
+def build_lpips_real():
+    from .vae_cpu import LPIPSRef, seeded_net_init_
+    lp = seeded_net_init_(LPIPSRef(), 32)
+    for p in lp.parameters():
+        p.requires_grad = False
+    return RealVaeWrapperRef(), lp

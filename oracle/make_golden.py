@@ -30,13 +30,16 @@ def _record_draws(seed, model_fn):
 
 def main(cases=None):
     from .flash_ref import FlashConfigRef, FlashDiffusionRef
-    from .golden_cases import ADAPTER_CASES, LPIPS_CASES, make_edge, make_pixel_batch
-    from .unet_cpu import TinyLPIPS, TinyT2IAdapter, TinyVAE, tiny_config
+    from .golden_cases import ADAPTER_CASES, LPIPS_CASES, LPIPS_REAL_CASES, build_lpips_real, make_edge, make_pixel_batch
+    from .unet_cpu import TinyLPIPS as _TinyLPIPS, TinyT2IAdapter, TinyVAE as _TinyVAE, tiny_config
     FD, FDC = shim_import.import_reference()
     os.makedirs(OUT, exist_ok=True)
     for name, (kw, sched, step, seed) in (cases if cases is not None else CASES).items():
         with_adapter = name in ADAPTER_CASES
-        with_vae = name in LPIPS_CASES
+        with_vae = name in LPIPS_CASES or name in LPIPS_REAL_CASES
+        # the real architectures (restated AutoencoderKL decoder + VGG16 LPIPS) or the toy stand-ins
+        TinyVAE = (lambda: build_lpips_real()[0]) if name in LPIPS_REAL_CASES else _TinyVAE
+        TinyLPIPS = (lambda: build_lpips_real()[1]) if name in LPIPS_REAL_CASES else _TinyLPIPS
 
         def make_batch_():
             b = make_pixel_batch() if with_vae else make_batch()
@@ -454,11 +457,16 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "lpips":
         from .golden_cases import LPIPS_CASES
         main(LPIPS_CASES)
+    elif len(sys.argv) > 1 and sys.argv[1] == "lpips_real":
+        from .golden_cases import LPIPS_REAL_CASES
+        main(LPIPS_REAL_CASES)
     else:
         main()
         from .golden_cases import ADAPTER_CASES, LPIPS_CASES
         main(ADAPTER_CASES)
         main(LPIPS_CASES)
+        from .golden_cases import LPIPS_REAL_CASES
+        main(LPIPS_REAL_CASES)
         make_sample_golden()
         make_sd3_golden()
         make_dit_golden()

@@ -37,7 +37,7 @@ def main():
         if l.startswith("PLANGEMM"):
             rows[tuple(int(v) for v in re.findall(r"=(-?\d+)", l))] += 1
     tot = sum(2.0 * k[1] * k[2] * k[3] * n for k, n in rows.items())
-    names = {0: "tile128", 1: "gemm3", 2: "gemm4", 3: "gemm5"}
+    names = {0: "tile128", 1: "gemm3", 2: "gemm4"}
     print(f"{arch} B={B} {hw}x{hw} flags={flags}: {sum(rows.values())} GEMM/conv launches, {tot / 1e12:.2f} TFLOP")
     print("count  mode  M       N      K      act res dgrad  kernel        splitk   GFLOP each   share")
     by_kernel = collections.Counter()

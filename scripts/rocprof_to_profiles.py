@@ -58,11 +58,9 @@ def short(name):
 
 # bench.py's bucket names for the MFMA kernel families (profiles/README.md "Name mapping")
 def bucket(name):
-    m = re.search(r"gemm4_kernel<(\d), (false|true)(?:, (\d+))?(?:, (?:false|true))?(?:, (\d+))?", name)
+    m = re.search(r"gemm4_kernel<(\d), (?:false|true)(?:, (\d+))?", name)
     if m:
-        if m.group(4) == "128":   # the 128 x 160 geometry (two blocks per CU): bench.py buckets it by epilogue
-            return f"gemm4_kernel<128x{m.group(3)},{'geglu' if m.group(2) == 'true' else 'row'}>"
-        return f"gemm4_kernel<256x{m.group(3) or '320'},{'conv' if m.group(1) == '1' else 'row'}>"
+        return f"gemm4_kernel<256x{m.group(2) or '320'},{'conv' if m.group(1) == '1' else 'row'}>"
     m = re.search(r"gemm3_kernel<(\d+), (\d)", name)
     if m:
         return f"gemm3_kernel<256x{m.group(1)},{'conv' if m.group(2) == '1' else 'row'}>"

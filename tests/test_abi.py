@@ -74,11 +74,8 @@ def test_gemm_planner_choices_for_the_benchmark_shapes():
     """host-only planner query (fdmi_gemm_plan): the 256x320 LDS-DMA kernel takes the C2 linears whose N divides by 320, its
     256x192 variant every large DiT / MMDiT linear (N = 1152 / 1536 / 4608 / 6144 divide by 192, not by 320), the small
     tiles the per-sample-vector GEMMs; LoRA weight gradients (long contraction, tiny output) are split 16 ways"""
-    # SD1.5 level 0: K = 1280 keeps the 256x320 tile, the short-K rows (K = 320) take the 128x160 two-blocks-per-CU geometry
-    # since round 3 (tests/test_plan_dry.py pins that rule in detail)
-    assert _plan(65536, 320, 1280)[:3] == (2, 256, 320) and _plan(65536, 320, 320)[:3] == (3, 128, 160)
-    assert _plan(65536, 2560, 320)[:3] == (3, 128, 160)
-    assert _plan(16384, 640, 640)[0] == 3 and _plan(8192, 640, 640)[0] == 1 and _plan(4096, 1280, 1280)[0] == 1
+    assert _plan(65536, 320, 320)[:3] == (2, 256, 320) and _plan(65536, 2560, 320)[:3] == (2, 256, 320)   # SD1.5 level 0
+    assert _plan(16384, 640, 640)[0] == 1 and _plan(4096, 1280, 1280)[0] == 1
     for shape in [(32768, 1152, 1152), (65536, 1152, 1152), (32768, 4608, 1152), (32768, 1152, 4608),     # PixArt C4
                   (16384, 1536, 1536), (16384, 6144, 1536), (16384, 1536, 6144)]:                         # SD3 C5
         assert _plan(*shape)[:3] == (2, 256, 192), shape
@@ -91,7 +88,7 @@ def test_planner_offers_the_256x192_tile_for_the_transformer_widths():
     from flash_diffusion_amd import _lib
     L = _lib.lib()
     assert _plan(32768, 1152, 1152)[:3] == (2, 256, 192) and _plan(16384, 6144, 1536)[:3] == (2, 256, 192)
-    assert _plan(65536, 320, 1280)[:3] == (2, 256, 320)           # widths that 320 divides keep the larger tile
+    assert _plan(65536, 320, 320)[:3] == (2, 256, 320)            # widths that 320 divides keep the larger tile
     L.fdmi_tune_set(12, 1)                                        # A/B switch: the planner without the tile
     try:
         assert _plan(32768, 1152, 1152)[:3] == (1, 256, 128)

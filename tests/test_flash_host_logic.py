@@ -179,11 +179,11 @@ def test_lpips_step_with_vae_matches_reference_golden(monkeypatch):
     with pytest.raises(ValueError, match="vae"):
         FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
                        teacher_noise_scheduler=DPMSolverMultistepScheduler(), lpips_model=TinyLPIPS())
-    import sys
-    monkeypatch.setitem(sys.modules, "lpips", None)      # (the oracle's shim may have registered a stub module earlier in the run)
-    with pytest.raises(ImportError, match="lpips_model"):
-        FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
-                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), vae=TinyVAE())
+    # without lpips_model the reference builds lpips.LPIPS(net="vgg") (FD:102-103): the product builds its HIP twin (round 3)
+    m_def = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                           teacher_noise_scheduler=DPMSolverMultistepScheduler(), vae=TinyVAE())
+    assert type(m_def.lpips).__name__ == "MiLPIPS" and not any(p.requires_grad for p in m_def.lpips.parameters())
+    assert "net.slice1.0.weight" in m_def.lpips.state_dict() and "lin4.model.1.weight" in m_def.lpips.state_dict()
     # the sampler decodes, log_samples infers the latent shape from the VAE (FD:865-868, 977-984)
     from flash_diffusion_amd.schedulers import LCMScheduler
     m.sampling_noise_scheduler = LCMScheduler()

@@ -12,9 +12,10 @@
 
 Weights and inputs of the hashed fixtures are rebuilt on the GPU by oracle/hash_init.py (bit-identical to the host's).
 Tolerances (stated): bf16 forwards rel. Frobenius < 3e-2 (the bar of tests/test_unet_gpu.py::test_sd15_full_size_forward_B1);
-bf16 steps: teacher / student output 4e-2 / 1e-2, losses 4e-2, per-tensor gradient norm within 10 % and projection on a seeded
-direction within 15 % of the tensor's norm (tensors carrying >= 5 % of the largest norm), the tensors stored in full: cosine
-> 0.98; fp32 steps: north_star's 1e-3 on every loss term, 1e-4 on the outputs, 1e-2 on the gradient norms / projections."""
+bf16 steps: teacher / student output 5e-2 / 1e-2 (measured on the first GPU run of round 3, profiles/r3_parity_fullsize.txt: 3.1e-2 /
+4.2e-3 with four teacher steps, 2.3e-2 / 4.2e-3 with one), losses 3e-2 (measured 1.0e-2), per-tensor gradient norm within 4 %
+(1.3 %) and projection on a seeded direction within 12 % of the tensor's norm (6 %; tensors carrying >= 5 % of the largest norm),
+the tensors stored in full: cosine > 0.999 (0.9998); fp32 steps: north_star's 1e-3 on every loss term, 1e-4 on the outputs, 1e-2 on the gradient norms / projections."""
 import copy
 import os
 
@@ -114,7 +115,7 @@ def _check_projected_grads(tag, m, blob, g, fp32):
     if fp32:
         assert worst_n <= 1e-2 and worst_p <= 1e-2 and all(r <= 1e-2 for r, _ in full.values()), (worst_n, worst_p, full)
     else:
-        assert worst_n_big <= 0.10 and worst_p_big <= 0.15 and all(c > 0.98 for _, c in full.values()), \
+        assert worst_n_big <= 0.04 and worst_p_big <= 0.12 and all(c > 0.999 for _, c in full.values()), \
             (worst_n_big, worst_p_big, full)
 
 
@@ -129,7 +130,7 @@ def _check_outputs(tag, m, g, out, fp32):
             if k in g["terms"] and k not in ("K_step", "guidance", "n_teacher_steps") and g["terms"][k] != 0}
     log(f"step {tag}: " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + f" loss_rel={lerr[0]:.3e},{lerr[1]:.3e} "
         f"terms={ {k: f'{v:.1e}' for k, v in terr.items()} }")
-    o_t, o_s, l_tol = (1e-4, 1e-4, 1e-3) if fp32 else (4e-2, 1e-2, 4e-2)
+    o_t, o_s, l_tol = (1e-4, 1e-4, 1e-3) if fp32 else (5e-2, 1e-2, 3e-2)
     assert errs["noisy_sample"] < 1e-6 and errs["teacher_output"] <= o_t and errs["student_output"] <= o_s, errs
     assert lerr[0] <= l_tol and lerr[1] <= l_tol, lerr
     assert all(v <= l_tol for v in terr.values()), terr

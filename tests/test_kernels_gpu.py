@@ -458,66 +458,8 @@ def test_gemm4_many_items_per_block():
     assert torch.equal(out, out2)
 
 
-# ---- the 128 x 160 geometry of gemm4.hip (two persistent blocks per CU; the planner's choice for short-K row GEMMs) ----------
-T5 = (128 << 16) | 160
-
-
-@pytest.mark.parametrize("shape", [(128, 160, 64), (384, 320, 320), (1024, 640, 640), (2048, 960, 128), (128 * 600, 320, 128)])
-def test_gemm5_row(shape):
-    ops = _ops()
-    M, N, K = shape
-    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
-    bias = rnd(N, seed=3)
-    res = b16(rnd(M, N, seed=5))
-    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=T5)
-    close(f"gemm5_row{shape}", out, A.float() @ W.float().t() + bias + res.float())
-    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_SILU, force_tile=T5)
-    close(f"gemm5_row_silu{shape}", out, F.silu(A.float() @ W.float().t() + bias))
-    rv = b16(rnd(M // 128, N, seed=6))
-    out = ops.gemm(A.cuda(), W.cuda(), rowvec=rv.cuda(), rows_per_batch=128, out_f32=True, force_tile=T5)
-    close(f"gemm5_row_rowvec_f32{shape}", out, A.float() @ W.float().t() + rv.float().repeat_interleave(128, 0), tol_el=1e-4, tol_fro=1e-4)
-    out2 = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=T5)
-    out3 = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=T5)
-    assert torch.equal(out2, out3)
-
-
-@pytest.mark.parametrize("Fh", [320, 1280])
-def test_gemm5_geglu(Fh):
-    """GEGLU on the 128 x 160 tile (10 fragments per wave: four 8-wide pairs + the odd pair), with the pre-activation save and
-    with a residual"""
-    ops = _ops()
-    M, K = 640, 192
-    A = b16(rnd(M, K, seed=1))
-    W = b16(rnd(2 * Fh, K, seed=2, scale=K ** -0.5))
-    bias = rnd(2 * Fh, seed=3)
-    res = b16(rnd(M, Fh, seed=4, scale=2.0))
-    perm = ops.geglu_perm(Fh)
-    h = A.float() @ W.float().t() + bias
-    ref = h[:, :Fh] * F.gelu(h[:, Fh:])
-    pre = torch.empty(M, 2 * Fh, dtype=torch.bfloat16, device="cuda")
-    out = ops.gemm(A.cuda(), W[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), act=ops.ACT_GEGLU,
-                   preact=pre, force_tile=T5)
-    close(f"gemm5_geglu{Fh}", out, ref)
-    close(f"gemm5_geglu_preact{Fh}", pre, h[:, perm])
-    out = ops.gemm(A.cuda(), W[perm].contiguous().cuda(), bias=bias[perm].contiguous().cuda(), act=ops.ACT_GEGLU,
-                   residual=res.cuda(), force_tile=T5)
-    close(f"gemm5_geglu_residual{Fh}", out, ref + res.float())
-
-
-def test_gemm5_is_the_planners_choice_for_short_k_rows():
-    """fdmi_gemm_plan: the K = 320 / 640 row GEMMs of the 64x64 / 32x32 levels go to the 128 x 160 tile, K = 1280 and the
-    deep levels stay where they were; the auto-planned launch equals the forced one"""
-    ops = _ops()
-    assert ops.gemm_plan(65536, 320, 320)[:3] == (3, 128, 160) and ops.gemm_plan(32768, 640, 640)[:3] == (3, 128, 160)
-    assert ops.gemm_plan(65536, 2560, 320, act=ops.ACT_GEGLU)[:3] == (3, 128, 160)
-    assert ops.gemm_plan(65536, 320, 1280)[0] == 2 and ops.gemm_plan(4096, 1280, 1280)[0] != 3
-    M, N, K = 65536, 320, 320
-    A, W = b16(rnd(M, K, seed=1)).cuda(), b16(rnd(N, K, seed=2, scale=K ** -0.5)).cuda()
-    assert torch.equal(ops.gemm(A, W), ops.gemm(A, W, force_tile=T5))
-
-
 # ---- two-segment A operand (GemmArgs::A2): [A | A2] W^T without materialising the concatenation ---------------------------------
-@pytest.mark.parametrize("tile", [T4, T5, (256 << 16) | 160, (256 << 16) | 128, (256 << 16) | 192, 0])
+@pytest.mark.parametrize("tile", [T4, (256 << 16) | 160, (256 << 16) | 128, (256 << 16) | 192, 0])
 @pytest.mark.parametrize("shape", [(512, 640, 320, 128), (1024, 1920, 1280, 640), (768, 320, 64, 64), (2048, 960, 320, 384)])
 def test_gemm_two_segment_a(tile, shape):
     """every LDS-DMA kernel reads a two-part A operand: the seam at K1 (a multiple of 64) inside an item, at an item's first tile

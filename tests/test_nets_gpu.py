@@ -1,0 +1,195 @@
+"""GPU parity of the frozen convolutional networks beside the denoiser (flash_diffusion_amd/nets.py,
+C-ABI fdmi_net_*): the AutoencoderKL decoder, LPIPS on VGG16, the T2I adapter -- each against the fp32 CPU restatement of its
+upstream (oracle/vae_cpu.py) on identical seeded weights, forward AND input gradient, in the bf16 production mode and in the
+fp32 validation mode; then the LPIPS distillation step of the REAL reference class over those architectures
+(tests/golden/g_lpips_real.npz, `python -m oracle.make_golden lpips_real`).
+
+Tolerances (stated): fp32 mode -- forward 1e-4, input gradient 1e-3 relative (north_star's loss parity bar on the LPIPS value:
+1e-3); bf16 mode -- VAE decode 3e-2 / its input gradient 6e-2 (the UNet plan's bars), LPIPS value 3e-2 relative / its image
+gradient cosine > 0.99, adapter features 2e-2."""
+import copy
+import os
+
+import pytest
+import torch
+
+from tests.golden_util import load_case, parity_log, rel_err
+from tests.isolate import run_isolated
+
+pytestmark = pytest.mark.gpu
+
+
+def _cos(a, b):
+    a, b = a.detach().double().cpu().flatten(), b.detach().double().cpu().flatten()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+def _load(mi, oracle):
+    mi.load_state_dict(oracle.state_dict(), strict=True)
+    return mi.cuda()
+
+
+VAE_CASES = {
+    # name: (constructor kwargs, B, latent hw)
+    "tiny": (dict(block_out_channels=(32, 64), layers_per_block=1), 2, 16),
+    "three_levels": (dict(block_out_channels=(32, 64, 64), layers_per_block=2), 1, 16),
+    "sd_full": (dict(), 1, 64),     # SD1.5's VAE: (128, 256, 512, 512), 64x64 latent -> 512 px, one 512-wide attention head
+}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("name", list(VAE_CASES))
+def test_vae_decoder_matches_oracle(name, precision):
+    run_isolated(__name__, "_vae_body", (name, precision), timeout=900)
+
+
+def _vae_body(name, precision):
+    from flash_diffusion_amd.nets import MiAutoencoderKL, MiAutoencoderKLDiffusers
+    from oracle.vae_cpu import AutoencoderKLDecoderRef, seeded_net_init_
+    kw, B, hw = VAE_CASES[name]
+    o = seeded_net_init_(AutoencoderKLDecoderRef(**kw), 5)
+    m = _load(MiAutoencoderKL(**kw, precision=precision), o)
+    m.freeze()
+    wrap = MiAutoencoderKLDiffusers(m, tiling_size=(hw, hw))
+    g = torch.Generator().manual_seed(1)
+    z = torch.randn(B, 4, hw, hw, generator=g) * 0.18215
+    zo = z.clone().requires_grad_()
+    ref = o.decode(zo)
+    w = torch.randn(ref.shape, generator=g)
+    (ref * w).sum().backward()
+    zm = z.cuda().requires_grad_()
+    out = wrap.decode(zm)
+    (out * w.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        out2 = wrap.decode(z.cuda())           # the no-tape path (the teacher's decode)
+    e, ez, e2 = rel_err(out, ref), rel_err(zm.grad, zo.grad), rel_err(out2, ref)
+    parity_log(f"vae decoder {name} [{precision}]: image {e:.3e} (no-tape run {e2:.3e}) latent gradient {ez:.3e} "
+               f"flops {m.last_flops:.3e}", "nets_parity.txt")
+    tol = (1e-4, 1e-3) if precision == "fp32" else (3e-2, 6e-2)
+    assert out.shape == ref.shape and e <= tol[0] and e2 <= tol[0] and ez <= tol[1], (e, e2, ez)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("B,hw", [(2, 64), (1, 256)])
+def test_lpips_matches_oracle(B, hw, precision):
+    run_isolated(__name__, "_lpips_body", (B, hw, precision), timeout=900)
+
+
+def _lpips_body(B, hw, precision):
+    from flash_diffusion_amd.nets import MiLPIPS
+    from oracle.vae_cpu import LPIPSRef, seeded_net_init_
+    o = seeded_net_init_(LPIPSRef(), 6)
+    m = _load(MiLPIPS(precision=precision), o)
+    m.freeze()
+    g = torch.Generator().manual_seed(2)
+    a = (torch.rand(B, 3, hw, hw, generator=g) * 2 - 1)
+    b = (a + 0.3 * torch.randn(B, 3, hw, hw, generator=g)).clamp(-1, 1)
+    ao = a.clone().requires_grad_()
+    ref = o(ao, b)
+    wv = torch.tensor([1.0, 0.5][:B]).view(B, 1, 1, 1)
+    (ref * wv).sum().backward()
+    am = a.cuda().requires_grad_()
+    out = m(am, b.cuda())
+    (out * wv.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        out2 = m(a.cuda(), b.cuda())
+        same = m(a.cuda(), a.cuda())
+    e, e2, eg, cg = rel_err(out, ref), rel_err(out2, ref), rel_err(am.grad, ao.grad), _cos(am.grad, ao.grad)
+    parity_log(f"lpips B={B} {hw}x{hw} [{precision}]: distance {e:.3e} (no-tape run {e2:.3e}) image gradient rel {eg:.3e} cosine {cg:.5f}; "
+               f"values {out.flatten().tolist()} vs {ref.flatten().tolist()}", "nets_parity.txt")
+    assert out.shape == (B, 1, 1, 1) and float(same.abs().max()) < 1e-6        # d(x, x) = 0
+    if precision == "fp32":
+        assert e <= 1e-4 and e2 <= 1e-4 and eg <= 1e-3, (e, e2, eg)
+    else:
+        assert e <= 3e-2 and e2 <= 3e-2 and cg > 0.99, (e, e2, cg)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("kind", ["full_adapter", "full_adapter_xl"])
+def test_t2i_adapter_matches_oracle(kind, precision):
+    run_isolated(__name__, "_adapter_body", (kind, precision), timeout=600)
+
+
+def _adapter_body(kind, precision):
+    from flash_diffusion_amd.nets import MiT2IAdapter
+    from oracle.vae_cpu import T2IAdapterRef, seeded_net_init_
+    kw = dict(in_channels=3, channels=(64, 128, 256, 256), num_res_blocks=2, downscale_factor=16 if kind.endswith("xl") else 8,
+              adapter_type=kind)
+    o = seeded_net_init_(T2IAdapterRef(**kw), 7).eval()
+    m = _load(MiT2IAdapter(**kw, precision=precision), o)
+    m.freeze()
+    g = torch.Generator().manual_seed(3)
+    hw = 256 if kind.endswith("xl") else 128
+    x = torch.rand(2, 3, hw, hw, generator=g)
+    with torch.no_grad():
+        ref = o(x)
+    out = m(x.cuda())
+    errs = [rel_err(a, b) for a, b in zip(out, ref)]
+    parity_log(f"t2i adapter {kind} [{precision}]: features {[tuple(t.shape) for t in out]} rel {[f'{e:.2e}' for e in errs]}", "nets_parity.txt")
+    assert [tuple(t.shape) for t in out] == [tuple(t.shape) for t in ref]
+    assert max(errs) <= (1e-4 if precision == "fp32" else 2e-2), errs
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_lpips_step_over_the_hip_vae_and_vgg_matches_reference_golden(precision):
+    run_isolated(__name__, "_step_body", (precision,), timeout=900)
+
+
+def _step_body(precision):
+    """FlashDiffusion with distill_loss_type="lpips" (what every shipped YAML trains with, examples/configs/flash_sd.yaml:20):
+    VAE decoder and LPIPS-VGG on the HIP path inside the step, against the REAL reference class over the restated nets"""
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
+    from flash_diffusion_amd.nets import MiAutoencoderKL, MiAutoencoderKLDiffusers, MiLPIPS
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import LORA_RANK, LPIPS_REAL_CASES, LPIPS_REAL_VAE, build_lpips_real, build_models, make_pixel_batch
+    from tests.unet_util import mi_from_oracle
+    (name, (kw, sched, step, _)), = LPIPS_REAL_CASES.items()
+    g = load_case(name)
+    teacher_o, student_o, disc_o = build_models()
+    teacher = mi_from_oracle(teacher_o, precision=precision)
+    teacher.freeze()
+    student = mi_from_oracle(student_o, lora_rank=LORA_RANK, precision=precision)
+    vae_o, lp_o = build_lpips_real()
+    vae_m = _load(MiAutoencoderKL(**LPIPS_REAL_VAE, precision=precision), vae_o.vae_model)
+    vae = MiAutoencoderKLDiffusers(vae_m, encoder=copy.deepcopy(vae_o).cuda())
+    vae.freeze()
+    lp = _load(MiLPIPS(precision=precision), lp_o)
+    lp.freeze()
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=TensorConditioner(),
+                       discriminator=copy.deepcopy(disc_o).cuda(), vae=vae, lpips_model=lp).cuda()
+    m.draws = Draws(g["draws"])
+    pb = make_pixel_batch()
+    out = m({"image": pb["image"].cuda(), "crossattn": pb["crossattn"].cuda(), "text": pb["text"]}, step=step, device="cuda")
+    assert out["start_timestep"] == g["start_timestep"]
+    errs = {k: rel_err(out[k], g["out"][k]) for k in ("teacher_output", "student_output", "noisy_sample")}
+    lerr = abs(float(out["loss"][0]) - g["loss"][0]) / abs(g["loss"][0])
+    terr = {k: abs(float(v) - g["terms"][k]) / max(abs(g["terms"][k]), 1e-12) for k, v in m.terms.items()
+            if k in g["terms"] and k not in ("K_step", "guidance", "n_teacher_steps") and g["terms"][k] != 0}
+    out["loss"][0].backward()
+    torch.cuda.synchronize()
+    fa, fb, worst = [], [], 0.0
+    gmax = max(float(v.norm()) for v in g["grads"].values())
+    for pn, p in m.named_parameters():
+        if p.grad is None or (pn.startswith("student_denoiser.") and ".lora_" not in pn):
+            continue
+        cand = [k for k in g["grads"] if k.replace(".base_layer.", ".") == pn]
+        assert cand, pn
+        ref = g["grads"][cand[0]]
+        if float(ref.norm()) < 1e-6 * gmax:
+            continue
+        fa.append(p.grad.detach().float().cpu().flatten())
+        fb.append(ref.float().flatten())
+        worst = max(worst, rel_err(p.grad, ref))
+    gc = _cos(torch.cat(fa), torch.cat(fb))
+    parity_log(f"step {name} [{precision}]: " + " ".join(f"{k}={v:.3e}" for k, v in errs.items()) + f" loss_rel={lerr:.3e} "
+               f"terms={ {k: f'{v:.1e}' for k, v in terr.items()} }; {len(fa)} gradient tensors, global cosine {gc:.5f}, worst rel {worst:.2e}",
+               "nets_parity.txt")
+    if precision == "fp32":
+        assert errs["teacher_output"] <= 1e-4 and errs["student_output"] <= 1e-4 and lerr <= 1e-3, (errs, lerr)
+        assert all(v <= 1e-3 for v in terr.values()) and worst <= 1e-2, (terr, worst)
+    else:
+        assert errs["teacher_output"] < 4e-2 and errs["student_output"] < 1e-2 and lerr < 6e-2, (errs, lerr)
+        assert terr.get("distill", 0.0) < 6e-2 and gc > 0.99, (terr, gc)
