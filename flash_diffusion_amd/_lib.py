@@ -127,6 +127,7 @@ _SIGS = {
     "fdmi_wgrad_tn_f32": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]),
     "fdmi_attn_scratch_elems_f32": (i64, [i32, i32, i32, i32, i32]),
     "fdmi_attn_fwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, i64, vp]),
+    "fdmi_attn_causal_fwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, f32, vp, i64, vp]),
     "fdmi_attn_bwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp,
                                 i64, vp]),
     "fdmi_groupnorm_fwd_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),

@@ -947,7 +947,10 @@ static int check_attn(const AttnArgs& a) {
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
-  // query fragments per wave: 2 for d <= 64; 1 for larger heads (register pressure at 2 waves/SIMD)
+  // query fragments per wave: 2 for d <= 64; 1 for larger heads (register pressure at 2 waves/SIMD).  A/B switch 27 = 1: two
+  // fragments also for the 96-wide instantiations (d = 72 PixArt, d = 80 SD1.5 level 1: 204 VGPRs, still two waves per SIMD;
+  // every K / V^T fragment read from LDS then feeds twice the MFMAs)
+  if (fdmi_tune_get(27)) { ATTN_DISPATCH4(fwd_t, 2, 2, 1) }
   ATTN_DISPATCH4(fwd_t, 2, 1, 1)
 }
 int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st) {

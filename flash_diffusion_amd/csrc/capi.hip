@@ -328,6 +328,10 @@ int fdmi_attn_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, 
                       int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream) {
   return launch_attn32_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, d, scale, scratch, scratch_elems, (hipStream_t)stream);
 }
+int fdmi_attn_causal_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O,
+                             int64_t ldo, int B, int H, int S, int d, float scale, float* scratch, int64_t scratch_elems, void* stream) {
+  return launch_attn32_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, S, S, d, scale, scratch, scratch_elems, (hipStream_t)stream, 1);
+}
 int fdmi_attn_bwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
                       int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
                       int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream) {

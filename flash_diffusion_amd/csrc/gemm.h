@@ -3,7 +3,8 @@
 #include "common.h"
 
 enum { GEMM_ROW = 0, GEMM_CONV = 1 };
-enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2, ACT_RELU = 3 /* conv + ReLU of the VGG16 feature stack (LPIPS) */ };
+enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2, ACT_RELU = 3 /* conv + ReLU of the VGG16 feature stack (LPIPS) */,
+       ACT_GELU = 4 /* exact (erf) GELU: the MLP of OpenCLIP-style text encoders */ };
 
 struct GemmArgs {
   int M = 0, N = 0, K = 0;

@@ -62,6 +62,9 @@ __device__ __forceinline__ void epi_store(const GemmArgs& a, int act, int64_t m,
   } else if (act == ACT_RELU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  } else if (act == ACT_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;

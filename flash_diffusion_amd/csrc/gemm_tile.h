@@ -51,6 +51,9 @@ __device__ __forceinline__ void epi_store3(const GemmArgs& a, int act, int64_t m
   } else if (act == ACT_RELU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+  } else if (act == ACT_GELU) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -123,6 +126,9 @@ __device__ __forceinline__ void epi_finish8(const GemmArgs& a, int act, int64_t 
   } else if (act == ACT_RELU) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+  } else if (act == ACT_GELU) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -527,6 +533,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
           } else if (a.act == ACT_RELU) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = fmaxf(v[r], 0.f);
+          } else if (a.act == ACT_GELU) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
           }
           if (a.out_f32) {
             float* c = (float*)a.C + m * a.ldc + n;

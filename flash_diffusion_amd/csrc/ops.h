@@ -150,7 +150,8 @@ int launch_wgrad_tn32(const float* X, int64_t ldx, const float* Y, int64_t ldy, 
                       hipStream_t st);
 int64_t attn32_scratch_elems(int B, int H, int Sq, int Skv, int bwd);   // floats of scratch the two calls below want
 int launch_attn32_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
-                      int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st);
+                      int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st,
+                      int causal = 0);   // causal: key j attends query i only for j <= i (the CLIP text encoder; Sq == Skv)
 int launch_attn32_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
                       int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
                       int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st);

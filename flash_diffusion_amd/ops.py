@@ -10,7 +10,7 @@ from ._lib import GemmDesc, check, lib, ptr, stream_ptr
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4
 # Every activation op below dispatches on the dtype of its operand: bf16 tensors run the measured MFMA path, fp32 tensors the
 # fp32 VALIDATION kernels (csrc/ref32.hip: exact-f32 MFMA, fp32 storage, fp64 statistics) -- the parity gate against the fp32
 # oracle.  A model picks one of the two with its `precision` argument; nothing mixes them.
@@ -276,6 +276,21 @@ def attn_fwd(q, k, v, H, scale, need_lse=False, out=None, lse_out=None):
     check(lib().fdmi_attn_fwd(ptr(q), q.stride(1), ptr(k), k.stride(1), ptr(v), v.stride(1), ptr(o), o.stride(1),
                               ptr(vt), ptr(lse), B, H, Sq, Skv, d, scale, stream_ptr()))
     return (o, lse) if need_lse else o
+
+
+def attn_causal_fwd(q, k, v, H, scale):
+    """causal self-attention, forward only (the frozen text encoders): q, k, v [B, S, H*d] -> o.  Scores are materialised by the
+    exact-f32 kernels in both precisions (S = 77: the cost is nil); bf16 operands are staged through fp32 copies."""
+    B, S, Cc = q.shape
+    d = Cc // H
+    qf, kf, vf = (t if t.dtype == F32 else t.float() for t in (q, k, v))
+    qf, kf, vf = qf.contiguous(), kf.contiguous(), vf.contiguous()
+    o = torch.empty_like(qf)
+    n = lib().fdmi_attn_scratch_elems_f32(B, H, S, S, 0)
+    sc = torch.empty(n, dtype=F32, device=q.device)
+    check(lib().fdmi_attn_causal_fwd_f32(ptr(qf), qf.stride(1), ptr(kf), kf.stride(1), ptr(vf), vf.stride(1), ptr(o), o.stride(1), B, H,
+                                         S, d, scale, ptr(sc), n, stream_ptr()))
+    return o if q.dtype == F32 else f32_to_bf16(o)
 
 
 def attn_bwd(q, k, v, o, do, lse, H, scale, out=None):

@@ -190,6 +190,10 @@ int fdmi_wgrad_tn_f32(const float* X, int64_t ldx, const float* Y, int64_t ldy, 
 int64_t fdmi_attn_scratch_elems_f32(int B, int H, int Sq, int Skv, int bwd);
 int fdmi_attn_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
                       int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream);
+/* causal self-attention (key j attends query i only for j <= i), forward only: the text encoders of the conditioners
+ * (transformers' CLIPTextModel behind embedders/clip/clip_embedder_model.py:10-104) run frozen under no_grad            */
+int fdmi_attn_causal_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O,
+                             int64_t ldo, int B, int H, int S, int d, float scale, float* scratch, int64_t scratch_elems, void* stream);
 int fdmi_attn_bwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
                       int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
                       int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream);

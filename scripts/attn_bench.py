@@ -5,7 +5,8 @@ from flash_diffusion_amd import ops
 from kbench import timeit
 BF = torch.bfloat16
 for (B, S, Skv, H, d) in [(16, 4096, 4096, 8, 40), (32, 4096, 4096, 8, 40), (16, 4096, 77, 8, 40), (16, 1024, 1024, 8, 80), (16, 256, 256, 8, 160),
-                          (8, 4096, 4096, 10, 64), (16, 1024, 1024, 20, 64)]:
+                          (8, 4096, 4096, 10, 64), (16, 1024, 1024, 20, 64), (8, 4096, 4096, 16, 72), (16, 4096, 4096, 16, 72), (8, 4096, 120, 16, 72),
+                          (32, 1024, 1024, 8, 80), (8, 4429, 4429, 24, 64)]:
     q = torch.randn(B, S, H * d, device="cuda").to(BF)
     k = torch.randn(B, Skv, H * d, device="cuda").to(BF)
     v = torch.randn(B, Skv, H * d, device="cuda").to(BF)
