@@ -164,4 +164,10 @@ def test_two_rank_replicas_are_identical_and_equal_the_averaged_single_process(t
     dist_ = float((r0 - ref["a"]).abs().max())
     n_off = int(((r0 - ref["a"]).abs() > 1e-5).sum())
     assert dist_ <= 3 * noise + 1e-6 or n_off <= 0.005 * r0.numel(), (dist_, noise, n_off, r0.numel())
-    assert float((r0 - ref["a"]).abs().mean()) < 1e-5       # and the two trajectories moved together
+    # ... and the two trajectories moved together: the mean distance is within 3x the mean distance of two single-process runs
+    mean_noise = float((ref["a"] - ref["b"]).abs().mean())
+    mean_dist = float((r0 - ref["a"]).abs().mean())
+    from tests.golden_util import parity_log
+    parity_log(f"two ranks vs single process: max |diff| {dist_:.3e} (two single runs: {noise:.3e}), mean |diff| {mean_dist:.3e} "
+               f"(two single runs: {mean_noise:.3e}), {n_off} of {r0.numel()} elements off by > 1e-5", "multiproc_parity.txt")
+    assert mean_dist <= 3 * mean_noise + 1e-6, (mean_dist, mean_noise)
