@@ -851,6 +851,399 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* O, int64_
   }
 }
 
+// =============================================================================================
+// forward on 32x32x16 MFMAs (round 3), head dims <= 64, LDS-DMA staged K / V^T tiles as above.
+//
+// Why a second forward kernel: the 16x16x32 kernel is ISSUE-bound at d = 40 -- 28 MFMAs and ~136 other instructions per
+// (64 keys x 32 queries) wave tile, and a SIMD issues one instruction per ~4 cycles whatever pipe it goes to, so the matrix pipe
+// idles while exp / max / cvt / ds_read issue (VALU 61 % + MFMA 28 % busy).  32x32x16 MFMAs do the same
+// FLOPs in HALF the instructions (14 per tile: 2 key blocks x KS k-steps of K Q^T with the head dim padded to 16 KS instead of 64,
+// 2 d-blocks x 4 key steps of V^T P), a query's 64 scores of a tile sit in TWO lanes (l, l ^ 32) instead of four, so the row
+// maximum is one cross-lane step, and the 8 consecutive C registers of a (key block, half) ARE the B operand of one V^T P step:
+// no cross-lane traffic between the two products.  All MFMAs are compiler builtins: hazards and accumulator placement are the
+// compiler's job (the inline-asm accumulation of the 16x16 kernel needed hand-placed wait states).
+//
+// Fragment maps (32x32x16 bf16): A[i = l & 31][k = 8 (l >> 5) + e], B[k = 8 (l >> 5) + e][j = l & 31], e = 0..7;
+// C[row = (reg & 3) + 8 (reg >> 2) + 4 (l >> 5)][col = l & 31].  S^T = K Q^T: rows = keys, cols = queries; lane l holds, for query
+// l & 31, the keys 8 i + 4 h + r (h = l >> 5) of each 32-key block in reg 4 i + r.  O^T = V^T P: the contraction slot e of half h in
+// key step s = 2 kb + hs is key 32 kb + 16 hs + 8 (e >> 2) + 4 h + (e & 3) = the key of C register 8 hs + e of block kb: P feeds
+// straight from the registers, and the V^T fragment reads the same permutation from LDS (two 8-byte reads, 16 bytes apart).
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+#define MFMA32(A, B, C) __builtin_amdgcn_mfma_f32_32x32x16_bf16(A, B, C, 0, 0, 0)
+__device__ __forceinline__ float other32(float v) {  // value of lane l ^ 32
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return (threadIdx.x & 32) ? __uint_as_float(r[0]) : __uint_as_float(r[1]);
+}
+
+// KS: 16-wide k-steps of K Q^T (3: d <= 48, 4: d <= 64).  ONES: V^T carries a row of ones at dd = d (< 64): the denominator
+// accumulates in O^T row d; otherwise a VALU row sum.
+//
+// Issue-slot economy of the tile body (what this kernel is about):
+//  * the K tile is staged with its rows PERMUTED inside every group of 16 keys (row rho holds key rho with bits 2 and 3 swapped):
+//    softmax does not care about key order, and with that order the 8 contraction slots of a lane half in a V^T P step are 8
+//    CONSECUTIVE keys of V^T's (memory-order) tile -- one ds_read_b128 per V^T fragment instead of two ds_read_b64;
+//  * the two LDS stages are two straight-line copies of the body (template SLOT): every LDS address is lane offset + immediate;
+//  * -m lives in a register block that is the read-only C operand of the first K Q^T MFMA of a block (no per-tile accumulator
+//    initialisation);
+//  * the lazy-maximum check of the common tile does not compute a maximum at all: the probabilities are packed to bf16 anyway,
+//    bf16 bit patterns of non-negative numbers order like integers, so a chain of packed 16-bit maxima over the 16 packed
+//    registers (v_pk_max_u16) tells whether any probability exceeded 2^TAU.  Only then (rare, wave-uniform) the tile is
+//    recomputed from LDS with the classic maximum / re-base sequence.
+typedef unsigned short us2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pkmax(uint32_t x, uint32_t y) {
+  return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(us2_t, x), __builtin_bit_cast(us2_t, y)));
+}
+__host__ __device__ __forceinline__ int attn32_keyperm(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
+// LDS-DMA piece with a uniform 64-bit base (SGPR pair) + a 32-bit lane offset: the pointers advance on the scalar unit
+__device__ __forceinline__ void attn_glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr));
+}
+__device__ __forceinline__ float round_bf16(float x) { return __uint_as_float(pack2bf(x, 0.f) << 16); }
+
+// MT ("m through the contraction", d % 8 == 0 and d < 16 KS): the running reference maximum m rides in the first padded k slot:
+// K'[key][d] = 1 for every key (written into the LDS tile's padding ONCE -- the DMA never touches padded chunks), Q'[q][d] = -m
+// (bf16; m is kept bf16-representable so that the subtraction is exact), so K' Q'^T = s - m with a ZERO C operand: no register
+// block for -m, no per-tile accumulator initialisation -- 16 registers less, which is what lets three waves share a SIMD.
+template <int KS, bool ONES, bool MT>
+__global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int KBYTES = 64 * 128, STAGEB = 2 * 64 * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, n = lane & 31;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh - b * a.H;
+  const int hoff = hd * a.d;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int SP = attn_spad(a.Skv), DVP = attn_dvpad(a.d);
+  const float sc = a.scale * 1.4426950408889634f;
+
+  // padding of the K tiles (chunks from d / 8 on) and V^T rows from dvpad(d) on, both stages: written once, never by the DMA
+  for (int idx = tid; idx < 2 * 2 * 64 * 8; idx += 256) {
+    const int c = idx & 7, row = (idx >> 3) & 63, kv = (idx >> 9) & 1, stg = idx >> 10;
+    const bool pad = kv ? row >= DVP : c * 8 >= a.d;
+    if (pad) {
+      uint4 val = make_uint4(0, 0, 0, 0);
+      if (MT && !kv && c * 8 == a.d) val.x = 0x3F80u;   // bf16 1.0 at column d
+      *(uint4*)(smem + stg * STAGEB + kv * KBYTES + row * 128 + ((c ^ ((row >> 1) & 7)) * 16)) = val;
+    }
+  }
+
+  // Q fragments (B operand of K Q^T), scaled by scale * log2(e): the MFMA output is the exp2 argument
+  union QF { bf16x8 v; uint4 u4; uint32_t u[4]; } qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks].u4 = make_uint4(0, 0, 0, 0);
+    const int c = 16 * ks + 8 * h, row = q0 + n;
+    if (row < a.Sq && c < a.d) qf[ks].u4 = *(const uint4*)(a.Q + ((int64_t)b * a.Sq + row) * a.ldq + hoff + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      qf[ks].u[e] = pack2bf(__uint_as_float(qf[ks].u[e] << 16) * sc, __uint_as_float(qf[ks].u[e] & 0xffff0000u) * sc);
+  }
+  f32x16 o[2], cinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    o[0][r] = 0.f;
+    o[1][r] = 0.f;
+    cinit[r] = 0.f;
+  }
+  float m = NEG_BIG, lsum = 0.f;
+  auto set_m = [&](float mv) __attribute__((always_inline)) {   // publish the reference maximum to the next K Q^T
+    m = mv;
+    if (MT) {
+      const uint32_t nb = pack2bf(-mv, 0.f) & 0xffffu;
+      const bool mine = h == ((a.d >> 3) & 1);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        if (mine && ks == (a.d >> 4)) qf[ks].u[0] = (qf[ks].u[0] & 0xffff0000u) | nb;
+    } else {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) cinit[r] = -mv;
+    }
+  };
+
+  // per-lane fragment offsets inside a tile (rows of 128 B; chunk c of row r sits at physical chunk c ^ ((r >> 1) & 7)); the second
+  // 32-row block is the same offset + 4096 (the swizzle term only sees n)
+  int kofs[KS], vofs[4];
+  {
+    const int sw = (n >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kofs[ks] = n * 128 + (((2 * ks + h) ^ sw) * 16);
+#pragma unroll
+    for (int st = 0; st < 4; ++st) vofs[st] = KBYTES + n * 128 + (((2 * st + h) ^ sw) * 16);   // keys 16 st + 8 h .. + 7
+  }
+
+  const int nt = (a.Skv + KVB - 1) / KVB;
+  const bool ragged = (a.Skv % KVB) != 0;
+  // ---- LDS-DMA staging: 4 pieces of 1 KiB per wave per tile (K rows 8 (wave + 4 i) .., V^T rows likewise); K rows permuted.  Uniform
+  // tile bases advance on the scalar unit, the lane offsets are fixed; padded K chunks / V^T rows are not fetched (lanes off) ----
+  const int drow = 8 * wave + (lane >> 3), dpc = lane & 7, dc = dpc ^ ((drow >> 1) & 7);   // (row + 32: same swizzle term)
+  const bool kok = dc * 8 < a.d;
+  unsigned koff[2], voff[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    koff[i] = (unsigned)((attn32_keyperm(drow + 32 * i) * a.ldk + dc * 8) * 2);
+    voff[i] = (unsigned)(((drow + 32 * i) * SP + dc * 8) * 2);
+  }
+  const char* kbase = (const char*)(a.K + ((int64_t)b * a.Skv) * a.ldk + hoff);
+  const char* vbase = (const char*)(a.VT + (((int64_t)b * a.H + hd) * DVP) * SP);
+  const int64_t kstep = (int64_t)KVB * a.ldk * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)((ATTN_LDS_AS char*)smem);
+  auto dma_issue = [&](int t) __attribute__((always_inline)) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (t & 1) * STAGEB + wave * 1024);
+    const bool last_ragged = ragged && t == nt - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool keyok = !last_ragged || t * KVB + attn32_keyperm(drow + 32 * i) < a.Skv;
+      if (kok && keyok) attn_glds16_s(kbase, koff[i], base + i * 4096);
+      if (8 * (wave + 4 * i) < DVP) attn_glds16_s(vbase, voff[i], base + KBYTES + i * 4096);
+    }
+    kbase += kstep;
+    vbase += KVB * 2;
+  };
+  dma_issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  constexpr float TAU = 16.f;
+  constexpr uint32_t TAU_BF16 = (uint32_t)(127 + 16) << 7;   // bf16 bits of 2^TAU
+  // S^T blocks of the tile in stage SLOT: scores minus the reference maximum (MT: through the contraction; else the C operand)
+  auto qk = [&](auto slot_tag, f32x16 (&s)[2]) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const char* base = smem + SLOT * STAGEB;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16x8 kfr[KS];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) kfr[ks] = *(const bf16x8*)(base + kb * 4096 + kofs[ks]);
+      if (MT) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        s[kb] = MFMA32(kfr[0], qf[0].v, z);
+      } else {
+        s[kb] = MFMA32(kfr[0], qf[0].v, cinit);
+      }
+#pragma unroll
+      for (int ks = 1; ks < KS; ++ks) s[kb] = MFMA32(kfr[ks], qf[ks].v, s[kb]);
+    }
+  };
+  auto pack = [&](const f32x16 (&s)[2], uint4 (&pb)[4]) {   // key step st = 2 kb + hs <- C registers 8 hs .. 8 hs + 7 of block kb
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      const int kb = st >> 1, r0 = 8 * (st & 1);
+      pb[st] = make_uint4(pack2bf(s[kb][r0], s[kb][r0 + 1]), pack2bf(s[kb][r0 + 2], s[kb][r0 + 3]), pack2bf(s[kb][r0 + 4], s[kb][r0 + 5]),
+                          pack2bf(s[kb][r0 + 6], s[kb][r0 + 7]));
+    }
+  };
+  auto pv = [&](auto slot_tag, const uint4 (&pb)[4]) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const char* base = smem + SLOT * STAGEB;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) {
+      union { uint4 u; bf16x8 v; } p8;
+      p8.u = pb[st];
+#pragma unroll
+      for (int db = 0; db < 2; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[st]), p8.v, o[db]);
+    }
+  };
+  // classic body: row maximum, re-base m (FIRST: m := the maximum), exp2, row sum.  Used for tile 0, the ragged tail and the rare
+  // tile whose scores run more than TAU past the reference maximum.  s arrives relative to the current m (0 before tile 0).
+  auto classic = [&](auto first_tag, auto tail_tag, f32x16 (&s)[2], int t) {
+    constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
+    if (TAIL) {
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * KVB + attn32_keyperm(32 * kb + 8 * (r >> 2) + 4 * h + (r & 3)) >= a.Skv) s[kb][r] = NEG_BIG;
+    }
+    float mx = fmaxf(s[0][0], s[1][0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s[0][r], s[1][r]));
+    mx = fmaxf(mx, other32(mx));
+    float up, alpha = 1.f;
+    if (FIRST) {
+      up = MT ? round_bf16(mx) : mx;
+      set_m(up);
+    } else {
+      const float mnew = MT ? round_bf16(m + fmaxf(mx, 0.f)) : m + fmaxf(mx, 0.f);   // the reference only ever rises
+      up = mnew - m;
+      alpha = fast_exp2(-up);
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+      set_m(mnew);
+    }
+    float ps = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float p = fast_exp2(s[kb][r] - up);
+        s[kb][r] = p;
+        if (!ONES) ps += p;
+      }
+    if (!ONES) lsum = lsum * alpha + ps;
+  };
+  // common body: no maximum -- exp2 straight away, pack, packed-integer overflow check; redo classically if it fires.  The tile is
+  // processed as two halves of 32 keys (the two S^T blocks): both blocks' K Q^T MFMAs are issued first, then per half exp2 / pack /
+  // check / its four V^T P MFMAs -- half 0's exponentials run under block 1's K Q^T, half 1's under half 0's V^T P.
+  auto qk_block = [&](const char* base, int kb) __attribute__((always_inline)) -> f32x16 {   // one S^T block (32 keys) relative to the current m
+    bf16x8 kfr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kfr[ks] = *(const bf16x8*)(base + kb * 4096 + kofs[ks]);
+    f32x16 acc;
+    if (MT) {
+      f32x16 z;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      acc = MFMA32(kfr[0], qf[0].v, z);
+    } else {
+      acc = MFMA32(kfr[0], qf[0].v, cinit);
+    }
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) acc = MFMA32(kfr[ks], qf[ks].v, acc);
+    return acc;
+  };
+  auto rebase_half = [&](const f32x16 sh) __attribute__((always_inline)) -> float {   // sh relative to the current m; returns the shift applied
+    float mx = sh[0];
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sh[r]);
+    mx = fmaxf(mx, other32(mx));
+    const float mnew = MT ? round_bf16(m + fmaxf(mx, 0.f)) : m + fmaxf(mx, 0.f);
+    const float up = mnew - m, alpha = fast_exp2(-up);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
+    if (!ONES) lsum *= alpha;
+    set_m(mnew);
+    return up;
+  };
+  // one half: sh = this block's scores (exp2 arguments), snext = the other block's (adjusted if this half re-bases and KB == 0)
+  auto half = [&](const char* base, auto kb_tag, f32x16 sh, f32x16& snext) __attribute__((always_inline)) {
+    constexpr int KB = decltype(kb_tag)::value;
+    float ps = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      sh[r] = fast_exp2(sh[r]);
+      if (!ONES) ps += sh[r];
+    }
+    uint4 pb0 = make_uint4(pack2bf(sh[0], sh[1]), pack2bf(sh[2], sh[3]), pack2bf(sh[4], sh[5]), pack2bf(sh[6], sh[7]));
+    uint4 pb1 = make_uint4(pack2bf(sh[8], sh[9]), pack2bf(sh[10], sh[11]), pack2bf(sh[12], sh[13]), pack2bf(sh[14], sh[15]));
+    const uint32_t c = pkmax(pkmax(pkmax(pb0.x, pb0.y), pkmax(pb0.z, pb0.w)), pkmax(pkmax(pb1.x, pb1.y), pkmax(pb1.z, pb1.w)));
+    const bool over = (c & 0xffffu) > TAU_BF16 || (c >> 16) > TAU_BF16;
+    if (__builtin_expect(__any(over), 0)) {
+      asm volatile("" ::: "memory");   // keep the block conditional (no speculation into the common path)
+      sh = qk_block(base, KB);         // recompute (relative to the m the block was issued with), re-base, redo the exponentials
+      const float up = rebase_half(sh);
+      ps = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        sh[r] = fast_exp2(sh[r] - up);
+        if (!ONES) ps += sh[r];
+      }
+      if (KB == 0) {   // block 1's scores were issued against the old reference
+#pragma unroll
+        for (int r = 0; r < 16; ++r) snext[r] -= up;
+      }
+      pb0 = make_uint4(pack2bf(sh[0], sh[1]), pack2bf(sh[2], sh[3]), pack2bf(sh[4], sh[5]), pack2bf(sh[6], sh[7]));
+      pb1 = make_uint4(pack2bf(sh[8], sh[9]), pack2bf(sh[10], sh[11]), pack2bf(sh[12], sh[13]), pack2bf(sh[14], sh[15]));
+    }
+    if (!ONES) lsum += ps;
+    union { uint4 u; bf16x8 v; } p0, p1;
+    p0.u = pb0;
+    p1.u = pb1;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB]), p0.v, o[db]);
+#pragma unroll
+    for (int db = 0; db < 2; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB + 1]), p1.v, o[db]);
+  };
+  auto fast = [&](auto slot_tag, int t) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    const char* base = smem + SLOT * STAGEB;
+    f32x16 s0 = qk_block(base, 0);
+    f32x16 s1 = qk_block(base, 1);
+    half(base, std::integral_constant<int, 0>{}, s0, s1);
+    half(base, std::integral_constant<int, 1>{}, s1, s1);
+  };
+  auto slow = [&](auto slot_tag, auto first_tag, auto tail_tag, int t) __attribute__((always_inline)) {
+    f32x16 s[2];
+    uint4 pb[4];
+    qk(slot_tag, s);
+    classic(first_tag, tail_tag, s, t);
+    pack(s, pb);
+    pv(slot_tag, pb);
+  };
+
+  auto stage = [&](int t) __attribute__((always_inline)) {
+    __syncthreads();  // stage t & 1 is complete (and, before tile 0, the padding); every wave is done with the other stage
+    if (t + 1 < nt) dma_issue(t + 1);
+  };
+  auto landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  const int nfull = ragged ? nt - 1 : nt;
+  if (nfull > 0) {
+    stage(0);
+    slow(S0{}, std::true_type{}, std::false_type{}, 0);
+    landed();
+    int t = 1;
+    for (; t + 1 < nfull; t += 2) {   // two tiles per trip: stage 1, then stage 0
+      stage(t);
+      fast(S1{}, t);
+      landed();
+      stage(t + 1);
+      fast(S0{}, t + 1);
+      landed();
+    }
+    if (t < nfull) {
+      stage(t);
+      fast(S1{}, t);
+      landed();
+    }
+  }
+  if (ragged) {
+    stage(nt - 1);
+    if (nt == 1) slow(S0{}, std::true_type{}, std::true_type{}, 0);
+    else if ((nt - 1) & 1) slow(S1{}, std::false_type{}, std::true_type{}, nt - 1);
+    else slow(S0{}, std::false_type{}, std::true_type{}, nt - 1);
+  }
+  // ---- epilogue: O[q][dd] = O^T[dd][q] / l ----
+  float lt;
+  if (ONES) {   // the denominator is O^T row d: block d / 32, register 4 ((d % 32) / 8) + (d % 4), lane half ((d % 8) / 4)
+    const int dl = a.d & 31, reg = 4 * (dl >> 3) + (dl & 3), hh = (dl & 7) >> 2;
+    float v = 0.f;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        if (db == (a.d >> 5) && r == reg) v = o[db][r];
+    lt = __shfl(v, hh * 32 + n, 64);
+  } else {
+    lt = lsum + other32(lsum);
+  }
+  const float inv = 1.f / lt;
+  const int q = q0 + n;
+  if (q < a.Sq) {
+    if (a.lse && h == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + q] = m + log2f(lt);
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int dd = 32 * db + 8 * i + 4 * h;
+        if (dd < a.d) {
+          uint2 pk;
+          pk.x = pack2bf(o[db][4 * i] * inv, o[db][4 * i + 1] * inv);
+          pk.y = pack2bf(o[db][4 * i + 2] * inv, o[db][4 * i + 3] * inv);
+          *(uint2*)(a.out + ((int64_t)b * a.Sq + q) * a.ldout + hoff + dd) = pk;
+        }
+      }
+  }
+}
+
 template <typename KernelT>
 int set_smem(KernelT k, int bytes) {
   FDMI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -876,10 +1269,39 @@ int fwd_t(const AttnArgs& a, hipStream_t st) {
     }
     once = smem;
   }
-  dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
   const bool ones = a.vt_ones && a.d < DV;
+  if constexpr (CAN_DMA) {
+    // 32x32x16 kernel (round 3) for the 64-wide DMA-staged case; A/B switch 26 = 1 keeps the 16x16x32 kernel
+    // measured (profiles/r3_attn_ab.txt): the 32x32x16 kernel wins for d < 64 (d = 40: +13..16 %), the 16x16x32 kernel at d = 64
+    // (+3..11 %), which therefore keeps it.  A/B switch 26 = 1: 16x16x32 for every head dim
+    if (dma && fdmi_tune_get(26) == 0 && a.d < 64) {
+      static bool once32 = false;
+      // (KS, ONES, MT): d <= 40 -> (3, *, true); d = 48 -> (3, false, false) (no spare k slot, no spare V^T row); d = 56 -> (4, *, true)
+#define ATTN32_ALL(F) F(3, true, true) F(3, false, true) F(3, false, false) F(4, true, true) F(4, false, true)
+      if (!once32) {
+#define ATTN32_SET(KS_, ON_, MT_) if (set_smem(attn_fwd32_kernel<KS_, ON_, MT_>, smem_dma)) return -2;
+        ATTN32_ALL(ATTN32_SET)
+#undef ATTN32_SET
+        once32 = true;
+      }
+      dim3 g32(cdiv(a.Sq, 128), a.B * a.H);
+      const bool ones32 = a.vt_ones && a.d < attn_dvpad(a.d);   // (the transposer's spare padded row dd = d)
+      const int ks32 = a.d <= 48 ? 3 : 4;
+      const bool mt32 = a.d < 16 * ks32;                         // spare k slot for the running maximum
+#define ATTN32_GO(KS_, ON_, MT_)                                                                                     \
+  if (ks32 == KS_ && ones32 == ON_ && mt32 == MT_)                                                                   \
+    FDMI_KLAUNCH(prof, (attn_fwd32_kernel<KS_, ON_, MT_>), g32, dim3(256), smem_dma, st, a);
+      ATTN32_ALL(ATTN32_GO)
+#undef ATTN32_GO
+#undef ATTN32_ALL
+      if (prof) fdmi_prof_end(st);
+      FDMI_HIP(hipGetLastError());
+      return 0;
+    }
+  }
+  dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   if constexpr (CAN_DMA) {
     if (dma) {
       if (ones) FDMI_KLAUNCH(prof, (attn_fwd_kernel<DK, DV, NF, true, true>), grid, dim3(256), smem, st, a);
@@ -947,10 +1369,10 @@ static int check_attn(const AttnArgs& a) {
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
-  // query fragments per wave: 2 for d <= 64; 1 for larger heads (register pressure at 2 waves/SIMD).  A/B switch 27 = 1: two
-  // fragments also for the 96-wide instantiations (d = 72 PixArt, d = 80 SD1.5 level 1: 204 VGPRs, still two waves per SIMD;
-  // every K / V^T fragment read from LDS then feeds twice the MFMAs)
-  if (fdmi_tune_get(27)) { ATTN_DISPATCH4(fwd_t, 2, 2, 1) }
+  // query fragments per wave: 2 for d <= 96 (the 96-wide instantiations -- d = 72 PixArt, d = 80 SD1.5 level 1 -- take 204 VGPRs,
+  // still two waves per SIMD; every K / V^T fragment read from LDS then feeds twice the MFMAs: +17..24 % at d = 72 / 80,
+  // profiles/r3_attn_ab.txt; A/B switch 27 = 1 restores one fragment), 1 for larger heads
+  if (fdmi_tune_get(27) == 0) { ATTN_DISPATCH4(fwd_t, 2, 2, 1) }
   ATTN_DISPATCH4(fwd_t, 2, 1, 1)
 }
 int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st) {

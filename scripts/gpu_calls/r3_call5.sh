@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-3 fifth GPU call: the 3-waves-per-SIMD 32x32x16 attention forward (running maximum through the contraction): parity, op A/B.
+set -u
+out=gpurun_out/r3c5
+mkdir -p "$out"
+cd "$(dirname "$0")/../.." || exit 1
+export TMPDIR=/tmp
+run() { name=$1; shift; echo "== $name: $*"; ( "$@" ) > "$out/$name.log" 2>&1; echo "   exit $? ($(tail -1 "$out/$name.log" | cut -c1-300))"; }
+run 01_pytest timeout 600 python -m pytest tests/test_kernels_gpu.py -q -rxXsf -p no:cacheprovider -k "attention"
+grep -h "FAILED\|passed\|failed" "$out/01_pytest.log" | tail -8
+run 02_attn_bench timeout 600 python scripts/attn_bench.py
+cat "$out/02_attn_bench.log" | cut -c1-400
