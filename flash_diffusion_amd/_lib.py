@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("splitk", i32), ("ws", vp),
         ("accum_atomic", i32), ("force_tile", i32), ("use_glds", i32),
         ("A2", vp), ("lda2", i64), ("K1", i32),
+        ("rowvec_mul", i32),
     ]
 
 

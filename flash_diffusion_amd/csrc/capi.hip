@@ -94,6 +94,7 @@ static GemmArgs gemm_args_from(const fdmi_gemm_desc* d) {
   a.force_tile = d->force_tile;
   a.use_glds = d->use_glds;
   a.A2 = (const bf16_t*)d->A2; a.lda2 = d->lda2; a.K1 = d->K1;
+  a.rowvec_mul = d->rowvec_mul;
   return a;
 }
 int fdmi_gemm_a2_ok(const fdmi_gemm_desc* d) { return d != nullptr && gemm_a2_ok(gemm_args_from(d)) ? 1 : 0; }

@@ -41,6 +41,11 @@ __device__ __forceinline__ float erf_fast(float x) {
   return copysignf(r, x);
 }
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
+// tanh-approximated GELU: 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3): one exp, one rcp
+__device__ __forceinline__ float gelu_tanh_fast(float x) {
+  const float u2 = 1.5957691216057308f * fmaf(0.044715f * x * x, x, x);
+  return x * rcp_fast(1.f + __expf(-u2));
+}
 __device__ __forceinline__ float dgelu_f(float x) {
   float cdf = 0.5f * (1.f + erf_fast(x * 0.70710678118654752f));
   float pdf = 0.39894228040143268f * __expf(-0.5f * x * x);

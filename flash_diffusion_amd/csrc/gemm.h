@@ -4,7 +4,7 @@
 
 enum { GEMM_ROW = 0, GEMM_CONV = 1 };
 enum { ACT_NONE = 0, ACT_SILU = 1, ACT_GEGLU = 2, ACT_RELU = 3 /* conv + ReLU of the VGG16 feature stack (LPIPS) */,
-       ACT_GELU = 4 /* exact (erf) GELU: the MLP of OpenCLIP-style text encoders */ };
+       ACT_GELU = 4, ACT_GELU_TANH = 5 /* exact (erf) GELU: the MLP of OpenCLIP-style text encoders */ };
 
 struct GemmArgs {
   int M = 0, N = 0, K = 0;
@@ -24,6 +24,8 @@ struct GemmArgs {
   // epilogue:  v = alpha*acc + bias[n] + rowvec[m / rows_per_batch][n] + residual[m][n]; act
   const float* bias = nullptr;
   const bf16_t* rowvec = nullptr; int64_t rowvec_ld = 0; int rows_per_batch = 1;
+  int rowvec_mul = 0;             // 1: the row vector MULTIPLIES: v = (alpha*acc + bias[n]) * rowvec[m / rows_per_batch][n] + residual[m][n]
+                                  // (the adaLN gate of the transformer denoisers; not with ACT_GEGLU)
   const bf16_t* residual = nullptr; int64_t ldr = 0;
   int act = ACT_NONE;             // ACT_GEGLU: N pre-activation columns in 16-wide (value|gate)
                                   // interleave -> N/2 output columns

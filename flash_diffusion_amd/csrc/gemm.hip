@@ -38,7 +38,7 @@ __device__ __forceinline__ void epi_terms(const GemmArgs& a, int64_t m, int n, f
     const bf16_t* rv = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (n + r < a.N) v[r] += bf2f(rv[r]);
+      if (n + r < a.N) v[r] = a.rowvec_mul ? v[r] * bf2f(rv[r]) : v[r] + bf2f(rv[r]);
   }
 }
 
@@ -65,6 +65,9 @@ __device__ __forceinline__ void epi_store(const GemmArgs& a, int act, int64_t m,
   } else if (act == ACT_GELU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+  } else if (act == ACT_GELU_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -578,6 +581,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   }
   if (a.A2) FDMI_CHECK(gemm_a2_ok(a), "gemm: a second A segment needs a row GEMM with M >= 256, N >= 128, K1 % 64 == 0, K % 64 == 0");
   if (a.act == ACT_GEGLU) FDMI_CHECK((a.N % 32) == 0, "geglu: N must be a multiple of 32");
+  if (a.rowvec_mul) FDMI_CHECK(a.rowvec != nullptr && a.act != ACT_GEGLU, "gemm: rowvec_mul needs a row vector and is not available with GEGLU");
   if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic);
   if (a.A2) FDMI_CHECK(p.big != 0, "gemm: a second A segment is read by the LDS-DMA kernels only (forced tile?)");

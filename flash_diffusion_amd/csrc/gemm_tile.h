@@ -29,7 +29,7 @@ __device__ __forceinline__ void epi_terms3(const GemmArgs& a, int64_t m, int n, 
     const bf16_t* rv = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
 #pragma unroll
     for (int r = 0; r < 4; ++r)
-      if (n + r < a.N) v[r] += bf2f(rv[r]);
+      if (n + r < a.N) v[r] = a.rowvec_mul ? v[r] * bf2f(rv[r]) : v[r] + bf2f(rv[r]);
   }
 }
 __device__ __forceinline__ void epi_store3(const GemmArgs& a, int act, int64_t m, int nout, int Nout, float v[4]) {
@@ -54,6 +54,9 @@ __device__ __forceinline__ void epi_store3(const GemmArgs& a, int act, int64_t m
   } else if (act == ACT_GELU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = gelu_f(v[r]);
+  } else if (act == ACT_GELU_TANH) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_fast(v[r]);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -105,8 +108,13 @@ __device__ __forceinline__ void epi_terms8(const GemmArgs& a, int64_t m, int n, 
   }
   if (a.rowvec) {
     const u16x8 rv = *(const u16x8*)(a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n);
+    if (a.rowvec_mul) {
 #pragma unroll
-    for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
+      for (int r = 0; r < 8; ++r) v[r] *= bf2f(rv[r]);
+    } else {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
+    }
   }
 }
 // activation + store of 8 consecutive columns (the residual, if any, already added)
@@ -129,6 +137,9 @@ __device__ __forceinline__ void epi_finish8(const GemmArgs& a, int act, int64_t 
   } else if (act == ACT_GELU) {
 #pragma unroll
     for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+  } else if (act == ACT_GELU_TANH) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_fast(v[r]);
   }
   if (a.out_f32) {
     float* c = (float*)a.C + m * a.ldc + nout;
@@ -520,8 +531,13 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
           }
           if (a.rowvec) {
             const u16x8 rv = *(const u16x8*)(a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n);
+            if (a.rowvec_mul) {
 #pragma unroll
-            for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
+              for (int r = 0; r < 8; ++r) v[r] *= bf2f(rv[r]);
+            } else {
+#pragma unroll
+              for (int r = 0; r < 8; ++r) v[r] += bf2f(rv[r]);
+            }
           }
           if (has_res) {
 #pragma unroll
@@ -536,6 +552,9 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
           } else if (a.act == ACT_GELU) {
 #pragma unroll
             for (int r = 0; r < 8; ++r) v[r] = gelu_f(v[r]);
+          } else if (a.act == ACT_GELU_TANH) {
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_fast(v[r]);
           }
           if (a.out_f32) {
             float* c = (float*)a.C + m * a.ldc + n;

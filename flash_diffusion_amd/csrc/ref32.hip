@@ -173,11 +173,15 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmArgs a, int kspli
     }
     float v = a.alpha * Cs[row][col];
     if (bias) v += bias[n];
-    if (rowvec) v += rowvec[(m / a.rows_per_batch) * a.rowvec_ld + n];
+    if (rowvec) {
+      const float rv = rowvec[(m / a.rows_per_batch) * a.rowvec_ld + n];
+      v = a.rowvec_mul ? v * rv : v + rv;
+    }
     if (residual) v += residual[m * a.ldr + n];
     if (a.act == ACT_SILU) v = silu32(v);
     else if (a.act == ACT_RELU) v = fmaxf(v, 0.f);
     else if (a.act == ACT_GELU) v = gelu32(v);
+    else if (a.act == ACT_GELU_TANH) v = 0.5f * v * (1.f + tanhf(0.7978845608028654f * fmaf(0.044715f * v * v, v, v)));
     C[m * a.ldc + n] = v;
   }
 }

@@ -167,6 +167,22 @@ def _silu(x):
     return _SiluFn.apply(x, torch.is_grad_enabled() and x.requires_grad)
 
 
+def _linear_gelu(lin, x):
+    """FeedForward's first projection + tanh-GELU (diffusers GELU(approximate="tanh"))"""
+    if lin.fusable(x):
+        return lin(x, act=ops.ACT_GELU_TANH)
+    f = lin(x)
+    return _GeluTanhFn.apply(f, torch.is_grad_enabled() and f.requires_grad)
+
+
+def _linear_gate_res(lin, x, gate, res, rpb):
+    """res + gate[sample] * lin(x): the adaLN gate + residual after an attention / feed-forward output projection"""
+    if lin.fusable(x, gate, res):
+        return lin(x, residual=res, gate=(gate, rpb))
+    y = lin(x)
+    return _GateResFn.apply(y, gate, res, rpb, torch.is_grad_enabled() and (y.requires_grad or gate.requires_grad or res.requires_grad))
+
+
 class _GeluTanhFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, need_bwd):
@@ -276,8 +292,21 @@ class MiLinear(nn.Module):
         self.lora_B = nn.ModuleDict({"default": _Leaf(b)})
         self.rank = r
 
-    def forward(self, x, residual=None, out_f32=False):
+    def fusable(self, *ts):
+        """True when this call needs no autograd edge and carries no LoRA pair: activation / gate may ride in the GEMM epilogue"""
+        return self.rank == 0 and not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts))
+
+    def forward(self, x, residual=None, out_f32=False, act=0, gate=None):
+        """act / gate (= (vector [B, out], rows per sample): y = (x W^T + b) * gate[sample] + residual) only where fusable():
+        one launch instead of GEMM + element-wise pass (the frozen teacher's whole forward, the student's sampler)"""
         assert x.dtype in (BF16, F32) and x.dim() == 2 and x.stride(1) == 1 and x.shape[1] == self.in_features
+        if act or gate is not None:
+            assert self.fusable(x, residual, gate[0] if gate is not None else None)
+            wb, _ = self.base16(x.dtype)
+            self.count(2.0 * x.shape[0] * self.out_features * self.in_features)
+            return ops.gemm(x, wb, bias=self.bias, residual=residual, out_f32=out_f32, act=act,
+                            rowvec=gate[0] if gate is not None else None, rows_per_batch=gate[1] if gate is not None else 1,
+                            rowvec_mul=gate is not None)
         need_bwd = torch.is_grad_enabled() and (x.requires_grad or self.rank > 0
                                                 or (residual is not None and residual.requires_grad))
         A = self.lora_A.default.weight if self.rank else None
@@ -540,12 +569,14 @@ class MiTransformer2DModel(_DenoiserBase):
             self._mask_cache = (key, None if all(n == L for n in lens) else lens)
         return self._mask_cache[1]
 
-    def _attn(self, a: _Attention, xq, xkv, B, Sq, Skv, lens, residual=None):
+    def _attn(self, a: _Attention, xq, xkv, B, Sq, Skv, lens, residual=None, gate=None):
         q = a.to_q(xq).view(B, Sq, -1)
         k = a.to_k(xkv).view(B, Skv, -1)
         v = a.to_v(xkv).view(B, Skv, -1)
         nb = torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
         o = _AttnFn.apply(q, k, v, a.heads, a.scale, lens, nb, self).view(B * Sq, -1)
+        if gate is not None:
+            return _linear_gate_res(a.to_out[0], o, gate, residual, Sq)
         return a.to_out[0](o, residual=residual)
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
@@ -594,8 +625,7 @@ class MiTransformer2DModel(_DenoiserBase):
         L = crossattn.shape[1]
         ctx = crossattn.to(self.dt).reshape(B * L, -1).contiguous()
         if self.caption_projection is not None:
-            t1 = self.caption_projection.linear_1(ctx)
-            ctx = self.caption_projection.linear_2(_GeluTanhFn.apply(t1, grad and t1.requires_grad))
+            ctx = self.caption_projection.linear_2(_linear_gelu(self.caption_projection.linear_1, ctx))
         lens = self._key_lens(mask, L)
 
         eps = c["norm_eps"]
@@ -603,14 +633,11 @@ class MiTransformer2DModel(_DenoiserBase):
             mod = (blk.scale_shift_table[None] + mod6).to(self.dt)     # shift_msa, scale_msa, gate_msa, shift_mlp, ...
             nb = grad and (hid.requires_grad or mod.requires_grad)
             n1 = _LnModFn.apply(hid, mod[:, 0], mod[:, 1], T, eps, nb)
-            a1 = self._attn(blk.attn1, n1, n1, B, T, T, None)
-            hid = _GateResFn.apply(a1, mod[:, 2], hid, T, grad and (a1.requires_grad or mod.requires_grad or hid.requires_grad))
+            hid = self._attn(blk.attn1, n1, n1, B, T, T, None, residual=hid, gate=mod[:, 2])
             hid = self._attn(blk.attn2, hid, ctx, B, T, L, lens, residual=hid)
             nb = grad and (hid.requires_grad or mod.requires_grad)
             n2 = _LnModFn.apply(hid, mod[:, 3], mod[:, 4], T, eps, nb)
-            f = blk.ff.net[0].proj(n2)
-            f = blk.ff.net[2](_GeluTanhFn.apply(f, grad and f.requires_grad))
-            hid = _GateResFn.apply(f, mod[:, 5], hid, T, grad and (f.requires_grad or mod.requires_grad or hid.requires_grad))
+            hid = _linear_gate_res(blk.ff.net[2], _linear_gelu(blk.ff.net[0].proj, n2), mod[:, 5], hid, T)
 
         fin = (self.scale_shift_table[None] + emb.float()[:, None]).to(self.dt)                    # shift, scale
         n = _LnModFn.apply(hid, fin[:, 0], fin[:, 1], T, 1e-6, grad and (hid.requires_grad or fin.requires_grad))
@@ -721,9 +748,6 @@ class MiSD3Transformer2DModel(_DenoiserBase):
             self._pos_cache[key] = pe.to(device).to(self.dt).expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
         return self._pos_cache[key]
 
-    def _ff(self, ff: _FF, n, grad):
-        f = ff.net[0].proj(n)
-        return ff.net[2](_GeluTanhFn.apply(f, grad and f.requires_grad))
 
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
                 conditioning: Dict[str, Dict[str, torch.Tensor]], hidden_states_masks: Optional[torch.Tensor] = None,
@@ -776,17 +800,13 @@ class MiSD3Transformer2DModel(_DenoiserBase):
             k = torch.cat([a.to_k(n).view(B, T, D), a.add_k_proj(nc).view(B, L, D)], dim=1)
             v = torch.cat([a.to_v(n).view(B, T, D), a.add_v_proj(nc).view(B, L, D)], dim=1)
             o = _AttnFn.apply(q, k, v, H, a.scale, None, need(q, k, v), self)
-            ox = a.to_out[0](o[:, :T].reshape(B * T, D))
-            x = _GateResFn.apply(ox, m[:, 2], x, T, need(ox, m, x))
+            x = _linear_gate_res(a.to_out[0], o[:, :T].reshape(B * T, D), m[:, 2], x, T)
             n2 = _LnModFn.apply(x, m[:, 3], m[:, 4], T, eps, need(x, m))
-            f = self._ff(blk.ff, n2, grad)
-            x = _GateResFn.apply(f, m[:, 5], x, T, need(f, m, x))
+            x = _linear_gate_res(blk.ff.net[2], _linear_gelu(blk.ff.net[0].proj, n2), m[:, 5], x, T)
             if not blk.context_pre_only:
-                oc = a.to_add_out(o[:, T:].reshape(B * L, D))
-                ctx = _GateResFn.apply(oc, mc[:, 2], ctx, L, need(oc, mc, ctx))
+                ctx = _linear_gate_res(a.to_add_out, o[:, T:].reshape(B * L, D), mc[:, 2], ctx, L)
                 n2c = _LnModFn.apply(ctx, mc[:, 3], mc[:, 4], L, eps, need(ctx, mc))
-                fc = self._ff(blk.ff_context, n2c, grad)
-                ctx = _GateResFn.apply(fc, mc[:, 5], ctx, L, need(fc, mc, ctx))
+                ctx = _linear_gate_res(blk.ff_context.net[2], _linear_gelu(blk.ff_context.net[0].proj, n2c), mc[:, 5], ctx, L)
 
         mo = self.norm_out(st)                                        # (scale, shift)
         n = _LnModFn.apply(x, mo[:, 1], mo[:, 0], T, eps, need(x, mo))

@@ -10,7 +10,7 @@ from ._lib import GemmDesc, check, lib, ptr, stream_ptr
 
 BF16 = torch.bfloat16
 F32 = torch.float32
-ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_RELU, ACT_GELU, ACT_GELU_TANH = 0, 1, 2, 3, 4, 5
 # Every activation op below dispatches on the dtype of its operand: bf16 tensors run the measured MFMA path, fp32 tensors the
 # fp32 VALIDATION kernels (csrc/ref32.hip: exact-f32 MFMA, fp32 storage, fp64 statistics) -- the parity gate against the fp32
 # oracle.  A model picks one of the two with its `precision` argument; nothing mixes them.
@@ -54,7 +54,7 @@ def geglu_perm(n_half, device=None):
 # ---- GEMM / conv -------------------------------------------------------------------------------
 def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows_per_batch=1, residual=None,
          act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1, ws=None, accum_atomic=False,
-         force_tile=0, use_glds=True, conv=None, gn=None, A2=None):
+         force_tile=0, use_glds=True, conv=None, gn=None, A2=None, rowvec_mul=False):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue).  conv: dict(Hin,Win,Cin,Hout,Wout,KH,KW,stride,pad,ups,dgrad)
     with A the NHWC activation.  gn=(stats [B,G,2] f32 zeroed, rows_per_sample): the epilogue also accumulates the GroupNorm
     sums of the output (fdmi_gemm_gn; raises when the problem's kernel cannot -- ask gemm_gn_ok first)."""
@@ -79,6 +79,7 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
     d.A, d.W, d.ldw = ptr(A), ptr(W), W.stride(0)
     d.bias = ptr(bias)
     d.rowvec, d.rowvec_ld, d.rows_per_batch = ptr(rowvec), (rowvec.stride(0) if rowvec is not None else 0), rows_per_batch
+    d.rowvec_mul = int(bool(rowvec_mul))       # gate: (acc + bias) * rowvec + residual
     d.residual, d.ldr = ptr(residual), (residual.stride(0) if residual is not None else 0)
     d.act = act
     d.preact, d.ldp = ptr(preact), (preact.stride(0) if preact is not None else 0)

@@ -39,7 +39,8 @@ int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches
 
 /* ---------------- GEMM / implicit-GEMM convolution (bf16 MFMA, fp32 accumulate) ----------------
  * out[M,N] = A[M,K] * W[N,K]^T ; epilogue v = alpha*acc + bias[n] + rowvec[m/rows_per_batch][n]
- *            + residual[m][n]; act (0 none, 1 SiLU, 2 GEGLU on 16-wide (value|gate) interleave).
+ *            + residual[m][n]; act (0 none, 1 SiLU, 2 GEGLU on 16-wide (value|gate) interleave, 3 ReLU, 4 GELU (erf),
+ *            5 GELU (tanh approximation: diffusers FeedForward "gelu-approximate", PixArt / SD3 blocks)).
  * mode 0: A is row-major [M][lda].  mode 1: A is an NHWC activation gathered as im2col
  * (Hin,Win,Cin -> Hout,Wout; KHxKW, stride 1|2, zero pad, ups: fused nearest-2x upsample of the
  * input; dgrad: gather form of the transposed convolution).                                     */
@@ -66,6 +67,10 @@ typedef struct fdmi_gemm_desc {
    * (y = [x | t] [W | B]^T, peft's y = W x + B A x, examples/train_flash_sd.py:191-200) through ONE GEMM without materialising
    * the concatenated operand.  fdmi_gemm_a2_ok (host only) says whether the problem qualifies.                          */
   const void* A2; int64_t lda2; int32_t K1;
+  /* 1: the row vector multiplies instead of adding: v = (alpha*acc + bias[n]) * rowvec[m/rows_per_batch][n] + residual[m][n]
+   * -- the adaLN gate + residual of a transformer denoiser block (diffusers BasicTransformerBlock ada_norm_single:
+   * hidden_states = gate_msa * attn_output + hidden_states; JointTransformerBlock likewise) in the projection's epilogue.  */
+  int32_t rowvec_mul;
 } fdmi_gemm_desc;
 int fdmi_gemm_a2_ok(const fdmi_gemm_desc* d);
 int fdmi_gemm(const fdmi_gemm_desc* d, void* stream);

@@ -8,7 +8,7 @@ import math
 import torch
 
 BF16 = torch.bfloat16
-ACT_NONE, ACT_SILU, ACT_GEGLU = 0, 1, 2
+ACT_NONE, ACT_SILU, ACT_GEGLU, ACT_RELU, ACT_GELU, ACT_GELU_TANH = 0, 1, 2, 3, 4, 5
 
 
 def _dev(t):
@@ -16,19 +16,29 @@ def _dev(t):
 
 
 def gemm(A, W, *, bias=None, residual=None, act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1,
-         accum_atomic=False, **kw):
+         accum_atomic=False, rowvec=None, rows_per_batch=1, rowvec_mul=False, **kw):
     assert A.dtype == BF16 and W.dtype == BF16 and A.shape[1] == W.shape[1] and A.shape[1] % 8 == 0, (A.shape, W.shape)
     assert A.stride(1) == 1 and W.stride(1) == 1 and A.stride(0) % 8 == 0 and W.stride(0) % 8 == 0
     v = alpha * (A.float() @ W.float().t())
     if bias is not None:
         assert bias.dtype == torch.float32
         v = v + bias
+    if rowvec is not None:      # per-sample row vector: added, or (rowvec_mul) the adaLN gate multiplying before the residual
+        assert rowvec.dtype == BF16 and rowvec.stride(1) == 1 and rowvec.stride(0) % 8 == 0 and v.shape[0] % rows_per_batch == 0
+        rv = rowvec.float().repeat_interleave(rows_per_batch, dim=0)
+        v = v * rv if rowvec_mul else v + rv
+    else:
+        assert not rowvec_mul
     if residual is not None:
         assert residual.dtype == BF16 and residual.shape == v.shape
         v = v + residual.float()
     assert preact is None, "the GEMM epilogue saves pre-activations only for GEGLU"
     if act == ACT_SILU:
         v = torch.nn.functional.silu(v)
+    elif act == ACT_GELU_TANH:
+        v = torch.nn.functional.gelu(v, approximate="tanh")
+    elif act == ACT_GELU:
+        v = torch.nn.functional.gelu(v)
     else:
         assert act == ACT_NONE
     if out is not None:

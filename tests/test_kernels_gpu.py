@@ -100,6 +100,38 @@ def test_gemm_epilogues(glds):
     close("gemm_epi_f32", out, A.float() @ W.float().t() + bias, tol_el=1e-4, tol_fro=1e-4)
 
 
+@pytest.mark.parametrize("M,N,K", [(192, 328, 256), (512, 1152, 1152), (512, 4608, 1152), (1024, 320, 1280), (512, 640, 640)])
+def test_gemm_gate_and_gelu_tanh_epilogues(M, N, K):
+    """The transformer denoisers' fused epilogues on every tile family (small tiles, 256 x {128,160} ring, 256 x 192 / 320):
+    y = (x W^T + b) * gate[sample] + residual (adaLN gate, GemmArgs::rowvec_mul) and tanh-GELU (ACT_GELU_TANH); bf16 and the
+    fp32 validation kernel."""
+    ops = _ops()
+    rpb = 64
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias = rnd(N, seed=3)
+    gate = b16(rnd(M // rpb, N, seed=4))
+    res = b16(rnd(M, N, seed=5))
+    h = A.float() @ W.float().t() + bias
+    ref_gate = h * gate.float().repeat_interleave(rpb, 0) + res.float()
+    ref_gelu = F.gelu(h, approximate="tanh")
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), rowvec=gate.cuda(), rows_per_batch=rpb, rowvec_mul=True, residual=res.cuda())
+    close(f"gemm_gate_res {M, N, K}", out, ref_gate)
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_GELU_TANH)
+    close(f"gemm_gelu_tanh {M, N, K}", out, ref_gelu)
+    # a strided gate view (column block of a [B, 6, N] modulation table, as the denoisers pass it)
+    table = b16(rnd(M // rpb, 6 * N, seed=6)).cuda()
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), rowvec=table[:, 2 * N:3 * N], rows_per_batch=rpb, rowvec_mul=True,
+                   residual=res.cuda())
+    close(f"gemm_gate_view {M, N, K}", out, h * table[:, 2 * N:3 * N].float().cpu().repeat_interleave(rpb, 0) + res.float())
+    if M <= 512 and N <= 1152:
+        A32, W32 = A.float().cuda(), W.float().cuda()
+        out = ops.gemm(A32, W32, bias=bias.cuda(), rowvec=gate.float().cuda(), rows_per_batch=rpb, rowvec_mul=True,
+                       residual=res.float().cuda())
+        close(f"gemm32_gate_res {M, N, K}", out, ref_gate, tol_el=1e-5, tol_fro=1e-5)
+        out = ops.gemm(A32, W32, bias=bias.cuda(), act=ops.ACT_GELU_TANH)
+        close(f"gemm32_gelu_tanh {M, N, K}", out, ref_gelu, tol_el=1e-5, tol_fro=1e-5)
+
+
 def test_gemm_geglu():
     ops = _ops()
     M, K, Fh = 200, 64, 96

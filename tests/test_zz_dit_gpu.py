@@ -121,6 +121,12 @@ def _body_test_dit_frozen_forward_matches_reference_golden(name):
         out = m(x.cuda(), t.cuda(), _to_cuda(cond))
     assert out.shape == g["out"]["frozen"].shape and out.dtype == torch.float32
     assert rel_err(out, g["out"]["frozen"]) < 2e-2, rel_err(out, g["out"]["frozen"])
+    # the same frozen model with a gradient flowing to its input (the GAN generator step through the teacher): the tanh-GELU
+    # and the adaLN gate + residual leave the GEMM epilogues and run as their own taped passes -- same function
+    out2 = m(x.cuda().requires_grad_(), t.cuda(), _to_cuda(cond))
+    assert out2.requires_grad
+    assert rel_err(out2, g["out"]["frozen"]) < 2e-2, rel_err(out2, g["out"]["frozen"])
+    assert rel_err(out2, out) < 1e-2, rel_err(out2, out)
 
 
 @pytest.mark.parametrize("name", list(DIT_CASES) + list(MMDIT_CASES))
