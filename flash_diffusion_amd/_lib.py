@@ -129,6 +129,11 @@ _SIGS = {
     "fdmi_attn_scratch_elems_f32": (i64, [i32, i32, i32, i32, i32]),
     "fdmi_attn_fwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, i64, vp]),
     "fdmi_attn_causal_fwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, f32, vp, i64, vp]),
+    "fdmi_attn_bias_fwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp, vp, vp, i64, vp]),
+    "fdmi_rmsnorm": (i32, [vp, vp, vp, i64, i32, f32, vp]),
+    "fdmi_rmsnorm_f32": (i32, [vp, vp, vp, i64, i32, f32, vp]),
+    "fdmi_mul": (i32, [vp, vp, vp, i64, vp]),
+    "fdmi_mul_f32": (i32, [vp, vp, vp, i64, vp]),
     "fdmi_attn_bwd_f32": (i32, [vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, vp, i64, i32, i32, i32, i32, i32, f32, vp,
                                 i64, vp]),
     "fdmi_groupnorm_fwd_f32": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),

@@ -333,6 +333,22 @@ int fdmi_attn_causal_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_
                              int64_t ldo, int B, int H, int S, int d, float scale, float* scratch, int64_t scratch_elems, void* stream) {
   return launch_attn32_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, S, S, d, scale, scratch, scratch_elems, (hipStream_t)stream, 1);
 }
+int fdmi_attn_bias_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
+                           int B, int H, int Sq, int Skv, int d, float scale, const float* bias, const float* kbias, float* scratch,
+                           int64_t scratch_elems, void* stream) {
+  return launch_attn32_fwd(Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Sq, Skv, d, scale, scratch, scratch_elems, (hipStream_t)stream, 0, bias,
+                           kbias);
+}
+int fdmi_rmsnorm(const void* x, const float* w, void* y, int64_t rows, int C, float eps, void* stream) {
+  return launch_rmsnorm((const bf16_t*)x, w, (bf16_t*)y, rows, C, eps, (hipStream_t)stream);
+}
+int fdmi_rmsnorm_f32(const float* x, const float* w, float* y, int64_t rows, int C, float eps, void* stream) {
+  return launch_rmsnorm32(x, w, y, rows, C, eps, (hipStream_t)stream);
+}
+int fdmi_mul(const void* a, const void* b, void* y, int64_t n, void* stream) {
+  return launch_ewise_mul((const bf16_t*)a, (const bf16_t*)b, (bf16_t*)y, n, (hipStream_t)stream);
+}
+int fdmi_mul_f32(const float* a, const float* b, float* y, int64_t n, void* stream) { return launch_ewise_mul32(a, b, y, n, (hipStream_t)stream); }
 int fdmi_attn_bwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
                       int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
                       int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream) {

@@ -236,6 +236,30 @@ __global__ __launch_bounds__(256) void lpips_input_bwd_kernel(const TT* dy, floa
   }
 }
 
+// T5LayerNorm (transformers T5LayerNorm, the T5 text encoder of the PixArt / SD3 conditioners): y = x * rsqrt(mean(x^2) + eps) * w --
+// no mean subtraction, no bias; statistics in fp32.  One wave per row.
+template <typename TT>
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const TT* x, const float* w, TT* y, int64_t rows, int C, float eps) {
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const TT* xr = x + row * C;
+  float ss = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float v = ldv(xr + c);
+    ss = fmaf(v, v, ss);
+  }
+  ss = wave_sum(ss);
+  const float r = rsqrtf(ss / (float)C + eps);
+  TT* yr = y + row * C;
+  for (int c = lane; c < C; c += 64) stv(yr + c, ldv(xr + c) * r * w[c]);
+}
+// y = a * b (the gate of T5's gated feed-forward: gelu_new(x Wi0^T) * (x Wi1^T))
+template <typename TT>
+__global__ __launch_bounds__(256) void ewise_mul_kernel(const TT* a, const TT* b, TT* y, int64_t n) {
+  NGRID_STRIDE(i, n) stv(y + i, ldv(a + i) * ldv(b + i));
+}
+
 }  // namespace
 
 #define NLAUNCH(kernel, total, ...)                                                     \
@@ -323,3 +347,15 @@ int launch_lpips_input_bwd(const bf16_t* dy, float* dx, int B, int HW, int Cpad,
 int launch_lpips_input_bwd32(const float* dy, float* dx, int B, int HW, int Cpad, const float* scale, hipStream_t st) {
   NLAUNCH(lpips_input_bwd_kernel<float>, (int64_t)B * 3 * HW, dy, dx, B, HW, Cpad, scale[0], scale[1], scale[2]);
 }
+int launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int64_t rows, int C, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(rmsnorm_kernel<bf16_t>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, y, rows, C, eps);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_rmsnorm32(const float* x, const float* w, float* y, int64_t rows, int C, float eps, hipStream_t st) {
+  hipLaunchKernelGGL(rmsnorm_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, x, w, y, rows, C, eps);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+int launch_ewise_mul(const bf16_t* a, const bf16_t* b, bf16_t* y, int64_t n, hipStream_t st) { NLAUNCH(ewise_mul_kernel<bf16_t>, n, a, b, y, n); }
+int launch_ewise_mul32(const float* a, const float* b, float* y, int64_t n, hipStream_t st) { NLAUNCH(ewise_mul_kernel<float>, n, a, b, y, n); }

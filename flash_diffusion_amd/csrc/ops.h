@@ -132,6 +132,11 @@ int launch_pixel_unshuffle32(const float* x, float* y, int B, int C, int H, int 
 int launch_nhwc_to_nchw_any(const bf16_t* x, float* y, int B, int C, int HW, hipStream_t st);
 int launch_nhwc_to_nchw_any32(const float* x, float* y, int B, int C, int HW, hipStream_t st);
 int launch_bf16_to_f32(const bf16_t* x, float* y, int64_t n, hipStream_t st);
+// T5 text encoder pieces: T5LayerNorm (RMS norm, fp32 weight), the gated feed-forward's product
+int launch_rmsnorm(const bf16_t* x, const float* w, bf16_t* y, int64_t rows, int C, float eps, hipStream_t st);
+int launch_rmsnorm32(const float* x, const float* w, float* y, int64_t rows, int C, float eps, hipStream_t st);
+int launch_ewise_mul(const bf16_t* a, const bf16_t* b, bf16_t* y, int64_t n, hipStream_t st);
+int launch_ewise_mul32(const float* a, const float* b, float* y, int64_t n, hipStream_t st);
 // out[b] += mean over the sample's pixels of sum_c w[c] (f0 / (|f0| + 1e-10) - f1 / (|f1| + 1e-10))^2 ; rows = B * HW pixel rows
 int launch_lpips_level_fwd(const bf16_t* f0, const bf16_t* f1, const float* w, float* out, int64_t rows, int HW, int C, hipStream_t st);
 int launch_lpips_level_fwd32(const float* f0, const float* f1, const float* w, float* out, int64_t rows, int HW, int C, hipStream_t st);
@@ -151,7 +156,9 @@ int launch_wgrad_tn32(const float* X, int64_t ldx, const float* Y, int64_t ldy, 
 int64_t attn32_scratch_elems(int B, int H, int Sq, int Skv, int bwd);   // floats of scratch the two calls below want
 int launch_attn32_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
                       int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st,
-                      int causal = 0);   // causal: key j attends query i only for j <= i (the CLIP text encoder; Sq == Skv)
+                      int causal = 0,    // causal: key j attends query i only for j <= i (the CLIP text encoder; Sq == Skv)
+                      const float* bias = nullptr,     // [H][Sq][Skv] added to the scaled scores (T5's relative-position bias)
+                      const float* kbias = nullptr);   // [B][Skv] additive key mask
 int launch_attn32_bwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
                       int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
                       int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st);

@@ -190,11 +190,20 @@ __global__ __launch_bounds__(256) void gemm32_kernel(const GemmArgs a, int kspli
 // attention pieces: row softmax of the materialised scores and its backward (in place)
 // ---------------------------------------------------------------------------------------------------------------------
 // causal_sq > 0: rows are queries i = row % causal_sq of a causal self-attention; keys j > i get probability 0
-__global__ __launch_bounds__(256) void softmax32_kernel(float* S, int64_t rows, int n, int64_t ld, int causal_sq = 0) {
+// bias [H][Sq][n] (shared by the samples; T5's relative-position bias) and kbias [sample][n] (additive key mask, e.g. 0 / -inf-like)
+// are added to the scores first when given (rows = samples * H * Sq, row = (sample * H + h) * Sq + i)
+__global__ __launch_bounds__(256) void softmax32_kernel(float* S, int64_t rows, int n, int64_t ld, int causal_sq = 0,
+                                                        const float* bias = nullptr, const float* kbias = nullptr, int H = 1, int Sq = 1) {
   const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
   float* s = S + row * ld;
+  if (bias || kbias) {
+    const int64_t hi = row % ((int64_t)H * Sq), smp = row / ((int64_t)H * Sq);
+    const float* br = bias ? bias + hi * n : nullptr;
+    const float* kr = kbias ? kbias + smp * n : nullptr;
+    for (int j = lane; j < n; j += 64) s[j] += (br ? br[j] : 0.f) + (kr ? kr[j] : 0.f);
+  }
   if (causal_sq > 0) {
     const int nv = (int)(row % causal_sq) + 1;
     for (int j = nv + lane; j < n; j += 64) s[j] = 0.f;   // (the masked tail; the rest of the kernel sees n = i + 1 keys)
@@ -611,7 +620,7 @@ static GemmArgs attn32_gemm(int M, int N, int K, const float* A, int64_t lda, in
 // O = softmax(scale Q K^T) V on [B, S, ld] operands with head h at column offset h * d
 int launch_attn32_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
                       int B, int H, int Sq, int Skv, int d, float scale, float* scratch, int64_t scratch_elems, hipStream_t st,
-                      int causal) {
+                      int causal, const float* bias, const float* kbias) {
   FDMI_CHECK(!causal || Sq == Skv, "attn32: the causal mask is defined for self-attention (Sq == Skv)");
   const int64_t Sp = attn32_skvp(Skv), per = (int64_t)H * Sq * Sp;
   const int cb = (int)(scratch_elems / per < B ? scratch_elems / per : B);
@@ -623,7 +632,8 @@ int launch_attn32_fwd(const float* Q, int64_t ldq, const float* K, int64_t ldk, 
     s.a_b1 = (int64_t)Sq * ldq; s.a_b2 = d; s.w_b1 = (int64_t)Skv * ldk; s.w_b2 = d; s.c_b1 = per; s.c_b2 = (int64_t)Sq * Sp;
     if (int rc = launch_gemm32(s, st)) return rc;
     const int64_t rows = (int64_t)nb * H * Sq;
-    hipLaunchKernelGGL(softmax32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, scratch, rows, Skv, Sp, causal ? Sq : 0);
+    hipLaunchKernelGGL(softmax32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, scratch, rows, Skv, Sp, causal ? Sq : 0, bias,
+                       kbias ? kbias + (int64_t)b0 * Skv : nullptr, H, Sq);
     GemmArgs o = attn32_gemm(Sq, d, Skv, scratch, Sp, 1, V + (int64_t)b0 * Skv * ldv, 1, ldv, O + (int64_t)b0 * Sq * ldo, ldo, 1.f,
                              nb, H);
     o.a_b1 = per; o.a_b2 = (int64_t)Sq * Sp; o.w_b1 = (int64_t)Skv * ldv; o.w_b2 = d; o.c_b1 = (int64_t)Sq * ldo; o.c_b2 = d;

@@ -294,6 +294,39 @@ def attn_causal_fwd(q, k, v, H, scale):
     return o if q.dtype == F32 else f32_to_bf16(o)
 
 
+def attn_bias_fwd(q, k, v, H, scale, bias=None, kbias=None):
+    """softmax(scale q k^T + bias[h] + kbias[b]) v, forward only (the frozen T5 text encoder): q [B, Sq, H*d], k / v [B, Skv, H*d],
+    bias [H, Sq, Skv] f32 or None, kbias [B, Skv] f32 or None.  Exact-f32 materialised scores in both precisions."""
+    B, Sq, Cc = q.shape
+    Skv, d = k.shape[1], Cc // H
+    qf, kf, vf = (t.contiguous() if t.dtype == F32 else t.float().contiguous() for t in (q, k, v))
+    assert bias is None or (bias.dtype == F32 and bias.is_contiguous() and tuple(bias.shape) == (H, Sq, Skv))
+    assert kbias is None or (kbias.dtype == F32 and kbias.is_contiguous() and tuple(kbias.shape) == (B, Skv))
+    o = torch.empty_like(qf)
+    n = lib().fdmi_attn_scratch_elems_f32(B, H, Sq, Skv, 0)
+    sc = torch.empty(n, dtype=F32, device=q.device)
+    check(lib().fdmi_attn_bias_fwd_f32(ptr(qf), qf.stride(1), ptr(kf), kf.stride(1), ptr(vf), vf.stride(1), ptr(o), o.stride(1), B, H,
+                                       Sq, Skv, d, scale, ptr(bias), ptr(kbias), ptr(sc), n, stream_ptr()))
+    return o if q.dtype == F32 else f32_to_bf16(o)
+
+
+def rmsnorm(x, w, eps):
+    """T5LayerNorm: x [rows, C] (bf16 / f32) * rsqrt(mean(x^2) + eps) * w (f32)"""
+    _dev(x)
+    assert x.dim() == 2 and x.is_contiguous() and w.dtype == F32 and w.numel() == x.shape[1]
+    y = torch.empty_like(x)
+    check((lib().fdmi_rmsnorm_f32 if _f32(x) else lib().fdmi_rmsnorm)(ptr(x), ptr(w), ptr(y), x.shape[0], x.shape[1], eps, stream_ptr()))
+    return y
+
+
+def mul(a, b):
+    _dev(a)
+    assert a.shape == b.shape and a.dtype == b.dtype and a.is_contiguous() and b.is_contiguous()
+    y = torch.empty_like(a)
+    check((lib().fdmi_mul_f32 if _f32(a) else lib().fdmi_mul)(ptr(a), ptr(b), ptr(y), a.numel(), stream_ptr()))
+    return y
+
+
 def attn_bwd(q, k, v, o, do, lse, H, scale, out=None):
     B, Sq, Cc = q.shape
     Skv = k.shape[1]

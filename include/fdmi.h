@@ -199,6 +199,17 @@ int fdmi_attn_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, 
  * (transformers' CLIPTextModel behind embedders/clip/clip_embedder_model.py:10-104) run frozen under no_grad            */
 int fdmi_attn_causal_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O,
                              int64_t ldo, int B, int H, int S, int d, float scale, float* scratch, int64_t scratch_elems, void* stream);
+/* T5 text encoder (transformers' T5EncoderModel behind embedders/t5/t5_embedder_model.py:11-104; frozen, forward only):
+ * attention whose scaled scores receive bias[H][Sq][Skv] (the relative-position bias, shared by the samples; may be NULL) and
+ * kbias[B][Skv] (additive key mask; may be NULL) before the softmax; T5LayerNorm y = x * rsqrt(mean(x^2) + eps) * w (bf16 / fp32
+ * storage, fp32 weight); the element-wise product of the gated feed-forward.                                               */
+int fdmi_attn_bias_fwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, float* O, int64_t ldo,
+                           int B, int H, int Sq, int Skv, int d, float scale, const float* bias, const float* kbias, float* scratch,
+                           int64_t scratch_elems, void* stream);
+int fdmi_rmsnorm(const void* x, const float* w, void* y, int64_t rows, int C, float eps, void* stream);
+int fdmi_rmsnorm_f32(const float* x, const float* w, float* y, int64_t rows, int C, float eps, void* stream);
+int fdmi_mul(const void* a, const void* b, void* y, int64_t n, void* stream);
+int fdmi_mul_f32(const float* a, const float* b, float* y, int64_t n, void* stream);
 int fdmi_attn_bwd_f32(const float* Q, int64_t ldq, const float* K, int64_t ldk, const float* V, int64_t ldv, const float* dO,
                       int64_t lddo, float* dQ, int64_t lddq, float* dK, int64_t lddk, float* dV, int64_t lddv, int B, int H, int Sq,
                       int Skv, int d, float scale, float* scratch, int64_t scratch_elems, void* stream);
