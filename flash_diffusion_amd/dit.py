@@ -33,6 +33,16 @@ PIXART_LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0", "proj_in", "proj_out"
                        "linear", "linear_1", "linear_2")      # examples/train_flash_pixart.py:240-253
 
 
+# split-K of the projections: the context-stream GEMMs (a few hundred to a few thousand rows against K = 1152 ... 6144) fill a quarter
+# of the chip with one tile wave, so for M <= SPLITK_ROWS the launcher's planner decides per problem (ops.gemm(splitk=0)); measured
+# (profiles/r3_dit_ab.txt): for every M, C5 -2.0 % but C4 +1.2 % (its rank-64 GEMMs over 32768 rows split 2-way and pay the finalize)
+SPLITK_ROWS = int(__import__("os").environ.get("FDMI_DIT_SPLITK_ROWS", "4096"))
+
+
+def _sk(x):
+    return 0 if x.shape[0] <= SPLITK_ROWS else 1
+
+
 def _pad8(n):
     return (n + 7) // 8 * 8
 
@@ -47,11 +57,11 @@ class _LinearFn(torch.autograd.Function):
         M = x.shape[0]
         t = None
         if A is None:
-            y = ops.gemm(x, wb, bias=lin.bias, residual=residual, out_f32=out_f32)
+            y = ops.gemm(x, wb, bias=lin.bias, residual=residual, out_f32=out_f32, splitk=_sk(x))
         else:
             ab, _, bb, _ = lin.lora16(x.dtype)
-            t = ops.gemm(x, ab)
-            y0 = ops.gemm(x, wb, bias=lin.bias, residual=residual)
+            t = ops.gemm(x, ab, splitk=_sk(x))
+            y0 = ops.gemm(x, wb, bias=lin.bias, residual=residual, splitk=_sk(x))
             y = ops.gemm(t, bb, residual=y0, out_f32=out_f32)
         lin.count(2.0 * M * lin.out_features * lin.in_features
                   + (2.0 * M * lin.rank * (lin.in_features + lin.out_features) if A is not None else 0.0))
@@ -74,7 +84,7 @@ class _LinearFn(torch.autograd.Function):
         flops = 0.0
         if ctx.lora:
             _, abt, _, bbt = lin.lora16(x.dtype)
-            u = ops.gemm(dy, bbt)                                       # dL/d(A x)            [M, r]
+            u = ops.gemm(dy, bbt, splitk=_sk(x))                        # dL/d(A x)            [M, r]
             gv = lin._gviews           # views into the model's flat LoRA gradient (set by _reflatten_lora) or None
             # weight gradients by the TN kernel on the row-major operands (wgrad.hip): no transposed copies
             r = lin.rank
@@ -95,7 +105,7 @@ class _LinearFn(torch.autograd.Function):
         dx = None
         M = dy.shape[0]
         if ctx.needs_input_grad[0]:
-            dx = ops.gemm(dy, wtb)
+            dx = ops.gemm(dy, wtb, splitk=_sk(dy))
             flops += 2.0 * M * lin.out_features * lin.in_features
             if ctx.lora:
                 _, abt, _, _ = lin.lora16(dy.dtype)
@@ -306,7 +316,7 @@ class MiLinear(nn.Module):
             self.count(2.0 * x.shape[0] * self.out_features * self.in_features)
             return ops.gemm(x, wb, bias=self.bias, residual=residual, out_f32=out_f32, act=act,
                             rowvec=gate[0] if gate is not None else None, rows_per_batch=gate[1] if gate is not None else 1,
-                            rowvec_mul=gate is not None)
+                            rowvec_mul=gate is not None, splitk=_sk(x))
         need_bwd = torch.is_grad_enabled() and (x.requires_grad or self.rank > 0
                                                 or (residual is not None and residual.requires_grad))
         A = self.lora_A.default.weight if self.rank else None

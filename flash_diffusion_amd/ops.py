@@ -56,7 +56,7 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
          act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1, ws=None, accum_atomic=False,
          force_tile=0, use_glds=True, conv=None, gn=None, A2=None, rowvec_mul=False):
     """out[M,N] = A[M,K] @ W[N,K]^T (+epilogue).  conv: dict(Hin,Win,Cin,Hout,Wout,KH,KW,stride,pad,ups,dgrad)
-    with A the NHWC activation.  gn=(stats [B,G,2] f32 zeroed, rows_per_sample): the epilogue also accumulates the GroupNorm
+    with A the NHWC activation.  splitk: 1 none, > 1 forced, 0 the planner's choice (slab workspace sized to it).  gn=(stats [B,G,2] f32 zeroed, rows_per_sample): the epilogue also accumulates the GroupNorm
     sums of the output (fdmi_gemm_gn; raises when the problem's kernel cannot -- ask gemm_gn_ok first)."""
     _dev(A)
     d = GemmDesc()
@@ -95,10 +95,15 @@ def gemm(A, W, *, M=None, N=None, K=None, lda=None, bias=None, rowvec=None, rows
         out = torch.empty(M, Nout, dtype=torch.float32 if out_f32 else BF16, device=A.device)
     d.C, d.ldc, d.out_f32 = ptr(out), out.stride(0), int(out.dtype == torch.float32)
     d.alpha = alpha
-    if splitk != 1 and not accum_atomic and ws is None:  # fp32 slabs [splitk][M][N] (auto: up to 16)
+    d.accum_atomic, d.force_tile, d.use_glds = int(accum_atomic), force_tile, int(use_glds)
+    if splitk <= 0 and not accum_atomic and ws is None:   # auto: ask the launcher's planner (host only), size the slabs to its choice
+        d.splitk, d.ws = 0, None
+        pk = [C.c_int32() for _ in range(4)]
+        check(lib().fdmi_gemm_plan(C.byref(d), *[C.byref(x) for x in pk]))
+        splitk = pk[3].value
+    if splitk != 1 and not accum_atomic and ws is None:  # fp32 slabs [splitk][M][N]
         ws = torch.empty((splitk if splitk > 1 else 16) * M * N, dtype=torch.float32, device=A.device)
     d.splitk, d.ws = splitk, ptr(ws)
-    d.accum_atomic, d.force_tile, d.use_glds = int(accum_atomic), force_tile, int(use_glds)
     if gn is not None:
         stats, rows = gn
         assert stats.dtype == torch.float32 and stats.is_contiguous() and stats.shape[2] == 2

@@ -100,7 +100,8 @@ def test_gemm_epilogues(glds):
     close("gemm_epi_f32", out, A.float() @ W.float().t() + bias, tol_el=1e-4, tol_fro=1e-4)
 
 
-@pytest.mark.parametrize("M,N,K", [(192, 328, 256), (512, 1152, 1152), (512, 4608, 1152), (1024, 320, 1280), (512, 640, 640)])
+@pytest.mark.parametrize("M,N,K", [(192, 328, 256), (512, 1152, 1152), (512, 4608, 1152), (1024, 320, 1280), (512, 640, 640),
+                                   (1344, 1536, 1536), (960, 64, 1152)])
 def test_gemm_gate_and_gelu_tanh_epilogues(M, N, K):
     """The transformer denoisers' fused epilogues on every tile family (small tiles, 256 x {128,160} ring, 256 x 192 / 320):
     y = (x W^T + b) * gate[sample] + residual (adaLN gate, GemmArgs::rowvec_mul) and tanh-GELU (ACT_GELU_TANH); bf16 and the
@@ -123,6 +124,12 @@ def test_gemm_gate_and_gelu_tanh_epilogues(M, N, K):
     out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), rowvec=table[:, 2 * N:3 * N], rows_per_batch=rpb, rowvec_mul=True,
                    residual=res.cuda())
     close(f"gemm_gate_view {M, N, K}", out, h * table[:, 2 * N:3 * N].float().cpu().repeat_interleave(rpb, 0) + res.float())
+    # the planner's own split-K choice (ops.gemm(splitk=0)): the slab finalize kernel applies the same epilogue
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), rowvec=gate.cuda(), rows_per_batch=rpb, rowvec_mul=True, residual=res.cuda(),
+                   splitk=0)
+    close(f"gemm_gate_res auto-splitk {M, N, K}", out, ref_gate)
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), act=ops.ACT_GELU_TANH, splitk=3)
+    close(f"gemm_gelu_tanh splitk 3 {M, N, K}", out, ref_gelu)
     if M <= 512 and N <= 1152:
         A32, W32 = A.float().cuda(), W.float().cuda()
         out = ops.gemm(A32, W32, bias=bias.cuda(), rowvec=gate.float().cuda(), rows_per_batch=rpb, rowvec_mul=True,
