@@ -908,10 +908,19 @@ __device__ __forceinline__ float round_bf16(float x) { return __uint_as_float(pa
 // K'[key][d] = 1 for every key (written into the LDS tile's padding ONCE -- the DMA never touches padded chunks), Q'[q][d] = -m
 // (bf16; m is kept bf16-representable so that the subtraction is exact), so K' Q'^T = s - m with a ZERO C operand: no register
 // block for -m, no per-tile accumulator initialisation -- 16 registers less, which is what lets three waves share a SIMD.
-template <int KS, bool ONES, bool MT>
-__global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(const AttnArgs a) {
+//
+// Head dims 64 < d <= 80 (KS = 5, DB = 3: PixArt's d = 72, SD1.5's d = 80 level): the fifth k-step's 16 columns live in a second K
+// sub-tile of 32-byte rows (K_B: key rho at rho * 32, two chunks), V^T carries a third block of 32 rows; the 16x16x32 kernel pads
+// these heads to 96 on both products (25 % idle MFMA work), here K Q^T runs 80 wide and V^T P 96 rows.
+template <int KS, int DB>
+struct Attn32Lds {
+  static constexpr int KA = 64 * 128, VT = DB * 32 * 128, KB = KS > 4 ? 64 * 32 : 0, STAGE = KA + VT + KB;
+};
+template <int KS, int DB, bool ONES, bool MT>
+__global__ __launch_bounds__(256, (MT && ONES && KS < 5) ? 3 : 2) void attn_fwd32_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int KBYTES = 64 * 128, STAGEB = 2 * 64 * 128;
+  using L = Attn32Lds<KS, DB>;
+  constexpr int KBYTES = L::KA, STAGEB = L::STAGE, KBOFF = L::KA + L::VT;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, n = lane & 31;
   const int bh = blockIdx.y, b = bh / a.H, hd = bh - b * a.H;
   const int hoff = hd * a.d;
@@ -919,14 +928,26 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
   const int SP = attn_spad(a.Skv), DVP = attn_dvpad(a.d);
   const float sc = a.scale * 1.4426950408889634f;
 
-  // padding of the K tiles (chunks from d / 8 on) and V^T rows from dvpad(d) on, both stages: written once, never by the DMA
-  for (int idx = tid; idx < 2 * 2 * 64 * 8; idx += 256) {
-    const int c = idx & 7, row = (idx >> 3) & 63, kv = (idx >> 9) & 1, stg = idx >> 10;
-    const bool pad = kv ? row >= DVP : c * 8 >= a.d;
+  // padding of the K tiles (columns from d on) and V^T rows from dvpad(d) on, both stages: written once, never by the DMA
+  for (int idx = tid; idx < 2 * (STAGEB / 16); idx += 256) {
+    const int stg = idx / (STAGEB / 16), off = (idx - stg * (STAGEB / 16)) * 16;
+    bool pad, one;
+    if (off < KBYTES) {                 // K_A: row of 128 B, logical chunk = physical ^ swizzle
+      const int row = off >> 7, c = ((off >> 4) & 7) ^ ((row >> 1) & 7);
+      pad = c * 8 >= a.d;
+      one = c * 8 == a.d;
+    } else if (off < KBOFF) {           // V^T rows
+      pad = ((off - KBYTES) >> 7) >= DVP;
+      one = false;
+    } else {                            // K_B: key rho at rho * 32, chunk cB = columns 64 + 8 cB ..
+      const int cB = ((off - KBOFF) >> 4) & 1;
+      pad = 64 + 8 * cB >= a.d;
+      one = 64 + 8 * cB == a.d;
+    }
     if (pad) {
       uint4 val = make_uint4(0, 0, 0, 0);
-      if (MT && !kv && c * 8 == a.d) val.x = 0x3F80u;   // bf16 1.0 at column d
-      *(uint4*)(smem + stg * STAGEB + kv * KBYTES + row * 128 + ((c ^ ((row >> 1) & 7)) * 16)) = val;
+      if (MT && one) val.x = 0x3F80u;   // bf16 1.0 at column d
+      *(uint4*)(smem + stg * STAGEB + off) = val;
     }
   }
 
@@ -941,11 +962,11 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
     for (int e = 0; e < 4; ++e)
       qf[ks].u[e] = pack2bf(__uint_as_float(qf[ks].u[e] << 16) * sc, __uint_as_float(qf[ks].u[e] & 0xffff0000u) * sc);
   }
-  f32x16 o[2], cinit;
+  f32x16 o[DB], cinit;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    o[0][r] = 0.f;
-    o[1][r] = 0.f;
+#pragma unroll
+    for (int db = 0; db < DB; ++db) o[db][r] = 0.f;
     cinit[r] = 0.f;
   }
   float m = NEG_BIG, lsum = 0.f;
@@ -969,7 +990,8 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
   {
     const int sw = (n >> 1) & 7;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kofs[ks] = n * 128 + (((2 * ks + h) ^ sw) * 16);
+    for (int ks = 0; ks < KS; ++ks)
+      kofs[ks] = ks < 4 ? n * 128 + (((2 * ks + h) ^ sw) * 16) : KBOFF + n * 32 + h * 16;   // (block kb: + 4096 kb in K_A, + 1024 kb in K_B)
 #pragma unroll
     for (int st = 0; st < 4; ++st) vofs[st] = KBYTES + n * 128 + (((2 * st + h) ^ sw) * 16);   // keys 16 st + 8 h .. + 7
   }
@@ -980,12 +1002,15 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
   // tile bases advance on the scalar unit, the lane offsets are fixed; padded K chunks / V^T rows are not fetched (lanes off) ----
   const int drow = 8 * wave + (lane >> 3), dpc = lane & 7, dc = dpc ^ ((drow >> 1) & 7);   // (row + 32: same swizzle term)
   const bool kok = dc * 8 < a.d;
-  unsigned koff[2], voff[2];
+  unsigned koff[2], voff[DB];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    koff[i] = (unsigned)((attn32_keyperm(drow + 32 * i) * a.ldk + dc * 8) * 2);
-    voff[i] = (unsigned)(((drow + 32 * i) * SP + dc * 8) * 2);
-  }
+  for (int i = 0; i < 2; ++i) koff[i] = (unsigned)((attn32_keyperm(drow + 32 * i) * a.ldk + dc * 8) * 2);
+#pragma unroll
+  for (int i = 0; i < DB; ++i) voff[i] = (unsigned)(((drow + 32 * i) * SP + dc * 8) * 2);
+  // K_B (KS = 5): 64 keys x 32 B = two pieces, issued by waves 0 and 1: lane l -> LDS row 32 wave + l / 2, chunk l % 2
+  const int brow = 32 * (wave & 1) + (lane >> 1), bc = lane & 1;
+  const bool bok = KS > 4 && wave < 2 && 64 + 8 * bc < a.d;
+  const unsigned kboff = (unsigned)((attn32_keyperm(brow) * a.ldk + 64 + 8 * bc) * 2);
   const char* kbase = (const char*)(a.K + ((int64_t)b * a.Skv) * a.ldk + hoff);
   const char* vbase = (const char*)(a.VT + (((int64_t)b * a.H + hd) * DVP) * SP);
   const int64_t kstep = (int64_t)KVB * a.ldk * 2;
@@ -997,7 +1022,13 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
     for (int i = 0; i < 2; ++i) {
       const bool keyok = !last_ragged || t * KVB + attn32_keyperm(drow + 32 * i) < a.Skv;
       if (kok && keyok) attn_glds16_s(kbase, koff[i], base + i * 4096);
+    }
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
       if (8 * (wave + 4 * i) < DVP) attn_glds16_s(vbase, voff[i], base + KBYTES + i * 4096);
+    if (KS > 4) {
+      const bool keyok = !last_ragged || t * KVB + attn32_keyperm(brow) < a.Skv;
+      if (bok && keyok) attn_glds16_s(kbase, kboff, base + KBOFF);     // (base already carries wave * 1024)
     }
     kbase += kstep;
     vbase += KVB * 2;
@@ -1007,28 +1038,30 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
 
   constexpr float TAU = 16.f;
   constexpr uint32_t TAU_BF16 = (uint32_t)(127 + 16) << 7;   // bf16 bits of 2^TAU
-  // S^T blocks of the tile in stage SLOT: scores minus the reference maximum (MT: through the contraction; else the C operand)
-  auto qk = [&](auto slot_tag, f32x16 (&s)[2]) {
-    constexpr int SLOT = decltype(slot_tag)::value;
-    const char* base = smem + SLOT * STAGEB;
+  // one S^T block (32 keys) of the tile at `base`: scores minus the reference maximum (MT: through the contraction; else the C operand)
+  auto qk_block = [&](const char* base, int kb) __attribute__((always_inline)) -> f32x16 {
+    bf16x8 kfr[KS];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      bf16x8 kfr[KS];
+    for (int ks = 0; ks < KS; ++ks) kfr[ks] = *(const bf16x8*)(base + (ks < 4 ? kb * 4096 : kb * 1024) + kofs[ks]);
+    f32x16 acc;
+    if (MT) {
+      f32x16 z;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) kfr[ks] = *(const bf16x8*)(base + kb * 4096 + kofs[ks]);
-      if (MT) {
-        f32x16 z;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) z[r] = 0.f;
-        s[kb] = MFMA32(kfr[0], qf[0].v, z);
-      } else {
-        s[kb] = MFMA32(kfr[0], qf[0].v, cinit);
-      }
-#pragma unroll
-      for (int ks = 1; ks < KS; ++ks) s[kb] = MFMA32(kfr[ks], qf[ks].v, s[kb]);
+      for (int r = 0; r < 16; ++r) z[r] = 0.f;
+      acc = MFMA32(kfr[0], qf[0].v, z);
+    } else {
+      acc = MFMA32(kfr[0], qf[0].v, cinit);
     }
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) acc = MFMA32(kfr[ks], qf[ks].v, acc);
+    return acc;
   };
-  auto pack = [&](const f32x16 (&s)[2], uint4 (&pb)[4]) {   // key step st = 2 kb + hs <- C registers 8 hs .. 8 hs + 7 of block kb
+  auto qk = [&](auto slot_tag, f32x16 (&s)[2]) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    s[0] = qk_block(smem + SLOT * STAGEB, 0);
+    s[1] = qk_block(smem + SLOT * STAGEB, 1);
+  };
+  auto pack = [&](const f32x16 (&s)[2], uint4 (&pb)[4]) __attribute__((always_inline)) {   // key step st = 2 kb + hs <- C registers 8 hs .. 8 hs + 7 of block kb
 #pragma unroll
     for (int st = 0; st < 4; ++st) {
       const int kb = st >> 1, r0 = 8 * (st & 1);
@@ -1036,7 +1069,7 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
                           pack2bf(s[kb][r0 + 6], s[kb][r0 + 7]));
     }
   };
-  auto pv = [&](auto slot_tag, const uint4 (&pb)[4]) {
+  auto pv = [&](auto slot_tag, const uint4 (&pb)[4]) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     const char* base = smem + SLOT * STAGEB;
 #pragma unroll
@@ -1044,12 +1077,12 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
       union { uint4 u; bf16x8 v; } p8;
       p8.u = pb[st];
 #pragma unroll
-      for (int db = 0; db < 2; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[st]), p8.v, o[db]);
+      for (int db = 0; db < DB; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[st]), p8.v, o[db]);
     }
   };
   // classic body: row maximum, re-base m (FIRST: m := the maximum), exp2, row sum.  Used for tile 0, the ragged tail and the rare
   // tile whose scores run more than TAU past the reference maximum.  s arrives relative to the current m (0 before tile 0).
-  auto classic = [&](auto first_tag, auto tail_tag, f32x16 (&s)[2], int t) {
+  auto classic = [&](auto first_tag, auto tail_tag, f32x16 (&s)[2], int t) __attribute__((always_inline)) {
     constexpr bool FIRST = decltype(first_tag)::value, TAIL = decltype(tail_tag)::value;
     if (TAIL) {
 #pragma unroll
@@ -1071,7 +1104,7 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
       up = mnew - m;
       alpha = fast_exp2(-up);
 #pragma unroll
-      for (int db = 0; db < 2; ++db)
+      for (int db = 0; db < DB; ++db)
 #pragma unroll
         for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
       set_m(mnew);
@@ -1090,23 +1123,6 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
   // common body: no maximum -- exp2 straight away, pack, packed-integer overflow check; redo classically if it fires.  The tile is
   // processed as two halves of 32 keys (the two S^T blocks): both blocks' K Q^T MFMAs are issued first, then per half exp2 / pack /
   // check / its four V^T P MFMAs -- half 0's exponentials run under block 1's K Q^T, half 1's under half 0's V^T P.
-  auto qk_block = [&](const char* base, int kb) __attribute__((always_inline)) -> f32x16 {   // one S^T block (32 keys) relative to the current m
-    bf16x8 kfr[KS];
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) kfr[ks] = *(const bf16x8*)(base + kb * 4096 + kofs[ks]);
-    f32x16 acc;
-    if (MT) {
-      f32x16 z;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) z[r] = 0.f;
-      acc = MFMA32(kfr[0], qf[0].v, z);
-    } else {
-      acc = MFMA32(kfr[0], qf[0].v, cinit);
-    }
-#pragma unroll
-    for (int ks = 1; ks < KS; ++ks) acc = MFMA32(kfr[ks], qf[ks].v, acc);
-    return acc;
-  };
   auto rebase_half = [&](const f32x16 sh) __attribute__((always_inline)) -> float {   // sh relative to the current m; returns the shift applied
     float mx = sh[0];
 #pragma unroll
@@ -1115,7 +1131,7 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
     const float mnew = MT ? round_bf16(m + fmaxf(mx, 0.f)) : m + fmaxf(mx, 0.f);
     const float up = mnew - m, alpha = fast_exp2(-up);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[db][r] *= alpha;
     if (!ONES) lsum *= alpha;
@@ -1157,9 +1173,9 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
     p0.u = pb0;
     p1.u = pb1;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB]), p0.v, o[db]);
+    for (int db = 0; db < DB; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB]), p0.v, o[db]);
 #pragma unroll
-    for (int db = 0; db < 2; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB + 1]), p1.v, o[db]);
+    for (int db = 0; db < DB; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB + 1]), p1.v, o[db]);
   };
   auto fast = [&](auto slot_tag, int t) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
@@ -1217,7 +1233,7 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
     const int dl = a.d & 31, reg = 4 * (dl >> 3) + (dl & 3), hh = (dl & 7) >> 2;
     float v = 0.f;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         if (db == (a.d >> 5) && r == reg) v = o[db][r];
@@ -1230,7 +1246,7 @@ __global__ __launch_bounds__(256, (MT && ONES) ? 3 : 2) void attn_fwd32_kernel(c
   if (q < a.Sq) {
     if (a.lse && h == 0) a.lse[((int64_t)b * a.H + hd) * a.Sq + q] = m + log2f(lt);
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int dd = 32 * db + 8 * i + 4 * h;
@@ -1248,6 +1264,42 @@ template <typename KernelT>
 int set_smem(KernelT k, int bytes) {
   FDMI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
   return 0;
+}
+
+// 32x32x16 forward (round 3) for head dims < 64 and 64 < d <= 80; returns 1 when it took the problem, 0 when the 16x16x32 family should,
+// < 0 on error.  Measured (profiles/r3_attn_ab.txt): wins for d < 64 (d = 40: +13..16 %) and 64 < d <= 80; the 16x16x32 kernel keeps
+// d = 64 (+3..11 %).  A/B switch 26 = 1: 16x16x32 for every head dim; switch 11 != 0 (register staging experiments) likewise.
+static int launch_attn_fwd32(const AttnArgs& a, hipStream_t st) {
+  if (fdmi_tune_get(26) != 0 || fdmi_tune_get(11) != 0) return 0;
+  if (!(a.d < 64 || (a.d > 64 && a.d <= 80))) return 0;
+  // (KS, DB, ONES, MT): d <= 40 -> (3, 2, *, true); d = 48 -> (3, 2, false, false) (no spare k slot, no spare V^T row); d = 56 -> (4, 2, *,
+  // true); d = 72 -> (5, 3, *, true); d = 80 -> (5, 3, false, false)
+#define ATTN32_ALL(F)                                                                                                             \
+  F(3, 2, true, true) F(3, 2, false, true) F(3, 2, false, false) F(4, 2, true, true) F(4, 2, false, true) F(5, 3, true, true)      \
+  F(5, 3, false, true) F(5, 3, false, false)
+  static bool once32 = false;
+  if (!once32) {
+#define ATTN32_SET(KS_, DB_, ON_, MT_) \
+  if (set_smem(attn_fwd32_kernel<KS_, DB_, ON_, MT_>, 2 * Attn32Lds<KS_, DB_>::STAGE)) return -2;
+    ATTN32_ALL(ATTN32_SET)
+#undef ATTN32_SET
+    once32 = true;
+  }
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  dim3 g32(cdiv(a.Sq, 128), a.B * a.H);
+  const bool ones32 = a.vt_ones && a.d < attn_dvpad(a.d);   // (the transposer's spare padded row dd = d)
+  const int ks32 = a.d <= 48 ? 3 : (a.d < 64 ? 4 : 5), db32 = a.d < 64 ? 2 : 3;
+  const bool mt32 = a.d < 16 * ks32;                         // spare k slot for the running maximum
+#define ATTN32_GO(KS_, DB_, ON_, MT_)                                                                                             \
+  if (ks32 == KS_ && db32 == DB_ && ones32 == ON_ && mt32 == MT_)                                                                 \
+    FDMI_KLAUNCH(prof, (attn_fwd32_kernel<KS_, DB_, ON_, MT_>), g32, dim3(256), (2 * Attn32Lds<KS_, DB_>::STAGE), st, a);
+  ATTN32_ALL(ATTN32_GO)
+#undef ATTN32_GO
+#undef ATTN32_ALL
+  if (prof) fdmi_prof_end(st);
+  FDMI_HIP(hipGetLastError());
+  return 1;
 }
 
 template <int DK, int DV, int NF>
@@ -1272,35 +1324,6 @@ int fwd_t(const AttnArgs& a, hipStream_t st) {
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
   const bool ones = a.vt_ones && a.d < DV;
-  if constexpr (CAN_DMA) {
-    // 32x32x16 kernel (round 3) for the 64-wide DMA-staged case; A/B switch 26 = 1 keeps the 16x16x32 kernel
-    // measured (profiles/r3_attn_ab.txt): the 32x32x16 kernel wins for d < 64 (d = 40: +13..16 %), the 16x16x32 kernel at d = 64
-    // (+3..11 %), which therefore keeps it.  A/B switch 26 = 1: 16x16x32 for every head dim
-    if (dma && fdmi_tune_get(26) == 0 && a.d < 64) {
-      static bool once32 = false;
-      // (KS, ONES, MT): d <= 40 -> (3, *, true); d = 48 -> (3, false, false) (no spare k slot, no spare V^T row); d = 56 -> (4, *, true)
-#define ATTN32_ALL(F) F(3, true, true) F(3, false, true) F(3, false, false) F(4, true, true) F(4, false, true)
-      if (!once32) {
-#define ATTN32_SET(KS_, ON_, MT_) if (set_smem(attn_fwd32_kernel<KS_, ON_, MT_>, smem_dma)) return -2;
-        ATTN32_ALL(ATTN32_SET)
-#undef ATTN32_SET
-        once32 = true;
-      }
-      dim3 g32(cdiv(a.Sq, 128), a.B * a.H);
-      const bool ones32 = a.vt_ones && a.d < attn_dvpad(a.d);   // (the transposer's spare padded row dd = d)
-      const int ks32 = a.d <= 48 ? 3 : 4;
-      const bool mt32 = a.d < 16 * ks32;                         // spare k slot for the running maximum
-#define ATTN32_GO(KS_, ON_, MT_)                                                                                     \
-  if (ks32 == KS_ && ones32 == ON_ && mt32 == MT_)                                                                   \
-    FDMI_KLAUNCH(prof, (attn_fwd32_kernel<KS_, ON_, MT_>), g32, dim3(256), smem_dma, st, a);
-      ATTN32_ALL(ATTN32_GO)
-#undef ATTN32_GO
-#undef ATTN32_ALL
-      if (prof) fdmi_prof_end(st);
-      FDMI_HIP(hipGetLastError());
-      return 0;
-    }
-  }
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   if constexpr (CAN_DMA) {
     if (dma) {
@@ -1369,6 +1392,7 @@ static int check_attn(const AttnArgs& a) {
 
 int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
+  if (const int rc = launch_attn_fwd32(a, st)) return rc < 0 ? rc : 0;
   // query fragments per wave: 2 for d <= 96 (the 96-wide instantiations -- d = 72 PixArt, d = 80 SD1.5 level 1 -- take 204 VGPRs,
   // still two waves per SIMD; every K / V^T fragment read from LDS then feeds twice the MFMAs: +17..24 % at d = 72 / 80,
   // profiles/r3_attn_ab.txt; A/B switch 27 = 1 restores one fragment), 1 for larger heads

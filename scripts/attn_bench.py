@@ -14,7 +14,7 @@ for (B, S, Skv, H, d) in [(16, 4096, 4096, 8, 40), (32, 4096, 4096, 8, 40), (16,
     v = torch.randn(B, Skv, H * d, device="cuda").to(BF)
     res = []
     # default: 32x32x16 forward for d < 64, two query fragments for 64 < d <= 96; the switches restore round 2's choices
-    variants = (("default", ()), ("16x16x32 (26=1)", ((26, 1),)), ("QF=1 (27=1)", ((27, 1),)), ("default again", ()))
+    variants = (("default", ()), ("16x16x32 (26=1)", ((26, 1),)), ("16x16x32 QF=1 (26=1,27=1)", ((26, 1), (27, 1))), ("default again", ()))
     for name, kn in variants:
         for k_, v_ in kn:
             L.fdmi_tune_set(k_, v_)

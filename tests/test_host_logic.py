@@ -434,3 +434,14 @@ def test_scheduler_lists_are_sized_by_lr_schedulers_name_like_the_reference():
     c2 = TrainingConfig(optimizers_name=["AdamW", "AdamW"], learning_rates=[1e-2, 1e-2], lr_schedulers_name=["StepLR", "StepLR"],
                         lr_schedulers_kwargs=[dict(step_size=1), dict(step_size=2)], lr_schedulers_frequency=[2, 3])
     assert c2.lr_schedulers_frequency == [2, 3] and c2.lr_schedulers_interval == ["step", "step"]
+
+
+def test_t5_relative_position_buckets_match_transformers():
+    """host part of the T5 text encoder (flash_diffusion_amd/t5.py): the bidirectional bucketing of key - query positions"""
+    from transformers.models.t5.modeling_t5 import T5Attention
+    from flash_diffusion_amd.t5 import relative_position_bucket
+    for S, nb, md in ((120, 32, 128), (512, 32, 128), (77, 16, 20)):
+        pos = torch.arange(S)
+        rel = pos[None, :] - pos[:, None]
+        ref = T5Attention._relative_position_bucket(rel, bidirectional=True, num_buckets=nb, max_distance=md)
+        assert torch.equal(relative_position_bucket(rel, nb, md), ref)

@@ -302,6 +302,10 @@ ATTN = [
     # compiler placed accumulator copies right behind the last asynchronous MFMAs for head dims 56 and 64)
     (1, 2, 128, 128, 64), (1, 2, 256, 192, 64), (1, 2, 64, 1024, 64), (1, 2, 128, 128, 56), (2, 4, 128, 256, 48), (1, 2, 128, 256, 24),
     (1, 2, 128, 192, 96), (1, 2, 128, 192, 88), (1, 2, 64, 192, 128), (1, 2, 64, 128, 120), (1, 2, 64, 192, 160), (1, 2, 64, 128, 16),
+    # the 32x32x16 forward's 80-wide instantiations (d = 72: running maximum in column 72 of the second K sub-tile, ones row 72 of V^T;
+    # d = 80: neither): one tile, odd / even whole-tile counts, ragged tails, Sq off the 128-query block
+    (1, 2, 64, 64, 72), (2, 3, 300, 448, 72), (1, 2, 128, 150, 72), (1, 16, 1024, 1024, 72), (1, 2, 64, 64, 80), (2, 3, 300, 448, 80),
+    (1, 2, 128, 150, 80), (1, 4, 130, 384, 80),
 ]
 
 
@@ -335,7 +339,8 @@ def test_attention_fwd_bwd(cfg):
     close(f"attn_dv{cfg}", dv, vr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
 
 
-@pytest.mark.parametrize("d,factor", [(40, 6.0), (40, 60.0), (64, 6.0), (64, 60.0), (80, 6.0)])
+@pytest.mark.parametrize("d,factor", [(40, 6.0), (40, 60.0), (64, 6.0), (64, 60.0), (80, 6.0), (72, 6.0), (72, 60.0), (80, 60.0), (56, 60.0),
+                                      (48, 60.0)])
 def test_attention_spike_forces_rescale(d, factor):
     """One key dominates one query late in the sequence: the online-softmax re-base branch must fire.  Factor 60 drives
     exp2(s - m) of the maximum-free common tile body (head dims <= 64) to +inf before the re-base: the tile is recomputed.
@@ -371,7 +376,8 @@ def test_attention_fwd_variants_agree():
     ops = _ops()
     from flash_diffusion_amd import _lib
     L = _lib.lib()
-    for (B, H, Sq, Skv, d) in [(2, 4, 320, 1000, 40), (1, 2, 4096, 4096, 40), (1, 3, 200, 77, 64), (1, 2, 1024, 1024, 64), (1, 2, 130, 640, 32)]:
+    for (B, H, Sq, Skv, d) in [(2, 4, 320, 1000, 40), (1, 2, 4096, 4096, 40), (1, 3, 200, 77, 64), (1, 2, 1024, 1024, 64), (1, 2, 130, 640, 32),
+                               (1, 4, 1024, 1024, 72), (2, 2, 320, 120, 72), (1, 4, 1024, 1024, 80), (1, 2, 200, 333, 80)]:
         q, k, v = (b16(rnd(B, n, H * d, seed=s)).cuda() for n, s in ((Sq, 1), (Skv, 2), (Skv, 3)))
         o_new, lse_new = ops.attn_fwd(q, k, v, H, d ** -0.5, need_lse=True)
         L.fdmi_tune_set(26, 1)
