@@ -1271,7 +1271,7 @@ int set_smem(KernelT k, int bytes) {
 // d = 64 (+3..11 %).  A/B switch 26 = 1: 16x16x32 for every head dim; switch 11 != 0 (register staging experiments) likewise.
 static int launch_attn_fwd32(const AttnArgs& a, hipStream_t st) {
   if (fdmi_tune_get(26) != 0 || fdmi_tune_get(11) != 0) return 0;
-  if (!(a.d < 64 || (a.d > 64 && a.d <= 80))) return 0;
+  if (!(a.d < 64 || (a.d > 64 && a.d <= 80))) return 0;   // (d = 64 on this kernel, KS = 4 with the C-operand block: 3..7 % slower)
   // (KS, DB, ONES, MT): d <= 40 -> (3, 2, *, true); d = 48 -> (3, 2, false, false) (no spare k slot, no spare V^T row); d = 56 -> (4, 2, *,
   // true); d = 72 -> (5, 3, *, true); d = 80 -> (5, 3, false, false)
 #define ATTN32_ALL(F)                                                                                                             \
