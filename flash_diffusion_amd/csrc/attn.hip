@@ -522,7 +522,7 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 //   P^T = exp2(sc K Q^T - lse),  dP^T = V dO^T,  dS^T = P^T (dP^T - delta) scale,  dQ^T += K^T dS^T
 // =============================================================================================
 template <int DK, int DV, int QF>
-__global__ __launch_bounds__(256, (DK <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, ((DK <= 64 || (DK <= 96 && QF == 1)) ? 2 : 1)) void attn_bwd_dq_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sK = smem;
   char* sVr = sK + RowTile<DK>::BYTES;
@@ -650,7 +650,7 @@ __global__ __launch_bounds__(256, (DK <= 64 ? 2 : 1)) void attn_bwd_dq_kernel(co
 //   dP = dO V^T,  dS = P (dP - delta[q]) scale,  dV^T += dO^T P,  dK^T += Q^T dS
 // =============================================================================================
 template <int DK, int DV, int KF>
-__global__ __launch_bounds__(256, (DK <= 64 ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a) {
+__global__ __launch_bounds__(256, ((DK <= 64 || (DK <= 96 && KF == 1)) ? 2 : 1)) void attn_bwd_dkv_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sQ = smem;
   char* sdO = sQ + RowTile<DK>::BYTES;
@@ -896,6 +896,10 @@ __device__ __forceinline__ uint32_t pkmax(uint32_t x, uint32_t y) {
 __host__ __device__ __forceinline__ int attn32_keyperm(int r) { return (r & ~12) | ((r & 4) << 1) | ((r & 8) >> 1); }
 // LDS-DMA piece with a uniform 64-bit base (SGPR pair) + a 32-bit lane offset: the pointers advance on the scalar unit
 __device__ __forceinline__ void attn_glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+  // (the base is wave-uniform by construction; say so explicitly -- the divergence analysis does not always see it through a tile loop)
+  const uint64_t pv = (uint64_t)(uintptr_t)sbase;
+  const uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pv), phi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pv >> 32));
+  sbase = (const void*)(uintptr_t)(((uint64_t)phi << 32) | (uint64_t)plo);   // (readfirstlane returns int: widen as unsigned)
   unsigned keep;
   asm volatile(
       "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -1260,6 +1264,210 @@ __global__ __launch_bounds__(256, (MT && ONES && KS < 5) ? 3 : 2) void attn_fwd3
   }
 }
 
+// =============================================================================================
+// backward dQ on 32x32x16 MFMAs (round 3; head dims <= 80): the forward's structure without the online softmax -- the log-sum-exp is
+// known, so P^T = exp2(K Q'^T - lse) directly (C operand = -lse).  Per 64-key tile: S^T and dP^T = V dO^T (V staged row-major with the
+// same permuted key rows as K), dS^T = P^T (dP^T - delta), dQ^T += K^T dS^T with K^T fragments as single b128 reads (the forward's
+// V^T P product with K^T in V^T's place).  32 queries per wave, 128 per block, two LDS stages filled by LDS-DMA.
+// Stage layout: [K_A 8K][V_A 8K][K^T DB x 4K][K_B 2K][V_B 2K] (the _B sub-tiles -- columns 64.. of K / V, 32-byte rows -- only for KS = 5)
+template <int KS, int DB>
+struct AttnDq32Lds {
+  static constexpr int VOFF = 8192, TOFF = 16384, KBOFF = TOFF + DB * 4096, VBOFF = KBOFF + 2048, STAGE = KBOFF + (KS > 4 ? 4096 : 0);
+};
+template <int KS, int DB>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = AttnDq32Lds<KS, DB>;
+  constexpr int STAGEB = L::STAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, n = lane & 31;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh - b * a.H;
+  const int hoff = hd * a.d;
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  const int SP = attn_spad(a.Skv), DVP = attn_dvpad(a.d);
+  const float sc = a.scale * 1.4426950408889634f;
+
+  // the whole LDS image starts as zeros: padded columns / rows are never fetched, and rows of a ragged last tile keep finite values
+  for (int idx = tid; idx < 2 * STAGEB / 16; idx += 256) *(uint4*)(smem + idx * 16) = make_uint4(0, 0, 0, 0);
+
+  union QF { bf16x8 v; uint4 u4; uint32_t u[4]; } qf[KS], dof[KS];
+  const int qrow = q0 + n;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    qf[ks].u4 = make_uint4(0, 0, 0, 0);
+    dof[ks].u4 = make_uint4(0, 0, 0, 0);
+    const int c = 16 * ks + 8 * h;
+    if (qrow < a.Sq && c < a.d) {
+      qf[ks].u4 = *(const uint4*)(a.Q + ((int64_t)b * a.Sq + qrow) * a.ldq + hoff + c);
+      dof[ks].u4 = *(const uint4*)(a.dO + ((int64_t)b * a.Sq + qrow) * a.lddo + hoff + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)   // S comes out in exp2 units
+      qf[ks].u[e] = pack2bf(__uint_as_float(qf[ks].u[e] << 16) * sc, __uint_as_float(qf[ks].u[e] & 0xffff0000u) * sc);
+  }
+  const bool qok = qrow < a.Sq;
+  const float nlse = qok ? -a.lse[((int64_t)b * a.H + hd) * a.Sq + qrow] : -1.0e30f;
+  const float dl = qok ? a.delta[((int64_t)b * a.H + hd) * a.Sq + qrow] : 0.f;
+  f32x16 acc[DB], cinit;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db) acc[db][r] = 0.f;
+    cinit[r] = nlse;
+  }
+
+  int kofs[KS], tofs[4];
+  {
+    const int sw = (n >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) kofs[ks] = ks < 4 ? n * 128 + (((2 * ks + h) ^ sw) * 16) : L::KBOFF + n * 32 + h * 16;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) tofs[st] = L::TOFF + n * 128 + (((2 * st + h) ^ sw) * 16);
+  }
+
+  const int nt = (a.Skv + KVB - 1) / KVB;
+  const bool ragged = (a.Skv % KVB) != 0;
+  // ---- LDS-DMA staging (scalar tile bases, fixed lane offsets): K_A / V_A rows 8 (wave + 4 i) .. (permuted keys), K^T rows likewise,
+  // K_B by waves 0 / 1 and V_B by waves 2 / 3 (64 keys x 32 B = two pieces each) ----
+  const int drow = 8 * wave + (lane >> 3), dpc = lane & 7, dc = dpc ^ ((drow >> 1) & 7);
+  const bool kok = dc * 8 < a.d;
+  unsigned koff[2], voff[2], toff[DB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    koff[i] = (unsigned)((attn32_keyperm(drow + 32 * i) * a.ldk + dc * 8) * 2);
+    voff[i] = (unsigned)((attn32_keyperm(drow + 32 * i) * a.ldv + dc * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < DB; ++i) toff[i] = (unsigned)(((drow + 32 * i) * SP + dc * 8) * 2);
+  const int brow = 32 * (wave & 1) + (lane >> 1), bc = lane & 1;
+  const bool bok = KS > 4 && 64 + 8 * bc < a.d;
+  const unsigned boff = (unsigned)((attn32_keyperm(brow) * (wave < 2 ? a.ldk : a.ldv) + 64 + 8 * bc) * 2);
+  const char* kbase = (const char*)(a.K + ((int64_t)b * a.Skv) * a.ldk + hoff);
+  const char* vbase = (const char*)(a.V + ((int64_t)b * a.Skv) * a.ldv + hoff);
+  const char* tbase = (const char*)(a.KT + (((int64_t)b * a.H + hd) * DVP) * SP);
+  const int64_t kstep = (int64_t)KVB * a.ldk * 2, vstep = (int64_t)KVB * a.ldv * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)((ATTN_LDS_AS char*)smem);
+  auto dma_issue = [&](int t) __attribute__((always_inline)) {
+    const unsigned base = __builtin_amdgcn_readfirstlane(lds0 + (t & 1) * STAGEB + wave * 1024);
+    const bool last_ragged = ragged && t == nt - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool keyok = !last_ragged || t * KVB + attn32_keyperm(drow + 32 * i) < a.Skv;
+      if (kok && keyok) {
+        attn_glds16_s(kbase, koff[i], base + i * 4096);
+        attn_glds16_s(vbase, voff[i], base + L::VOFF + i * 4096);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+      if (8 * (wave + 4 * i) < DVP) attn_glds16_s(tbase, toff[i], base + L::TOFF + i * 4096);
+    if (KS > 4) {
+      const bool keyok = !last_ragged || t * KVB + attn32_keyperm(brow) < a.Skv;
+      if (bok && keyok) {   // (base carries wave * 1024: waves 0 / 1 -> K_B rows 0.. / 32.., waves 2 / 3 -> V_B = K_B + 2048)
+        if (wave < 2) attn_glds16_s(kbase, boff, base + L::KBOFF);
+        else attn_glds16_s(vbase, boff, base + L::KBOFF);
+      }
+    }
+    kbase += kstep;
+    vbase += vstep;
+    tbase += KVB * 2;
+  };
+  __syncthreads();   // the zero image is complete before the first piece lands
+  dma_issue(0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  // one 32-key block of K Q'^T - lse (V = false: C = cinit) or of V dO^T (V = true: C = 0); the V sub-tiles sit at fixed distances
+  // from the K ones (V_A = K_A + 8192, V_B = K_B + 2048)
+  auto block = [&](const char* base, const QF (&bf)[KS], int kb, auto v_tag) __attribute__((always_inline)) -> f32x16 {
+    constexpr bool V = decltype(v_tag)::value;
+    bf16x8 fr[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      fr[ks] = *(const bf16x8*)(base + (ks < 4 ? (V ? L::VOFF : 0) + kb * 4096 : (V ? 2048 : 0) + kb * 1024) + kofs[ks]);
+    f32x16 r;
+    if (!V) {
+      r = MFMA32(fr[0], bf[0].v, cinit);
+    } else {
+      f32x16 z;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z[i] = 0.f;
+      r = MFMA32(fr[0], bf[0].v, z);
+    }
+#pragma unroll
+    for (int ks = 1; ks < KS; ++ks) r = MFMA32(fr[ks], bf[ks].v, r);
+    return r;
+  };
+  auto tile = [&](auto slot_tag, auto tail_tag, int t) __attribute__((always_inline)) {
+    constexpr int SLOT = decltype(slot_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const char* base = smem + SLOT * STAGEB;
+    f32x16 s[2], dp[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      s[kb] = block(base, qf, kb, std::false_type{});
+      dp[kb] = block(base, dof, kb, std::true_type{});
+    }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * KVB + attn32_keyperm(32 * kb + 8 * (r >> 2) + 4 * h + (r & 3)) >= a.Skv) s[kb][r] = NEG_BIG;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[kb][r] = fast_exp2(s[kb][r]) * (dp[kb][r] - dl);   // the softmax scale is applied once, in the epilogue
+      union { uint4 u; bf16x8 v; } p0, p1;
+      p0.u = make_uint4(pack2bf(s[kb][0], s[kb][1]), pack2bf(s[kb][2], s[kb][3]), pack2bf(s[kb][4], s[kb][5]), pack2bf(s[kb][6], s[kb][7]));
+      p1.u = make_uint4(pack2bf(s[kb][8], s[kb][9]), pack2bf(s[kb][10], s[kb][11]), pack2bf(s[kb][12], s[kb][13]), pack2bf(s[kb][14], s[kb][15]));
+#pragma unroll
+      for (int db = 0; db < DB; ++db) acc[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + tofs[2 * kb]), p0.v, acc[db]);
+#pragma unroll
+      for (int db = 0; db < DB; ++db) acc[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + tofs[2 * kb + 1]), p1.v, acc[db]);
+    }
+  };
+  auto stage = [&](int t) __attribute__((always_inline)) {
+    __syncthreads();
+    if (t + 1 < nt) dma_issue(t + 1);
+  };
+  auto landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  const int nfull = ragged ? nt - 1 : nt;
+  int t = 0;
+  for (; t + 1 < nfull; t += 2) {
+    stage(t);
+    tile(S0{}, std::false_type{}, t);
+    landed();
+    stage(t + 1);
+    tile(S1{}, std::false_type{}, t + 1);
+    landed();
+  }
+  if (t < nfull) {
+    stage(t);
+    tile(S0{}, std::false_type{}, t);
+    landed();
+  }
+  if (ragged) {
+    stage(nt - 1);
+    if ((nt - 1) & 1) tile(S1{}, std::true_type{}, nt - 1);
+    else tile(S0{}, std::true_type{}, nt - 1);
+  }
+  // ---- epilogue: dQ[q][dd] = scale * dQ^T[dd][q] ----
+  if (qrow < a.Sq) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int dd = 32 * db + 8 * i + 4 * h;
+        if (dd < a.d) {
+          uint2 pk;
+          pk.x = pack2bf(acc[db][4 * i] * a.scale, acc[db][4 * i + 1] * a.scale);
+          pk.y = pack2bf(acc[db][4 * i + 2] * a.scale, acc[db][4 * i + 3] * a.scale);
+          *(uint2*)(a.out + ((int64_t)b * a.Sq + qrow) * a.ldout + hoff + dd) = pk;
+        }
+      }
+  }
+}
+
 template <typename KernelT>
 int set_smem(KernelT k, int bytes) {
   FDMI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1339,6 +1547,30 @@ int fwd_t(const AttnArgs& a, hipStream_t st) {
   FDMI_HIP(hipGetLastError());
   return 0;
 }
+// 32x32x16 backward-dQ for head dims <= 80; returns 1 when it took the problem.  A/B switch 35 = 1: the 16x16x32 kernels.
+static int launch_attn_bwd_dq32(const AttnArgs& a, hipStream_t st) {
+  if (fdmi_tune_get(35) != 0 || a.d > 80) return 0;
+#define DQ32_ALL(F) F(3, 2) F(4, 2) F(5, 3)
+  static bool once = false;
+  if (!once) {
+#define DQ32_SET(KS_, DB_) if (set_smem(attn_bwd_dq32_kernel<KS_, DB_>, (2 * AttnDq32Lds<KS_, DB_>::STAGE))) return -2;
+    DQ32_ALL(DQ32_SET)
+#undef DQ32_SET
+    once = true;
+  }
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DQ, 6.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  dim3 grid(cdiv(a.Sq, 128), a.B * a.H);
+  const int ks = a.d <= 48 ? 3 : (a.d <= 64 ? 4 : 5), db = a.d <= 64 ? 2 : 3;
+#define DQ32_GO(KS_, DB_) \
+  if (ks == KS_ && db == DB_) FDMI_KLAUNCH(prof, (attn_bwd_dq32_kernel<KS_, DB_>), grid, dim3(256), (2 * AttnDq32Lds<KS_, DB_>::STAGE), st, a);
+  DQ32_ALL(DQ32_GO)
+#undef DQ32_GO
+#undef DQ32_ALL
+  if (prof) fdmi_prof_end(st);
+  FDMI_HIP(hipGetLastError());
+  return 1;
+}
 template <int DK, int DV, int NF>
 int dq_t(const AttnArgs& a, hipStream_t st) {
   constexpr int smem = 2 * RowTile<DK>::BYTES + TrTile<DV>::BYTES;
@@ -1401,10 +1633,13 @@ int launch_attn_fwd(const AttnArgs& a, hipStream_t st) {
 }
 int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
+  if (const int rc = launch_attn_bwd_dq32(a, st)) return rc < 0 ? rc : 0;
+  if (fdmi_tune_get(34) == 0) { ATTN_DISPATCH4(dq_t, 2, 1, 1) }   // 96-wide heads: one fragment, two blocks per CU (switch 34 = 1: two, one)
   ATTN_DISPATCH(dq_t, 2, 1)
 }
 int launch_attn_bwd_dkv(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
+  if (fdmi_tune_get(34) == 0) { ATTN_DISPATCH4(dkv_t, 2, 1, 1) }
   ATTN_DISPATCH(dkv_t, 2, 1)
 }
 

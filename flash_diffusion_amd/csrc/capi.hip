@@ -19,8 +19,8 @@ hipEvent_t prof_event() {
   return e;
 }
 }  // namespace
-static int g_tune[32] = {0};
-int fdmi_tune_get(int key) { return (key >= 0 && key < 32) ? g_tune[key] : 0; }
+static int g_tune[64] = {0};
+int fdmi_tune_get(int key) { return (key >= 0 && key < 64) ? g_tune[key] : 0; }
 bool fdmi_prof_on() { return g_prof; }
 // tune 20 = 0 (default): the launch that follows takes the record's two events as its own start / stop events
 // (FDMI_KLAUNCH -> hipExtLaunchKernelGGL); 1: the events are recorded on the stream around the launch
@@ -45,7 +45,7 @@ void fdmi_prof_end(hipStream_t st) {
 extern "C" {
 
 int fdmi_tune_set(int key, int value) {
-  FDMI_CHECK(key >= 0 && key < 32, "tune key out of range");
+  FDMI_CHECK(key >= 0 && key < 64, "tune key out of range");
   g_tune[key] = value;
   return 0;
 }
