@@ -1468,6 +1468,244 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_dq32_kernel(const AttnArgs a)
   }
 }
 
+// =============================================================================================
+// backward dK / dV on 32x32x16 MFMAs (round 3; head dims <= 80).  Per wave 32 keys (their K / V fragments live in registers as the B
+// operands), per block 128; loop over 64-query tiles staged by LDS-DMA: Q and dO row-major with permuted rows (the A operands of
+// S = Q K'^T and dP = dO V^T), Q^T and dO^T (A operands of dK^T += Q^T dS and dV^T += dO^T P, single b128 fragment reads), and the
+// tile's lse / delta rows (64 floats each, permuted like the rows, fetched by the dword LDS-DMA).  The row vectors never touch the VALU:
+// K enters negated (x = lse - S with C = lse straight from LDS, P = exp2(-x) through the source modifier), V enters negated
+// (y = delta - dP with C = delta, dS = P * (-y)).  Stage layout: [Q_A 8K][dO_A 8K][Q^T DB x 4K][dO^T DB x 4K][Q_B 2K][dO_B 2K][lse][delta]
+template <int KS, int DB>
+struct AttnDkv32Lds {
+  static constexpr int DOOFF = 8192, QTOFF = 16384, DOTOFF = QTOFF + DB * 4096, QBOFF = DOTOFF + DB * 4096, LOFF = QBOFF + (KS > 4 ? 4096 : 0),
+                       STAGE = LOFF + 1024;
+};
+__device__ __forceinline__ void attn_glds4_s(const void* sbase, unsigned voff, unsigned lds_addr) {   // 4 bytes per lane
+  const uint64_t pv = (uint64_t)(uintptr_t)sbase;
+  const uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pv), phi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pv >> 32));
+  sbase = (const void*)(uintptr_t)(((uint64_t)phi << 32) | (uint64_t)plo);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr));
+}
+// WDV / WDK: which of the two gradients this launch produces.  The 80-wide heads (KS = 5, DB = 3) need ~330 registers for both at once;
+// they run as two launches (dV: S, P, dV^T; dK: S, P, dP, dS, dK^T: 27 instead of 22 MFMAs per 32 x 32 block, at two waves per SIMD
+// without scratch) -- the fused form spilled 94 registers.
+template <int KS, int DB, int NSTAGE, bool WDV, bool WDK>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkv32_kernel(const AttnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  using L = AttnDkv32Lds<KS, DB>;
+  constexpr int STAGEB = L::STAGE;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, h = lane >> 5, n = lane & 31;
+  const int bh = blockIdx.y, b = bh / a.H, hd = bh - b * a.H;
+  const int hoff = hd * a.d;
+  const int k0 = blockIdx.x * 128 + wave * 32;
+  const int SPq = attn_spad(a.Sq), DVP = attn_dvpad(a.d);
+  const float sc = a.scale * 1.4426950408889634f;
+
+  for (int idx = tid; idx < NSTAGE * STAGEB / 16; idx += 256) *(uint4*)(smem + idx * 16) = make_uint4(0, 0, 0, 0);
+
+  // this wave's keys: -sc K and -V fragments (B operands)
+  union QF { bf16x8 v; uint4 u4; uint32_t u[4]; } kf[KS], vf[KS];
+  const int krow = k0 + n;
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    kf[ks].u4 = make_uint4(0, 0, 0, 0);
+    vf[ks].u4 = make_uint4(0, 0, 0, 0);
+    const int c = 16 * ks + 8 * h;
+    if (krow < a.Skv && c < a.d) {
+      kf[ks].u4 = *(const uint4*)(a.K + ((int64_t)b * a.Skv + krow) * a.ldk + hoff + c);
+      vf[ks].u4 = *(const uint4*)(a.V + ((int64_t)b * a.Skv + krow) * a.ldv + hoff + c);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      kf[ks].u[e] = pack2bf(__uint_as_float(kf[ks].u[e] << 16) * -sc, __uint_as_float(kf[ks].u[e] & 0xffff0000u) * -sc);
+      if (WDK) vf[ks].u[e] ^= 0x80008000u;   // -V (sign bits)
+    }
+  }
+  f32x16 adv[WDV ? DB : 1], adk[WDK ? DB : 1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r)
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      if (WDV) adv[db][r] = 0.f;
+      if (WDK) adk[db][r] = 0.f;
+    }
+
+  int qofs[KS], tofs[4];
+  {
+    const int sw = (n >> 1) & 7;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qofs[ks] = ks < 4 ? n * 128 + (((2 * ks + h) ^ sw) * 16) : L::QBOFF + n * 32 + h * 16;
+#pragma unroll
+    for (int st = 0; st < 4; ++st) tofs[st] = L::QTOFF + n * 128 + (((2 * st + h) ^ sw) * 16);
+  }
+
+  const int nt = (a.Sq + KVB - 1) / KVB;
+  const bool ragged = (a.Sq % KVB) != 0;
+  // ---- LDS-DMA staging: Q_A / dO_A rows 8 (wave + 4 i) .. (permuted queries), Q^T / dO^T rows likewise, Q_B by waves 0 / 1 and dO_B by
+  // waves 2 / 3, lse by wave 0 and delta by wave 1 (one dword piece each, lane l <- query keyperm(l)) ----
+  const int drow = 8 * wave + (lane >> 3), dpc = lane & 7, dc = dpc ^ ((drow >> 1) & 7);
+  const bool cok = dc * 8 < a.d;
+  unsigned qoff[2], dooff[2], toff[DB];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    qoff[i] = (unsigned)((attn32_keyperm(drow + 32 * i) * a.ldq + dc * 8) * 2);
+    dooff[i] = (unsigned)((attn32_keyperm(drow + 32 * i) * a.lddo + dc * 8) * 2);
+  }
+#pragma unroll
+  for (int i = 0; i < DB; ++i) toff[i] = (unsigned)(((drow + 32 * i) * SPq + dc * 8) * 2);
+  const int brow = 32 * (wave & 1) + (lane >> 1), bc = lane & 1;
+  const bool bok = KS > 4 && 64 + 8 * bc < a.d;
+  const unsigned boff = (unsigned)((attn32_keyperm(brow) * (wave < 2 ? a.ldq : a.lddo) + 64 + 8 * bc) * 2);
+  const unsigned loff = (unsigned)(attn32_keyperm(lane) * 4);
+  const char* qbase = (const char*)(a.Q + ((int64_t)b * a.Sq) * a.ldq + hoff);
+  const char* dobase = (const char*)(a.dO + ((int64_t)b * a.Sq) * a.lddo + hoff);
+  const char* qtbase = (const char*)(a.QT + (((int64_t)b * a.H + hd) * DVP) * SPq);
+  const char* dotbase = (const char*)(a.dOT + (((int64_t)b * a.H + hd) * DVP) * SPq);
+  const char* lbase = (const char*)(a.lse + ((int64_t)b * a.H + hd) * a.Sq);
+  const char* dbase = (const char*)(a.delta + ((int64_t)b * a.H + hd) * a.Sq);
+  const int64_t qstep = (int64_t)KVB * a.ldq * 2, dostep = (int64_t)KVB * a.lddo * 2;
+  const unsigned lds0 = (unsigned)(uintptr_t)((ATTN_LDS_AS char*)smem);
+  auto dma_issue = [&](int t) __attribute__((always_inline)) {
+    const unsigned sbase0 = __builtin_amdgcn_readfirstlane(lds0 + (NSTAGE > 1 ? (t & 1) * STAGEB : 0));
+    const unsigned base = __builtin_amdgcn_readfirstlane(sbase0 + wave * 1024);
+    const bool last_ragged = ragged && t == nt - 1;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool rowok = !last_ragged || t * KVB + attn32_keyperm(drow + 32 * i) < a.Sq;
+      if (cok && rowok) {
+        attn_glds16_s(qbase, qoff[i], base + i * 4096);
+        if (WDK) attn_glds16_s(dobase, dooff[i], base + L::DOOFF + i * 4096);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < DB; ++i)
+      if (8 * (wave + 4 * i) < DVP) {
+        if (WDK) attn_glds16_s(qtbase, toff[i], base + L::QTOFF + i * 4096);
+        if (WDV) attn_glds16_s(dotbase, toff[i], base + L::DOTOFF + i * 4096);
+      }
+    if (KS > 4) {
+      const bool rowok = !last_ragged || t * KVB + attn32_keyperm(brow) < a.Sq;
+      if (bok && rowok) {   // (base carries wave * 1024: waves 0 / 1 -> Q_B, waves 2 / 3 -> dO_B = Q_B + 2048)
+        if (wave < 2) attn_glds16_s(qbase, boff, base + L::QBOFF);
+        else if (WDK) attn_glds16_s(dobase, boff, base + L::QBOFF);
+      }
+    }
+    if (wave < 2) {
+      const bool rowok = !last_ragged || t * KVB + attn32_keyperm(lane) < a.Sq;
+      if (rowok) {
+        if (wave == 0) attn_glds4_s(lbase, loff, sbase0 + L::LOFF);
+        else if (WDK) attn_glds4_s(dbase, loff, sbase0 + L::LOFF + 256);
+      }
+    }
+    qbase += qstep;
+    dobase += dostep;
+    qtbase += KVB * 2;
+    dotbase += KVB * 2;
+    lbase += KVB * 4;
+    dbase += KVB * 4;
+  };
+
+  auto tile = [&](const char* base, auto tail_tag, int t) __attribute__((always_inline)) {
+    constexpr bool TAIL = decltype(tail_tag)::value;
+    const float* sL = (const float*)(base + L::LOFF);
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      // x = lse - S, y = delta - dP: the row vectors are the C operands (rows 8 i + 4 h + j of the block <-> registers 4 i + j)
+      f32x16 x, y;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float4 lv = *(const float4*)(sL + 32 * qb + 8 * i + 4 * h);
+        x[4 * i] = lv.x; x[4 * i + 1] = lv.y; x[4 * i + 2] = lv.z; x[4 * i + 3] = lv.w;
+        if (WDK) {
+          const float4 dv = *(const float4*)(sL + 64 + 32 * qb + 8 * i + 4 * h);
+          y[4 * i] = dv.x; y[4 * i + 1] = dv.y; y[4 * i + 2] = dv.z; y[4 * i + 3] = dv.w;
+        }
+      }
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int off = (ks < 4 ? qb * 4096 : qb * 1024) + qofs[ks];
+        x = MFMA32(*(const bf16x8*)(base + off), kf[ks].v, x);
+        if (WDK) y = MFMA32(*(const bf16x8*)(base + off + (ks < 4 ? L::DOOFF : 2048)), vf[ks].v, y);
+      }
+      if (TAIL) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          if (t * KVB + attn32_keyperm(32 * qb + 8 * (r >> 2) + 4 * h + (r & 3)) >= a.Sq) x[r] = 1.0e30f;
+      }
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        x[r] = fast_exp2(-x[r]);                 // P
+        if (WDK) y[r] = x[r] * -y[r];            // dS (the softmax scale is applied once, to dK, in the epilogue)
+      }
+      union { uint4 u; bf16x8 v; } p0, p1, s0, s1;
+      p0.u = make_uint4(pack2bf(x[0], x[1]), pack2bf(x[2], x[3]), pack2bf(x[4], x[5]), pack2bf(x[6], x[7]));
+      p1.u = make_uint4(pack2bf(x[8], x[9]), pack2bf(x[10], x[11]), pack2bf(x[12], x[13]), pack2bf(x[14], x[15]));
+      if (WDK) {
+        s0.u = make_uint4(pack2bf(y[0], y[1]), pack2bf(y[2], y[3]), pack2bf(y[4], y[5]), pack2bf(y[6], y[7]));
+        s1.u = make_uint4(pack2bf(y[8], y[9]), pack2bf(y[10], y[11]), pack2bf(y[12], y[13]), pack2bf(y[14], y[15]));
+      }
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        if (WDV) adv[db] = MFMA32(*(const bf16x8*)(base + (L::DOTOFF - L::QTOFF) + db * 4096 + tofs[2 * qb]), p0.v, adv[db]);
+        if (WDK) adk[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + tofs[2 * qb]), s0.v, adk[db]);
+      }
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        if (WDV) adv[db] = MFMA32(*(const bf16x8*)(base + (L::DOTOFF - L::QTOFF) + db * 4096 + tofs[2 * qb + 1]), p1.v, adv[db]);
+        if (WDK) adk[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + tofs[2 * qb + 1]), s1.v, adk[db]);
+      }
+    }
+  };
+  auto landed = [&]() __attribute__((always_inline)) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); };
+  __syncthreads();   // the zero image is complete before the first piece lands
+  if (NSTAGE > 1) {
+    dma_issue(0);
+    landed();
+    for (int t = 0; t < nt; ++t) {
+      __syncthreads();   // stage t & 1 complete; every wave is done with the other stage
+      if (t + 1 < nt) dma_issue(t + 1);
+      if (ragged && t == nt - 1) tile(smem + (t & 1) * STAGEB, std::true_type{}, t);
+      else tile(smem + (t & 1) * STAGEB, std::false_type{}, t);
+      landed();
+    }
+  } else {
+    for (int t = 0; t < nt; ++t) {
+      if (t) __syncthreads();   // every wave is done with the previous tile
+      dma_issue(t);
+      landed();
+      __syncthreads();
+      if (ragged && t == nt - 1) tile(smem, std::true_type{}, t);
+      else tile(smem, std::false_type{}, t);
+    }
+  }
+  // ---- epilogue: dV[key][dd] = dV^T[dd][key], dK[key][dd] = scale * dK^T[dd][key] ----
+  if (krow < a.Skv) {
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int dd = 32 * db + 8 * i + 4 * h;
+        if (dd < a.d) {
+          uint2 pk;
+          if (WDK) {
+            pk.x = pack2bf(adk[db][4 * i] * a.scale, adk[db][4 * i + 1] * a.scale);
+            pk.y = pack2bf(adk[db][4 * i + 2] * a.scale, adk[db][4 * i + 3] * a.scale);
+            *(uint2*)(a.dK + ((int64_t)b * a.Skv + krow) * a.lddk + hoff + dd) = pk;
+          }
+          if (WDV) {
+            pk.x = pack2bf(adv[db][4 * i], adv[db][4 * i + 1]);
+            pk.y = pack2bf(adv[db][4 * i + 2], adv[db][4 * i + 3]);
+            *(uint2*)(a.dV + ((int64_t)b * a.Skv + krow) * a.lddv + hoff + dd) = pk;
+          }
+        }
+      }
+  }
+}
+
 template <typename KernelT>
 int set_smem(KernelT k, int bytes) {
   FDMI_HIP(hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
@@ -1571,6 +1809,35 @@ static int launch_attn_bwd_dq32(const AttnArgs& a, hipStream_t st) {
   FDMI_HIP(hipGetLastError());
   return 1;
 }
+// 32x32x16 backward-dK/dV for head dims <= 80; returns 1 when it took the problem.
+static int launch_attn_bwd_dkv32(const AttnArgs& a, hipStream_t st) {
+  // A/B switch 36: 1 = the 16x16x32 kernel always, 2 = this kernel for every problem with d <= 80 (the parity tests flip both)
+  if (fdmi_tune_get(36) == 1 || a.d > 80) return 0;
+  if (fdmi_tune_get(36) != 2 && (int64_t)cdiv(a.Skv, 128) * a.B * a.H < 512)
+    return 0;   // few keys (cross-attention): the 64-key blocks of the 16x16x32 kernel fill the chip better (Skv = 120, d = 72: 401 vs 459 us)
+#define DKV32_ALL(F) F(3, 2, 2, true, true) F(4, 2, 2, true, true) F(5, 3, 1, true, false) F(5, 3, 1, false, true)
+  static bool once = false;
+  if (!once) {
+#define DKV32_SET(KS_, DB_, NS_, DV_, DK_) \
+  if (set_smem(attn_bwd_dkv32_kernel<KS_, DB_, NS_, DV_, DK_>, (NS_ * AttnDkv32Lds<KS_, DB_>::STAGE))) return -2;
+    DKV32_ALL(DKV32_SET)
+#undef DKV32_SET
+    once = true;
+  }
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DKV, 8.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  dim3 grid(cdiv(a.Skv, 128), a.B * a.H);
+  const int ks = a.d <= 48 ? 3 : (a.d <= 64 ? 4 : 5), db = a.d <= 64 ? 2 : 3;
+#define DKV32_GO(KS_, DB_, NS_, DV_, DK_) \
+  if (ks == KS_ && db == DB_)             \
+    FDMI_KLAUNCH(prof, (attn_bwd_dkv32_kernel<KS_, DB_, NS_, DV_, DK_>), grid, dim3(256), (NS_ * AttnDkv32Lds<KS_, DB_>::STAGE), st, a);
+  DKV32_ALL(DKV32_GO)
+#undef DKV32_GO
+#undef DKV32_ALL
+  if (prof) fdmi_prof_end(st);
+  FDMI_HIP(hipGetLastError());
+  return 1;
+}
 template <int DK, int DV, int NF>
 int dq_t(const AttnArgs& a, hipStream_t st) {
   constexpr int smem = 2 * RowTile<DK>::BYTES + TrTile<DV>::BYTES;
@@ -1639,6 +1906,7 @@ int launch_attn_bwd_dq(const AttnArgs& a, hipStream_t st) {
 }
 int launch_attn_bwd_dkv(const AttnArgs& a, hipStream_t st) {
   if (check_attn(a)) return -1;
+  if (const int rc = launch_attn_bwd_dkv32(a, st)) return rc < 0 ? rc : 0;
   if (fdmi_tune_get(34) == 0) { ATTN_DISPATCH4(dkv_t, 2, 1, 1) }
   ATTN_DISPATCH(dkv_t, 2, 1)
 }

@@ -337,6 +337,20 @@ def test_attention_fwd_bwd(cfg):
     close(f"attn_dq{cfg}", dq, qr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
     close(f"attn_dk{cfg}", dk, kr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
     close(f"attn_dv{cfg}", dv, vr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
+    if d <= 80:   # both backward families on every such shape: 32x32x16 (switch 36 = 2 lifts its few-keys rule) and 16x16x32 (35 = 36 = 1)
+        from flash_diffusion_amd import _lib
+        L = _lib.lib()
+        for tag, knobs in (("32x32x16", ((35, 0), (36, 2))), ("16x16x32", ((35, 1), (36, 1)))):
+            try:
+                for kk, vv in knobs:
+                    L.fdmi_tune_set(kk, vv)
+                dq, dk, dv = ops.attn_bwd(q.cuda(), k.cuda(), v.cuda(), o, do.cuda(), lse, H, scale)
+            finally:
+                L.fdmi_tune_set(35, 0)
+                L.fdmi_tune_set(36, 0)
+            close(f"attn_dq {tag} {cfg}", dq, qr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
+            close(f"attn_dk {tag} {cfg}", dk, kr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
+            close(f"attn_dv {tag} {cfg}", dv, vr.grad, tol_el=2 ** -5, tol_fro=1.2e-2)
 
 
 @pytest.mark.parametrize("d,factor", [(40, 6.0), (40, 60.0), (64, 6.0), (64, 60.0), (80, 6.0), (72, 6.0), (72, 60.0), (80, 60.0), (56, 60.0),
