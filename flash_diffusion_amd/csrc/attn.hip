@@ -1714,9 +1714,11 @@ int set_smem(KernelT k, int bytes) {
 
 // 32x32x16 forward (round 3) for head dims < 64 and 64 < d <= 80; returns 1 when it took the problem, 0 when the 16x16x32 family should,
 // < 0 on error.  Measured (profiles/r3_attn_ab.txt): wins for d < 64 (d = 40: +13..16 %) and 64 < d <= 80; the 16x16x32 kernel keeps
-// d = 64 (+3..11 %).  A/B switch 26 = 1: 16x16x32 for every head dim; switch 11 != 0 (register staging experiments) likewise.
+// d = 64 (+3..11 %).  Switch 11 != 0 (register staging experiments): 16x16x32 as well.
 static int launch_attn_fwd32(const AttnArgs& a, hipStream_t st) {
-  if (fdmi_tune_get(26) != 0 || fdmi_tune_get(11) != 0) return 0;
+  // A/B switch 26: 1 = the 16x16x32 kernels always, 2 = this kernel for every problem in its head-dim range (the parity tests flip both)
+  if (fdmi_tune_get(26) == 1 || fdmi_tune_get(11) != 0) return 0;
+  if (fdmi_tune_get(26) != 2 && a.Skv <= 128) return 0;   // one or two key tiles (cross-attention): 41 vs 45 us at Skv = 77, 73 vs 83 at 120
   if (!(a.d < 64 || (a.d > 64 && a.d <= 80))) return 0;   // (d = 64 on this kernel, KS = 4 with the C-operand block: 3..7 % slower)
   // (KS, DB, ONES, MT): d <= 40 -> (3, 2, *, true); d = 48 -> (3, 2, false, false) (no spare k slot, no spare V^T row); d = 56 -> (4, 2, *,
   // true); d = 72 -> (5, 3, *, true); d = 80 -> (5, 3, false, false)
