@@ -141,11 +141,19 @@ def test_ctypes_argument_types_match_the_header_prototypes():
 
 
 def test_developer_knobs_cover_the_keys_in_use():
-    """fdmi_tune_set / fdmi_tune_value: keys 0..31 (knobs 9..16 are in use), unknown keys fail to set and read as 0"""
+    """fdmi_tune_set / fdmi_tune_value: keys 0..63; unknown keys fail to set and read as 0; every key the sources read is inside the
+    table (round 3: switches 32..34 were read by the kernels' launchers while the table had 32 entries -- they silently read 0)"""
+    import glob
+    import re
     from flash_diffusion_amd import _lib
     L = _lib.lib()
-    for k in (9, 10, 11, 12, 13, 14, 15, 16, 31):
+    src = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "flash_diffusion_amd", "csrc")
+    used = set()
+    for f in glob.glob(os.path.join(src, "*.hip")) + glob.glob(os.path.join(src, "*.h")):
+        used |= {int(m) for m in re.findall(r"fdmi_tune_get\((\d+)\)", open(f).read())}
+    assert used and max(used) < 64, sorted(used)
+    for k in sorted(used | {31, 63}):
         assert L.fdmi_tune_value(k) == 0
         assert L.fdmi_tune_set(k, 3) == 0 and L.fdmi_tune_value(k) == 3
         assert L.fdmi_tune_set(k, 0) == 0
-    assert L.fdmi_tune_set(32, 1) != 0 and L.fdmi_tune_value(32) == 0 and L.fdmi_tune_value(-1) == 0
+    assert L.fdmi_tune_set(64, 1) != 0 and L.fdmi_tune_value(64) == 0 and L.fdmi_tune_value(-1) == 0
