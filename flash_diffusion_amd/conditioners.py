@@ -8,7 +8,7 @@ tensor's rank (2 / 3 / 4); the wrapper concatenates same-key outputs (vector: di
 classifier-free-guidance dropout: a conditioner whose ``input_key`` is in ``ucg_keys`` is zeroed, otherwise it is zeroed
 with probability ``ucg_rate`` (one ``torch.rand(1)`` per conditioner with a positive rate, on the host, in list order --
 the reference's draw order) unless ``set_ucg_rate_zero``.  The sinusoidal embedding runs in the HIP kernel
-``fdmi_timestep_embed``.  The text encoders themselves (CLIP / T5) are outside the hot path."""
+``fdmi_timestep_embed``.  The text encoders themselves (CLIP / T5) are ``clip.py`` / ``t5.py`` (same C-ABI op layer)."""
 from __future__ import annotations
 
 import importlib

@@ -393,7 +393,7 @@ class FlashDiffusionSD3(nn.Module):
             finally:
                 cur.wait_stream(side)   # (also on an exception: nothing may reuse the teacher's buffers under the side stream)
             teacher_output.record_stream(cur)
-        if self.distill_loss_type == "lpips":     # FD3:391-411 (clamped crop bounds); the caller's VAE / LPIPS torch modules
+        if self.distill_loss_type == "lpips":     # FD3:391-411 (clamped crop bounds); VAE decoder / LPIPS: nets.py's HIP plans or the caller's modules
             so, to = student_output, teacher_output.detach()
             crop_h = max((so.shape[2] - 64) // 2, 0)
             crop_w = max((so.shape[3] - 64) // 2, 0)

@@ -99,8 +99,8 @@ def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77, vector_dim=0
 class SyntheticPromptEncoder:
     """Stands where ``StableDiffusion3Pipeline`` stands in FlashDiffusionSD3 (FD3:196-229): ``encode_prompt`` returns
     (prompt_embeds, negative_prompt_embeds, pooled, negative_pooled) -- synthetic embeddings of the SD3 shapes
-    ([B, 333, 4096] = 77 CLIP + 256 T5 tokens, pooled [B, 2048]); the unconditional ones are zeros.  The text
-    encoders themselves are outside the hot path."""
+    ([B, 333, 4096] = 77 CLIP + 256 T5 tokens, pooled [B, 2048]); the unconditional ones are zeros.  The bench
+    measures the step, not the encoders (``clip.py`` / ``t5.py`` run them on the same op layer when a caller wants text in)."""
 
     def __init__(self, B, L, ctx_dim, pooled_dim, device="cuda", seed=4321):
         g = torch.Generator(device="cpu").manual_seed(seed)
