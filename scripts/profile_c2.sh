@@ -3,7 +3,8 @@
 #   gpurun --timeout 1500 -- 'bash scripts/profile_c2.sh 2'          (argument: round number; optional 2nd: FDMI_TUNE value)
 # The summaries land in gpurun_out/prof/profiles/ (already converted); back in the authoring container:
 #   cp gpurun_out/prof/profiles/* profiles/ && cp gpurun_out/prof/bench.json profiles/r2_bench.json
-# Counter passes run with --kernel-trace only (gpurun refuses --pmc together with the hip/hsa/sys trace domains).
+# Counter passes run with --kernel-trace only (gpurun refuses --pmc together with the hip/hsa/sys trace domains); every rocprofv3
+# pass sits under its own `timeout` (round 3: a counter pass aborted and then hung in its signal handler for 20 minutes).
 set -u
 round=${1:-2}
 [ -n "${2:-}" ] && export FDMI_TUNE=$2
@@ -14,18 +15,18 @@ export TMPDIR=/tmp
 echo "== bench (defaults: the judged line)"
 python bench.py > "$out/bench.json" 2> "$out/bench.err"; tail -c 900 "$out/bench.json"
 echo "== rocprofv3 --kernel-trace --stats (4 steps: 1 warm-up + 2 timed + the profiled leg)"
-rocprofv3 --kernel-trace --stats -f csv -d "$out/stats" -o r${round} -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary \
+timeout -s KILL 420 rocprofv3 --kernel-trace --stats -f csv -d "$out/stats" -o r${round} -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/stats_bench.json" 2> "$out/stats.err"
 echo "== rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 3 steps each)"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$out/pmc_fetch" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
+timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$out/pmc_fetch" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err"
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d "$out/pmc_write" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
+timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d "$out/pmc_write" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/pmc_write_bench.json" 2> "$out/pmc_write.err"
 echo "== rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum (own pass: L2 hit rate per kernel)"
-rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -f csv -d "$out/pmc_tcc" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
+timeout -s KILL 240 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --kernel-trace -f csv -d "$out/pmc_tcc" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/pmc_tcc_bench.json" 2> "$out/pmc_tcc.err"
 echo "== rocprofv3 --pmc GRBM_GUI_ACTIVE (own pass: effective clock per kernel)"
-rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -f csv -d "$out/pmc_grbm" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
+timeout -s KILL 240 rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace -f csv -d "$out/pmc_grbm" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/pmc_grbm_bench.json" 2> "$out/pmc_grbm.err"
 python scripts/rocprof_to_profiles.py --round "$round" --steps 4 --stats-dir "$out/stats" --fetch-dir "$out/pmc_fetch" \
   --write-dir "$out/pmc_write" --tcc-dir "$out/pmc_tcc" --grbm-dir "$out/pmc_grbm" > "$out/summary.txt" 2>&1
