@@ -67,6 +67,10 @@ def bucket(name):
     m = re.search(r"gemm_kernel<(\d+), (\d+), (\d)", name)
     if m:
         return f"gemm_kernel<{m.group(1)},{m.group(2)},{'conv' if m.group(3) == '1' else 'row'}>"
+    for k, b in (("attn_fwd32_kernel", "attn_fwd_kernel"), ("attn_bwd_dq32_kernel", "attn_bwd_dq_kernel"),
+                 ("attn_bwd_dkv32_kernel", "attn_bwd_dkv_kernel")):      # the 32x32x16 family shares the bench's attention buckets
+        if k in name:
+            return b
     for k in ("attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "wgrad_tn_kernel"):
         if k in name:
             return k
