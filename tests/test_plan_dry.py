@@ -220,3 +220,57 @@ def test_plan_report_lists_the_forward_work_list():
     assert abs(float(head.group(2)) * 1e12 + attention - total) < 5e-3 * total
     share = float(re.search(r"gemm4\s+BN=320\s+(\d+\.\d)%", out).group(1))
     assert 60 < share < 80
+
+
+# ---- the frozen networks beside the denoiser (round 3): the same executor, walked without a GPU -------------------------------------
+def _net_cfg(kind, cin, cout, levels, lpb, down=8, xl=0):
+    c = _lib.NetCfg()
+    c.kind, c.in_channels, c.out_channels, c.n_levels, c.layers_per_block = kind, cin, cout, len(levels), lpb
+    for i, v in enumerate(levels):
+        c.block_out[i] = v
+    c.groups, c.eps, c.precision, c.adapter_downscale, c.adapter_xl = 32, 1e-6, 0, down, xl
+    for i in range(3):
+        c.lpips_shift[i], c.lpips_scale[i] = 0.0, 1.0
+    return c
+
+
+def _torch_flops(fn):
+    from torch.utils.flop_counter import FlopCounterMode
+    with FlopCounterMode(display=False) as fc:
+        fn()
+    return float(fc.get_total_flops())
+
+
+def test_frozen_net_plans_count_the_flops_of_the_upstream_modules():
+    """VAE decoder, LPIPS-VGG16 and T2I adapter plans (fdmi_net_create, csrc/unet.hip NetVae / NetVgg / NetAdapter) in workspace-query
+    mode against torch's FLOP counter over the oracle restatements of the upstream modules (oracle/vae_cpu.py, meta tensors): the plan
+    visits every convolution / attention of diffusers' AutoencoderKL decoder, lpips.LPIPS(net="vgg") and the full T2I adapter."""
+    import ctypes as C
+    from oracle.vae_cpu import AutoencoderKLDecoderRef, LPIPSRef, T2IAdapterRef
+    lib = _lib.lib()
+
+    def plan_flops(cfg, B, H, W):
+        h = lib.fdmi_net_create(C.byref(cfg))
+        assert h, lib.fdmi_last_error()
+        need = lib.fdmi_net_workspace_bytes(h, B, H, W, 0)
+        assert need > 0, lib.fdmi_last_error()
+        assert lib.fdmi_net_workspace_bytes(h, B, H, W, FDMI_UNET_SAVE) >= need        # the tape keeps activations
+        lib.fdmi_net_workspace_bytes(h, B, H, W, 0)
+        fl = lib.fdmi_unet_last_flops(h)
+        lib.fdmi_unet_destroy(h)
+        return fl
+
+    with torch.device("meta"):
+        dec, lp, ad = AutoencoderKLDecoderRef(), LPIPSRef(), T2IAdapterRef()
+        ref_vae = _torch_flops(lambda: dec.decode_raw(torch.empty(1, 4, 64, 64)))
+        ref_lp = _torch_flops(lambda: lp(torch.empty(2, 3, 256, 256), torch.empty(2, 3, 256, 256)))
+        ref_ad = _torch_flops(lambda: ad(torch.empty(1, 3, 512, 512)))
+    vae = plan_flops(_net_cfg(1, 4, 3, [128, 256, 512, 512], 2), 1, 64, 64)
+    assert abs(vae - ref_vae) < 1e-3 * ref_vae, (vae, ref_vae)              # SD VAE decoder: 2.51 TFLOP per 512-px image
+    assert 2.4e12 < vae < 2.6e12
+    lpv = plan_flops(_net_cfg(3, 3, 0, [], 0), 2, 256, 256)                 # kinds: 1 VAE decoder, 3 LPIPS-VGG16, 4 T2I adapter (fdmi.h)
+    # (the first VGG convolution runs on the 3 -> 8 zero-padded channels of the NHWC layout: + 64 * 256^2 * 9 * 5 * 2 flop per image)
+    pad = 4 * 64 * 256 * 256 * 9 * 5 * 2
+    assert abs(lpv - pad - ref_lp) < 2e-3 * ref_lp, (lpv, ref_lp, pad)
+    adv = plan_flops(_net_cfg(4, 3, 0, [320, 640, 1280, 1280], 2), 1, 512, 512)
+    assert abs(adv - ref_ad) < 1e-6 * ref_ad, (adv, ref_ad)
