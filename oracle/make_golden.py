@@ -325,14 +325,19 @@ def make_fullsize_golden(names=None):
 from .golden_cases import C1_KW, C1_SEED, build_c1_models, c1_grad_probe  # noqa: E402
 
 
-def make_c2_golden():
+def make_c2_golden(B=2):
     """One C2-shaped step (fixture tests/golden/c2_sd15_r128_n4.npz): the REAL reference class, full-size SD1.5, r128, all four
     teacher CFG steps, B = 2; stored like the C1 fixture (outputs, losses, per-tensor gradient norm + seeded projection, four
-    LoRA tensors in full)."""
+    LoRA tensors in full).  B = 16 (`python -m oracle.make_golden c2 16`, fixture c2_sd15_r128_n4_b16.npz) is BASELINE.json
+    configs[1] at its own batch: the shapes bench.py times (about a quarter of an hour on 8 host cores)."""
     from .flash_ref import FlashConfigRef, FlashDiffusionRef, timestep_pmf
     from .golden_cases import C2_KW, build_c2_models, c2_batch
     FD, FDC = shim_import.import_reference()
-    batch = c2_batch()
+    batch = c2_batch(B=B)
+    tag = "c2_sd15_r128_n4" + ("" if B == 2 else f"_b{B}")
+    if B > 2:      # host memory: fp32 SDPA (log-sum-exp saved) instead of materialised probabilities, in BOTH runs below
+        from . import unet_cpu
+        unet_cpu.FUSED_ATTENTION = True
     # the reference draws the start index from the pmf (FD:167): pick the seed whose draw is index 0 (= all four teacher steps)
     pmf = timestep_pmf(FlashConfigRef(**C2_KW), 4, 0)
     seed = None
@@ -354,11 +359,11 @@ def make_c2_golden():
     ora = FlashDiffusionRef(FlashConfigRef(**C2_KW), student_denoiser=student, teacher_denoiser=teacher,
                             teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=TensorConditioner(), discriminator=disc)
     torch.manual_seed(seed)
-    out2 = ora(c2_batch(), step=0, device="cpu")
+    out2 = ora(c2_batch(B=B), step=0, device="cpu")
     for k in ("teacher_output", "student_output", "noisy_sample"):
         assert torch.equal(out[k], out2[k]), k
     assert int(out["start_timestep"]) == 999, out["start_timestep"]    # start index 0 of the trailing K = 4 schedule: 4 teacher steps
-    blob = {"step": np.int64(0), "start_timestep": np.int64(out["start_timestep"]), "seed": np.int64(seed)}
+    blob = {"step": np.int64(0), "start_timestep": np.int64(out["start_timestep"]), "seed": np.int64(seed), "B": np.int64(B)}
     for k, v in ora.last_draws.values.items():
         blob["draw:" + k] = v.numpy()
     for k in ("teacher_output", "student_output", "noisy_sample"):
@@ -375,9 +380,9 @@ def make_c2_golden():
     lora = [n for n in names if ".lora_" in n]
     for n in lora[:2] + lora[-2:]:
         blob["grad:" + n] = grads[n].numpy()
-    path = os.path.join(OUT, "c2_sd15_r128_n4.npz")
+    path = os.path.join(OUT, tag + ".npz")
     np.savez_compressed(path, **blob)
-    print("c2_sd15_r128_n4 seed", seed, "loss", blob["loss:0"], "terms", {k: float(blob[k]) for k in blob if k.startswith("term:")},
+    print(tag, "seed", seed, "loss", blob["loss:0"], "terms", {k: float(blob[k]) for k in blob if k.startswith("term:")},
           "ngrads", len(names), os.path.getsize(path) // 1024, "KiB")
 
 
@@ -440,7 +445,7 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "full":
         make_fullsize_golden(sys.argv[2:] or None)
     elif len(sys.argv) > 1 and sys.argv[1] == "c2":
-        make_c2_golden()
+        make_c2_golden(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
     elif len(sys.argv) > 1 and sys.argv[1] == "gan":
         from .golden_cases import CASES as _C
         want = sys.argv[2:] or ("g_wgan", "d_wgan", "d_lsgan", "d_vanilla", "d_nonsat")

@@ -115,6 +115,9 @@ class LoraLinear(nn.Module):
         return self.base_layer(x) + self.scaling * self.lora_B["default"](self.lora_A["default"](x))
 
 
+FUSED_ATTENTION = False   # set by the generator of the large-batch fixture only (see Attention.forward)
+
+
 class Attention(nn.Module):
     def __init__(self, query_dim, heads, dim_head, cross_dim=None):
         super().__init__()
@@ -134,6 +137,11 @@ class Attention(nn.Module):
         q = self.to_q(x).view(B, S, H, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], H, -1).transpose(1, 2)
         v = self.to_v(ctx).view(B, ctx.shape[1], H, -1).transpose(1, 2)
+        if FUSED_ATTENTION and mask is None:
+            # memory only: the B = 16 fixture (oracle/make_golden.py c2 16) cannot keep 16 x 5 materialised [8, 4096, 4096]
+            # probability tensors for the backward in 62 GB of host memory; PyTorch's fp32 CPU kernel keeps the log-sum-exp
+            o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False, scale=self.scale)
+            return self.to_out[0](o.transpose(1, 2).reshape(B, S, -1))
         s = (q @ k.transpose(-1, -2)) * self.scale
         if mask is not None:
             s = s + mask

@@ -26,7 +26,68 @@ def bench(fns, reps):
     return a.elapsed_time(b) / reps * 1e3
 
 
+# gemm4 row-kernel variants (GemmArgs::dev through developer knob 40): L2 prefetch distance 1..3, residual touches (4), burst issue
+# (8); 16 / 32 / 48 are timing ablations (A re-read from its first tile / no epilogue / both: WRONG results, never a product path)
+DEV = [0, 1, 2, 3, 4, 6, 7, 8, 14, 16, 32, 48]
+
+
+def dev_sweep(reps):
+    """round 4: the 256x320 kernel of every row case under each GemmArgs::dev variant; the non-ablation variants must reproduce
+    the default's output bit for bit"""
+    from flash_diffusion_amd._lib import lib
+    L = lib()
+    cases = [(131072, 320, 320, True), (131072, 320, 320, False), (131072, 960, 320, False), (65536, 320, 320, True),
+             (131072, 320, 1280, True), (32768, 640, 640, True), (32768, 1920, 640, False), (32768, 640, 2560, True)]
+    tile = TILES["g4 256x320"]
+    for (M, N, K, res) in cases:
+        nset = min(6, max(2, int(600e6 // (2 * M * (K + N * (2 if res else 1)))) + 1))
+        sets = []
+        for s_ in range(nset):
+            A = torch.randn(M, K, device="cuda").to(BF)
+            W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
+            out = torch.empty(M, N, dtype=BF, device="cuda")
+            R = torch.randn(M, N, device="cuda").to(BF) if res else None
+            sets.append((A, W, out, R))
+        bias = torch.randn(N, device="cuda")
+        by = 2.0 * M * (K + N * (2 if res else 1)) + 2.0 * N * K
+        fns = [(lambda A=A, W=W, out=out, R=R: ops.gemm(A, W, bias=bias, residual=R, out=out, force_tile=tile)) for (A, W, out, R) in sets]
+        L.fdmi_tune_set(40, 0)
+        fns[0]()
+        ref = sets[0][2].clone()
+        line = f"M={M:6d} N={N:5d} K={K:5d} res={int(res)} |"
+        for d in DEV:
+            L.fdmi_tune_set(40, d)
+            us = bench(fns, reps)
+            tag = ""
+            if d < 16:
+                sets[0][2].zero_()
+                fns[0]()
+                torch.cuda.synchronize()
+                if not torch.equal(sets[0][2], ref):
+                    tag = f" MISMATCH({float((sets[0][2].float() - ref.float()).abs().max()):.3g})"
+            line += f" dev{d}: {us:6.1f} us {by / us / 1e6:4.2f} TB/s{tag} |"
+        L.fdmi_tune_set(40, 0)
+        print(line, flush=True)
+    for (M, N, K) in [(131072, 2560, 320), (65536, 2560, 320), (32768, 5120, 640)]:   # GEGLU: K loop vs epilogue (ablations only)
+        sets = []
+        for s_ in range(3):
+            A = torch.randn(M, K, device="cuda").to(BF)
+            W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
+            sets.append((A, W, torch.empty(M, N // 2, dtype=BF, device="cuda")))
+        bias = torch.randn(N, device="cuda")
+        fns = [(lambda A=A, W=W, out=out: ops.gemm(A, W, bias=bias, out=out, force_tile=tile, act=ops.ACT_GEGLU)) for (A, W, out) in sets]
+        line = f"M={M:6d} N={N:5d} K={K:5d} GEGLU |"
+        for d in (0, 16, 32, 48):
+            L.fdmi_tune_set(40, d)
+            us = bench(fns, reps)
+            line += f" dev{d}: {us:6.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF |"
+        L.fdmi_tune_set(40, 0)
+        print(line, flush=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "dev":
+        return dev_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 30)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
     cases = [  # (M, N, K, residual, geglu)
         (131072, 320, 320, True, False), (131072, 320, 320, False, False), (131072, 960, 320, False, False),
