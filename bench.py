@@ -124,7 +124,7 @@ def dominant_family(arch):
     sys.path.insert(0, os.path.join(ROOT, "scripts"))
     try:
         from rocprof_to_profiles import bucket
-        f = _latest_profile("r*_kernel_stats.csv" if arch == "sd15" else f"r*_kernel_stats_{arch}.csv")
+        f = _latest_profile("r*_kernel_stats.csv" if arch == "sd15" else f"r*_kernel_stats_{arch}*.csv")   # (e.g. r3_kernel_stats_sd3_call8.csv)
         if f is None:
             return None, None
         tot = {}
@@ -443,13 +443,16 @@ def main():
     # decode of both outputs' 64x64 crops (FD:383-397): SD1.5 AutoencoderKL decoder + VGG16 on the HIP path, student side taped ----
     lpips_leg = None
     if world == 1 and args.arch == "sd15" and not args.no_secondary:
+        from flash_diffusion_amd.nets import MiLPIPS
         from flash_diffusion_amd.workloads import sd_vae
         try:
             del pipe
         except NameError:
             pass
+        lp = MiLPIPS()      # random-init VGG16 / linear layers, like every other weight of the bench ("data": synthetic)
+        lp.freeze()
         m3 = build_flash(arch, lora_rank=rank_r, n_teacher_steps=args.teacher_steps, device="cuda", seed=0,
-                         distill_loss_type="lpips", vae=sd_vae())
+                         distill_loss_type="lpips", vae=sd_vae(), lpips_model=lp)
         p3 = TrainingPipeline(m3, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-5],
                                                  trainable_params=[["student_denoiser"]]), overlap=not args.no_overlap)
         p3.configure_optimizers()

@@ -36,9 +36,10 @@ struct GemmArgs {
   int accum_atomic = 0;           // C is f32 and receives atomicAdd(alpha*acc) (wgrad accumulation)
   int force_tile = 0;             // 0 auto; else (BM<<16 | BN)
   int use_glds = 1;               // LDS-DMA staging (1) or register staging (0)
-  // gemm4 row kernels: bits 0-1 = L2 prefetch distance of the A operand in K tiles (0 off), bit 2 = also touch the item's
-  // residual tile, bit 3 = issue a tile's ring pieces in one burst; bits 4 / 5 = timing ablations of scripts/rowbench.py (WRONG
-  // results: A re-read from its first tile / no epilogue).  0 = the launcher's default (developer knob 40)
+  // developer bits (0 = the launcher's default, knob 40).  16 / 32: timing ablations of scripts/rowbench.py on the gemm4 row
+  // kernels (WRONG results: A re-read from its first tile / no epilogue); 64: the general epilogue instead of the lean one
+  // (gemm_tile.h, A/B switch).  Round 4 also tried, measured and removed: L2 prefetch touches of the A / residual tiles and
+  // burst issue of the ring pieces (profiles/r4_rowbench_dev.txt: no gain -- the row kernels were epilogue-instruction-bound)
   int dev = 0;
   // optional: GroupNorm statistics of the tensor this GEMM produces, accumulated by the epilogue into
   // gn_stats[m / gn_rows][gn_G][2] += (sum, sum of squares) over the group's gn_cpg channels (pre-zeroed by the caller) so

@@ -568,6 +568,7 @@ struct GemmLog {
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a_in.f32) return launch_gemm32(a_in, stream);   // fp32 validation mode: its own kernel family (ref32.hip)
   GemmArgs a = a_in;
+  if (!a.dev) a.dev = fdmi_tune_get(40);   // developer bits (gemm.h)
   FDMI_CHECK(a.M > 0 && a.N > 0 && a.K > 0, "gemm: empty problem");
   FDMI_CHECK((a.K % 8) == 0 && (a.ldw % 8) == 0, "gemm: K and ldw must be multiples of 8");
   FDMI_CHECK(((uintptr_t)a.A % 16) == 0 && ((uintptr_t)a.W % 16) == 0, "gemm: operands must be 16-B aligned");

@@ -18,31 +18,6 @@
 
 namespace {
 
-// L2 prefetch: a 4-byte LDS-DMA per lane into a per-wave dummy LDS page that nothing reads.  The load has no register
-// destination (nothing for the compiler to keep live, nothing a late return could clobber) and costs one issue slot per wave; what
-// it buys is the 128-byte line it touches sitting in the XCD's L2 when the ring's 16-byte pieces ask for it two tiles later.
-__device__ __forceinline__ void glds4_touch(const void* gptr, unsigned lds_addr) {
-  unsigned keep;
-  asm volatile(
-      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
-      : "=&s"(keep)
-      : "v"(gptr), "s"(lds_addr));
-}
-// counted wait with a run-time (wave-uniform) count: the VMEM operations issued AFTER the ring pieces a tile waits for
-__device__ __forceinline__ void wait_vmcnt_n(int n) {
-  switch (n) {
-    case 0: wait_vmcnt<0>(); break;
-    case 1: wait_vmcnt<1>(); break;
-    case 2: wait_vmcnt<2>(); break;
-    case 3: wait_vmcnt<3>(); break;
-    case 4: wait_vmcnt<4>(); break;
-    case 5: wait_vmcnt<5>(); break;
-    case 6: wait_vmcnt<6>(); break;
-    case 7: wait_vmcnt<7>(); break;
-    default: wait_vmcnt<0>(); break;
-  }
-}
-
 // BN = 320 is the tile described above.  BN = 192 is the same pipeline for widths that 320 does not divide but 192 does --
 // the transformer denoisers' 1152 / 1536 / 4608 / 6144 (PixArt, SD3): 56 KB per tile, 110 flop/B, wave tile 64 x 96.
 // GN: the epilogue also accumulates the consumer's GroupNorm statistics (GemmArgs::gn_stats); a separate instantiation, so the
@@ -132,7 +107,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
         abase = a.A2 + (int64_t)(it.m0 + lr) * a.lda2 + (it.kbeg - a.K1) + c8;
         astep = 64 * a.lda2;
       } else {
-        abase = a.A + (int64_t)(((MODE == GEMM_ROW && (a.dev & 16)) ? 0 : it.m0) + lr) * a.lda + it.kbeg + c8;   // (dev & 16: timing ablation, A from L2)
+        abase = a.A + (int64_t)(((a.dev & 16) ? 0 : it.m0) + lr) * a.lda + it.kbeg + c8;   // (dev & 16: timing ablation, A from L2)
         astep = 64 * a.lda;
       }
       akpos = it.kbeg;
@@ -161,7 +136,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   const unsigned lds0 = (unsigned)(uintptr_t)((LDS_AS char*)smem);
   int iv = blockIdx.x, ikt = 0, ink = 0, islot = 0;
   bool ihave = false, idone = false;
-  bool inew = false;   // (L2 prefetch below) the issue cursor entered a new item since the last touch
   auto issue_prepare = [&]() -> bool {  // position the cursor on the next k-tile; false when none is left
     if (idone) return false;
     while (!ihave || ikt == ink) {
@@ -172,7 +146,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       }
       const Item it = item_of(iv);
       ihave = true;
-      inew = true;
       ikt = 0;
       ink = it.nk;
       if (ink > 0) setup_issue(it);
@@ -223,45 +196,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
     ++ikt;
   };
 
-  // ---- L2 prefetch of the row GEMMs' HBM operands (GemmArgs::dev).  The ring keeps ONE tile in flight, so a row GEMM whose A
-  // operand comes from HBM pays the miss latency once per K tile (every geometry stopped at 3.3 TB/s,
-  // profiles/r3_rowbench_gemm5.txt).  Behind the pieces of the tile it has just issued, a thread touches one 64-byte half line
-  // (row t >> 1, half t & 1) of the A tile PFD steps further along the block's flattened (item, k-tile) sequence and, when the
-  // issue cursor has entered a new item, the half lines of that item's residual tile.  Stateless: addresses are re-derived from the
-  // issue cursor (this kernel has no scalar or vector register to spare) ----
-  constexpr bool ROWPF = MODE == GEMM_ROW && !GN && !GEGLU;   // (GEGLU: eight N tiles share an A panel, it comes from L2)
-  constexpr int NRES = BN / 64;                       // 64-byte chunks of a residual row, two threads per row
-  const int PFD = (ROWPF && !a.A2) ? (a.dev & 3) : 0;
-  const bool PFR = ROWPF && (a.dev & 4) && a.residual != nullptr && !a.accum_atomic && a.splitk <= 1 && !GEGLU;
-  const bool BURST = ROWPF && (a.dev & 8) != 0;
-  auto pf_touch = [&]() -> int {   // returns the number of loads issued (wave-uniform)
-    if (!ROWPF) return 0;
-    int n = 0;
-    const unsigned dummy = (unsigned)__builtin_amdgcn_readfirstlane(lds0 + 2 * STAGE + wave * 256);
-    if (PFD > 0 && ihave && !idone) {
-      int tk = ikt - 1 + PFD, v = iv;                 // the tile issued last is (iv, ikt - 1)
-      Item it = item_of(v);
-      if (tk >= it.nk && v + G < Wtot) {
-        tk -= it.nk;
-        v += G;
-        it = item_of(v);
-      }
-      if (tk < it.nk) {
-        glds4_touch(a.A + (int64_t)(it.m0 + (tid >> 1)) * a.lda + it.kbeg + tk * 64 + (tid & 1) * 32, dummy);
-        n = 1;
-      }
-    }
-    if (PFR && inew && !idone) {
-      const Item it = item_of(iv);
-      const bf16_t* r = a.residual + (int64_t)(it.m0 + (tid >> 1)) * a.ldr + it.n0 + (tid & 1) * 32;
-#pragma unroll
-      for (int c = 0; c < NRES; ++c) glds4_touch(r + c * 64, dummy);
-      n += NRES;
-    }
-    inew = false;
-    return n;
-  };
-
   // ---- fragments ----
   f32x4 acc[NF][MF];
   bf16x8 af[2][MF], wq[4];
@@ -282,8 +216,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
     for (int i = 0; i < NP; ++i) piece(i, sa);
     issue_finish();
   }
-  int pend = 0;   // VMEM operations issued after the ring pieces of the tile waited for next
-  if (ROWPF && (PFD > 0 || PFR)) pend = pf_touch();
 
   int cslot = 0;
   for (int cv = blockIdx.x; cv < Wtot; cv += G) {
@@ -293,11 +225,8 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
 #pragma unroll
       for (int mf = 0; mf < MF; ++mf) acc[nf][mf] = (f32x4){0.f, 0.f, 0.f, 0.f};
     for (int t = 0; t < it.nk; ++t) {
-      // hand-over: this wave's pieces of tile k have landed and its reads of the other slot are done.  With the prefetch cursor
-      // running, the touches issued behind those pieces may stay in flight (VMEM returns in order: vmcnt(pend) covers the pieces);
-      // the first tile of an item drains everything -- the epilogue before it left stores on the counter
-      if (ROWPF && t > 0) wait_vmcnt_n(pend);
-      else wait_vmcnt<0>();
+      // hand-over: this wave's pieces of tile k have landed and its reads of the other slot are done
+      wait_vmcnt<0>();
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");  // (compiler) no LDS read of the new tile may be scheduled above the barrier
       // fragments of k-step 0 and the head of the W ring
@@ -308,10 +237,6 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       const bool have = issue_prepare();
       if (!have) park_issue();
       const unsigned sa = slot_base();
-      if (BURST) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) piece(i, sa);
-      }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int q = 0; q < NQ; ++q) {
@@ -326,15 +251,13 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
         for (int mf = 0; mf < MF; ++mf)
           acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 3], af[ks][mf], acc[nf][mf], 0, 0, 0);
         __builtin_amdgcn_s_setprio(0);
-        if (q < NP && !BURST) {
+        if (q < NP) {
           __builtin_amdgcn_sched_barrier(0);
           piece(q, sa);
         }
         __builtin_amdgcn_sched_barrier(0);
       }
       if (have) issue_finish();
-      pend = 0;
-      if (ROWPF && (PFD > 0 || PFR) && have) pend = pf_touch();
       cslot ^= 1;
     }
     // the next item's first tile is landing meanwhile
@@ -347,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
 template <int MODE, bool GEGLU, int BN, bool GN = false>
 int launch4_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
-  constexpr int smem = 2 * (256 + BN) * 128 + 8 * 256;   // two ring slots + the prefetch touches' dummy page (256 B per wave)
+  constexpr int smem = 2 * (256 + BN) * 128;
   if (!attr_set) {
     FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
@@ -381,9 +304,7 @@ bool gemm4_eligible(const GemmArgs& a, int BN) {
   if (a.act == ACT_GEGLU && (a.mode != GEMM_ROW || a.accum_atomic || fdmi_tune_get(9))) return false;
   return true;
 }
-int launch_gemm4(const GemmArgs& a_in, hipStream_t stream, int BN) {
-  GemmArgs a = a_in;
-  if (!a.dev) a.dev = fdmi_tune_get(40);
+int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
   FDMI_CHECK((a.M & 255) == 0 && (a.N % BN) == 0 && (a.K & 63) == 0, "gemm4: whole 256 x BN x 64 tiles only (its epilogue has no bounds checks)");
   if (BN == 192) {
     FDMI_CHECK(a.act != ACT_GEGLU, "gemm4: the 256 x 192 tile has no GEGLU epilogue");

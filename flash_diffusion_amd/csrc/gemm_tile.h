@@ -203,6 +203,189 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory");
 }
 
+// ---- lean epilogue of the common case (round 4).  Measured on the 256 x 320 row kernel (scripts/rowbench.py dev, knob 40 = 32:
+// the K loop alone): M = 131072, N = K = 320 with a residual runs 78 us of which 53 us are the general epilogue below -- 40
+// (column pair, row fragment) steps per lane of ~250 executed instructions each (64-bit address products per element, scalar
+// branches on run-time flags, v_readlane reloads of spilled scalars), i.e. the epilogue is instruction-bound at 3 TB/s, not
+// memory-bound.  This variant fixes the operand set at compile time (RES: a residual tile; ADD: the bias; VEC: the wave's row
+// of a per-sample vector; the terms are added in the general epilogue's order, so the results are bit-identical), hoists every pointer product out of the loops (one 64-bit pointer per lane,
+// row-fragment steps by addition, column pairs as immediate offsets) and keeps the residual one column pair ahead: ~40
+// instructions per 16-byte store.  Whole tiles, 8-column-aligned operands, bf16 output, no activation (epi_fast_ok).
+__device__ __forceinline__ bool epi_fast_ok(const GemmArgs& a) {
+  return !a.accum_atomic && a.splitk <= 1 && a.act == ACT_NONE && !a.out_f32 && !a.preact && a.alpha == 1.f &&
+         (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
+         (!a.rowvec || ((a.rowvec_ld & 7) == 0 && !a.rowvec_mul && (a.rows_per_batch & 63) == 0));
+}
+template <int NF, int MF, bool RES, bool ADD, bool VEC>
+__device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, int nw, f32x4 (&acc)[NF][MF], int g, int j) {
+  constexpr int NP = NF / 2;
+  const int col0 = nw + (g & 1) * 16 + (g >> 1) * 8;           // this lane's 8 columns of pair 0 (pair pr: + 32 pr)
+  bf16_t* const cp = (bf16_t*)a.C + (int64_t)(mw + j) * a.ldc + col0;
+  const bf16_t* const rp = RES ? a.residual + (int64_t)(mw + j) * a.ldr + col0 : nullptr;
+  const int64_t cstep = 16 * a.ldc, rstep = RES ? 16 * a.ldr : 0;   // one row fragment down
+  const float* const bp = ADD ? a.bias + col0 : nullptr;
+  // a 64-row wave tile lies inside one sample (rows_per_batch % 64 == 0): the per-sample vector is one row for the whole wave
+  const bf16_t* const vp = VEC ? a.rowvec + (int64_t)(mw / a.rows_per_batch) * a.rowvec_ld + col0 : nullptr;
+  u16x8 rnext[MF];
+#pragma unroll
+  for (int mf = 0; mf < MF; ++mf) {
+    rnext[mf] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    if (RES && NP > 0) rnext[mf] = *(const u16x8*)(rp + mf * rstep);
+  }
+#pragma unroll
+  for (int pr = 0; pr < NP; ++pr) {
+    const int nf = 2 * pr;
+    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (ADD) {
+      const float4 b0 = *(const float4*)(bp + 32 * pr), b1 = *(const float4*)(bp + 32 * pr + 4);
+      b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
+    }
+    if (VEC) {
+      const u16x8 t = *(const u16x8*)(vp + 32 * pr);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) r8[r] = bf2f(t[r]);
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
+      const u16x8 rcur = rnext[mf];
+      if (RES && pr + 1 < NP) rnext[mf] = *(const u16x8*)(rp + mf * rstep + 32 * (pr + 1));
+      float v[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[nf][mf][r];
+        v[4 + r] = acc[nf + 1][mf][r];
+      }
+      if (ADD) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += b8[r];
+      }
+      if (VEC) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += r8[r];
+      }
+      if (RES) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] += bf2f(rcur[r]);
+      }
+      uint4 pk;
+      pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+      if (a.dev & 128) asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));   // (timing ablation: no stores, WRONG results)
+      else *(uint4*)(cp + mf * cstep + 32 * pr) = pk;
+    }
+  }
+  if constexpr ((NF & 1) != 0) {   // BN = 160: the odd fragment, 4 columns per lane
+    const int cl = nw + (NF - 1) * 16 + g * 4;
+    bf16_t* const cq = (bf16_t*)a.C + (int64_t)(mw + j) * a.ldc + cl;
+    float b4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+    if (ADD) {
+      const float4 b = *(const float4*)(a.bias + cl);
+      b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
+    }
+    if (VEC) {
+      const u16x4 t = *(const u16x4*)(a.rowvec + (int64_t)(mw / a.rows_per_batch) * a.rowvec_ld + cl);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) r4[r] = bf2f(t[r]);
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        v[r] = acc[NF - 1][mf][r];
+        if (ADD) v[r] += b4[r];
+        if (VEC) v[r] += r4[r];
+      }
+      if (RES) {
+        const u16x4 t = *(const u16x4*)(a.residual + (int64_t)(mw + mf * 16 + j) * a.ldr + cl);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] += bf2f(t[r]);
+      }
+      uint2 pk;
+      pk.x = pack2bf(v[0], v[1]);
+      pk.y = pack2bf(v[2], v[3]);
+      *(uint2*)(cq + mf * cstep) = pk;
+    }
+  }
+}
+
+// GEGLU twin of the lean epilogue: out[m][n/2] = value * gelu(gate) of the 16-wide (value | gate) interleaved columns, bias
+// present, no row vector / residual, bf16 output (+ the pre-activation save of a taped forward: PRE).  NF % 2 == 0.
+__device__ __forceinline__ bool epi_fast_geglu_ok(const GemmArgs& a) {
+  return a.act == ACT_GEGLU && !a.accum_atomic && a.splitk <= 1 && !a.out_f32 && a.alpha == 1.f && a.bias && !a.rowvec && !a.residual &&
+         (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.preact || (a.ldp & 7) == 0);
+}
+template <int NF, int MF, bool PRE>
+__device__ __forceinline__ void tile_epilogue_fast_geglu(const GemmArgs& a, int mw, int nw, f32x4 (&acc)[NF][MF], int g, int j) {
+  constexpr int NQUAD = NF / 4;
+  // quad t = fragments 4t .. 4t+3 = (value, gate, value, gate): after the swaps even lane groups hold pair 2t, odd ones 2t + 1
+  const int q = g & 1, h8 = (g >> 1) * 8;
+  const int ncol = nw + q * 32 + h8;                          // value columns ncol .. +7 of quad 0, gate columns + 16 (quad t: + 64 t)
+  const int ocol = (nw >> 1) + q * 16 + h8;                   // output columns of quad 0 (quad t: + 32 t)
+  bf16_t* const cp = (bf16_t*)a.C + (int64_t)(mw + j) * a.ldc + ocol;
+  bf16_t* const pp = PRE ? a.preact + (int64_t)(mw + j) * a.ldp + ncol : nullptr;
+  const int64_t cstep = 16 * a.ldc, pstep = PRE ? 16 * a.ldp : 0;
+  const float* const bp = a.bias + ncol;
+#pragma unroll
+  for (int t = 0; t < NQUAD; ++t) {
+    const float4 v0 = *(const float4*)(bp + 64 * t), v1 = *(const float4*)(bp + 64 * t + 4);
+    const float4 g0 = *(const float4*)(bp + 64 * t + 16), g1 = *(const float4*)(bp + 64 * t + 20);
+    const float bv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w}, bg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        SWAP16(acc[4 * t][mf][r], acc[4 * t + 2][mf][r]);
+        SWAP16(acc[4 * t + 1][mf][r], acc[4 * t + 3][mf][r]);
+      }
+      float val[8], gate[8];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        val[r] = acc[4 * t][mf][r] + bv[r];       val[4 + r] = acc[4 * t + 2][mf][r] + bv[4 + r];
+        gate[r] = acc[4 * t + 1][mf][r] + bg[r];  gate[4 + r] = acc[4 * t + 3][mf][r] + bg[4 + r];
+      }
+      if (PRE) {
+        uint4 pk;
+        pk.x = pack2bf(val[0], val[1]); pk.y = pack2bf(val[2], val[3]); pk.z = pack2bf(val[4], val[5]); pk.w = pack2bf(val[6], val[7]);
+        *(uint4*)(pp + mf * pstep + 64 * t) = pk;
+        pk.x = pack2bf(gate[0], gate[1]); pk.y = pack2bf(gate[2], gate[3]); pk.z = pack2bf(gate[4], gate[5]); pk.w = pack2bf(gate[6], gate[7]);
+        *(uint4*)(pp + mf * pstep + 64 * t + 16) = pk;
+      }
+      uint4 o;
+      o.x = pack2bf(val[0] * gelu_f(gate[0]), val[1] * gelu_f(gate[1]));
+      o.y = pack2bf(val[2] * gelu_f(gate[2]), val[3] * gelu_f(gate[3]));
+      o.z = pack2bf(val[4] * gelu_f(gate[4]), val[5] * gelu_f(gate[5]));
+      o.w = pack2bf(val[6] * gelu_f(gate[6]), val[7] * gelu_f(gate[7]));
+      *(uint4*)(cp + mf * cstep + 32 * t) = o;
+    }
+  }
+  if constexpr ((NF & 3) != 0) {   // the odd (value, gate) pair of the wave tile (NF = 10): 4 columns per lane
+    constexpr int qq = NF / 2 - 1;
+    const int n = nw + qq * 32 + g * 4, no = (nw >> 1) + qq * 16 + g * 4;
+    const float4 bv = *(const float4*)(a.bias + n), bg = *(const float4*)(a.bias + n + 16);
+    bf16_t* const cq = (bf16_t*)a.C + (int64_t)(mw + j) * a.ldc + no;
+    bf16_t* const pq = PRE ? a.preact + (int64_t)(mw + j) * a.ldp + n : nullptr;
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const float val[4] = {acc[2 * qq][mf][0] + bv.x, acc[2 * qq][mf][1] + bv.y, acc[2 * qq][mf][2] + bv.z, acc[2 * qq][mf][3] + bv.w};
+      const float gate[4] = {acc[2 * qq + 1][mf][0] + bg.x, acc[2 * qq + 1][mf][1] + bg.y, acc[2 * qq + 1][mf][2] + bg.z,
+                             acc[2 * qq + 1][mf][3] + bg.w};
+      if (PRE) {
+        uint2 pk;
+        pk.x = pack2bf(val[0], val[1]); pk.y = pack2bf(val[2], val[3]);
+        *(uint2*)(pq + mf * pstep) = pk;
+        pk.x = pack2bf(gate[0], gate[1]); pk.y = pack2bf(gate[2], gate[3]);
+        *(uint2*)(pq + mf * pstep + 16) = pk;
+      }
+      uint2 o;
+      o.x = pack2bf(val[0] * gelu_f(gate[0]), val[1] * gelu_f(gate[1]));
+      o.y = pack2bf(val[2] * gelu_f(gate[2]), val[3] * gelu_f(gate[3]));
+      *(uint2*)(cq + mf * cstep) = o;
+    }
+  }
+}
+
 // epilogue of one wave: rows mw + mf*16 + j, columns nw + nf*16 + g*4 .. +3; z = split-K slab index
 // EPI selects the compiled paths: 0 = everything but GEGLU, 1 = GEGLU only, 2 = all
 // GN: also accumulate the consumer's GroupNorm statistics (full tiles, `wide` layout, no split-K: gemm_gn_ok)
@@ -249,6 +432,30 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
         }
       }
     return;
+  }
+  if constexpr (EPI != 1 && !GN) {
+    // (knob 40 = 64: the general epilogue below for every problem -- the A/B switch of the lean one)
+    if (epi_fast_ok(a) && !a.gn_stats && !(a.dev & 64) && (FULL || (mw + MF * 16 <= a.M && nw + NF * 16 <= a.N))) {
+      const int sel = (a.residual ? 4 : 0) | (a.bias ? 2 : 0) | (a.rowvec ? 1 : 0);
+      switch (sel) {
+        case 0: tile_epilogue_fast<NF, MF, false, false, false>(a, mw, nw, acc, g, j); break;
+        case 1: tile_epilogue_fast<NF, MF, false, false, true>(a, mw, nw, acc, g, j); break;
+        case 2: tile_epilogue_fast<NF, MF, false, true, false>(a, mw, nw, acc, g, j); break;
+        case 3: tile_epilogue_fast<NF, MF, false, true, true>(a, mw, nw, acc, g, j); break;
+        case 4: tile_epilogue_fast<NF, MF, true, false, false>(a, mw, nw, acc, g, j); break;
+        case 5: tile_epilogue_fast<NF, MF, true, false, true>(a, mw, nw, acc, g, j); break;
+        case 6: tile_epilogue_fast<NF, MF, true, true, false>(a, mw, nw, acc, g, j); break;
+        default: tile_epilogue_fast<NF, MF, true, true, true>(a, mw, nw, acc, g, j); break;
+      }
+      return;
+    }
+  }
+  if constexpr (EPI != 0 && (NF & 1) == 0 && !GN) {
+    if (epi_fast_geglu_ok(a) && !(a.dev & 64) && (FULL || (mw + MF * 16 <= a.M && nw + NF * 16 <= a.N))) {
+      if (a.preact) tile_epilogue_fast_geglu<NF, MF, true>(a, mw, nw, acc, g, j);
+      else tile_epilogue_fast_geglu<NF, MF, false>(a, mw, nw, acc, g, j);
+      return;
+    }
   }
   if (EPI != 0 && (EPI == 1 || a.act == ACT_GEGLU)) {
     // fragment 2q holds 16 value columns, fragment 2q+1 the matching 16 gate columns

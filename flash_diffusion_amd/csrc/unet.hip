@@ -607,7 +607,8 @@ static bool qkv_fusable(const fdmi_unet* U, const TBlockW& b) {
 // LoRA up-projection folded into the base GEMM as extra K tiles (bf16 plans; A/B switch 31 = 1 keeps the separate launches):
 // the seam of the two-segment operands sits at in (forward) / out (dgrad), so both and the rank must be multiples of 64
 static bool lora_foldable(const fdmi_unet* U, const Lora& l) {
-  return !U->f32 && !fdmi_tune_get(31) && l.on && (l.r % 64) == 0 && (l.in % 64) == 0 && (l.out % 64) == 0 && l.out >= 128;
+  return !U->f32 && !fdmi_tune_get(31) && l.on && (l.r % 64) == 0 && (l.in % 64) == 0 && (l.out % 64) == 0 && l.out >= 128 &&
+         l.in >= 128;   // (the folded dgrad is a GEMM with N = in: gemm_a2_ok wants N >= 128 for the forward AND the dgrad shape)
 }
 static int copy2d_dev(bf16_t* dst, int64_t ldd, const bf16_t* src, int64_t lds, int rows, int cols, hipStream_t st) {
   FDMI_HIP(hipMemcpy2DAsync(dst, (size_t)ldd * 2, src, (size_t)lds * 2, (size_t)cols * 2, rows, hipMemcpyDeviceToDevice, st));

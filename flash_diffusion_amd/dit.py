@@ -35,7 +35,8 @@ PIXART_LORA_TARGETS = ("to_q", "to_k", "to_v", "to_out.0", "proj_in", "proj_out"
 
 # split-K of the projections: the context-stream GEMMs (a few hundred to a few thousand rows against K = 1152 ... 6144) fill a quarter
 # of the chip with one tile wave, so for M <= SPLITK_ROWS the launcher's planner decides per problem (ops.gemm(splitk=0)); measured
-# (profiles/r3_dit_ab.txt): for every M, C5 -2.0 % but C4 +1.2 % (its rank-64 GEMMs over 32768 rows split 2-way and pay the finalize)
+# (profiles/r3_dit_ab.txt, call 9, same box back to back): splitting for every M: C5 -2.0 % but C4 +0.7 ... +1.2 % (its rank-64 GEMMs over 32768 rows split
+# 2-way and pay the finalize); only for M <= 4096: C4 -0.65 %, C5 -1.8 % against never splitting -- the default
 SPLITK_ROWS = int(__import__("os").environ.get("FDMI_DIT_SPLITK_ROWS", "4096"))
 
 

@@ -263,12 +263,21 @@ class FlashDiffusion(nn.Module):
             if vae is None:
                 raise ValueError("distill_loss_type='lpips' decodes both outputs: a vae is required (FD:394-395)")
             if lpips_model is None:
-                # the reference builds lpips.LPIPS(net="vgg") with its pretrained weights (FD:102-103).  The HIP twin has the
-                # same architecture and state_dict names (nets.MiLPIPS): built here with placeholder weights -- load the
-                # lpips / torchvision checkpoint into it (load_state_dict) for a real perceptual distance
+                # the reference builds lpips.LPIPS(net="vgg") with its PRETRAINED weights (FD:102-103, and fails at import time
+                # without the package).  The HIP twin (nets.MiLPIPS: same architecture, same state_dict names) takes those
+                # weights; without the `lpips` package there is nothing meaningful to train against, so this raises as the
+                # reference does -- pass lpips_model=MiLPIPS() explicitly for a run on placeholder weights (bench.py does)
                 from .nets import MiLPIPS
+                try:
+                    import lpips as _lpips
+                except ImportError as e:
+                    raise ImportError("distill_loss_type='lpips' with lpips_model=None needs the `lpips` package for the pretrained "
+                                      "VGG16 / linear-layer weights (FD:102-103); pass lpips_model=nets.MiLPIPS() loaded from a "
+                                      "checkpoint (or left on placeholder weights, explicitly) instead") from e
+                ref_lpips = _lpips.LPIPS(net="vgg")
                 lpips_model = MiLPIPS(precision="fp32" if getattr(student_denoiser, "config_dict", {}).get("precision") == "fp32"
                                       else "bf16")
+                lpips_model.load_state_dict(ref_lpips.state_dict())      # (drops lpips' duplicate `lins.*` entries)
                 lpips_model.freeze()
             self.lpips = lpips_model
         self.iter_steps = 0

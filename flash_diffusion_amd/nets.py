@@ -48,7 +48,8 @@ class _NetFn(torch.autograd.Function):
     def forward(ctx, mod, x, x2):
         out, slot = mod._run(x, x2, save=True)
         ctx.mod, ctx.slot, ctx.xshape = mod, slot, x.shape
-        weakref.finalize(ctx, mod._release, slot)
+        # a ctx that outlives its backward (a kept loss, a delayed GC) must not free the slot's NEXT tenant: release by generation
+        weakref.finalize(ctx, mod._release, slot, mod._gen.get(slot, 0))
         return out
 
     @staticmethod
@@ -81,6 +82,7 @@ class _NetBase(nn.Module):
         self._packed = False
         self._ws: Dict[int, torch.Tensor] = {}
         self._busy = set()
+        self._gen = {}          # per run slot: acquisition counter (a late finalizer only frees its own acquisition)
         self.last_flops = 0.0
 
     # ---- plan ----
@@ -99,10 +101,10 @@ class _NetBase(nn.Module):
         new = cls.__new__(cls)
         memo[id(self)] = new
         for k, v in self.__dict__.items():
-            if k in ("_handle", "_packed", "_ws", "_busy"):
+            if k in ("_handle", "_packed", "_ws", "_busy", "_gen"):
                 continue
             new.__dict__[k] = copy.deepcopy(v, memo)
-        new._handle, new._packed, new._ws, new._busy = None, False, {}, set()
+        new._handle, new._packed, new._ws, new._busy, new._gen = None, False, {}, set(), {}
         return new
 
     def load_state_dict(self, *a, **k):
@@ -142,8 +144,10 @@ class _NetBase(nn.Module):
             self._packed = True
         return h
 
-    def _release(self, slot):
-        self._busy.discard(slot)
+    def _release(self, slot, gen=None):
+        """free a tape slot; with `gen` only if the slot still belongs to that acquisition (unet._Plan.release's rule)"""
+        if gen is None or self._gen.get(slot, 0) == gen:
+            self._busy.discard(slot)
 
     def _workspace(self, slot, need, device):
         ws = self._ws.get(slot)
@@ -164,8 +168,12 @@ class _NetBase(nn.Module):
         B, _, H, W = x.shape
         slot = 0
         if save:
-            slot = next(s for s in range(1, 8) if s not in self._busy)
+            slot = next((s for s in range(1, 8) if s not in self._busy), None)
+            if slot is None:
+                raise RuntimeError(f"{type(self).__name__}: 7 taped forwards are outstanding (every run slot holds a tape whose "
+                                   "backward has not run); call backward() or drop the graphs before taping another forward")
             self._busy.add(slot)
+            self._gen[slot] = self._gen.get(slot, 0) + 1
         flags = FDMI_UNET_SAVE if save else 0
         need = L.fdmi_net_workspace_bytes(h, B, H, W, flags)
         if need < 0:
@@ -253,17 +261,21 @@ class MiAutoencoderKL(_NetBase):
                  latent_channels=4, norm_num_groups=32, scaling_factor=0.18215, precision="bf16", **unused):
         super().__init__()
         assert precision in ("bf16", "fp32")
+        latents_mean, latents_std = unused.pop("latents_mean", None), unused.pop("latents_std", None)
         for k, v in unused.items():
-            if k in ("down_block_types", "up_block_types", "act_fn", "sample_size", "force_upcast", "latents_mean", "latents_std",
-                     "use_quant_conv", "use_post_quant_conv", "mid_block_add_attention", "shift_factor"):
-                continue
-            raise NotImplementedError(f"{k}={v!r} is outside the reference's VAE configurations")
+            if k in ("down_block_types", "up_block_types", "act_fn", "sample_size", "force_upcast", "use_quant_conv", "shift_factor"):
+                continue          # encoder-side / bookkeeping keys: no effect on decode()
+            if (k, v) in (("use_post_quant_conv", True), ("mid_block_add_attention", True)):
+                continue          # the defaults: what the plan builds
+            # (use_post_quant_conv=False -- the SD3 VAE -- and mid_block_add_attention=False change the decoder's arithmetic:
+            # the plan always applies post_quant_conv and the mid-block attention, so these must not be dropped silently)
+            raise NotImplementedError(f"{k}={v!r} is outside the VAE decoder plan (post_quant_conv + mid-block attention are always built)")
         boc = list(block_out_channels)
         assert 1 <= len(boc) <= 4
         self.precision = precision
         self.config = type("Cfg", (), dict(scaling_factor=scaling_factor, latent_channels=latent_channels, in_channels=in_channels,
                                            out_channels=out_channels, block_out_channels=boc, layers_per_block=layers_per_block,
-                                           norm_num_groups=norm_num_groups, latents_mean=None, latents_std=None))()
+                                           norm_num_groups=norm_num_groups, latents_mean=latents_mean, latents_std=latents_std))()
         cfg = NetCfg()
         cfg.kind, cfg.in_channels, cfg.out_channels, cfg.n_levels = FDMI_NET_VAE_DECODER, latent_channels, out_channels, len(boc)
         for i, v in enumerate(boc):
@@ -355,6 +367,12 @@ class MiLPIPS(_NetBase):
 
     def _out_like(self, x):
         return torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """accepts ``lpips.LPIPS(net="vgg").state_dict()`` as it is: lpips 0.1.4 also registers its five linear layers in a
+        ModuleList (`lins.{k}.model.1.weight`, the same tensors as `lin{k}.model.1.weight`) -- those duplicates are dropped"""
+        sd = {k: v for k, v in state_dict.items() if not k.startswith("lins.")}
+        return super().load_state_dict(sd, strict=strict, **kw)
 
     def forward(self, in0, in1, retPerLayer=False, normalize=False):
         assert not retPerLayer

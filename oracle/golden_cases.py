@@ -460,3 +460,92 @@ def build_lpips_real():
     for p in lp.parameters():
         p.requires_grad = False
     return RealVaeWrapperRef(), lp
+
+
+# ---- full-width B = 1 STEPS of BASELINE.json configs[2..4]: SDXL UNet (examples/train_flash_sdxl.py:66-118),
+# PixArt-alpha XL/2 (train_flash_pixart.py:65-86), SD3-medium (train_flash_sd3.py:65-77) at 128x128 latents, ONE teacher CFG step
+# (K = [1]), rank-64 LoRA on the examples' target modules (non-zero B), l2 distillation + DMD + the lsgan term with each example's
+# own PatchGAN head at its real width, forward AND backward.  Made by the reference's REAL FlashDiffusion / FlashDiffusionSD3 over
+# the fp32 oracle denoisers (the wrappers' contract TW:49-92 / 113-155 is restated in PixartTransformerRef / SD3TransformerRef and
+# pinned to the real wrapper classes by the tiny fixtures); weights and inputs are hashed (oracle/hash_init.py), so the GPU tests
+# rebuild them bit for bit and the fixtures carry outputs, losses and per-tensor gradient norms / projections only. -----------------
+FULLSTEP_LORA_RANK = 64
+_FS_COMMON = dict(K=[1], num_iterations_per_K=[10], timestep_distribution="uniform", distill_loss_type="l2", gan_loss_type="lsgan",
+                  use_dmd_loss=True, dmd_loss_scale=0.3, adversarial_loss_scale=0.1)
+FULLSTEP_CASES = {
+    # name: (step class, config keywords, seed)
+    "step_sdxl": ("fd", dict(_FS_COMMON, guidance_scale_min=3.0, guidance_scale_max=13.0), 71),
+    "step_pixart": ("fd", dict(_FS_COMMON, guidance_scale_min=2.0, guidance_scale_max=9.0, ucg_keys=["text"], use_empty_prompt=True), 72),
+    "step_sd3": ("fd3", dict(_FS_COMMON, guidance_scale_min=3.0, guidance_scale_max=7.0), 73),
+}
+
+
+def fullstep_head(name):
+    """the PatchGAN head of the example: SDXL on the teacher's mid-block features [B, 1280, 32, 32] (train_flash_sdxl.py:238-267),
+    PixArt / SD3 on the prediction itself (train_flash_pixart.py:277-325: five strided stages; train_flash_sd3.py:145-183: four)"""
+    nn = torch.nn
+    if name == "step_sdxl":
+        c, f, n = 1280, 256, 3
+    elif name == "step_pixart":
+        c, f, n = 4, 64, 5
+    else:
+        c, f, n = 16, 64, 4
+    layers = [nn.Conv2d(c, f, 4, 2, 1, bias=False), nn.SiLU(True)]
+    for i in range(1, n):
+        layers += [nn.Conv2d(f << (i - 1), f << i, 4, 2, 1, bias=False), nn.GroupNorm(4, f << i), nn.SiLU(True)]
+    layers += [nn.Conv2d(f << (n - 1), 1, 4, 1, 0, bias=False), nn.Flatten()]
+    return nn.Sequential(*layers)
+
+
+def fullstep_oracle(name, lora_rank):
+    """empty fp32 oracle denoiser of the case (the `make` default of build_fullstep_models)"""
+    from . import dit_cpu, mmdit_cpu
+    from .unet_cpu import sdxl_config
+    if name == "step_sdxl":
+        m = UNet2DConditionRef(sdxl_config())
+        if lora_rank:
+            m.add_adapter(lora_rank)
+        return m
+    m = dit_cpu.PixartTransformerRef(**full_arch("full_pixart")) if name == "step_pixart" else \
+        mmdit_cpu.SD3TransformerRef(**full_arch("full_sd3"))
+    if lora_rank:
+        dit_cpu.add_lora_(m, lora_rank)
+    return m
+
+
+def build_fullstep_models(name, device="cpu", make=None):
+    """teacher (frozen) / student (r64 LoRA, non-zero B, base = the teacher's weights) / the example's head, hashed weights.
+    `make(lora_rank)` builds an empty denoiser with the oracle's parameter names (the GPU tests pass the HIP module)."""
+    from .hash_init import hash_init_
+    make = make or (lambda r: fullstep_oracle(name, r))
+    strip = lambda n: n.replace(".base_layer.", ".")
+    teacher = hash_init_(make(0).to(device), 11, rename=strip)
+    teacher.freeze()
+    student = hash_init_(make(FULLSTEP_LORA_RANK).to(device), 12, lora_b_std=0.02, rename=strip)
+    base = {strip(k): v for k, v in teacher.state_dict().items()}
+    with torch.no_grad():
+        for n, p in student.named_parameters():
+            if ".lora_" not in n:
+                p.copy_(base[strip(n)])
+    disc = hash_init_(fullstep_head(name).to(device), 13)
+    return teacher, student, disc
+
+
+def fullstep_inputs(name, device="cpu"):
+    """(batch, conditioner or text-embedding pipeline) of the case -- hashed, unit-variance, identical on host and GPU"""
+    from .flash_ref import TensorConditioner
+    if name == "step_sdxl":
+        return {"image": _hu((1, 4, 128, 128), 21, device), "crossattn": _hu((1, 77, 2048), 22, device),
+                "vector": _hu((1, 2816), 23, device), "text": ["a"]}, TensorConditioner()
+    if name == "step_pixart":
+        mask = torch.ones(1, 120, dtype=torch.long, device=device)
+        mask[:, 100:] = 0
+        empty = torch.zeros(1, 120, dtype=torch.long, device=device)
+        empty[:, :1] = 1
+        return {"image": _hu((1, 4, 128, 128), 21, device), "text": ["a"], "crossattn": _hu((1, 120, 4096), 22, device),
+                "crossattn_empty": _hu((1, 120, 4096), 24, device), "attention_mask": mask, "attention_mask_empty": empty,
+                "vector": _hu((1, 768), 23, device)}, PromptTableConditioner()
+    from .flash_sd3_ref import EmbeddingPipeline
+    pipe = EmbeddingPipeline(_hu((1, 333, 4096), 22, device), _hu((1, 2048), 23, device), _hu((1, 333, 4096), 24, device),
+                             _hu((1, 2048), 25, device))
+    return {"image": _hu((1, 16, 128, 128), 21, device), "text": ["a"]}, pipe

@@ -1,0 +1,16 @@
+#!/bin/bash
+# Round-4 second GPU call: the lean epilogue (gemm_tile.h: tile_epilogue_fast / _fast_geglu) -- per-shape timings against the
+# general epilogue (knob 40 = 64) with bit-equality of the outputs, the kernel / UNet / step parity tests, the step A/B
+set -u
+out=gpurun_out/r4c2
+mkdir -p "$out"
+cd "$(dirname "$0")/../.." || exit 1
+export TMPDIR=/tmp
+timeout 400 python scripts/rowbench.py dev 30 > "$out/rowbench_dev.txt" 2>&1
+cut -c1-700 "$out/rowbench_dev.txt"
+echo "== kernel + UNet + step parity"
+timeout 900 python -m pytest tests/test_kernels_gpu.py tests/test_unet_gpu.py tests/test_flash_gpu.py -x -q > "$out/pytest.log" 2>&1; tail -4 "$out/pytest.log"
+echo "== knob A/B"
+timeout 700 python scripts/knob_ab.py --rounds 3 --steps 3 --variants base --extra "general_epilogue:40=64" --legs > "$out/knob_ab.log" 2>&1
+grep -E "^(base|general|variant|leg|\{)" "$out/knob_ab.log" | cut -c1-400
+tail -5 "$out/knob_ab.log" | cut -c1-600

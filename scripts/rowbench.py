@@ -28,7 +28,7 @@ def bench(fns, reps):
 
 # gemm4 row-kernel variants (GemmArgs::dev through developer knob 40): L2 prefetch distance 1..3, residual touches (4), burst issue
 # (8); 16 / 32 / 48 are timing ablations (A re-read from its first tile / no epilogue / both: WRONG results, never a product path)
-DEV = [0, 1, 2, 3, 4, 6, 7, 8, 14, 16, 32, 48]
+DEV = [0, 64, 128, 16, 32, 48]  # 128: lean epilogue without its stores; 64: the general epilogue (A/B of the lean one); 16 / 32 / 48: timing ablations (wrong results)
 
 
 def dev_sweep(reps):
@@ -51,7 +51,7 @@ def dev_sweep(reps):
         bias = torch.randn(N, device="cuda")
         by = 2.0 * M * (K + N * (2 if res else 1)) + 2.0 * N * K
         fns = [(lambda A=A, W=W, out=out, R=R: ops.gemm(A, W, bias=bias, residual=R, out=out, force_tile=tile)) for (A, W, out, R) in sets]
-        L.fdmi_tune_set(40, 0)
+        L.fdmi_tune_set(40, 64)
         fns[0]()
         ref = sets[0][2].clone()
         line = f"M={M:6d} N={N:5d} K={K:5d} res={int(res)} |"
@@ -59,7 +59,7 @@ def dev_sweep(reps):
             L.fdmi_tune_set(40, d)
             us = bench(fns, reps)
             tag = ""
-            if d < 16:
+            if d == 0:
                 sets[0][2].zero_()
                 fns[0]()
                 torch.cuda.synchronize()
@@ -77,10 +77,20 @@ def dev_sweep(reps):
         bias = torch.randn(N, device="cuda")
         fns = [(lambda A=A, W=W, out=out: ops.gemm(A, W, bias=bias, out=out, force_tile=tile, act=ops.ACT_GEGLU)) for (A, W, out) in sets]
         line = f"M={M:6d} N={N:5d} K={K:5d} GEGLU |"
-        for d in (0, 16, 32, 48):
+        L.fdmi_tune_set(40, 64)
+        fns[0]()
+        ref = sets[0][2].clone()
+        for d in (0, 64, 16, 32, 48):
             L.fdmi_tune_set(40, d)
             us = bench(fns, reps)
-            line += f" dev{d}: {us:6.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF |"
+            tag = ""
+            if d == 0:
+                sets[0][2].zero_()
+                fns[0]()
+                torch.cuda.synchronize()
+                if not torch.equal(sets[0][2], ref):
+                    tag = f" MISMATCH({float((sets[0][2].float() - ref.float()).abs().max()):.3g})"
+            line += f" dev{d}: {us:6.1f} us {2.0 * M * N * K / us / 1e6:5.0f} TF{tag} |"
         L.fdmi_tune_set(40, 0)
         print(line, flush=True)
 

@@ -179,11 +179,33 @@ def test_lpips_step_with_vae_matches_reference_golden(monkeypatch):
     with pytest.raises(ValueError, match="vae"):
         FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
                        teacher_noise_scheduler=DPMSolverMultistepScheduler(), lpips_model=TinyLPIPS())
-    # without lpips_model the reference builds lpips.LPIPS(net="vgg") (FD:102-103): the product builds its HIP twin (round 3)
+    # without lpips_model the reference builds lpips.LPIPS(net="vgg") with its PRETRAINED weights (FD:102-103).  The product copies
+    # them into its HIP twin -- and refuses to train against placeholder weights when the package is absent
+    import sys
+    import types
+    if "lpips" not in sys.modules:
+        monkeypatch.setitem(sys.modules, "lpips", None)         # (import lpips -> ImportError, whatever the image has)
+        with pytest.raises(ImportError, match="lpips"):
+            FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                           teacher_noise_scheduler=DPMSolverMultistepScheduler(), vae=TinyVAE())
+    from flash_diffusion_amd.nets import MiLPIPS
+    donor = MiLPIPS()
+    sd = {k: torch.full_like(v, 0.25) for k, v in donor.state_dict().items()}
+    sd.update({f"lins.{l}.model.1.weight": sd[f"lin{l}.model.1.weight"] for l in range(5)})   # lpips 0.1.4's ModuleList duplicates
+
+    class _FakeLPIPS:
+        def __init__(self, net="vgg"):
+            assert net == "vgg"
+
+        def state_dict(self):
+            return sd
+    monkeypatch.setitem(sys.modules, "lpips", types.SimpleNamespace(LPIPS=_FakeLPIPS))
     m_def = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
                            teacher_noise_scheduler=DPMSolverMultistepScheduler(), vae=TinyVAE())
     assert type(m_def.lpips).__name__ == "MiLPIPS" and not any(p.requires_grad for p in m_def.lpips.parameters())
-    assert "net.slice1.0.weight" in m_def.lpips.state_dict() and "lin4.model.1.weight" in m_def.lpips.state_dict()
+    got = m_def.lpips.state_dict()
+    assert "net.slice1.0.weight" in got and "lin4.model.1.weight" in got and not any(k.startswith("lins.") for k in got)
+    assert all(torch.equal(got[k], sd[k]) for k in got if not k.startswith("scaling_layer."))   # the donor's weights, not placeholders
     # the sampler decodes, log_samples infers the latent shape from the VAE (FD:865-868, 977-984)
     from flash_diffusion_amd.schedulers import LCMScheduler
     m.sampling_noise_scheduler = LCMScheduler()

@@ -141,14 +141,23 @@ def test_c2_shaped_step_matches_reference_golden(precision):
     run_isolated(__name__, "_c2_body", (precision,), timeout=900)
 
 
-def _c2_body(precision):
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_c2_step_at_its_own_batch_matches_reference_golden(precision):
+    """BASELINE.json configs[1] at B = 16 -- the 2B = 32-row teacher and 16-row student shapes bench.py times (VERDICT r3 item
+    1b): fixture tests/golden/c2_sd15_r128_n4_b16.npz from the REAL reference class (`python -m oracle.make_golden c2 16`)"""
+    run_isolated(__name__, "_c2_body", (precision, 16), timeout=1200)
+
+
+def _c2_body(precision, B=2):
     from flash_diffusion_amd import workloads
     from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
     from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
     from flash_diffusion_amd.unet import MiUNet2DConditionModel
     from oracle.golden_cases import C2_KW, C2_LORA_RANK, build_c2_models, c2_batch
-    g = load_case("c2_sd15_r128_n4")
-    blob = np.load(os.path.join(GOLDEN_DIR, "c2_sd15_r128_n4.npz"))
+    tag = "c2_sd15_r128_n4" + ("" if B == 2 else f"_b{B}")
+    g = load_case(tag)
+    blob = np.load(os.path.join(GOLDEN_DIR, tag + ".npz"))
+    assert int(blob["B"]) == B if "B" in blob.files else B == 2
 
     def make(lora_rank):
         with torch.device("cuda"):
@@ -165,12 +174,13 @@ def _c2_body(precision):
                        discriminator=disc).cuda()
     assert type(m.discriminator).__name__ == "MiDiscriminator" and m.discriminator.precision == precision
     m.draws = Draws(g["draws"])
-    out = m(c2_batch("cuda"), step=0, device="cuda")
+    out = m(c2_batch("cuda", B=B), step=0, device="cuda")
     assert m.terms["n_teacher_steps"] == 4                  # the headline's four teacher CFG steps
-    _check_outputs(f"c2_sd15_r128_n4 [{precision}]", m, g, out, precision == "fp32")
+    assert tuple(out["student_output"].shape) == (B, 4, 64, 64)
+    _check_outputs(f"{tag} [{precision}]", m, g, out, precision == "fp32")
     out["loss"][0].backward()
     torch.cuda.synchronize()
-    _check_projected_grads(f"c2_sd15_r128_n4 [{precision}]", m, blob, g, precision == "fp32")
+    _check_projected_grads(f"{tag} [{precision}]", m, blob, g, precision == "fp32")
 
 
 def test_c1_full_size_step_bf16():
