@@ -334,6 +334,9 @@ def main():
     ln = (C.c_int64 * nb)()
     timing = "per-dispatch start/stop events (hipExtLaunchKernelGGL)"
     for attempt in (0, 1):
+        if os.environ.get("FDMI_BENCH_NO_PROFILE_LEG") == "1":   # (dev: counter-pass bisection, scripts/gpu_calls/r4_call5.sh)
+            ok = False
+            break
         if rank == 0:
             L.fdmi_tune_set(20, max(attempt, L.fdmi_tune_value(20)))
             L.fdmi_prof_enable(1)

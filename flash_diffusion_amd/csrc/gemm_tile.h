@@ -216,63 +216,143 @@ __device__ __forceinline__ bool epi_fast_ok(const GemmArgs& a) {
          (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
          (!a.rowvec || ((a.rowvec_ld & 7) == 0 && !a.rowvec_mul && (a.rows_per_batch & 63) == 0));
 }
-template <int NF, int MF, bool RES, bool ADD, bool VEC>
+// Line-wide accesses (round 4, scripts/ubench/stream_patterns.hip -> profiles/r4_stream_patterns.txt): a wave instruction of the
+// MFMA layout touches 16 rows x 64 bytes; a copy in that pattern runs at 3.66 TB/s, in whole 128-byte lines at 5.0 TB/s.  Two
+// column pairs P, P + 1 of a row fragment are therefore exchanged between lanes j and j ^ 8 of each 16-lane row (two DPP row
+// rotations per register): afterwards lane (g, j) holds rows j & 7 and (j & 7) + 8 of column pair P + (j >> 3), so that a wave
+// instruction covers 8 rows x 128 contiguous bytes.  `phase`: the wave tile starts in the second half of a line, its first pair
+// stays single.  Residual, bias and row vector are fetched in the exchanged layout, so nothing has to be exchanged back.
+__device__ __forceinline__ float dpp_ror8_hi(float keep, float src) {   // lanes j >= 8 of every 16-lane row := src of lane j - 8
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x128, 0xF, 0xC, false));
+}
+__device__ __forceinline__ float dpp_ror8_lo(float keep, float src) {   // lanes j < 8 := src of lane j + 8
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x128, 0xF, 0x3, false));
+}
+// the epilogue's walk as compile-time tables: unit k = (first pair, double?), micro-step i = one 16-byte residual chunk in
+// processing order (unit, row fragment, row of a double) -- the residual ring below is addressed by micro-step
+template <int NP, int MF, int PHASE>
+struct EpiWalk {
+  static constexpr int NU = PHASE == 2 ? NP : PHASE + (NP - PHASE) / 2 + ((NP - PHASE) & 1);
+  static constexpr __host__ __device__ int unit_p(int k) { return PHASE == 2 ? k : ((PHASE && k == 0) ? 0 : PHASE + 2 * (k - PHASE)); }
+  static constexpr __host__ __device__ bool unit_dbl(int k) { return PHASE != 2 && !(PHASE && k == 0) && unit_p(k) + 1 < NP; }
+  static constexpr __host__ __device__ int micro_count() {
+    int n = 0;
+    for (int k = 0; k < NU; ++k) n += MF * (unit_dbl(k) ? 2 : 1);
+    return n;
+  }
+  // micro-step i -> k * 64 + mf * 2 + s
+  static constexpr __host__ __device__ int micro(int i) {
+    int n = 0;
+    for (int k = 0; k < NU; ++k) {
+      const int per = unit_dbl(k) ? 2 : 1;
+      if (i < n + MF * per) return k * 64 + ((i - n) / per) * 2 + ((i - n) % per);
+      n += MF * per;
+    }
+    return -1;
+  }
+};
+template <int NF, int MF, bool RES, bool ADD, bool VEC, int PHASE>
 __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, int nw, f32x4 (&acc)[NF][MF], int g, int j) {
   constexpr int NP = NF / 2;
-  const int col0 = nw + (g & 1) * 16 + (g >> 1) * 8;           // this lane's 8 columns of pair 0 (pair pr: + 32 pr)
-  bf16_t* const cp = (bf16_t*)a.C + (int64_t)(mw + j) * a.ldc + col0;
-  const bf16_t* const rp = RES ? a.residual + (int64_t)(mw + j) * a.ldr + col0 : nullptr;
+  // units: a double (pairs P, P + 1: line-wide) or a single pair.  PHASE 0: doubles from pair 0; 1: pair 0 single, doubles from
+  // pair 1; 2: every pair single (A/B switch)
+  using Wk = EpiWalk<NP, MF, PHASE>;
+  constexpr int NU = Wk::NU, NS = Wk::micro_count(), RD = 4;   // RD: residual chunks in flight per lane
+  const int h = j >> 3, jr = j & 7;
+  const int col0 = nw + (g & 1) * 16 + (g >> 1) * 8;           // single pair pr: this lane's 8 columns start at col0 + 32 pr, row j
+  const int colT = col0 + 32 * h;                              // double (P, P + 1): columns colT + 32 P, rows jr and jr + 8
+  // ONE pointer per operand (the exchanged layout's); a single pair's row j = jr + 8 h, column col0 = colT - 32 h is an offset away
+  bf16_t* const cpT = (bf16_t*)a.C + (int64_t)(mw + jr) * a.ldc + colT;
+  const bf16_t* const rpT = RES ? a.residual + (int64_t)(mw + jr) * a.ldr + colT : nullptr;
   const int64_t cstep = 16 * a.ldc, rstep = RES ? 16 * a.ldr : 0;   // one row fragment down
-  const float* const bp = ADD ? a.bias + col0 : nullptr;
+  const int64_t c8 = 8 * a.ldc, r8s = RES ? 8 * a.ldr : 0;          // the second row of a double
+  const int csg = h ? (int)c8 - 32 : 0, rsg = (RES && h) ? (int)r8s - 32 : 0;   // (elements; 8 rows of any operand fit 31 bits)
   // a 64-row wave tile lies inside one sample (rows_per_batch % 64 == 0): the per-sample vector is one row for the whole wave
-  const bf16_t* const vp = VEC ? a.rowvec + (int64_t)(mw / a.rows_per_batch) * a.rowvec_ld + col0 : nullptr;
-  u16x8 rnext[MF];
+  const bf16_t* const vrow = VEC ? a.rowvec + (int64_t)(mw / a.rows_per_batch) * a.rowvec_ld : nullptr;
+  u16x8 rb[RD];
+  auto load_micro = [&](int i) {   // residual chunk of micro-step i into its ring register
+    if (!RES || i >= NS) return;
+    const int c = Wk::micro(i), k = c >> 6, mf = (c >> 1) & 31, s2 = c & 1;
+    if (Wk::unit_dbl(k)) rb[i % RD] = *(const u16x8*)(rpT + mf * rstep + 32 * Wk::unit_p(k) + (s2 ? r8s : 0));
+    else rb[i % RD] = *(const u16x8*)(rpT + rsg + mf * rstep + 32 * Wk::unit_p(k));
+  };
 #pragma unroll
-  for (int mf = 0; mf < MF; ++mf) {
-    rnext[mf] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
-    if (RES && NP > 0) rnext[mf] = *(const u16x8*)(rp + mf * rstep);
+  for (int i = 0; i < RD; ++i) {
+    rb[i] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
+    load_micro(i);
   }
+  auto finish = [&](float (&v)[8], const float (&b8)[8], const float (&r8)[8], const u16x8& res, bf16_t* dst) {
+    if (ADD) {
 #pragma unroll
-  for (int pr = 0; pr < NP; ++pr) {
-    const int nf = 2 * pr;
+      for (int r = 0; r < 8; ++r) v[r] += b8[r];
+    }
+    if (VEC) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += r8[r];
+    }
+    if (RES) {
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += bf2f(res[r]);
+    }
+    uint4 pk;
+    pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+    *(uint4*)dst = pk;
+  };
+  int mi = 0;   // micro-step (a compile-time constant at every use once the loops are unrolled)
+#pragma unroll
+  for (int k = 0; k < NU; ++k) {
+    const int P = Wk::unit_p(k);
+    const bool dbl = Wk::unit_dbl(k);
+    const int cb = (dbl ? colT : col0) + 32 * P;                // this lane's first column in this unit
     float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ADD) {
-      const float4 b0 = *(const float4*)(bp + 32 * pr), b1 = *(const float4*)(bp + 32 * pr + 4);
+      const float4 b0 = *(const float4*)(a.bias + cb), b1 = *(const float4*)(a.bias + cb + 4);
       b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
     }
     if (VEC) {
-      const u16x8 t = *(const u16x8*)(vp + 32 * pr);
+      const u16x8 t = *(const u16x8*)(vrow + cb);
 #pragma unroll
       for (int r = 0; r < 8; ++r) r8[r] = bf2f(t[r]);
     }
 #pragma unroll
     for (int mf = 0; mf < MF; ++mf) {
+      if (dbl) {
+        float va[8], vb[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
-      const u16x8 rcur = rnext[mf];
-      if (RES && pr + 1 < NP) rnext[mf] = *(const u16x8*)(rp + mf * rstep + 32 * (pr + 1));
-      float v[8];
+        for (int r = 0; r < 4; ++r) {
+          SWAP16(acc[2 * P][mf][r], acc[2 * P + 1][mf][r]);
+          SWAP16(acc[2 * P + 2][mf][r], acc[2 * P + 3][mf][r]);
+          va[r] = acc[2 * P][mf][r];     va[4 + r] = acc[2 * P + 1][mf][r];      // row j, pair P
+          vb[r] = acc[2 * P + 2][mf][r]; vb[4 + r] = acc[2 * P + 3][mf][r];      // row j, pair P + 1
+        }
+        float v0[8], v1[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        v[r] = acc[nf][mf][r];
-        v[4 + r] = acc[nf + 1][mf][r];
+        for (int r = 0; r < 8; ++r) {
+          v0[r] = dpp_ror8_hi(va[r], vb[r]);   // j < 8: (row j, P);      j >= 8: (row j - 8, P + 1)
+          v1[r] = dpp_ror8_lo(vb[r], va[r]);   // j < 8: (row j + 8, P);  j >= 8: (row j, P + 1)
+        }
+        const u16x8 res0 = rb[mi % RD];
+        load_micro(mi + RD);
+        finish(v0, b8, r8, res0, cpT + mf * cstep + 32 * P);
+        ++mi;
+        const u16x8 res1 = rb[mi % RD];
+        load_micro(mi + RD);
+        finish(v1, b8, r8, res1, cpT + mf * cstep + 32 * P + c8);
+        ++mi;
+      } else {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          SWAP16(acc[2 * P][mf][r], acc[2 * P + 1][mf][r]);
+          v[r] = acc[2 * P][mf][r];
+          v[4 + r] = acc[2 * P + 1][mf][r];
+        }
+        const u16x8 res0 = rb[mi % RD];
+        load_micro(mi + RD);
+        finish(v, b8, r8, res0, cpT + csg + mf * cstep + 32 * P);
+        ++mi;
       }
-      if (ADD) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += b8[r];
-      }
-      if (VEC) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += r8[r];
-      }
-      if (RES) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] += bf2f(rcur[r]);
-      }
-      uint4 pk;
-      pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
-      if (a.dev & 128) asm volatile("" ::"v"(pk.x), "v"(pk.y), "v"(pk.z), "v"(pk.w));   // (timing ablation: no stores, WRONG results)
-      else *(uint4*)(cp + mf * cstep + 32 * pr) = pk;
+      __builtin_amdgcn_sched_barrier(0);   // keep the next steps' loads / address math from piling up registers (the tile is at the VGPR cap)
     }
   }
   if constexpr ((NF & 1) != 0) {   // BN = 160: the odd fragment, 4 columns per lane
@@ -284,7 +364,7 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, in
       b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
     }
     if (VEC) {
-      const u16x4 t = *(const u16x4*)(a.rowvec + (int64_t)(mw / a.rows_per_batch) * a.rowvec_ld + cl);
+      const u16x4 t = *(const u16x4*)(vrow + cl);
 #pragma unroll
       for (int r = 0; r < 4; ++r) r4[r] = bf2f(t[r]);
     }
@@ -436,17 +516,26 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
   if constexpr (EPI != 1 && !GN) {
     // (knob 40 = 64: the general epilogue below for every problem -- the A/B switch of the lean one)
     if (epi_fast_ok(a) && !a.gn_stats && !(a.dev & 64) && (FULL || (mw + MF * 16 <= a.M && nw + NF * 16 <= a.N))) {
+      // knob 40 = 256: every pair single (the 16-row x 64-byte pattern of the MFMA layout), the A/B switch of the line-wide form
+      const int ph = (a.dev & 256) ? 2 : ((nw >> 5) & 1);
       const int sel = (a.residual ? 4 : 0) | (a.bias ? 2 : 0) | (a.rowvec ? 1 : 0);
+#define FDMI_EPI_FAST(R_, A_, V_)                                                                 \
+  do {                                                                                            \
+    if (ph == 0) tile_epilogue_fast<NF, MF, R_, A_, V_, 0>(a, mw, nw, acc, g, j);                 \
+    else if (ph == 1) tile_epilogue_fast<NF, MF, R_, A_, V_, 1>(a, mw, nw, acc, g, j);            \
+    else tile_epilogue_fast<NF, MF, R_, A_, V_, 2>(a, mw, nw, acc, g, j);                         \
+  } while (0)
       switch (sel) {
-        case 0: tile_epilogue_fast<NF, MF, false, false, false>(a, mw, nw, acc, g, j); break;
-        case 1: tile_epilogue_fast<NF, MF, false, false, true>(a, mw, nw, acc, g, j); break;
-        case 2: tile_epilogue_fast<NF, MF, false, true, false>(a, mw, nw, acc, g, j); break;
-        case 3: tile_epilogue_fast<NF, MF, false, true, true>(a, mw, nw, acc, g, j); break;
-        case 4: tile_epilogue_fast<NF, MF, true, false, false>(a, mw, nw, acc, g, j); break;
-        case 5: tile_epilogue_fast<NF, MF, true, false, true>(a, mw, nw, acc, g, j); break;
-        case 6: tile_epilogue_fast<NF, MF, true, true, false>(a, mw, nw, acc, g, j); break;
-        default: tile_epilogue_fast<NF, MF, true, true, true>(a, mw, nw, acc, g, j); break;
+        case 0: FDMI_EPI_FAST(false, false, false); break;
+        case 1: FDMI_EPI_FAST(false, false, true); break;
+        case 2: FDMI_EPI_FAST(false, true, false); break;
+        case 3: FDMI_EPI_FAST(false, true, true); break;
+        case 4: FDMI_EPI_FAST(true, false, false); break;
+        case 5: FDMI_EPI_FAST(true, false, true); break;
+        case 6: FDMI_EPI_FAST(true, true, false); break;
+        default: FDMI_EPI_FAST(true, true, true); break;
       }
+#undef FDMI_EPI_FAST
       return;
     }
   }

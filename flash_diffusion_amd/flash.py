@@ -101,8 +101,8 @@ class Draws:
     def randn_like(self, name, x):
         return self._get(name, lambda: torch.randn_like(x)).to(device=x.device, dtype=x.dtype)
 
-    def multinomial(self, name, prob, n, replacement=False):
-        return self._get(name, lambda: torch.multinomial(prob, n, replacement=replacement))
+    def multinomial(self, name, prob, n, replacement=False, generator=None):
+        return self._get(name, lambda: torch.multinomial(prob, n, replacement=replacement, generator=generator))
 
     def rand1(self, name):
         return self._get(name, lambda: torch.rand(1))
@@ -292,10 +292,19 @@ class FlashDiffusion(nn.Module):
         self.draws: Optional[Draws] = None
         self.last_draws: Optional[Draws] = None
         self.terms: Dict[str, Any] = {}
-        self.fixed_start_idx: Optional[int] = None     # benchmark / DDP: pin the teacher-step count
+        self.fixed_start_idx: Optional[int] = None     # benchmark: pin the teacher-step count
         self.fixed_guidance: Optional[float] = None
+        self.shared_start_rng: Optional[torch.Generator] = None   # data-parallel training: see share_start_idx()
 
     # ---- helpers -----------------------------------------------------------------------------------
+    def share_start_idx(self, seed: Optional[int]):
+        """Data-parallel training: the reference draws the start index per rank (FD:167), so every step would wait
+        for the rank that drew the longest teacher loop.  With a host generator seeded IDENTICALLY on every rank (the trainer
+        broadcasts rank 0's seed once) all ranks draw the same index from the same pmf at every step -- no communication in the
+        step, and each rank's marginal distribution of start indices is the reference's.  Noise, guidance scale and GAN draws
+        stay per rank.  seed=None switches back to per-rank draws."""
+        self.shared_start_rng = None if seed is None else torch.Generator().manual_seed(int(seed))
+
     def freeze(self):
         self.eval()
         for p in self.parameters():
@@ -327,7 +336,7 @@ class FlashDiffusion(nn.Module):
         if self.fixed_start_idx is not None:
             start_idx = torch.tensor([self.fixed_start_idx])
         else:
-            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
+            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self.shared_start_rng)
         t0 = self.teacher_noise_scheduler.timesteps[start_idx]
         self._start_t_host = int(t0.reshape(-1)[0])   # forward() reports it without a device round trip
         return start_idx, t0.to(device).repeat(num_samples)

@@ -174,9 +174,14 @@ class FlashDiffusionSD3(nn.Module):
         self.K_prev = self.K[0]
         self.draws: Optional[Draws] = None      # tests inject the reference's random draws here
         self.last_draws: Optional[Draws] = None
-        self.fixed_start_idx: Optional[int] = None     # benchmark / DDP: pin the teacher-step count (as FlashDiffusion)
+        self.fixed_start_idx: Optional[int] = None     # benchmark: pin the teacher-step count (as FlashDiffusion)
+        self.shared_start_rng: Optional[torch.Generator] = None   # data-parallel training: FlashDiffusion.share_start_idx
         self.fixed_guidance: Optional[float] = None
         self.terms: Dict[str, Any] = {}
+
+    def share_start_idx(self, seed: Optional[int]):
+        """one start index for all data-parallel ranks per step (FlashDiffusion.share_start_idx: identically seeded host generators)"""
+        self.shared_start_rng = None if seed is None else torch.Generator().manual_seed(int(seed))
 
     def freeze(self):
         self.eval()
@@ -346,7 +351,7 @@ class FlashDiffusionSD3(nn.Module):
         if self.fixed_start_idx is not None:
             start_idx = torch.tensor([self.fixed_start_idx])
         else:
-            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1)
+            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self.shared_start_rng)
         si = int(start_idx)
         t_host = sch.timesteps[si].reshape(1).repeat(B)                  # host values: no device round trip in the step
         start_t = t_host.to(z.device)

@@ -151,7 +151,7 @@ class FusedAdamW(torch.optim.Optimizer):
 
 class TrainingPipeline(nn.Module):
     def __init__(self, model: nn.Module, pipeline_config: TrainingConfig, verbose: bool = False, overlap: bool = True,
-                 **kwargs):
+                 share_start_idx: Optional[bool] = None, **kwargs):
         super().__init__()
         self.model = model
         self.pipeline_config = pipeline_config
@@ -160,6 +160,7 @@ class TrainingPipeline(nn.Module):
         self.automatic_optimization = True
         self.optims: List[torch.optim.Optimizer] = []
         self.overlap = overlap
+        self.reduced_grad_hook = None   # callable(optimizer, grad_scale): see _reduce_and_step
         self._comm_stream = None
         self._pending = None      # event recorded on the comm stream after the deferred optimizer step
         self._deferred = None     # (loss, optimizer index) whose backward + step the next before_student hook issues
@@ -169,6 +170,16 @@ class TrainingPipeline(nn.Module):
         # then the same code the 8-GPU job runs
         self.distributed = torch.distributed.is_initialized()
         self.timer = None
+        # Data-parallel training: all ranks run the SAME number of teacher steps per iteration -- the model's start
+        # index comes from a host generator seeded identically everywhere (rank 0's seed, broadcast once here; nothing is
+        # exchanged inside the step).  Default: on whenever more than one rank trains; share_start_idx=False restores the
+        # reference's per-rank draw (FD:167), where every step waits for the rank with the longest teacher loop.
+        self.share_start_idx = (self.world > 1) if share_start_idx is None else bool(share_start_idx)
+        if self.share_start_idx and hasattr(model, "share_start_idx"):
+            seed = [int(torch.randint(0, 2 ** 31 - 1, (1,)).item())]
+            if self.distributed and self.world > 1:
+                torch.distributed.broadcast_object_list(seed, src=0)
+            model.share_start_idx(seed[0])
 
     @property
     def device(self):
@@ -327,6 +338,10 @@ class TrainingPipeline(nn.Module):
                         for p in g["params"]:
                             if p.grad is not None:
                                 p.grad.div_(self.world)
+            if self.reduced_grad_hook is not None:
+                # test hook: called after the exchange, before the step, with the factor the step applies to the gradient
+                # (FusedAdamW folds the 1 / world mean into its update; the torch optimizers' grads are already divided)
+                self.reduced_grad_hook(opt, opt.grad_scale if isinstance(opt, FusedAdamW) else 1.0)
             opt.step()
             if side is not None:
                 self._pending = torch.cuda.Event()

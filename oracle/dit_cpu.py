@@ -97,6 +97,9 @@ class PixArtAlphaTextProjection(nn.Module):
 
 
 # ---- diffusers.models.attention (upstream semantics, ada_norm_single only) ------------------------------------------------
+FUSED_ATTENTION = False   # set by the generator of the full-width step fixtures only (see Attention.forward)
+
+
 class Attention(nn.Module):
     def __init__(self, query_dim, heads, dim_head, cross_dim=None, bias=True):
         super().__init__()
@@ -115,6 +118,9 @@ class Attention(nn.Module):
         q = self.to_q(x).view(B, S, H, -1).transpose(1, 2)
         k = self.to_k(ctx).view(B, ctx.shape[1], H, -1).transpose(1, 2)
         v = self.to_v(ctx).view(B, ctx.shape[1], H, -1).transpose(1, 2)
+        if FUSED_ATTENTION and mask is None:   # host memory only (the full-width step fixtures, oracle/make_golden.py fullstep)
+            o = F.scaled_dot_product_attention(q, k, v, dropout_p=0.0, is_causal=False, scale=self.scale)
+            return self.to_out[0](o.transpose(1, 2).reshape(B, S, -1))
         s = (q @ k.transpose(-1, -2)) * self.scale
         if mask is not None:            # additive bias [B, 1, L] -> every head and query
             s = s + mask[:, None]

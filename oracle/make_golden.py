@@ -325,6 +325,82 @@ def make_fullsize_golden(names=None):
 from .golden_cases import C1_KW, C1_SEED, build_c1_models, c1_grad_probe  # noqa: E402
 
 
+def make_fullstep_golden(names=None):
+    """Full-width B = 1 steps of C3 / C4 / C5 (tests/golden/step_{sdxl,pixart,sd3}.npz; golden_cases.FULLSTEP_CASES): the REAL
+    FlashDiffusion / FlashDiffusionSD3 over the fp32 oracle denoisers at their real widths, forward and backward; stored like the
+    C1 / C2 fixtures (draws, outputs, every loss term, per-tensor gradient norm + seeded projection, four LoRA tensors in full).
+    Host memory: the materialised attention probabilities of 28 blocks x 4096 tokens do not fit beside the models, so the oracle
+    denoisers run fp32 SDPA (log-sum-exp saved) in BOTH runs -- the same arithmetic in a different association order."""
+    import gc
+    import time
+    from . import dit_cpu, unet_cpu
+    from .flash_ref import FlashConfigRef, FlashDiffusionRef
+    from .flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from .golden_cases import FULLSTEP_CASES, build_fullstep_models, fullstep_inputs
+    from .sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    unet_cpu.FUSED_ATTENTION = True
+    dit_cpu.FUSED_ATTENTION = True
+    for name in (names or FULLSTEP_CASES):
+        kind, kw, seed = FULLSTEP_CASES[name]
+        t0 = time.time()
+
+        def build(real):
+            teacher, student, disc = build_fullstep_models(name)
+            batch, cond = fullstep_inputs(name)
+            if kind == "fd":
+                FD, FDC = shim_import.import_reference()
+                cls, cfg = (FD, FDC) if real else (FlashDiffusionRef, FlashConfigRef)
+                m = cls(cfg(**kw), student_denoiser=student, teacher_denoiser=teacher, teacher_noise_scheduler=SCHEDS["dpm"](),
+                        conditioner=cond, discriminator=disc)
+            else:
+                FD3, FD3C = shim_import.import_reference_sd3()
+                cls, cfg = (FD3, FD3C) if real else (FlashDiffusionSD3Ref, FlashSD3ConfigRef)
+                m = cls(cfg(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                        teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc, pipeline=cond)
+            return m, batch
+        ref, batch = build(True)
+        torch.manual_seed(seed)
+        out = ref(batch, step=0, device="cpu") if kind == "fd" else ref(batch, step=0)
+        out["loss"][0].backward()
+        grads = {n.replace(".base_layer.", "."): p.grad.clone() for n, p in ref.named_parameters() if p.grad is not None}
+        keep = {k: out[k].detach().clone() for k in ("teacher_output", "student_output", "noisy_sample")}
+        losses = [float(out["loss"][i]) for i in (0, 1)]
+        start_t = float(out["start_timestep"])
+        del ref, out
+        gc.collect()
+        t1 = time.time()
+        ora, batch2 = build(False)
+        torch.manual_seed(seed)
+        out2 = ora(batch2, step=0, device="cpu") if kind == "fd" else ora(batch2, step=0)
+        for k in keep:
+            assert torch.equal(keep[k], out2[k]), (name, k)
+        assert float(out2["loss"][0]) == losses[0], (name, float(out2["loss"][0]), losses[0])
+        blob = {"step": np.int64(0), "start_timestep": np.float64(start_t), "seed": np.int64(seed)}
+        for k, v in ora.last_draws.values.items():
+            blob["draw:" + k] = v.numpy()
+        for k, v in keep.items():
+            blob["out:" + k] = v.numpy()
+        for i in (0, 1):
+            blob[f"loss:{i}"] = np.float64(losses[i])
+        for k, v in getattr(ora, "terms", {}).items():
+            blob["term:" + k] = np.float64(float(v))
+        names_ = sorted(grads)
+        blob["gradnames"] = np.array(names_)
+        blob["gradnorm"] = np.array([float(grads[n].double().norm()) for n in names_])
+        blob["gradproj"] = np.array([float(grads[n].double().flatten() @ c1_grad_probe(grads[n].numel(), 1000 + i).double())
+                                     for i, n in enumerate(names_)])
+        lora = [n for n in names_ if ".lora_" in n]
+        for n in lora[:2] + lora[-2:]:
+            blob["grad:" + n] = grads[n].numpy()
+        path = os.path.join(OUT, name + ".npz")
+        np.savez_compressed(path, **blob)
+        print(name, "loss", losses, "terms", {k: float(blob[k]) for k in blob if k.startswith("term:")}, "ngrads", len(names_),
+              f"start_t {start_t} reference run {t1 - t0:.0f} s, restatement run {time.time() - t1:.0f} s", os.path.getsize(path) // 1024,
+              "KiB", flush=True)
+        del ora, out2, grads
+        gc.collect()
+
+
 def make_c2_golden(B=2):
     """One C2-shaped step (fixture tests/golden/c2_sd15_r128_n4.npz): the REAL reference class, full-size SD1.5, r128, all four
     teacher CFG steps, B = 2; stored like the C1 fixture (outputs, losses, per-tensor gradient norm + seeded projection, four
@@ -444,6 +520,8 @@ if __name__ == "__main__":
         make_pixart_step_golden()
     elif len(sys.argv) > 1 and sys.argv[1] == "full":
         make_fullsize_golden(sys.argv[2:] or None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "fullstep":
+        make_fullstep_golden(sys.argv[2:] or None)
     elif len(sys.argv) > 1 and sys.argv[1] == "c2":
         make_c2_golden(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
     elif len(sys.argv) > 1 and sys.argv[1] == "gan":

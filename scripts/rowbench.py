@@ -28,7 +28,7 @@ def bench(fns, reps):
 
 # gemm4 row-kernel variants (GemmArgs::dev through developer knob 40): L2 prefetch distance 1..3, residual touches (4), burst issue
 # (8); 16 / 32 / 48 are timing ablations (A re-read from its first tile / no epilogue / both: WRONG results, never a product path)
-DEV = [0, 64, 128, 16, 32, 48]  # 128: lean epilogue without its stores; 64: the general epilogue (A/B of the lean one); 16 / 32 / 48: timing ablations (wrong results)
+DEV = [0, 256, 64, 32]          # 256: lean epilogue, every pair single (16 rows x 64 B per instruction); 64: the general epilogue; 32: the K loop alone (wrong results)
 
 
 def dev_sweep(reps):
@@ -59,7 +59,7 @@ def dev_sweep(reps):
             L.fdmi_tune_set(40, d)
             us = bench(fns, reps)
             tag = ""
-            if d == 0:
+            if d in (0, 256):
                 sets[0][2].zero_()
                 fns[0]()
                 torch.cuda.synchronize()
@@ -80,7 +80,7 @@ def dev_sweep(reps):
         L.fdmi_tune_set(40, 64)
         fns[0]()
         ref = sets[0][2].clone()
-        for d in (0, 64, 16, 32, 48):
+        for d in (0, 64, 32):
             L.fdmi_tune_set(40, d)
             us = bench(fns, reps)
             tag = ""

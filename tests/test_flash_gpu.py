@@ -30,16 +30,30 @@ def log(msg):
         f.write(msg + "\n")
 
 
-# measurements of the bf16 path on these fixtures: (loss[0] rel, loss[1] rel), the LARGEST value seen over the runs of rounds 2 and 3
-# (profiles/r2_parity_flash.txt, profiles/r3_parity_flash.txt -- five builds with different attention / GEMM kernels).  The relative
-# error of one loss component moves by up to 4x between builds on the same fixture (g_dmd_lsgan 2.3e-3 -> 7.4e-3, d_vanilla's
-# discriminator loss 2.7e-5 -> 1.0e-2, d_wgan's generator loss 1.9e-3 -> 1.6e-2: means over a few dozen logits, or differences of
-# nearly equal means, of a tiny random-weight UNet), so a per-fixture bar would track noise.  The bar is 2x the largest value any
-# component reached on any fixture in any build (1.83e-2): LOSS_BAR.  (The fp32 gate holds the same quantities to 1e-3.)
-MEASURED = {"g_dmd_lsgan": (7.4e-3, 0.0), "d_hinge": (8.0e-4, 4.8e-3), "g_nonsat_teacher_real": (3.4e-3, 0.0),
-            "g_noreg_vanilla": (3.3e-3, 0.0), "g_wgan": (8.3e-3, 0.0), "d_wgan": (1.59e-2, 1.03e-2), "d_lsgan": (8.2e-3, 2.7e-3),
-            "d_vanilla": (1.83e-2, 1.01e-2), "d_nonsat": (4.1e-3, 4.9e-3)}
-LOSS_BAR = 2.0 * max(max(v) for v in MEASURED.values())
+# Per-fixture bars of the bf16 path.  MEASURED[name] = (loss[0] rel, loss[1] rel): the LARGEST value seen on that
+# fixture over every build of rounds 2 - 4 (profiles/r2_parity_flash.txt, r3_parity_flash.txt, r4_parity_flash.txt -- different
+# attention / GEMM / epilogue kernels; one component moves by up to 4x between builds on the same fixture: means over a few dozen
+# logits of a tiny random-weight UNet).  The bar of a fixture is 2x its own worst (floor 4e-3), no longer one bar for all.
+# TERM_MEASURED: the same for every loss TERM that carries >= 2 % of its step's loss (a term that is a difference of nearly equal
+# means -- g_dmd_lsgan's DMD term is 1.9e-3 of a loss of 10.2 -- has no meaningful relative error of its own; every term, small
+# or not, is additionally held to the fixture's loss bar as a fraction of the total loss, which is what catches a mis-scaled term).
+# (The fp32 gate, tests/test_fp32_gate_gpu.py, holds the same quantities to 1e-3.)
+MEASURED = {"g_dmd_lsgan": (7.8e-3, 0.0), "d_hinge": (1.8e-3, 4.8e-3), "g_nonsat_teacher_real": (5.5e-3, 0.0),
+            "g_noreg_vanilla": (6.9e-3, 0.0), "g_wgan": (1.0e-2, 0.0), "d_wgan": (1.59e-2, 1.44e-2), "d_lsgan": (9.0e-3, 2.7e-3),
+            "d_vanilla": (1.83e-2, 1.01e-2), "d_nonsat": (4.2e-3, 7.7e-3)}
+TERM_MEASURED = {("d_hinge", "gan_D"): 4.8e-3, ("d_lsgan", "gan_D"): 2.8e-3, ("d_nonsat", "gan_D"): 7.7e-3, ("d_vanilla", "gan_D"): 1.01e-2,
+                 ("d_wgan", "gan_D"): 1.44e-2, ("g_dmd_lsgan", "gan_G"): 4.3e-3, ("g_nonsat_teacher_real", "gan_G"): 4.2e-3,
+                 ("g_noreg_vanilla", "gan_G"): 6.9e-3, ("g_wgan", "gan_G"): 5.93e-2, ("g_nonsat_teacher_real", "dmd"): 2.83e-2}
+LOSS_FLOOR, TERM_FLOOR = 4e-3, 1e-2
+
+
+def loss_bar(name, i):
+    return max(2.0 * MEASURED[name][i], LOSS_FLOOR)
+
+
+def term_bar(name, term):
+    worst = TERM_MEASURED.get((name, term), MEASURED[name][0] if term == "distill" else 0.0)
+    return max(2.0 * worst, TERM_FLOOR)
 
 
 def build_product(kw, sched="dpm"):
@@ -83,7 +97,17 @@ def test_step_matches_reference_golden(name):
     assert errs["noisy_sample"] < 1e-6
     assert errs["teacher_output"] < 4e-2 and errs["student_output"] < 1e-2, errs
     for i in (0, 1):
-        assert lerr[i] < LOSS_BAR, (i, lerr, MEASURED[name])
+        assert lerr[i] < loss_bar(name, i), (i, lerr, MEASURED[name])
+    total = abs(g["loss"][step])
+    for k, v in m.terms.items():
+        if k in ("K_step", "guidance", "n_teacher_steps") or k not in g["terms"]:
+            continue
+        got, ref = (float(v) if torch.is_tensor(v) else v), g["terms"][k]
+        if k.endswith("_D") != (step == 1) and k.startswith("gan"):
+            continue                                   # (the other step's GAN term is not part of this step's loss)
+        assert abs(got - ref) <= loss_bar(name, step) * max(total, 1e-12), (k, got, ref, total)       # as a share of the loss
+        if abs(ref) >= 0.02 * total:
+            assert abs(got - ref) <= term_bar(name, k) * abs(ref), (k, got, ref, term_bar(name, k))   # on its own
     out["loss"][step].backward()
     torch.cuda.synchronize()
     n, worst_cos, worst_ratio = 0, 1.0, 0.0

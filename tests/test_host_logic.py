@@ -138,6 +138,112 @@ def test_data_parallel_all_reduce_gloo_world2():
         assert torch.allclose(v, res[0][k], atol=1e-6), k
 
 
+def _ddp_sgd_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    m = _Toy()
+    pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["SGD"], learning_rates=[0.5],
+                                              trainable_params=[["student_denoiser"]]), overlap=False)
+    pipe.configure_optimizers()
+    seen = []
+    pipe.reduced_grad_hook = lambda opt, scale: seen.append(
+        [p.grad.detach().clone() * scale for g in opt.param_groups for p in g["params"]])
+    g = torch.Generator().manual_seed(100 + rank)
+    pipe.training_step({"x": torch.randn(8, 4, generator=g)}, 0)
+    q.put((rank, {k: v.numpy().copy() for k, v in m.student_denoiser.state_dict().items()}, [t.numpy().copy() for t in seen[0]]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_exchange_is_a_mean_of_the_rank_gradients():
+    """AdamW is scale-invariant in the gradient, so comparing parameters after AdamW cannot tell a sum from a
+    mean.  Here (a) the gradient the step receives -- after the all-reduce, times the factor the step applies -- is compared with
+    the single-process mean of the two shard gradients, and (b) the optimizer is SGD (lr 0.5), whose update IS the gradient: the
+    two-rank parameters equal the mean-gradient step and are far from the sum-gradient step."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_sgd_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(60)
+    res = {r: ({k: torch.from_numpy(v) for k, v in sd.items()}, [torch.from_numpy(t) for t in gr]) for r, sd, gr in got}
+    torch.manual_seed(0)
+    m = _Toy()
+    params = list(m.student_denoiser.parameters())
+    before = [p.detach().clone() for p in params]
+    grads = []
+    for r in range(2):
+        g = torch.Generator().manual_seed(100 + r)
+        for p in params:
+            p.grad = None
+        m({"x": torch.randn(8, 4, generator=g)})["loss"][0].backward()
+        grads.append([p.grad.clone() for p in params])
+    mean = [(a + b) / 2 for a, b in zip(*grads)]
+    for r in (0, 1):
+        for gm, gg in zip(mean, res[r][1]):
+            assert torch.allclose(gg, gm, atol=1e-7, rtol=1e-6), "the step's gradient is not the mean over the ranks"
+    names = [k for k, _ in m.student_denoiser.named_parameters()]
+    for k, b, gm in zip(names, before, mean):
+        step_mean, step_sum = b - 0.5 * gm, b - 0.5 * 2 * gm
+        assert torch.allclose(res[0][0][k], step_mean, atol=1e-6), k
+        assert torch.equal(res[0][0][k], res[1][0][k])
+        assert (res[0][0][k] - step_sum).abs().max() > 10 * (res[0][0][k] - step_mean).abs().max() + 1e-5, "cannot tell sum from mean"
+
+
+def _start_idx_worker(rank, world, port, q, share):
+    """one rank: the PRODUCT FlashDiffusion's timestep selection (FD:135-177) under a TrainingPipeline; torch's global RNG is
+    seeded differently per rank, as in a real data-parallel job"""
+    import torch.distributed as dist
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import build_models
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(1000 + rank)
+    teacher, student, _ = build_models()
+    m = FlashDiffusion(FlashDiffusionConfig(K=[8], num_iterations_per_K=[100], timestep_distribution="uniform"),
+                       student_denoiser=student, teacher_denoiser=teacher, teacher_noise_scheduler=DPMSolverMultistepScheduler())
+    pipe = TrainingPipeline(m, TrainingConfig(optimizers_name=["AdamW"], learning_rates=[1e-3],
+                                              trainable_params=[["student_denoiser"]]), overlap=False,
+                            **({} if share is None else {"share_start_idx": share}))
+    assert pipe.share_start_idx == (True if share is None else share)
+    idx = []
+    for _ in range(24):
+        torch.randn(3)                                          # the ranks' global RNG streams drift apart, as noise draws do
+        idx.append(int(m._get_timesteps(Draws(), 2, 8, 0, "cpu")[0]))
+    q.put((rank, idx))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("share", [None, False])
+def test_ranks_share_the_start_index_by_default(share):
+    """SURVEY 8e / VERDICT r3 item 8: with more than one rank the trainer makes all ranks draw the SAME start index per step (same
+    teacher-loop length, nobody waits), from identically seeded host generators; share_start_idx=False is the reference's per-rank
+    draw.  Either way every rank's own sequence covers the K start indices (the marginal is the reference's pmf)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000 + (0 if share is None else 7)
+    procs = [ctx.Process(target=_start_idx_worker, args=(r, 2, port, q, share)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    assert all(0 <= i < 8 for i in res[0] + res[1]) and len(set(res[0])) >= 4
+    if share is None:
+        assert res[0] == res[1], (res[0], res[1])
+    else:
+        assert res[0] != res[1]                                 # 24 independent uniform draws over 8 values
+
+
 def test_lcm_scheduler_host_side_matches_oracle():
     """schedule selection and boundary scalings of the product LCMScheduler (host fp32 math) vs the oracle restatement"""
     from flash_diffusion_amd.schedulers import LCMScheduler

@@ -109,6 +109,8 @@ def _body_two_rank(rank, port, out_path):
     calls = []
     orig = dist.all_reduce
     dist.all_reduce = lambda *a, **k: (calls.append(a[0].numel()), orig(*a, **k))[1]
+    seen = []      # the gradient each step hands to AdamW: flat buffer after the exchange x the factor folded into the update
+    pipe.reduced_grad_hook = lambda opt, scale: seen.append((opt.flat_grad.detach().clone() * scale).cpu())
     for i in range(N_STEPS):
         torch.manual_seed(9000 + 10 * i + rank)        # this rank's own draws (noise, guidance) -- different per rank
         pipe.training_step(_shard(i, rank), i)
@@ -117,6 +119,8 @@ def _body_two_rank(rank, port, out_path):
     flat = m.student_denoiser.lora_flat().detach().cpu()
     assert len(calls) == N_STEPS and all(n == flat.numel() for n in calls), calls   # ONE collective on the flat gradient per step
     torch.save(flat, out_path)
+    assert len(seen) == N_STEPS
+    torch.save(seen[0], out_path + ".grad0")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -125,6 +129,8 @@ def _body_two_rank_reference(out_path):
     """ONE process fed both shards: per step the two backwards accumulate into the flat gradient, AdamW applies their mean --
     the arithmetic of _reduce_and_step (sum over ranks, 1/world folded into the fused AdamW).  Run twice for the yardstick."""
     import torch
+
+    grad0 = []
 
     def run():
         m, pipe = _tiny_pipe()
@@ -135,11 +141,13 @@ def _body_two_rank_reference(out_path):
                 torch.manual_seed(9000 + 10 * i + rank)
                 out = m(_shard(i, rank), device="cuda")
                 out["loss"][0].backward()
+            if i == 0:
+                grad0.append((opt.flat_grad.detach().clone() * 0.5).cpu())   # the MEAN of the two shard gradients
             opt.grad_scale = 0.5
             opt.step()
         torch.cuda.synchronize()
         return m.student_denoiser.lora_flat().detach().cpu()
-    torch.save({"a": run(), "b": run()}, out_path)
+    torch.save({"a": run(), "b": run(), "grad0_a": grad0[0], "grad0_b": grad0[1]}, out_path)
 
 
 def test_two_rank_replicas_are_identical_and_equal_the_averaged_single_process(tmp_path):
@@ -171,3 +179,14 @@ def test_two_rank_replicas_are_identical_and_equal_the_averaged_single_process(t
     parity_log(f"two ranks vs single process: max |diff| {dist_:.3e} (two single runs: {noise:.3e}), mean |diff| {mean_dist:.3e} "
                f"(two single runs: {mean_noise:.3e}), {n_off} of {r0.numel()} elements off by > 1e-5", "multiproc_parity.txt")
     assert mean_dist <= 3 * mean_noise + 1e-6, (mean_dist, mean_noise)
+    # gradient level (AdamW hides the gradient's scale): what the first step handed to AdamW -- the exchanged
+    # flat gradient times the folded 1 / world -- is the single-process MEAN of the two shard gradients (a sum would be 2x)
+    g0, g1 = torch.load(outs[0] + ".grad0"), torch.load(outs[1] + ".grad0")
+    assert torch.equal(g0, g1)
+    gm = ref["grad0_a"]
+    gnoise = float((ref["grad0_a"] - ref["grad0_b"]).norm() / gm.norm())
+    gerr = float((g0 - gm).norm() / gm.norm())
+    ratio = float(g0.norm() / gm.norm())
+    parity_log(f"two ranks, first step: exchanged gradient x grad_scale vs the single-process mean: rel {gerr:.3e} (two single runs: "
+               f"{gnoise:.3e}), norm ratio {ratio:.5f} (a sum would give 2)", "multiproc_parity.txt")
+    assert gerr <= max(10 * gnoise, 1e-4) and abs(ratio - 1.0) < 1e-3, (gerr, gnoise, ratio)
