@@ -107,7 +107,7 @@ int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_
   FDMI_CHECK(d != nullptr && kernel && BM && BN && splitk, "gemm_plan: null argument");
   const GemmArgs a = gemm_args_from(d);
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic || a.splitk <= 0);
-  *kernel = p.big; *BM = p.big == 3 ? 128 : (p.big ? 256 : p.BM); *BN = p.BN; *splitk = p.splitk;
+  *kernel = p.big; *BM = p.big ? 256 : p.BM; *BN = p.BN; *splitk = p.splitk;
   return 0;
 }
 

@@ -485,7 +485,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   if (a.force_tile) {
     p.BM = a.force_tile >> 16;
     p.BN = a.force_tile & 0xffff;
-    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : ((p.BM == 128 && p.BN == 320) ? 3 : 0);
+    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : 0;
     p.splitk = a.splitk > 0 ? a.splitk : 1;
     return p;
   }
@@ -512,13 +512,6 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   // 256 x 192 (the widths of the transformer denoisers, which 320 does not divide): measured -6.6 % on the C4 step against the
   // 256 x 128 ring kernel it displaces (profiles/r2_knob12_c4.txt); A/B switch 12 = 1 takes it out of the planner
   if (!fdmi_tune_get(12) && gemm4_eligible(a, 192)) consider(2, 256, 192, 256, 3.9);
-  // the deferred-epilogue tile (gemm6.hip) takes over from the 256 x 320 kernel where it applies and the K loop is short enough
-  // for the epilogue to matter (knob 42: 0 = off, 1 = every eligible problem, k > 1 = problems with K <= 64 k)
-  if (p.big == 2 && p.BN == 320 && p.splitk == 1 && fdmi_tune_get(42) && gemm6_eligible(a) &&
-      (fdmi_tune_get(42) == 1 || a.K <= 64 * fdmi_tune_get(42))) {
-    p.big = 3;
-    p.BM = 128;
-  }
   const bool geglu = a.act == ACT_GEGLU;
   if (a.A2) return p;   // a two-segment A operand: only the LDS-DMA kernels above read it (gemm_a2_ok)
   consider(0, 128, 128, 512, 1.05);
@@ -595,7 +588,6 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.A2) FDMI_CHECK(p.big != 0, "gemm: a second A segment is read by the LDS-DMA kernels only (forced tile?)");
   if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
   if (p.big == 2) FDMI_CHECK(gemm4_eligible(a, p.BN), "gemm: 256x320 / 256x192 tile not applicable to this problem");
-  if (p.big == 3) FDMI_CHECK(gemm6_eligible(a), "gemm: 128x320 deferred-epilogue tile not applicable to this problem");
   a.splitk = p.splitk;
   {  // every split must own at least one K tile (slabs of empty splits would stay uninitialised)
     const int kt = cdiv(a.K, 64);
@@ -609,9 +601,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     ++g_gemm_log.n[std::make_tuple(a.mode, a.M, a.N, a.K, a.act, (a.residual ? 1 : 0) | (a.preact ? 2 : 0) | (a.accum_atomic ? 4 : 0) | (a.out_f32 ? 8 : 0) | (a.dgrad ? 16 : 0),
                                    p.big ? p.big * 1000 + p.BN : p.BM * 1000 + p.BN, a.splitk)];
   int rc;
-  if (p.big == 3)
-    rc = launch_gemm6(a, stream);
-  else if (p.big == 2)
+  if (p.big == 2)
     rc = launch_gemm4(a, stream, p.BN);
   else if (p.big)
     rc = launch_gemm3(a, p.BN, stream);

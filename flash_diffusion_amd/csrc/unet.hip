@@ -723,7 +723,7 @@ struct Exec {
       if (!q.accum_atomic && q.splitk == 1 && gemm_ws_bytes(q)) q.splitk = 0;
       const GemmPlan p = plan_gemm(q, true);
       fprintf(stderr, "PLANGEMM mode=%d M=%d N=%d K=%d act=%d res=%d dgrad=%d atomic=%d kernel=%d BM=%d BN=%d splitk=%d\n", a.mode, a.M, a.N,
-              a.K, a.act, a.residual ? 1 : 0, a.dgrad, a.accum_atomic, p.big, p.big == 3 ? 128 : (p.big ? 256 : p.BM), p.BN, p.splitk);
+              a.K, a.act, a.residual ? 1 : 0, a.dgrad, a.accum_atomic, p.big, p.big ? 256 : p.BM, p.BN, p.splitk);
     }
     if (!a.accum_atomic && a.splitk == 1) {  // let the launcher split K when the tile grid under-fills the chip
       const size_t wsb = gemm_ws_bytes(a);

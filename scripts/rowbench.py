@@ -95,75 +95,7 @@ def dev_sweep(reps):
         print(line, flush=True)
 
 
-def g6_sweep(reps):
-    """round 4: the 128 x 320 deferred-epilogue kernel (gemm6.hip) against the 256 x 320 kernel on the row and conv shapes of C2;
-    outputs compared element-wise (bias enters gemm6 through the accumulators' initial value and a residual sum is rounded twice:
-    not bit-identical -- the bar is one bf16 unit of the largest magnitude)"""
-    t4, t6 = TILES["g4 256x320"], (128 << 16) | 320
-    cases = [(131072, 320, 320, True), (131072, 320, 320, False), (131072, 960, 320, False), (65536, 320, 320, True),
-             (131072, 320, 1280, True), (32768, 640, 640, True), (32768, 1920, 640, False), (32768, 640, 2560, True),
-             (65536, 320, 448, True), (8192, 1280, 1280, True)]
-    for (M, N, K, res) in cases:
-        nset = min(6, max(2, int(600e6 // (2 * M * (K + N * (2 if res else 1)))) + 1))
-        sets = []
-        for s_ in range(nset):
-            A = torch.randn(M, K, device="cuda").to(BF)
-            W = (torch.randn(N, K, device="cuda") * K ** -0.5).to(BF)
-            out = torch.empty(M, N, dtype=BF, device="cuda")
-            R = torch.randn(M, N, device="cuda").to(BF) if res else None
-            sets.append((A, W, out, R))
-        bias = torch.randn(N, device="cuda")
-        by = 2.0 * M * (K + N * (2 if res else 1)) + 2.0 * N * K
-        line = f"M={M:6d} N={N:5d} K={K:5d} res={int(res)} |"
-        ref = None
-        from flash_diffusion_amd._lib import lib
-        for name, tile in (("g4 256x320", t4), ("g6 128x320", t6), ("g4 K-loop", t4), ("g6 K-loop", t6)):
-            fns = [(lambda A=A, W=W, out=out, R=R: ops.gemm(A, W, bias=bias, residual=R, out=out, force_tile=tile)) for (A, W, out, R) in sets]
-            if name.endswith("K-loop"):
-                lib().fdmi_tune_set(40, 32)
-                us = bench(fns, reps)
-                lib().fdmi_tune_set(40, 0)
-                line += f" {name}: {us:6.1f} us |"
-                continue
-            us = bench(fns, reps)
-            sets[0][2].zero_()
-            fns[0]()
-            torch.cuda.synchronize()
-            tag = ""
-            if ref is None:
-                ref = sets[0][2].float().clone()
-            else:
-                d = (sets[0][2].float() - ref).abs()
-                tag = f" max|diff| {float(d.max()):.3g} (max|ref| {float(ref.abs().max()):.3g}, {int((d > 0).sum())} differ)"
-            line += f" {name}: {us:6.1f} us {by / us / 1e6:4.2f} TB/s {2.0 * M * N * K / us / 1e6:5.0f} TF{tag} |"
-        print(line, flush=True)
-    # implicit-GEMM convolutions (3x3, stride 1) with the time-embedding row vector and a residual
-    for (B, H, Cin, Cout, rv, res) in [(32, 64, 320, 320, True, False), (32, 64, 320, 320, False, True), (32, 32, 640, 640, True, False),
-                                      (32, 64, 640, 320, False, True), (32, 16, 1280, 1280, True, False)]:
-        x = torch.randn(B, H, H, Cin, device="cuda").to(BF)
-        w = ops.pack_conv_weight(torch.randn(Cout, Cin, 3, 3, device="cuda") * (9 * Cin) ** -0.5)
-        bias = torch.randn(Cout, device="cuda")
-        rvec = torch.randn(B, Cout, device="cuda").to(BF) if rv else None
-        R = torch.randn(B * H * H, Cout, device="cuda").to(BF) if res else None
-        line = f"conv3x3 B={B} {H}x{H} {Cin}->{Cout} rowvec={int(rv)} res={int(res)} |"
-        ref = None
-        for name, tile in (("g4 256x320", t4), ("g6 128x320", t6)):
-            out = torch.empty(B * H * H, Cout, dtype=BF, device="cuda")
-            fn = lambda: ops.conv2d_nhwc(x, w, KH=3, KW=3, pad=1, bias=bias, rowvec=rvec, rows_per_batch=H * H, residual=R, out=out, force_tile=tile)
-            us = bench([fn], reps)
-            tag = ""
-            if ref is None:
-                ref = out.float().clone()
-            else:
-                d = (out.float() - ref).abs()
-                tag = f" max|diff| {float(d.max()):.3g} (max|ref| {float(ref.abs().max()):.3g})"
-            line += f" {name}: {us:6.1f} us {2.0 * B * H * H * Cout * 9 * Cin / us / 1e6:5.0f} TF{tag} |"
-        print(line, flush=True)
-
-
 def main():
-    if len(sys.argv) > 1 and sys.argv[1] == "g6":
-        return g6_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 30)
     if len(sys.argv) > 1 and sys.argv[1] == "dev":
         return dev_sweep(int(sys.argv[2]) if len(sys.argv) > 2 else 30)
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 30
