@@ -145,6 +145,25 @@ def dominant_family(arch):
         sys.path.pop(0)
 
 
+def parity_record():
+    """the headline workload's measured distance to the reference's fixture, from the newest committed parity log of the GPU tests
+    (profiles/rN_parity_fullsize.txt: tests/test_fullsize_parity_gpu.py on BASELINE configs[1] at its own batch, B = 16, against
+    tests/golden/c2_sd15_r128_n4_b16.npz made by the REAL reference class).  fp32_gate: the validation precision north_star's
+    1e-3 is stated for; bf16: the kernels this bench times (the reference's own bf16-mixed sits at the same distance,
+    tests/test_precision_class.py)."""
+    import re
+    f = _latest_profile("r*_parity_fullsize.txt")
+    if f is None:
+        return None
+    rec = {"source": os.path.relpath(f, ROOT), "fixture": "tests/golden/c2_sd15_r128_n4_b16.npz (reference FlashDiffusion, SD1.5 r128, 4 teacher steps, B = 16)"}
+    for line in open(f):
+        m = re.match(r"step c2_sd15_r128_n4_b16 \[(bf16|fp32)\]: teacher_output=(\S+) student_output=(\S+) .* loss_rel=([0-9.e+-]+),", line)
+        if m:
+            rec["fp32_gate" if m.group(1) == "fp32" else "bf16"] = {"loss_rel": float(m.group(4)), "teacher_output_rel": float(m.group(2)),
+                                                                  "student_output_rel": float(m.group(3))}
+    return rec if ("bf16" in rec or "fp32_gate" in rec) else None
+
+
 def load_traffic(buckets):
     """HBM bytes per launch per kernel family from the newest profiles/rN_traffic.json -- for every family whose source files
     (flash_diffusion_amd._lib.kernel_source_hash) are the ones the counters were collected on.  Returns (unused, provenance,
@@ -497,7 +516,11 @@ def main():
                        "dev_switches": {k: os.environ[k] for k in ("FDMI_TUNE", "FDMI_TEACHER_LOOP", "FDMI_CFG_DEDUP",
                                                                    "FDMI_NO_CTX_CACHE", "FDMI_TEACHER_STREAM",
                                                                    "FDMI_DEFER_BACKWARD") if os.environ.get(k)}},
-            "roofline": roofline, "cpu_baseline": cpu, "secondary": {"sampler": sampler, "two_optimizer_step": two_opt, "lpips_step": lpips_leg},
+            "roofline": roofline, "cpu_baseline": cpu, "parity": parity_record() if headline else None,
+            # the like-for-like numbers of the reference's own loop, also kept under "secondary":
+            "two_optimizer_step_ms": two_opt["ms_per_step"] if two_opt else None,          # G + D training_step (TR:169-218)
+            "lpips_step_ms": lpips_leg["ms_per_step"] if lpips_leg else None,              # generator iteration with the YAMLs' lpips loss
+            "secondary": {"sampler": sampler, "two_optimizer_step": two_opt, "lpips_step": lpips_leg},
         }
         print(json.dumps(line))
     if world > 1:

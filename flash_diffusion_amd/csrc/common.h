@@ -40,7 +40,25 @@ __device__ __forceinline__ float erf_fast(float x) {
   const float r = 1.f - poly * __expf(-ax * ax);
   return copysignf(r, x);
 }
-__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.f + erf_fast(x * 0.70710678118654752f)); }
+// exact-GELU for the GEGLU epilogues (round 4; they are VALU-bound: half of a K = 320 GEGLU launch is its epilogue).
+// erfc(z) = 2^(-Q(z)) with Q a degree-6 polynomial without constant term, fitted on [0, 4] (weighted least squares on the
+// absolute error of erf; evaluated in fp32: |error of erf| <= 3.1e-7, the Abramowitz-Stegun form above has 1.5e-7 on paper and
+// 4.6e-7 through gelu in fp32 -- this one 5.1e-7).  With z = |x| / sqrt(2) folded into the coefficients and the 1/2 of
+// 0.5 x (1 + erf) folded into the exponent:   gelu(x) = max(x, 0) - |x| * 2^(-(1 + |x| P(|x|))),
+// one v_exp_f32 (natively base 2) and six fmas per element -- no reciprocal, no second transcendental, no copysign.
+// |x| is clamped to the fitted range (beyond it erfc < 2e-8 and the polynomial's negative leading term would take over).
+__device__ __forceinline__ float gelu_f(float x) {
+  const float a = fabsf(x);
+  const float c = fminf(a, 5.65685425f);
+  float t = -1.98600017e-05f;
+  t = fmaf(t, c, 0.000662309048f);
+  t = fmaf(t, c, -0.00775970362f);
+  t = fmaf(t, c, 0.0529644412f);
+  t = fmaf(t, c, 0.459066224f);
+  t = fmaf(t, c, 1.1511191f);
+  const float q1 = fmaf(t, c, 1.f);
+  return fmaxf(x, 0.f) - a * __builtin_amdgcn_exp2f(-q1);
+}
 // tanh-approximated GELU: 0.5 x (1 + tanh(u)) = x / (1 + exp(-2u)), u = sqrt(2/pi) (x + 0.044715 x^3): one exp, one rcp
 __device__ __forceinline__ float gelu_tanh_fast(float x) {
   const float u2 = 1.5957691216057308f * fmaf(0.044715f * x * x, x, x);

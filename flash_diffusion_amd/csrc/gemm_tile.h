@@ -251,7 +251,10 @@ struct EpiWalk {
     return -1;
   }
 };
-template <int NF, int MF, bool RES, bool ADD, bool VEC, int PHASE>
+// GNS: also accumulate the consumer's GroupNorm sums (GemmArgs::gn_stats, see gn_lane_add / gn_flush above): per unit the lane's
+// partial sums run over the unit's row fragments (all of one sample), then ONE cross-lane reduction over the lanes that hold the
+// same columns -- 16 for a single pair, 8 for a double (lanes j < 8 and j >= 8 hold different pairs there)
+template <int NF, int MF, bool RES, bool ADD, bool VEC, int PHASE, bool GNS = false>
 __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, int nw, f32x4 (&acc)[NF][MF], int g, int j) {
   constexpr int NP = NF / 2;
   // units: a double (pairs P, P + 1: line-wide) or a single pair.  PHASE 0: doubles from pair 0; 1: pair 0 single, doubles from
@@ -281,6 +284,8 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, in
     rb[i] = (u16x8){0, 0, 0, 0, 0, 0, 0, 0};
     load_micro(i);
   }
+  float gs[4] = {0.f, 0.f, 0.f, 0.f};   // (GNS) this unit's partial sums: group of the lane's first columns / the next group
+  int gsplit = 8;
   auto finish = [&](float (&v)[8], const float (&b8)[8], const float (&r8)[8], const u16x8& res, bf16_t* dst) {
     if (ADD) {
 #pragma unroll
@@ -297,6 +302,7 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, in
     uint4 pk;
     pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
     *(uint4*)dst = pk;
+    if (GNS) gn_lane_add<8>(v, gsplit, gs);
   };
   int mi = 0;   // micro-step (a compile-time constant at every use once the loops are unrolled)
 #pragma unroll
@@ -304,6 +310,10 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, in
     const int P = Wk::unit_p(k);
     const bool dbl = Wk::unit_dbl(k);
     const int cb = (dbl ? colT : col0) + 32 * P;                // this lane's first column in this unit
+    if (GNS) {
+      gs[0] = gs[1] = gs[2] = gs[3] = 0.f;
+      gsplit = (cb / a.gn_cpg + 1) * a.gn_cpg - cb;
+    }
     float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (ADD) {
       const float4 b0 = *(const float4*)(a.bias + cb), b1 = *(const float4*)(a.bias + cb + 4);
@@ -354,11 +364,33 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, in
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the next steps' loads / address math from piling up registers (the tile is at the VGPR cap)
     }
+    if (GNS) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+#pragma unroll
+        for (int o = 1; o < (dbl ? 8 : 16); o <<= 1) gs[q] += __shfl_xor(gs[q], o, 64);
+      }
+      if ((dbl ? jr : j) == 0) {
+        const int gA = cb / a.gn_cpg;
+        float* d = a.gn_stats + ((mw / a.gn_rows) * a.gn_G + gA) * 2;
+        atomicAdd(d, gs[0]);
+        atomicAdd(d + 1, gs[1]);
+        if ((cb + 7) / a.gn_cpg != gA) {
+          atomicAdd(d + 2, gs[2]);
+          atomicAdd(d + 3, gs[3]);
+        }
+      }
+    }
   }
   if constexpr ((NF & 1) != 0) {   // BN = 160: the odd fragment, 4 columns per lane
     const int cl = nw + (NF - 1) * 16 + g * 4;
     bf16_t* const cq = (bf16_t*)a.C + (int64_t)(mw + j) * a.ldc + cl;
     float b4[4] = {0.f, 0.f, 0.f, 0.f}, r4[4] = {0.f, 0.f, 0.f, 0.f};
+    int gsplit4 = 4;
+    if (GNS) {
+      gs[0] = gs[1] = gs[2] = gs[3] = 0.f;
+      gsplit4 = (cl / a.gn_cpg + 1) * a.gn_cpg - cl;
+    }
     if (ADD) {
       const float4 b = *(const float4*)(a.bias + cl);
       b4[0] = b.x; b4[1] = b.y; b4[2] = b.z; b4[3] = b.w;
@@ -386,7 +418,9 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, in
       pk.x = pack2bf(v[0], v[1]);
       pk.y = pack2bf(v[2], v[3]);
       *(uint2*)(cq + mf * cstep) = pk;
+      if (GNS) gn_lane_add<4>(v, gsplit4, gs);
     }
+    if (GNS) gn_flush(a, mw, cl, 4, j, gs);
   }
 }
 
@@ -513,17 +547,19 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
       }
     return;
   }
-  if constexpr (EPI != 1 && !GN) {
+  if constexpr (EPI != 1) {
     // (knob 40 = 64: the general epilogue below for every problem -- the A/B switch of the lean one)
-    if (epi_fast_ok(a) && !a.gn_stats && !(a.dev & 64) && (FULL || (mw + MF * 16 <= a.M && nw + NF * 16 <= a.N))) {
+    if (epi_fast_ok(a) && GN == (a.gn_stats != nullptr) && !(a.dev & 64) && (FULL || (mw + MF * 16 <= a.M && nw + NF * 16 <= a.N))) {
       // knob 40 = 256: every pair single (the 16-row x 64-byte pattern of the MFMA layout), the A/B switch of the line-wide form
-      const int ph = (a.dev & 256) ? 2 : ((nw >> 5) & 1);
+      // (the GroupNorm-sum instantiations keep every pair single: with the doubles' extra live registers hipcc spilled an LDS
+      // offset of the conv kernel's K LOOP -- and waits vmcnt(0), i.e. for the whole LDS-DMA ring, at its reload)
+      const int ph = ((a.dev & 256) || GN) ? 2 : ((nw >> 5) & 1);
       const int sel = (a.residual ? 4 : 0) | (a.bias ? 2 : 0) | (a.rowvec ? 1 : 0);
 #define FDMI_EPI_FAST(R_, A_, V_)                                                                 \
   do {                                                                                            \
-    if (ph == 0) tile_epilogue_fast<NF, MF, R_, A_, V_, 0>(a, mw, nw, acc, g, j);                 \
-    else if (ph == 1) tile_epilogue_fast<NF, MF, R_, A_, V_, 1>(a, mw, nw, acc, g, j);            \
-    else tile_epilogue_fast<NF, MF, R_, A_, V_, 2>(a, mw, nw, acc, g, j);                         \
+    if (!GN && ph == 0) tile_epilogue_fast<NF, MF, R_, A_, V_, 0, false>(a, mw, nw, acc, g, j);   \
+    else if (!GN && ph == 1) tile_epilogue_fast<NF, MF, R_, A_, V_, 1, false>(a, mw, nw, acc, g, j); \
+    else tile_epilogue_fast<NF, MF, R_, A_, V_, 2, GN>(a, mw, nw, acc, g, j);                     \
   } while (0)
       switch (sel) {
         case 0: FDMI_EPI_FAST(false, false, false); break;

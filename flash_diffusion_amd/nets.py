@@ -17,6 +17,7 @@ stream and the autograd edge around the one forward / backward call.  GPU only: 
 from __future__ import annotations
 
 import ctypes as C
+import math
 import weakref
 from typing import Dict, List, Optional, Sequence
 
@@ -299,15 +300,20 @@ class MiAutoencoderKL(_NetBase):
 
 class MiAutoencoderKLDiffusers(nn.Module):
     """Drop-in for the reference wrapper ``AutoencoderKLDiffusers`` (vae/autoencoderKL.py:9-128): ``decode(z)`` divides by the
-    scaling factor (or applies latents_mean / latents_std) and runs the decoder; latents larger than ``tiling_size`` would be
-    tiled by the reference (the 64x64 LPIPS crops never are) -- not built.  ``encoder``: an optional torch module with the
-    wrapper's ``encode(x) -> latents`` contract for recipes that feed pixels (the encode runs under no_grad, outside the path)."""
+    scaling factor (or applies latents_mean / latents_std) and runs the decoder; latents larger than ``tiling_size`` are decoded
+    in overlapping tiles merged with the reference's gaussian weights (autoencoderKL.py:80-123, models/utils.py:12-257) -- here
+    ALL tiles of ALL samples go through the decoder plan as batches and are merged on the device (the reference decodes tile
+    by tile and merges on the host; ``decode`` returns a device tensor).  ``encoder``: an optional torch module with the wrapper's
+    ``encode(x) -> latents`` contract for recipes that feed pixels (the encode runs under no_grad, outside the path)."""
 
-    def __init__(self, vae_model: MiAutoencoderKL, input_key="image", tiling_size=(64, 64), encoder: Optional[nn.Module] = None):
+    def __init__(self, vae_model: MiAutoencoderKL, input_key="image", tiling_size=(64, 64), tiling_overlap=(16, 16),
+                 encoder: Optional[nn.Module] = None, tile_batch: int = 8):
         super().__init__()
         self.vae_model = vae_model
-        self.config = type("Cfg", (), dict(input_key=input_key, tiling_size=tuple(tiling_size)))()
+        self.config = type("Cfg", (), dict(input_key=input_key, tiling_size=tuple(tiling_size), tiling_overlap=tuple(tiling_overlap)))()
         self.tiling_size = tuple(tiling_size)
+        self.tiling_overlap = tuple(tiling_overlap)
+        self.tile_batch = int(tile_batch)           # tiles per decoder launch (bounds the plan's workspace)
         self.encoder = encoder
         self.downsampling_factor = vae_model._up
         self.latent_channels = vae_model.config.latent_channels
@@ -331,8 +337,51 @@ class MiAutoencoderKLDiffusers(nn.Module):
         else:
             z = z / c.scaling_factor
         if z.shape[2] > self.tiling_size[0] or z.shape[3] > self.tiling_size[1]:
-            raise NotImplementedError("tiled decoding (latents larger than tiling_size) is outside the distillation path")
+            return self._decode_tiled(z)
         return self.vae_model.decode(z).sample
+
+    @staticmethod
+    def _gaussian_weights(tile_w, tile_h, device):
+        """models/utils.py:155-201 (fp64, as numpy computes them there); the x midpoint is (w - 1) / 2, the y midpoint h / 2"""
+        var = 0.01
+        x = torch.arange(tile_w, dtype=torch.float64)
+        y = torch.arange(tile_h, dtype=torch.float64)
+        mx, my = (tile_w - 1) / 2, tile_h / 2
+        xp = torch.exp(-(x - mx) * (x - mx) / (tile_w * tile_w) / (2 * var)) / math.sqrt(2 * math.pi * var)
+        yp = torch.exp(-(y - my) * (y - my) / (tile_h * tile_h) / (2 * var)) / math.sqrt(2 * math.pi * var)
+        return torch.outer(yp, xp).to(device)
+
+    def _decode_tiled(self, z, decode_fn=None):
+        """autoencoderKL.py:86-123: tiles of `tiling_size` every `tiling_size - overlap` latents (trailing ones smaller: zero-padded
+        for the decoder, cropped afterwards), gaussian-weighted merge.  Same arithmetic as the reference (fp32 accumulators, fp64
+        weights), tiles batched through the decoder."""
+        decode_fn = decode_fn or (lambda t: self.vae_model.decode(t).sample)
+        B, C, H, W = z.shape
+        th, tw = self.tiling_size
+        ov_h = self.tiling_overlap[0] if H > th else 0
+        ov_w = self.tiling_overlap[1] if W > tw else 0
+        assert ov_h < th and ov_w < tw, "tiling_overlap must be smaller than tiling_size (the reference's tile step is their difference)"
+        f = self.downsampling_factor
+        origins = [(i, j) for i in range(0, H, th - ov_h) for j in range(0, W, tw - ov_w)]
+        tiles = torch.zeros(B * len(origins), C, th, tw, dtype=z.dtype, device=z.device)
+        shapes = []
+        for b in range(B):
+            for k, (i, j) in enumerate(origins):
+                t = z[b, :, i:i + th, j:j + tw]
+                tiles[b * len(origins) + k, :, :t.shape[1], :t.shape[2]] = t
+                if b == 0:
+                    shapes.append((t.shape[1], t.shape[2]))
+        dec = torch.cat([decode_fn(tiles[s:s + self.tile_batch]) for s in range(0, tiles.shape[0], self.tile_batch)], 0)
+        oc = dec.shape[1]
+        out = torch.zeros(B, oc, H * f, W * f, dtype=torch.float32, device=z.device)
+        wsum = torch.zeros(1, 1, H * f, W * f, dtype=torch.float32, device=z.device)
+        for k, (i, j) in enumerate(origins):
+            hh, ww = shapes[k][0] * f, shapes[k][1] * f
+            w = self._gaussian_weights(ww, hh, z.device)
+            sl = (slice(None), slice(None), slice(i * f, i * f + hh), slice(j * f, j * f + ww))
+            out[sl] += dec[k::len(origins), :, :hh, :ww] * w
+            wsum[sl] += w
+        return out / wsum
 
 
 # ====================================================================================================================

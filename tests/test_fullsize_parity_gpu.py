@@ -183,6 +183,62 @@ def _c2_body(precision, B=2):
     _check_projected_grads(f"{tag} [{precision}]", m, blob, g, precision == "fp32")
 
 
+# ---- 1a: full-width B = 1 STEPS of C3 / C4 / C5 -------------------------------------------------------------------------
+def _have(name):
+    return os.path.exists(os.path.join(GOLDEN_DIR, name + ".npz"))
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
+@pytest.mark.parametrize("name", ["step_sdxl", "step_pixart", "step_sd3"])
+def test_full_width_step_matches_reference_golden(name, precision):
+    """SDXL UNet / PixArt-alpha XL/2 / SD3-medium at 128x128 latents, rank-64 LoRA, one teacher CFG step, l2 + DMD + lsgan with the
+    example's own PatchGAN head at its real width: forward AND backward against tests/golden/step_*.npz (the REAL FlashDiffusion /
+    FlashDiffusionSD3 over the fp32 oracle denoisers, `python -m oracle.make_golden fullstep`)."""
+    assert _have(name), f"tests/golden/{name}.npz is missing (python -m oracle.make_golden fullstep {name})"
+    run_isolated(__name__, "_fullstep_body", (name, precision), timeout=1500)
+
+
+def _fullstep_body(name, precision):
+    from flash_diffusion_amd import workloads
+    from flash_diffusion_amd.dit import MiSD3Transformer2DModel, MiTransformer2DModel
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from flash_diffusion_amd.unet import MiUNet2DConditionModel
+    from oracle.golden_cases import FULLSTEP_CASES, FULLSTEP_LORA_RANK, build_fullstep_models, fullstep_inputs
+    kind, kw, _ = FULLSTEP_CASES[name]
+    g = load_case(name)
+    blob = np.load(os.path.join(GOLDEN_DIR, name + ".npz"))
+    cls, arch = {"step_sdxl": (MiUNet2DConditionModel, workloads.SDXL), "step_pixart": (MiTransformer2DModel, workloads.PIXART),
+                 "step_sd3": (MiSD3Transformer2DModel, workloads.SD3)}[name]
+
+    def make(lora_rank):
+        with torch.device("cuda"):
+            m = cls(**arch, precision=precision)
+        m = m.cuda()
+        if lora_rank:
+            m.add_adapter(lora_rank)
+        return m
+    teacher, student, disc = build_fullstep_models(name, "cuda", make)
+    teacher.freeze()
+    assert student.lora_rank == FULLSTEP_LORA_RANK
+    batch, cond = fullstep_inputs(name, "cuda")
+    if kind == "fd":
+        m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                           teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=cond, discriminator=disc).cuda()
+    else:
+        m = FlashDiffusionSD3(FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                              teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), discriminator=disc, pipeline=cond).cuda()
+    assert type(m.discriminator).__name__ == "MiDiscriminator"
+    m.discriminator.precision = precision
+    m.draws = Draws(g["draws"])
+    out = m(batch, step=0, device="cuda") if kind == "fd" else m(batch, step=0)
+    _check_outputs(f"{name} [{precision}]", m, g, out, precision == "fp32")
+    out["loss"][0].backward()
+    torch.cuda.synchronize()
+    _check_projected_grads(f"{name} [{precision}]", m, blob, g, precision == "fp32")
+
+
 def test_c1_full_size_step_bf16():
     run_isolated(__name__, "_c1_bf16_body", (), timeout=900)
 

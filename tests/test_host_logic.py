@@ -551,3 +551,27 @@ def test_t5_relative_position_buckets_match_transformers():
         rel = pos[None, :] - pos[:, None]
         ref = T5Attention._relative_position_bucket(rel, bidirectional=True, num_buckets=nb, max_distance=md)
         assert torch.equal(relative_position_bucket(rel, nb, md), ref)
+
+
+def test_tiled_vae_decode_merges_like_the_reference():
+    """MiAutoencoderKLDiffusers._decode_tiled (tiles batched through the decoder, merged where they are) with a toy decoder on
+    the host against oracle/tiler_ref.py (pinned to the reference's Tiler): partial trailing tiles, asymmetric overlaps, batch"""
+    from types import SimpleNamespace
+    from flash_diffusion_amd.nets import MiAutoencoderKLDiffusers
+    from oracle.tiler_ref import tiled_decode_ref
+    torch.manual_seed(1)
+    mix = torch.randn(3, 4)
+
+    def decode(t):
+        u = torch.nn.functional.interpolate(t, scale_factor=4, mode="nearest")
+        o = torch.einsum("oc,bchw->bohw", mix, u)
+        return o + 0.01 * torch.arange(o.shape[-1])[None, None, None, :]
+    fake = SimpleNamespace(_up=4, config=SimpleNamespace(latent_channels=4, scaling_factor=1.0, latents_mean=None, latents_std=None))
+    for (H, W, ts, ov, tb) in [(40, 52, (16, 16), (4, 4), 8), (32, 32, (16, 16), (4, 4), 3), (33, 47, (16, 24), (5, 7), 1)]:
+        w = MiAutoencoderKLDiffusers.__new__(MiAutoencoderKLDiffusers)
+        torch.nn.Module.__init__(w)
+        w.vae_model, w.tiling_size, w.tiling_overlap, w.tile_batch, w.downsampling_factor = fake, ts, ov, tb, 4
+        z = torch.randn(3, 4, H, W)
+        got = w._decode_tiled(z, decode_fn=decode)
+        ref = tiled_decode_ref(z, decode, ts, ov, 4)
+        assert got.shape == ref.shape and float((got - ref).abs().max()) <= 1e-6 * float(ref.abs().max()), (H, W)

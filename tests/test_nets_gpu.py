@@ -41,6 +41,37 @@ VAE_CASES = {
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
+def test_tiled_vae_decode_matches_the_reference_tiling(precision):
+    """latents larger than `tiling_size` (every 128x128-latent recipe at sampling time: FD:754-915 -> autoencoderKL.py:80-123): the
+    HIP decoder over batched tiles + on-device gaussian merge against the oracle decoder driven by oracle/tiler_ref.py (pinned to
+    the reference's Tiler); a 40x52 latent with 16x16 tiles and 4-latent overlaps: 4 x 5 tiles per sample, partial trailing tiles"""
+    run_isolated(__name__, "_tiled_body", (precision,), timeout=900)
+
+
+def _tiled_body(precision):
+    from flash_diffusion_amd.nets import MiAutoencoderKL, MiAutoencoderKLDiffusers
+    from oracle.tiler_ref import tiled_decode_ref
+    from oracle.vae_cpu import AutoencoderKLDecoderRef, seeded_net_init_
+    kw = dict(block_out_channels=(32, 64, 64), layers_per_block=1)
+    o = seeded_net_init_(AutoencoderKLDecoderRef(**kw), 5)
+    m = _load(MiAutoencoderKL(**kw, precision=precision), o)
+    m.freeze()
+    wrap = MiAutoencoderKLDiffusers(m, tiling_size=(16, 16), tiling_overlap=(4, 4), tile_batch=6)
+    g = torch.Generator().manual_seed(2)
+    z = torch.randn(2, 4, 40, 52, generator=g) * 0.18215
+    with torch.no_grad():
+        ref = tiled_decode_ref(z / 0.18215, o.decode_raw, (16, 16), (4, 4), scale=4)
+        out = wrap.decode(z.cuda())
+        small = wrap.decode(z[:, :, :16, :16].cuda())            # at or below the tile size: the plain decode
+        ref_small = o.decode(z[:, :, :16, :16])
+    torch.cuda.synchronize()
+    e, es = rel_err(out, ref), rel_err(small, ref_small)
+    parity_log(f"tiled vae decode 40x52 latents, 16x16 tiles [{precision}]: image {e:.3e} (untiled 16x16: {es:.3e})", "nets_parity.txt")
+    tol = 1e-4 if precision == "fp32" else 3e-2
+    assert tuple(out.shape) == (2, 3, 160, 208) and out.is_cuda and e <= tol and es <= tol, (e, es)
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("name", list(VAE_CASES))
 def test_vae_decoder_matches_oracle(name, precision):
     run_isolated(__name__, "_vae_body", (name, precision), timeout=900)

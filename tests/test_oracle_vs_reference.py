@@ -489,3 +489,35 @@ def test_sd3_lpips_distill_with_vae_restatement_is_bit_identical(step, px):
         assert list(res[0]) == list(res[1]) and len(res[0]) == 2
         for k in res[0]:
             assert res[0][k].shape == (2, 3, 32, 32) and torch.equal(res[0][k], res[1][k]), k
+
+
+def test_tiled_decode_restatement_matches_the_reference_tiler():
+    """oracle/tiler_ref.py (the checker of the HIP VAE's tiled decode) against the reference's OWN Tiler / pad
+    (/root/reference/src/flash/models/utils.py, imported unmodified) driven as autoencoderKL.py:86-123 drives them: bit-identical,
+    including the trailing partial tiles and the asymmetric gaussian midpoints"""
+    shim_import.import_reference()
+    from flash.models.utils import Tiler, pad
+    from oracle.tiler_ref import tiled_decode_ref
+    torch.manual_seed(0)
+    mix = torch.randn(3, 4)
+
+    def decode(t):      # a toy decoder: x4 nearest upsample, channel mix, a position-dependent term
+        u = torch.nn.functional.interpolate(t, scale_factor=4, mode="nearest")
+        o = torch.einsum("oc,bchw->bohw", mix, u)
+        return o + 0.01 * torch.arange(o.shape[-1])[None, None, None, :]
+
+    def reference(z, ts, ov, scale):
+        samples = []
+        for i in range(z.shape[0]):
+            tiler = Tiler()
+            tiles = tiler.get_tiles(input=z[i].unsqueeze(0), tile_size=ts, overlap_size=ov, scale=scale, out_channels=3)
+            for a, row in enumerate(tiles):
+                for b, tile in enumerate(row):
+                    shp = tile.shape
+                    d = decode(pad(tile, base_h=ts[0], base_w=ts[1]))
+                    tiles[a][b] = d[0, :, :int(shp[2] * scale), :int(shp[3] * scale)].cpu().unsqueeze(0)
+            samples.append(tiler.merge_tiles(tiles=tiles))
+        return torch.cat(samples, 0)
+    for (H, W, ts, ov) in [(40, 52, (16, 16), (4, 4)), (32, 32, (16, 16), (4, 4)), (20, 16, (16, 16), (6, 2)), (33, 47, (16, 24), (5, 7))]:
+        z = torch.randn(2, 4, H, W)
+        assert torch.equal(reference(z, ts, ov, 4), tiled_decode_ref(z, decode, ts, ov, 4)), (H, W, ts, ov)
