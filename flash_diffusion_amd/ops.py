@@ -121,7 +121,9 @@ def tune(key):
 def wgrad_tn(X, Y, out):
     """out[N1, N2] (f32, accumulated) += X[M, N1]^T @ Y[M, N2]: both operands row-major bf16, contraction over the rows"""
     M = X.shape[0]
-    assert Y.shape[0] == M and X.stride(1) == 1 and Y.stride(1) == 1 and out.dtype == torch.float32 and out.stride(1) == 1
+    # (a size-1 trailing dimension carries an arbitrary stride -- e.g. the [M, 1] logit gradient of a PatchGAN head's last conv)
+    unit = lambda t: t.shape[1] == 1 or t.stride(1) == 1
+    assert Y.shape[0] == M and unit(X) and unit(Y) and out.dtype == torch.float32 and unit(out)
     if _f32(X):
         check(lib().fdmi_wgrad_tn_f32(ptr(X), X.stride(0), ptr(Y), Y.stride(0), M, X.shape[1], Y.shape[1], ptr(out), out.stride(0),
                                       stream_ptr()))

@@ -9,6 +9,7 @@ set -u
 round=${1:-2}
 [ -n "${2:-}" ] && export FDMI_TUNE=$2
 out=gpurun_out/prof
+rm -rf "$out"
 mkdir -p "$out"
 cd "$(dirname "$0")/.." || exit 1
 export TMPDIR=/tmp
@@ -18,8 +19,23 @@ echo "== rocprofv3 --kernel-trace --stats (4 steps: 1 warm-up + 2 timed + the pr
 timeout -s KILL 420 rocprofv3 --kernel-trace --stats -f csv -d "$out/stats" -o r${round} -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/stats_bench.json" 2> "$out/stats.err"
 echo "== rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, 3 steps each)"
-timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$out/pmc_fetch" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
-  > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err"
+# The FETCH_SIZE pass aborts now and then with HSA_STATUS_ERROR_INVALID_PACKET_FORMAT ~15 s in (round 3: every time on one box;
+# round 4: call 5 passed, call 10 failed, the WRITE / TCC / GRBM passes of the same call passed): retry, then fall back to the
+# three raw counters FETCH_SIZE is derived from on gfx950 (counter_defs.yaml) in one pass
+fetch_ok=0
+for try in 1 2 3; do
+  rm -rf "$out/pmc_fetch"
+  timeout -s KILL 240 rocprofv3 --pmc FETCH_SIZE --kernel-trace -f csv -d "$out/pmc_fetch" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
+    > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err"
+  if ls "$out"/pmc_fetch/*counter_collection.csv > /dev/null 2>&1 && ! grep -q INVALID_PACKET "$out/pmc_fetch.err"; then fetch_ok=1; echo "FETCH_SIZE pass: ok (try $try)"; break; fi
+  echo "FETCH_SIZE pass: failed (try $try): $(grep -c INVALID_PACKET "$out/pmc_fetch.err") malformed-packet lines"
+done
+if [ "$fetch_ok" = 0 ]; then
+  rm -rf "$out/pmc_fetch"
+  timeout -s KILL 240 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum --kernel-trace -f csv -d "$out/pmc_fetch" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
+    > "$out/pmc_fetch_bench.json" 2> "$out/pmc_fetch.err"
+  echo "raw TCC_EA0_RDREQ / RDREQ_32B / BUBBLE pass: $(ls "$out"/pmc_fetch/*counter_collection.csv 2>/dev/null | wc -l) counter file(s)"
+fi
 timeout -s KILL 240 rocprofv3 --pmc WRITE_SIZE --kernel-trace -f csv -d "$out/pmc_write" -o r${round} -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-secondary \
   > "$out/pmc_write_bench.json" 2> "$out/pmc_write.err"
 echo "== rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum (own pass: L2 hit rate per kernel)"

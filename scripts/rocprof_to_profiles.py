@@ -169,6 +169,11 @@ def main():
         return
     # FETCH_SIZE / WRITE_SIZE are reported in KB (MI355X_MICROARCH.md, HBM section); FETCH_SIZE x 2 on gfx950
     fetch, write = counter(a.fetch_dir, "FETCH_SIZE"), counter(a.write_dir, "WRITE_SIZE")
+    if not fetch:   # the raw counters FETCH_SIZE is derived from on gfx950 (counter_defs.yaml), collected when the derived pass aborts:
+        # FETCH_SIZE [KB] = (BUBBLE * 128 + (RDREQ - BUBBLE - RDREQ_32B) * 64 + RDREQ_32B * 32) / 1024
+        rd, r32, bub = (counter(a.fetch_dir, n) for n in ("TCC_EA0_RDREQ_sum", "TCC_EA0_RDREQ_32B_sum", "TCC_BUBBLE_sum"))
+        fetch = {n: (c, (bub.get(n, (0, 0.0))[1] * 128 + (v - bub.get(n, (0, 0.0))[1] - r32.get(n, (0, 0.0))[1]) * 64
+                         + r32.get(n, (0, 0.0))[1] * 32) / 1024) for n, (c, v) in rd.items()}
     out = {"source": f"profiles/r{a.round}_pmc_hbm_traffic{a.tag}.csv (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes; "
                      "fetch doubled per the gfx950 correction)", "kernels": {}}
     with open(f"{pre}_pmc_hbm_traffic{a.tag}.csv", "w") as fh:
