@@ -164,6 +164,53 @@ def parity_record():
     return rec if ("bf16" in rec or "fp32_gate" in rec) else None
 
 
+_PLAN_CHILD = """
+import sys; sys.path.insert(0, %r)
+import torch
+from flash_diffusion_amd import _lib, workloads
+from flash_diffusion_amd.unet import MiUNet2DConditionModel
+B, flags, lora = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+with torch.device("meta"):
+    m = MiUNet2DConditionModel(**workloads.SD15)
+    if lora:
+        m.add_adapter(lora)
+assert _lib.lib().fdmi_unet_workspace_bytes(m._plan().handle, B, 64, 64, 77, flags) > 0
+"""
+
+
+def algorithmic_bytes(batch, teacher_steps, lora_rank):
+    """{bench bucket: (algorithmic HBM bytes per step, launches per step)} of the C2 step's GEMM / conv launches: every operand of a
+    launch touched ONCE (A + W + C, + the residual; a GEGLU output is N / 2 wide; a 3x3 convolution's A operand is its input
+    tensor, taken as M * Cin elements -- exact for the stride-1 convolutions that carry the time, 4x too small / large for the
+    three down / up-sampling ones).  From the C++ plan's own work list in workspace-query mode (FDMI_PLAN_LOG, no GPU work): the
+    teacher's 2B forward x teacher_steps + the student's taped forward and backward.  None when the query fails."""
+    import re
+    import subprocess
+    tot = {}
+    try:
+        for (B, flags, lora, times) in ((2 * batch, 8, 0, teacher_steps), (batch, 1, lora_rank, 1)):
+            err = subprocess.run([sys.executable, "-c", _PLAN_CHILD % ROOT, str(B), str(flags), str(lora)],
+                                 env=dict(os.environ, FDMI_PLAN_LOG="1"), capture_output=True, text=True, check=True, timeout=300).stderr
+            for l in err.splitlines():
+                if not l.startswith("PLANGEMM"):
+                    continue
+                mode, M, N, K, act, res, dgrad, atomic, kern, BM, BN, sk = (int(v) for v in re.findall(r"=(-?\d+)", l))
+                if kern == 2:
+                    key = f"gemm4_kernel<256x{BN},{'conv' if mode else 'row'}>"
+                elif kern == 1:
+                    key = f"gemm3_kernel<256x{BN},{'conv' if mode else 'row'}>"
+                else:
+                    key = f"gemm_kernel<{BM},{BN},{'conv' if mode else 'row'}>"
+                nout = N // 2 if act == 2 else N
+                a_el = M * (K // 9 if (mode and K % 9 == 0) else K)
+                by = 2.0 * (a_el + N * K + M * nout * (2 if res else 1))
+                b0, n0 = tot.get(key, (0.0, 0))
+                tot[key] = (b0 + by * times, n0 + times)
+    except Exception:
+        return None
+    return tot
+
+
 def load_traffic(buckets):
     """HBM bytes per launch per kernel family from the newest profiles/rN_traffic.json -- for every family whose source files
     (flash_diffusion_amd._lib.kernel_source_hash) are the ones the counters were collected on.  Returns (unused, provenance,
@@ -396,6 +443,13 @@ def main():
         # HBM bytes per launch of that kernel family: PMC numbers cannot be collected from inside this process, so the
         # committed rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summary of this same command is read back (null if absent)
         traffic, traffic_src, traffic_all = load_traffic([r[0] for r in rows])
+        algo = algorithmic_bytes(B, args.teacher_steps, rank_r) if args.arch == "sd15" else None
+
+        def _traffic_ratio(key):   # counted HBM bytes per launch / algorithmic bytes per launch of a family (None without both)
+            if not algo or key not in algo or traffic_all.get(key) is None:
+                return None, None
+            per = algo[key][0] / max(algo[key][1], 1)
+            return per, traffic_all[key] / per
         fam = {}
         for key, label in (("gemm4_kernel<256x320,row>", "gemm4_row"), ("gemm4_kernel<256x320,conv>", "gemm4_conv"),
                            ("gemm4_kernel<256x192,row>", "gemm4_192_row"), ("attn_fwd_kernel", "attn_fwd")):
@@ -403,9 +457,11 @@ def main():
                 r = byname[key]
                 fam[label] = {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),
                               "frac": round(r[2] / (r[1] * 1e-3) / PEAK_BF16, 4), "launches": int(r[3]),
-                              "traffic": traffic_all.get(key)}
+                              "traffic": traffic_all.get(key), "algorithmic_bytes_per_launch": _traffic_ratio(key)[0],
+                              "traffic_over_algorithmic": _traffic_ratio(key)[1]}
         roofline = {"bound": "mfma", "kernel": name, "kernel_chosen_by": dominant_src, "achieved": ach, "peak": PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic_all.get(name),
+                    "algorithmic_bytes_per_launch": _traffic_ratio(name)[0], "traffic_over_algorithmic": _traffic_ratio(name)[1],
                     "traffic_source": traffic_src, "launches_per_step": int(tln),
                     "avg_launch_us": tms * 1e3 / tln, "algorithmic_gflop_per_launch": tfl / tln / 1e9,
                     "families": fam,

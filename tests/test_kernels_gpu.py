@@ -698,3 +698,68 @@ def test_gemm3_conv_fwd_and_dgrad(cfg, tile):
         dx = ops.conv2d_nhwc(dyn, ops.pack_conv_weight_dgrad(w.float()).cuda(), KH=k, KW=k, stride=s, pad=p, dgrad=1,
                              out_hw=(H << ups, W << ups), force_tile=tile)
         close(f"conv3_dgrad{cfg}_{tile:x}", dx.permute(0, 3, 1, 2), xin.grad)
+
+
+# ---- round 4: the lean / line-wide epilogues store exactly what the general epilogue stores ------------------------------------------
+EPI_CASES = [
+    # (kind, tile, M or (B, H), N, K or Cin, bias, residual, rowvec, gn)
+    ("row", (256 << 16) | 320, 1024, 320, 320, True, True, False, False),
+    ("row", (256 << 16) | 320, 512, 960, 320, True, False, False, False),
+    ("row", (256 << 16) | 320, 512, 640, 1280, False, True, False, False),
+    ("row", (256 << 16) | 320, 768, 320, 64, False, False, False, False),
+    ("row", (256 << 16) | 192, 512, 1152, 1152, True, True, False, False),
+    ("row", (256 << 16) | 160, 1232, 320, 768, True, True, False, False),      # ragged M: partial tiles fall back per wave
+    ("row", (256 << 16) | 128, 2048, 128, 320, False, True, False, False),
+    ("row", (256 << 16) | 128, 512, 384, 128, True, False, False, False),
+    ("conv", (256 << 16) | 320, (2, 32), 320, 320, True, False, True, False),
+    ("conv", (256 << 16) | 320, (2, 32), 640, 320, True, True, False, False),
+    ("conv", (256 << 16) | 160, (2, 16), 320, 640, True, True, True, False),
+    ("conv", (256 << 16) | 320, (2, 32), 320, 320, True, True, True, True),   # GroupNorm sums from the epilogue
+    ("row", (256 << 16) | 320, 2048, 320, 320, True, True, False, True),
+]
+
+
+@pytest.mark.parametrize("case", EPI_CASES)
+def test_lean_and_line_wide_epilogues_store_what_the_general_one_stores(case):
+    """developer knob 40: 64 = the general epilogue for every problem, 256 = lean with every column pair single (the MFMA layout's
+    16-row x 64-byte accesses), 0 = lean with the line-wide lane exchange.  Same accumulators, same order of the terms: the three
+    outputs must be BIT-identical (and the GroupNorm sums equal up to the order of the float atomics)."""
+    ops = _ops()
+    from flash_diffusion_amd._lib import lib
+    kind, tile, Mspec, N, Kc, has_b, has_r, has_v, has_gn = case
+    if kind == "row":
+        M, B, HW = Mspec, (Mspec // 512 if has_gn else 1), (512 if has_gn else Mspec)
+        A = b16(rnd(M, Kc, seed=1)).cuda()
+        w = b16(rnd(N, Kc, seed=2, scale=Kc ** -0.5)).cuda()
+        kw = {}
+    else:
+        B, H = Mspec
+        HW, M = H * H, B * H * H
+        A = b16(rnd(B, H, H, Kc, seed=1)).cuda()
+        w = ops.pack_conv_weight(b16(rnd(N, Kc, 3, 3, seed=2, scale=(9 * Kc) ** -0.5)).float()).cuda()
+        kw = dict(M=M, conv=dict(Hin=H, Win=H, Cin=Kc, Hout=H, Wout=H, KH=3, KW=3, stride=1, pad=1))
+    if has_b:
+        kw["bias"] = rnd(N, seed=3).cuda()
+    if has_r:
+        kw["residual"] = b16(rnd(M, N, seed=4)).cuda()
+    if has_v:
+        kw["rowvec"], kw["rows_per_batch"] = b16(rnd(B, N, seed=5)).cuda(), HW
+    outs, sums = {}, {}
+    try:
+        for knob in (64, 256, 0):
+            lib().fdmi_tune_set(40, knob)
+            if has_gn:
+                st = torch.zeros(B, 32, 2, dtype=torch.float32, device="cuda")
+                outs[knob] = ops.gemm(A, w, gn=(st, HW), **kw)
+                sums[knob] = st
+            else:
+                outs[knob] = ops.gemm(A, w, force_tile=tile, **kw)
+            torch.cuda.synchronize()
+    finally:
+        lib().fdmi_tune_set(40, 0)
+    assert torch.isfinite(outs[64].float()).all()
+    assert torch.equal(outs[256], outs[64]), f"lean epilogue differs from the general one: {case}"
+    assert torch.equal(outs[0], outs[64]), f"line-wide epilogue differs from the general one: {case}"
+    if has_gn:
+        for knob in (256, 0):
+            close(f"epi_gn_sums{case}[{knob}]", sums[knob], sums[64], tol_el=1e-5, tol_fro=1e-5)

@@ -189,4 +189,7 @@ def test_two_rank_replicas_are_identical_and_equal_the_averaged_single_process(t
     ratio = float(g0.norm() / gm.norm())
     parity_log(f"two ranks, first step: exchanged gradient x grad_scale vs the single-process mean: rel {gerr:.3e} (two single runs: "
                f"{gnoise:.3e}), norm ratio {ratio:.5f} (a sum would give 2)", "multiproc_parity.txt")
-    assert gerr <= max(10 * gnoise, 1e-4) and abs(ratio - 1.0) < 1e-3, (gerr, gnoise, ratio)
+    # yardstick: two single-process runs of this tiny bf16 model differ by gnoise themselves (float atomics of the weight-gradient
+    # kernels on gradients that are sums of cancelling terms: 4.4e-2 on the first GPU run of round 4, where the two-rank gradient
+    # sat at 4.4e-2 from the mean with a norm ratio of 1.0019) -- a SUM instead of the mean would be at distance 1 with ratio 2
+    assert gerr <= max(3 * gnoise, 1e-4) and abs(ratio - 1.0) <= max(gnoise, 1e-3), (gerr, gnoise, ratio)

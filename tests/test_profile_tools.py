@@ -42,3 +42,18 @@ def test_converter_reproduces_the_round1_figures(tmp_path):
         for suf in ("_kernel_stats.csv", "_pmc_hbm_traffic.csv", "_traffic.json", "_l2_hit_rate.csv"):
             if os.path.exists(pre + suf):
                 os.remove(pre + suf)
+
+
+def test_bench_algorithmic_bytes_walks_the_plan_of_the_headline_step():
+    """bench.py's algorithmic bytes per GEMM family come from the C++ plan's work list in workspace-query mode (no GPU): the launch
+    counts of the 256 x 320 kernels are the ones rocprofv3 sees per step (profiles/r4_kernel_stats.csv: 423 + 80 + 14 row, 90 + 100
+    conv), and one operand pass of a family's mean launch is tens to hundreds of MB."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_for_algo", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    algo = bench.algorithmic_bytes(16, 4, 128)
+    assert algo is not None
+    assert algo["gemm4_kernel<256x320,row>"][1] == 517 and algo["gemm4_kernel<256x320,conv>"][1] == 190
+    for key, (by, n) in algo.items():
+        assert n > 0 and 1e6 < by / n < 1e9, (key, by, n)
