@@ -46,7 +46,18 @@ class NetCfg(C.Structure):
                 ("lpips_scale", f32 * 3), ("adapter_downscale", i32), ("adapter_xl", i32)]
 
 
+class DitCfg(C.Structure):
+    _fields_ = [("kind", i32), ("in_channels", i32), ("out_channels", i32), ("patch_size", i32), ("num_layers", i32),
+                ("heads", i32), ("head_dim", i32), ("cross_dim", i32), ("caption_channels", i32), ("tdim", i32),
+                ("vec_dim", i32), ("n_vec", i32), ("attention_bias", i32), ("norm_eps", f32), ("precision", i32)]
+
+
 _SIGS = {
+    "fdmi_dit_create": (vp, [C.POINTER(DitCfg)]),
+    "fdmi_dit_workspace_bytes": (i64, [vp, i32, i32, i32, i32, i32, i32]),
+    "fdmi_dit_forward": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
+    "fdmi_dit_backward": (i32, [vp, i32, vp, vp, vp]),
+    "fdmi_unet_declare_lora": (i32, [vp, C.c_char_p, i32]),
     "fdmi_unet_create": (vp, [C.POINTER(UNetCfg)]),
     "fdmi_unet_destroy": (None, [vp]),
     "fdmi_unet_num_params": (i64, [vp]),

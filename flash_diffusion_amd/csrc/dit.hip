@@ -2,6 +2,7 @@
 // the gated residual, tanh-GELU and its derivative, and the per-sample column sums that give the gradients of the
 // adaLN shift / scale / gate vectors.  All bf16 token-major [rows][C], 16-byte accesses, fp32 arithmetic.
 #include "ops.h"
+#include "dit_ops.h"
 
 static inline int nblocks(int64_t total, int cap = 8192) {
   int64_t b = (total + 255) / 256;
@@ -125,4 +126,105 @@ int launch_batch_colsum(const bf16_t* dy, const bf16_t* x, const float* stats, f
                      x, stats, out0, out1, rows_per_batch, C);
   FDMI_HIP(hipGetLastError());
   return 0;
+}
+
+// ---- layout / per-sample-vector kernels of the transformer-denoiser PLANS (unet.hip: fdmi_dit_*) ----------------------------
+// TO = bf16_t (the measured plans) or float (the fp32 validation plans); small tensors or pure data movement, one element per lane.
+namespace {
+template <typename TO> __device__ __forceinline__ TO cvt_out(float v);
+template <> __device__ __forceinline__ bf16_t cvt_out<bf16_t>(float v) { return f2bf(v); }
+template <> __device__ __forceinline__ float cvt_out<float>(float v) { return v; }
+__device__ __forceinline__ float cvt_in(bf16_t v) { return bf2f(v); }
+__device__ __forceinline__ float cvt_in(float v) { return v; }
+
+// x [B][C][H][W] f32 <-> patches [B * h * w][C * p * p], column = (c, py, px): the patch-embedding convolution (kernel = stride
+// = p) as a linear map.  BWD: gx = the same map read backwards (every input element belongs to exactly one patch).
+template <typename TO, bool BWD>
+__global__ __launch_bounds__(256) void patchify_kernel(const float* x, TO* pt, float* gx, int B, int C, int H, int W, int p) {
+  const int h = H / p, w = W / p, cols = C * p * p;
+  const int64_t total = (int64_t)B * h * w * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % cols);
+    const int64_t tok = i / cols;
+    const int px = col % p, py = (col / p) % p, c = col / (p * p);
+    const int wx = (int)(tok % w), hy = (int)((tok / w) % h), b = (int)(tok / ((int64_t)h * w));
+    const int64_t xi = (((int64_t)b * C + c) * H + hy * p + py) * W + wx * p + px;
+    if (BWD) gx[xi] = cvt_in(pt[i]);
+    else pt[i] = cvt_out<TO>(x[xi]);
+  }
+}
+// tokens [B * h * w][p * p * oc], column = (py, px, c)  <->  images [B][keep][H][W] f32 (the first `keep` of the oc channels:
+// the wrappers drop a learned-variance half, tranformers.py:91 / :154).  BWD: d tokens from d images, zero in the dropped channels.
+template <typename TO, bool BWD>
+__global__ __launch_bounds__(256) void unpatchify_kernel(TO* tk, float* img, int B, int oc, int keep, int H, int W, int p) {
+  const int h = H / p, w = W / p, cols = p * p * oc;
+  const int64_t total = (int64_t)B * h * w * cols;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int col = (int)(i % cols);
+    const int64_t tok = i / cols;
+    const int c = col % oc, px = (col / oc) % p, py = col / (oc * p);
+    const int wx = (int)(tok % w), hy = (int)((tok / w) % h), b = (int)(tok / ((int64_t)h * w));
+    const int64_t xi = (((int64_t)b * keep + c) * H + hy * p + py) * W + wx * p + px;
+    if (BWD) tk[i] = cvt_out<TO>(c < keep ? img[xi] : 0.f);
+    else if (c < keep) img[xi] = cvt_in(tk[i]);
+  }
+}
+// dst[b][i] = table[i] + src[b][i % src_cols]   (a scale-shift table plus the per-sample modulation vectors, in fp32, one rounding)
+template <typename TO>
+__global__ __launch_bounds__(256) void add_table_kernel(const TO* src, int src_cols, const float* table, TO* dst, int B, int n) {
+  const int64_t total = (int64_t)B * n;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % n);
+    const int64_t b = i / n;
+    dst[i] = cvt_out<TO>(table[c] + cvt_in(src[b * src_cols + c % src_cols]));
+  }
+}
+// dst[b][col0 + c] (+)= src[b][c]   (fp32 column sums into the gradient of a modulation tensor)
+template <typename TO>
+__global__ __launch_bounds__(256) void vec_grad_add_kernel(const float* src, TO* dst, int64_t ldd, int col0, int B, int C, int accumulate) {
+  const int64_t total = (int64_t)B * C;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const int64_t b = i / C;
+    TO* d = dst + b * ldd + col0 + c;
+    *d = cvt_out<TO>(src[i] + (accumulate ? cvt_in(*d) : 0.f));
+  }
+}
+}  // namespace
+
+#define DIT_LAUNCH(kernel, total, ...)                                                              \
+  hipLaunchKernelGGL(kernel, dim3(nblocks(total)), dim3(256), 0, st, __VA_ARGS__);                  \
+  FDMI_HIP(hipGetLastError());                                                                      \
+  return 0;
+
+int launch_patchify(const float* x, void* patches, int B, int C, int H, int W, int p, int f32, hipStream_t st) {
+  FDMI_CHECK(p > 0 && H % p == 0 && W % p == 0, "patchify: H, W must be multiples of the patch size");
+  const int64_t total = (int64_t)B * C * H * W;
+  if (f32) { DIT_LAUNCH((patchify_kernel<float, false>), total, x, (float*)patches, (float*)nullptr, B, C, H, W, p) }
+  DIT_LAUNCH((patchify_kernel<bf16_t, false>), total, x, (bf16_t*)patches, (float*)nullptr, B, C, H, W, p)
+}
+int launch_patchify_bwd(const void* dpatches, float* gx, int B, int C, int H, int W, int p, int f32, hipStream_t st) {
+  const int64_t total = (int64_t)B * C * H * W;
+  if (f32) { DIT_LAUNCH((patchify_kernel<float, true>), total, (const float*)nullptr, (float*)dpatches, gx, B, C, H, W, p) }
+  DIT_LAUNCH((patchify_kernel<bf16_t, true>), total, (const float*)nullptr, (bf16_t*)dpatches, gx, B, C, H, W, p)
+}
+int launch_unpatchify(const void* tokens, float* img, int B, int oc, int keep, int H, int W, int p, int f32, hipStream_t st) {
+  FDMI_CHECK(p > 0 && H % p == 0 && W % p == 0 && keep > 0 && keep <= oc, "unpatchify: bad geometry");
+  const int64_t total = (int64_t)B * oc * H * W;
+  if (f32) { DIT_LAUNCH((unpatchify_kernel<float, false>), total, (float*)tokens, img, B, oc, keep, H, W, p) }
+  DIT_LAUNCH((unpatchify_kernel<bf16_t, false>), total, (bf16_t*)tokens, img, B, oc, keep, H, W, p)
+}
+int launch_unpatchify_bwd(const float* gimg, void* dtokens, int B, int oc, int keep, int H, int W, int p, int f32, hipStream_t st) {
+  const int64_t total = (int64_t)B * oc * H * W;
+  if (f32) { DIT_LAUNCH((unpatchify_kernel<float, true>), total, (float*)dtokens, (float*)gimg, B, oc, keep, H, W, p) }
+  DIT_LAUNCH((unpatchify_kernel<bf16_t, true>), total, (bf16_t*)dtokens, (float*)gimg, B, oc, keep, H, W, p)
+}
+int launch_add_table(const void* src, int src_cols, const float* table, void* dst, int B, int n, int f32, hipStream_t st) {
+  FDMI_CHECK(src_cols > 0 && n % src_cols == 0, "add_table: the table width must be a multiple of the vector width");
+  if (f32) { DIT_LAUNCH(add_table_kernel<float>, (int64_t)B * n, (const float*)src, src_cols, table, (float*)dst, B, n) }
+  DIT_LAUNCH(add_table_kernel<bf16_t>, (int64_t)B * n, (const bf16_t*)src, src_cols, table, (bf16_t*)dst, B, n)
+}
+int launch_vec_grad_add(const float* src, void* dst, int64_t ldd, int col0, int B, int C, int accumulate, int f32, hipStream_t st) {
+  if (f32) { DIT_LAUNCH(vec_grad_add_kernel<float>, (int64_t)B * C, src, (float*)dst, ldd, col0, B, C, accumulate) }
+  DIT_LAUNCH(vec_grad_add_kernel<bf16_t>, (int64_t)B * C, src, (bf16_t*)dst, ldd, col0, B, C, accumulate)
 }

@@ -1,0 +1,739 @@
+// Plans of the transformer denoisers on the tape executor of unet.hip (this file is included there, inside its anonymous
+// namespace, after `struct Exec`): the native replacement of
+//   DiffusersTransformer2DWrapper.forward      (/root/reference/src/flash/models/transformers/tranformers.py:49-92, with the
+//                                               reference's AdaLayerNormSingle, transformers/utils.py:8-102)  -- PixArt-alpha
+//   DiffusersSD3Transformer2DWrapper.forward   (tranformers.py:113-155)                                      -- SD3 MMDiT
+// and of their autograd backward.  One plan = one denoiser: parameters registered under their state_dict names and packed once
+// (fdmi_unet_set_param), LoRA pairs on any linear (fdmi_unet_set_lora; peft semantics, examples/train_flash_pixart.py:237-256 /
+// train_flash_sd3.py:100-121), token-major activations [B * T][C] bump-allocated from the caller's workspace, a tape of
+// backward closures.  The GEMMs, the fused q / k / v projection with folded LoRA up-projections, flash attention and the tape
+// mechanics are the UNet plan's (Exec::linear_w / linear_qkv / attention); what the transformers add is below: LayerNorm with the
+// adaLN modulate and the gradients of the modulation vectors, the gated residual, tanh-GELU, patch (un)folding, the joint
+// [latent | text] sequence of the MMDiT, a key-padding mask as per-sample prefix lengths.
+
+#define DIT_NULL(x) do { if ((x)) return nullptr; } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// plan construction
+// ---------------------------------------------------------------------------------------------
+static void dit_emb(Builder& b, const std::string& name, DitEmbW& e, int in, int dim) {
+  b.lin_lora(name + ".linear_1", e.l1, dim, in, true);
+  b.lin_lora(name + ".linear_2", e.l2, dim, dim, true);
+}
+static void dit_attn(Builder& b, const std::string& name, AttnW& a, int D, int kv, bool bias) {
+  b.lin_lora(name + ".to_q", a.q, D, D, bias);
+  b.lin_lora(name + ".to_k", a.k, D, kv, bias);
+  b.lin_lora(name + ".to_v", a.v, D, kv, bias);
+  b.lin_lora(name + ".to_out.0", a.o, D, D, true);
+}
+
+int build_dit(fdmi_unet* U) {
+  const fdmi_dit_config& c = U->dcfg;
+  FDMI_CHECK(c.kind == FDMI_DIT_PIXART || c.kind == FDMI_DIT_MMDIT, "dit: kind must be FDMI_DIT_PIXART or FDMI_DIT_MMDIT");
+  FDMI_CHECK(c.heads > 0 && c.head_dim > 0 && c.head_dim % 8 == 0 && c.head_dim <= 160, "dit: head_dim must be a multiple of 8, <= 160");
+  FDMI_CHECK(c.patch_size > 0 && c.in_channels > 0 && c.out_channels > 0 && c.num_layers > 0, "dit: bad geometry");
+  FDMI_CHECK((c.in_channels * c.patch_size * c.patch_size) % 8 == 0 && (c.out_channels * c.patch_size * c.patch_size) % 8 == 0,
+             "dit: channels * patch^2 must be a multiple of 8");
+  FDMI_CHECK(c.tdim > 0 && c.tdim % 8 == 0, "dit: the sinusoidal timestep embedding width must be a multiple of 8");
+  U->dit = std::make_unique<NetDit>();
+  NetDit& N = *U->dit;
+  const int D = c.heads * c.head_dim, p = c.patch_size;
+  N.tw.C = D;
+  N.tw.heads = c.heads;
+  Builder b{U};
+  b.lin_lora("pos_embed.proj", N.patch, D, c.in_channels * p * p, true);
+  if (c.kind == FDMI_DIT_PIXART) {
+    FDMI_CHECK(c.cross_dim > 0 && c.cross_dim % 8 == 0 && c.caption_channels % 8 == 0, "dit: cross_dim / caption_channels must be multiples of 8");
+    dit_emb(b, "adaln_single.timestep_embedder", N.temb, c.tdim, D);
+    if (c.vec_dim > 0) {
+      FDMI_CHECK(c.vec_dim % 8 == 0 && (c.n_vec == 0 || (D % c.n_vec == 0 && (D / c.n_vec) % 8 == 0)), "dit: vector conditioning widths must be multiples of 8");
+      if (c.n_vec > 0) {
+        for (int i = 0; i < c.n_vec; ++i) {
+          N.addemb.push_back(std::make_unique<DitEmbW>());
+          dit_emb(b, "adaln_single.add_embedding." + std::to_string(i), *N.addemb.back(), c.vec_dim, D / c.n_vec);
+        }
+      } else {
+        N.addemb.push_back(std::make_unique<DitEmbW>());
+        dit_emb(b, "adaln_single.add_embedding", *N.addemb.back(), c.vec_dim, D);
+      }
+    }
+    b.lin_lora("adaln_single.linear", N.ada, 6 * D, D, true);
+    if (c.caption_channels > 0) {
+      FDMI_CHECK(c.cross_dim == D, "dit: the caption projection feeds the cross-attention: cross_dim must equal heads * head_dim");
+      dit_emb(b, "caption_projection", N.cap, c.caption_channels, D);
+    }
+    for (int i = 0; i < c.num_layers; ++i) {
+      auto blk = std::make_unique<DitBlockW>();
+      const std::string bn = "transformer_blocks." + std::to_string(i);
+      dit_attn(b, bn + ".attn1", blk->at.a1, D, D, c.attention_bias != 0);
+      dit_attn(b, bn + ".attn2", blk->at.a2, D, c.cross_dim, c.attention_bias != 0);
+      b.lin_lora(bn + ".ff.net.0.proj", blk->ff1, 4 * D, D, true);
+      b.lin_lora(bn + ".ff.net.2", blk->ff2, D, 4 * D, true);
+      b.vec(bn + ".scale_shift_table", &blk->table, 6 * D);
+      N.blocks.push_back(std::move(blk));
+    }
+    b.vec("scale_shift_table", &N.table, 2 * D);
+  } else {
+    FDMI_CHECK(c.caption_channels > 0 && c.caption_channels % 8 == 0 && c.vec_dim > 0 && c.vec_dim % 8 == 0,
+               "dit: joint_attention_dim / pooled_projection_dim must be positive multiples of 8");
+    dit_emb(b, "time_text_embed.timestep_embedder", N.temb, c.tdim, D);
+    dit_emb(b, "time_text_embed.text_embedder", N.text, c.vec_dim, D);
+    b.lin_lora("context_embedder", N.ctx_emb, D, c.caption_channels, true);
+    for (int i = 0; i < c.num_layers; ++i) {
+      auto blk = std::make_unique<MmBlockW>();
+      blk->pre_only = i == c.num_layers - 1;
+      const std::string bn = "transformer_blocks." + std::to_string(i);
+      b.lin_lora(bn + ".norm1.linear", blk->n1, 6 * D, D, true);
+      b.lin_lora(bn + ".norm1_context.linear", blk->n1c, (blk->pre_only ? 2 : 6) * D, D, true);
+      dit_attn(b, bn + ".attn", blk->x.a1, D, D, true);
+      b.lin_lora(bn + ".attn.add_q_proj", blk->c.a1.q, D, D, true);
+      b.lin_lora(bn + ".attn.add_k_proj", blk->c.a1.k, D, D, true);
+      b.lin_lora(bn + ".attn.add_v_proj", blk->c.a1.v, D, D, true);
+      b.lin_lora(bn + ".ff.net.0.proj", blk->ff1, 4 * D, D, true);
+      b.lin_lora(bn + ".ff.net.2", blk->ff2, D, 4 * D, true);
+      if (!blk->pre_only) {
+        b.lin_lora(bn + ".attn.to_add_out", blk->c.a1.o, D, D, true);
+        b.lin_lora(bn + ".ff_context.net.0.proj", blk->ffc1, 4 * D, D, true);
+        b.lin_lora(bn + ".ff_context.net.2", blk->ffc2, D, 4 * D, true);
+      }
+      N.mblocks.push_back(std::move(blk));
+    }
+    b.lin_lora("norm_out.linear", N.norm_out, 2 * D, D, true);
+  }
+  b.lin_lora("proj_out", N.proj_out, p * p * c.out_channels, D, true);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ops (forward + recorded backward), on top of Exec
+// ---------------------------------------------------------------------------------------------
+static inline int DF(const Exec& E) { return E.f32() ? 1 : 0; }
+static T* dit_lin(Exec& E, T* x, LinearW& L, T* residual = nullptr, bool need_dx = true) {
+  return E.linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr, need_dx);
+}
+// the gradient of an op's single input: written in place when nothing has reached x yet, staged and added otherwise
+template <typename Fw>
+static int dit_dx(Exec& E, T* x, Fw write) {
+  bf16_t* dx = E.grad_of(x);
+  FDMI_CHECK(dx, "dit: workspace exhausted (grad)");
+  if (!x->ginit) {
+    RET_IF(write(dx));
+    x->ginit = true;
+    return 0;
+  }
+  bf16_t* tmp = (bf16_t*)E.R.tmp((size_t)x->rows * x->cols * E.es());
+  FDMI_CHECK(tmp, "dit: workspace exhausted (grad)");
+  RET_IF(write(tmp));
+  return E.add_grad(x, tmp, x->cols, 0, x->cols);
+}
+// fp32 column sums [B][C] into columns col0.. of a modulation tensor's gradient (zero-filled at its first use)
+static int dit_mod_grad_add(Exec& E, T* mod, int col0, const float* src, int B, int C) {
+  bf16_t* g = E.grad_of(mod);
+  FDMI_CHECK(g, "dit: workspace exhausted (grad)");
+  if (!mod->ginit) {
+    if (!E.R.dry()) FDMI_HIP(hipMemsetAsync(g, 0, (size_t)mod->rows * mod->cols * E.es(), E.st));
+    mod->ginit = true;
+  }
+  if (!E.R.dry()) RET_IF(launch_vec_grad_add(src, g, mod->cols, col0, B, C, 1, DF(E), E.st));
+  return 0;
+}
+
+enum { DIT_SILU = 0, DIT_GELU_TANH = 1 };
+static T* dit_act(Exec& E, T* x, int kind) {
+  Run& R = E.R;
+  T* y = R.mk(x->rows, x->cols);
+  DIT_NULL(!y);
+  const int64_t n = x->rows * x->cols;
+  if (!R.dry()) {
+    if (kind == DIT_SILU)
+      DIT_NULL(E.f32() ? launch_silu32(Exec::F(x->p), Exec::F(y->p), n, E.st) : launch_silu(x->p, y->p, n, E.st));
+    else
+      DIT_NULL(E.f32() ? launch_gelu_tanh32(Exec::F(x->p), Exec::F(y->p), n, E.st) : launch_gelu_tanh(x->p, y->p, n, E.st));
+  }
+  if (R.save) {
+    R.tape.push_back([x, y, kind, n](Exec& E) -> int {
+      if (!y->g) return 0;
+      return dit_dx(E, x, [&](bf16_t* dst) -> int {
+        if (E.R.dry()) return 0;
+        if (kind == DIT_SILU)
+          return E.f32() ? launch_silu32_bwd(Exec::F(x->p), Exec::F(y->g), Exec::F(dst), n, E.st) : launch_silu_bwd(x->p, y->g, dst, n, E.st);
+        return E.f32() ? launch_gelu_tanh32_bwd(Exec::F(x->p), Exec::F(y->g), Exec::F(dst), n, E.st)
+                       : launch_gelu_tanh_bwd(x->p, y->g, dst, n, E.st);
+      });
+    });
+    R.mark_out({y});
+  }
+  return y;
+}
+
+// out[b][i] = table[i] + src[b][i % src->cols]: a block's scale_shift_table plus the shared modulation vectors
+// (tranformers.py / diffusers BasicTransformerBlock "ada_norm_single": scale_shift_table[None] + timestep.reshape(B, 6, -1))
+static T* dit_add_table(Exec& E, T* src, const float* table, int n) {
+  Run& R = E.R;
+  T* y = R.mk(src->rows, n);
+  DIT_NULL(!y);
+  if (!R.dry()) DIT_NULL(launch_add_table(src->p, src->cols, table, y->p, (int)src->rows, n, DF(E), E.st));
+  if (R.save) {
+    R.tape.push_back([src, y, n](Exec& E) -> int {
+      if (!y->g || !y->ginit) return 0;
+      for (int c0 = 0; c0 < n; c0 += src->cols) RET_IF(E.add_grad(src, y->g, n, c0, src->cols));
+      return 0;
+    });
+    R.mark_out({y});
+  }
+  return y;
+}
+
+// out = base + [parts ...] (concatenated along the columns): the embedding sums in front of the blocks
+static T* dit_cat_add(Exec& E, T* base, const std::vector<T*>& parts) {
+  Run& R = E.R;
+  T* y = R.mk(base->rows, base->cols);
+  DIT_NULL(!y);
+  if (!R.dry()) {
+    DIT_NULL(E.l_copy2d(base->p, base->cols, 0, y->p, y->cols, 0, base->rows, base->cols, 0));
+    int c0 = 0;
+    for (T* pt : parts) {
+      DIT_NULL(E.l_copy2d(pt->p, pt->cols, 0, y->p, y->cols, c0, pt->rows, pt->cols, 1));
+      c0 += pt->cols;
+    }
+  }
+  if (R.save) {
+    R.tape.push_back([base, y, parts](Exec& E) -> int {
+      if (!y->g) return 0;
+      RET_IF(E.add_grad(base, y->g, y->cols, 0, y->cols));
+      int c0 = 0;
+      for (T* pt : parts) {
+        RET_IF(E.add_grad(pt, y->g, y->cols, c0, pt->cols));
+        c0 += pt->cols;
+      }
+      return 0;
+    });
+    R.mark_out({y});
+  }
+  return y;
+}
+
+// y = LayerNorm(x) * (1 + scale[sample]) + shift[sample], no affine parameters; shift / scale = column blocks of `mod` [B][k C]
+// (AdaLayerNormSingle / AdaLayerNormZero / AdaLayerNormContinuous).  mod_grad: the modulation vectors carry a gradient (a LoRA
+// sits on the projections that made them): d scale = sum_rows dy * xhat, d shift = sum_rows dy, per sample.
+static T* dit_ln_mod(Exec& E, T* x, T* mod, int shift_col, int scale_col, int rpb, float eps, bool mod_grad) {
+  Run& R = E.R;
+  const int C = x->cols;
+  T* y = R.mk(x->rows, C);
+  float* stats = (R.save && mod_grad) ? (float*)R.arena.alloc((size_t)x->rows * 2 * sizeof(float)) : nullptr;
+  DIT_NULL(!y || (R.save && mod_grad && !stats));
+  const int64_t ld = mod->cols;
+  E.U->hbm[HBM_LN] += 2.0 * E.es() * x->rows * C;
+  if (!R.dry())
+    DIT_NULL(E.f32() ? launch_layernorm32_fwd(Exec::F(x->p), nullptr, nullptr, Exec::F(mod->p) + shift_col, Exec::F(mod->p) + scale_col, ld,
+                                              rpb, Exec::F(y->p), x->rows, C, eps, E.st, stats)
+                     : launch_layernorm_fwd(x->p, nullptr, nullptr, mod->p + shift_col, mod->p + scale_col, ld, rpb, y->p, x->rows, C, eps,
+                                            E.st, stats));
+  if (R.save) {
+    R.tape.push_back([x, y, mod, shift_col, scale_col, rpb, eps, mod_grad, stats, ld, C](Exec& E) -> int {
+      if (!y->g) return 0;
+      bf16_t* dx = E.grad_of(x);
+      FDMI_CHECK(dx, "dit: workspace exhausted (grad)");
+      E.U->hbm[HBM_LN] += (x->ginit ? 4.0 : 3.0) * E.es() * x->rows * C;
+      if (!E.R.dry())
+        RET_IF(E.f32() ? launch_layernorm32_bwd(Exec::F(x->p), Exec::F(y->g), nullptr, Exec::F(mod->p) + scale_col, ld, rpb, Exec::F(dx),
+                                                x->rows, C, eps, x->ginit ? 1 : 0, E.st)
+                       : launch_layernorm_bwd(x->p, y->g, nullptr, mod->p + scale_col, ld, rpb, dx, x->rows, C, eps, x->ginit ? 1 : 0, E.st));
+      x->ginit = true;
+      if (mod_grad) {
+        const int B = (int)(x->rows / rpb);
+        float* ds = (float*)E.R.tmp((size_t)B * C * sizeof(float));
+        float* dh = (float*)E.R.tmp((size_t)B * C * sizeof(float));
+        FDMI_CHECK(ds && dh, "dit: workspace exhausted (grad)");
+        if (!E.R.dry())
+          RET_IF(E.f32() ? launch_batch_colsum32(Exec::F(y->g), Exec::F(x->p), stats, ds, dh, B, rpb, C, E.st)
+                         : launch_batch_colsum(y->g, x->p, stats, ds, dh, B, rpb, C, E.st));
+        RET_IF(dit_mod_grad_add(E, mod, scale_col, ds, B, C));
+        RET_IF(dit_mod_grad_add(E, mod, shift_col, dh, B, C));
+        E.R.rfree(stats, (size_t)x->rows * 2 * sizeof(float));
+      }
+      return 0;
+    });
+    R.mark_out({y});
+  }
+  return y;
+}
+
+// out = res + gate[sample] * y   (gate = a column block of `mod`)
+static T* dit_gate_res(Exec& E, T* y, T* mod, int gate_col, T* res, int rpb, bool mod_grad) {
+  Run& R = E.R;
+  const int C = y->cols;
+  T* o = R.mk(y->rows, C);
+  DIT_NULL(!o);
+  const int64_t ld = mod->cols;
+  if (!R.dry())
+    DIT_NULL(E.f32() ? launch_gate_residual32(Exec::F(y->p), Exec::F(mod->p) + gate_col, ld, Exec::F(res->p), Exec::F(o->p), y->rows, C, rpb, E.st)
+                     : launch_gate_residual(y->p, mod->p + gate_col, ld, res->p, o->p, y->rows, C, rpb, E.st));
+  if (R.save) {
+    R.tape.push_back([y, o, mod, gate_col, res, rpb, mod_grad, ld, C](Exec& E) -> int {
+      if (!o->g) return 0;
+      RET_IF(E.add_grad(res, o->g, C, 0, C));
+      bf16_t* dy = E.grad_of(y);
+      FDMI_CHECK(dy, "dit: workspace exhausted (grad)");
+      if (!E.R.dry())   // dy (+)= gate * d out
+        RET_IF(E.f32() ? launch_gate_residual32(Exec::F(o->g), Exec::F(mod->p) + gate_col, ld, y->ginit ? Exec::F(dy) : nullptr, Exec::F(dy),
+                                                y->rows, C, rpb, E.st)
+                       : launch_gate_residual(o->g, mod->p + gate_col, ld, y->ginit ? dy : nullptr, dy, y->rows, C, rpb, E.st));
+      y->ginit = true;
+      if (mod_grad) {   // d gate = sum_rows d out * y, per sample
+        const int B = (int)(y->rows / rpb);
+        float* dg = (float*)E.R.tmp((size_t)B * C * sizeof(float));
+        FDMI_CHECK(dg, "dit: workspace exhausted (grad)");
+        if (!E.R.dry())
+          RET_IF(E.f32() ? launch_batch_colsum32(Exec::F(o->g), Exec::F(y->p), nullptr, dg, nullptr, B, rpb, C, E.st)
+                         : launch_batch_colsum(o->g, y->p, nullptr, dg, nullptr, B, rpb, C, E.st));
+        RET_IF(dit_mod_grad_add(E, mod, gate_col, dg, B, C));
+      }
+      return 0;
+    });
+    R.mark_out({o});
+  }
+  return o;
+}
+
+// a run without a tape, on a linear without LoRA, folds the activation / the gate and residual into the GEMM's epilogue
+// (the frozen teacher's whole forward, the student's sampler): one launch instead of GEMM + element-wise pass
+static bool dit_fusable(const Exec& E, const LinearW& L) { return !E.R.save && !L.lora.on && !E.f32(); }
+
+static T* dit_linear_gelu(Exec& E, T* x, LinearW& L, bool need_dx = true) {
+  if (dit_fusable(E, L)) {
+    T* y = E.R.mk(x->rows, L.w.N);
+    DIT_NULL(!y);
+    DIT_NULL(E.gemm_rows(x->p, x->cols, x->rows, L.w.w, L.w.N, L.w.K, L.w.bias, y->p, L.w.N, nullptr, 0, ACT_GELU_TANH));
+    return y;
+  }
+  T* f = dit_lin(E, x, L, nullptr, need_dx);
+  return f ? dit_act(E, f, DIT_GELU_TANH) : nullptr;
+}
+
+static T* dit_linear_gate_res(Exec& E, T* x, LinearW& L, T* mod, int gate_col, T* res, int rpb, bool mod_grad) {
+  if (dit_fusable(E, L)) {
+    T* y = E.R.mk(x->rows, L.w.N);
+    DIT_NULL(!y);
+    GemmArgs a = Exec::rows_args(x->p, x->cols, x->rows, L.w.w, L.w.N, L.w.K, L.w.bias, y->p, L.w.N, res->p, res->cols);
+    a.rowvec = mod->p + gate_col;
+    a.rowvec_ld = mod->cols;
+    a.rows_per_batch = rpb;
+    a.rowvec_mul = 1;
+    DIT_NULL(E.gemm(a));
+    return y;
+  }
+  T* y = dit_lin(E, x, L);
+  return y ? dit_gate_res(E, y, mod, gate_col, res, rpb, mod_grad) : nullptr;
+}
+
+// q / k / v of one input: the fused projection where the plan has it (bf16, all-or-none LoRA), three GEMMs otherwise
+static int dit_qkv(Exec& E, T* x, TBlockW& b, int D, T** q, T** k, T** v) {
+  if (qkv_fusable(E.U, b) && (E.R.dry() || b.qkv.w)) {
+    T* y = E.linear_qkv(x, b, D);
+    FAIL_IF_NULL(y);
+    *q = E.R.view(y, 0, D); *k = E.R.view(y, D, D); *v = E.R.view(y, 2 * D, D);
+  } else {
+    *q = E.linear(x, b.a1.q); *k = E.linear(x, b.a1.k); *v = E.linear(x, b.a1.v);
+  }
+  FAIL_IF_NULL(*q); FAIL_IF_NULL(*k); FAIL_IF_NULL(*v);
+  return 0;
+}
+
+// cross-attention over a caption whose padding is masked: `lens` = valid keys per sample (a prefix, the tokenizer's padding);
+// one launch per sample on its prefix, outputs into the rows of one tensor.  lens == nullptr: every key counts.
+static T* dit_cross_attention(Exec& E, T* q, T* k, T* v, int B, int H, int Sq, int L, const std::vector<int>& lens) {
+  if (lens.empty()) return E.attention(q, k, v, B, H, Sq, L);
+  Run& R = E.R;
+  T* o = R.mk(q->rows, q->cols);
+  DIT_NULL(!o);
+  for (int b = 0; b < B; ++b) {
+    const int n = lens[b];
+    T* qb = R.rowview(q, (int64_t)b * Sq, Sq);
+    T* kb = R.rowview(k, (int64_t)b * L, n);
+    T* vb = R.rowview(v, (int64_t)b * L, n);
+    T* ob = R.rowview(o, (int64_t)b * Sq, Sq);
+    DIT_NULL(!E.attention(qb, kb, vb, 1, H, Sq, n, nullptr, false, ob));
+  }
+  if (R.save) {   // (pushed last = replayed first: the masked keys' gradient rows are zero, the per-sample launches fill the rest)
+    R.tape.push_back([o, k, v](Exec& E) -> int {
+      if (!o->g) return 0;
+      for (T* t : {k, v}) {
+        bf16_t* g = E.grad_of(t);
+        FDMI_CHECK(g && !t->ginit, "dit: workspace exhausted / masked keys with a second consumer");
+        if (!E.R.dry()) FDMI_HIP(hipMemsetAsync(g, 0, (size_t)t->rows * t->cols * E.es(), E.st));
+        t->ginit = true;
+      }
+      return 0;
+    });
+  }
+  return o;
+}
+
+// the joint sequence of the MMDiT: J [B * (na + nb)][w] = per sample [a's rows ; b's rows] (a [B * na][w], b [B * nb][w])
+static T* dit_join(Exec& E, T* a, T* b, int B, int na, int nb) {
+  Run& R = E.R;
+  const int w = a->cols, S = na + nb;
+  T* J = R.mk((int64_t)B * S, w);
+  DIT_NULL(!J);
+  E.U->hbm[HBM_COPY2D] += 2.0 * E.es() * J->rows * w;
+  if (!R.dry()) {
+    DIT_NULL(E.l_copy2d(a->p, (int64_t)na * w, 0, J->p, (int64_t)S * w, 0, B, na * w, 0));
+    DIT_NULL(E.l_copy2d(b->p, (int64_t)nb * w, 0, E.off(J->p, (int64_t)na * w), (int64_t)S * w, 0, B, nb * w, 0));
+  }
+  if (R.save) {
+    R.tape.push_back([a, b, J, B, na, nb, w, S](Exec& E) -> int {
+      if (!J->g) return 0;
+      E.U->hbm[HBM_COPY2D] += 2.0 * E.es() * J->rows * w;
+      T* part[2] = {a, b};
+      const int n[2] = {na, nb};
+      for (int s = 0; s < 2; ++s) {
+        bf16_t* g = E.grad_of(part[s]);
+        FDMI_CHECK(g, "dit: workspace exhausted (grad)");
+        if (!E.R.dry())
+          RET_IF(E.l_copy2d(E.off(J->g, s ? (int64_t)na * w : 0), (int64_t)S * w, 0, g, (int64_t)n[s] * w, 0, B, n[s] * w, part[s]->ginit ? 1 : 0));
+        part[s]->ginit = true;
+      }
+      return 0;
+    });
+    R.mark_out({J});
+  }
+  return J;
+}
+// ... and its inverse after the attention: a [B * na][w] and (want_b) b [B * nb][w] out of J
+static int dit_split(Exec& E, T* J, int B, int na, int nb, bool want_b, T** oa, T** ob) {
+  Run& R = E.R;
+  const int w = J->cols, S = na + nb;
+  T* a = R.mk((int64_t)B * na, w);
+  T* b = want_b ? R.mk((int64_t)B * nb, w) : nullptr;
+  FAIL_IF_NULL(a);
+  if (want_b) FAIL_IF_NULL(b);
+  E.U->hbm[HBM_COPY2D] += 2.0 * E.es() * (a->rows + (b ? b->rows : 0)) * w;
+  if (!R.dry()) {
+    RET_IF(E.l_copy2d(J->p, (int64_t)S * w, 0, a->p, (int64_t)na * w, 0, B, na * w, 0));
+    if (b) RET_IF(E.l_copy2d(E.off(J->p, (int64_t)na * w), (int64_t)S * w, 0, b->p, (int64_t)nb * w, 0, B, nb * w, 0));
+  }
+  if (R.save) {
+    R.tape.push_back([a, b, J, B, na, nb, w, S](Exec& E) -> int {
+      if (!a->g && !(b && b->g)) return 0;
+      bf16_t* g = E.grad_of(J);
+      FDMI_CHECK(g, "dit: workspace exhausted (grad)");
+      T* part[2] = {a, b};
+      const int n[2] = {na, nb};
+      for (int s = 0; s < 2; ++s) {
+        bf16_t* dst = E.off(g, s ? (int64_t)na * w : 0);
+        if (part[s] && part[s]->g) {
+          if (!E.R.dry()) RET_IF(E.l_copy2d(part[s]->g, (int64_t)n[s] * w, 0, dst, (int64_t)S * w, 0, B, n[s] * w, J->ginit ? 1 : 0));
+        } else if (!J->ginit && !E.R.dry()) {   // nothing came back through this part: its rows of d J are zero
+          FDMI_HIP(hipMemset2DAsync(dst, (size_t)S * w * E.es(), 0, (size_t)n[s] * w * E.es(), B, E.st));
+        }
+      }
+      J->ginit = true;
+      return 0;
+    });
+    R.mark_out({a, b});
+  }
+  *oa = a;
+  *ob = b;
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// forward graphs
+// ---------------------------------------------------------------------------------------------
+// A run without a tape keeps nothing of a block but its output(s), which only the next block reads: blocks bump-allocate from two
+// alternating regions of the workspace (block i from region i % 2, rewound at its start), so a frozen forward needs the prologue
+// plus two blocks' worth of buffers whatever the depth.  The blocks are identical, so block i + 2 fits where block i was; leave()
+// checks it.  (fp32 validation plans keep the plain bump allocation: their attention scratch is allocated once, inside block 0.)
+struct DitPingPong {
+  Arena& a;
+  bool on;
+  size_t start[2] = {0, 0}, end[2] = {0, 0};
+  int cur = 0, i = 0;
+  void enter(int block) {
+    if (!on) return;
+    i = block;
+    cur = block & 1;
+    if (block < 2) {
+      a.off = (a.off + 255) & ~(size_t)255;
+      start[cur] = a.off;
+    } else {
+      a.off = start[cur];
+    }
+  }
+  int leave() {
+    if (!on) return 0;
+    if (i < 2) end[cur] = a.off;
+    FDMI_CHECK(a.off <= end[cur], "dit: a block outgrew the workspace region of the block two before it");
+    return 0;
+  }
+  void done() {
+    if (on) a.off = a.peak;   // what follows the blocks reads the last block's output: allocate behind everything
+  }
+};
+struct DitIn {
+  const float *x, *t, *ctx, *vec, *pos;
+  std::vector<int> lens;   // empty: no key mask
+  float* out;
+  int B, H, W, L, keep;
+};
+
+// f32 device tensor -> an activation tensor of the plan's element type
+static T* dit_input(Exec& E, const float* src, int64_t rows, int cols) {
+  T* t = E.R.mk(rows, cols);
+  DIT_NULL(!t);
+  if (!E.R.dry()) {
+    if (E.f32()) {
+      if (hipMemcpyAsync(t->p, src, (size_t)rows * cols * 4, hipMemcpyDeviceToDevice, E.st) != hipSuccess) {
+        fdmi_set_error("dit: copying an input failed");
+        return nullptr;
+      }
+    } else {
+      DIT_NULL(launch_f32_to_bf16(src, t->p, rows * cols, E.st));
+    }
+  }
+  return t;
+}
+// linear_2(silu(linear_1(x))): TimestepEmbedding / PixArtAlphaTextProjection-style two-layer embedders on per-sample vectors
+static T* dit_embed(Exec& E, T* x, DitEmbW& e, bool need_dx) {
+  T* a = dit_lin(E, x, e.l1, nullptr, need_dx);
+  DIT_NULL(!a);
+  a = dit_act(E, a, DIT_SILU);
+  DIT_NULL(!a);
+  return dit_lin(E, a, e.l2);
+}
+
+int run_dit(fdmi_unet* U, Run& R, const DitIn& in, int flags) {
+  NetDit& N = *U->dit;
+  const fdmi_dit_config& c = U->dcfg;
+  Exec E{U, R, R.st};
+  E.splitk_max_rows = 4096;   // (profiles/r3_dit_ab.txt: splitting K pays for the context-stream and per-sample-vector GEMMs only)
+  run_reset(U, R, flags);
+  hipStream_t st = R.st;
+  if (!R.dry() && U->fused_dirty) RET_IF(build_fused_operands(U, st));
+  if (!U->loras.empty()) RET_IF(E.lora_refresh());
+  const int B = in.B, H = in.H, W = in.W, L = in.L;
+  const int p = c.patch_size, D = c.heads * c.head_dim, Tn = (H / p) * (W / p), heads = c.heads;
+  const int f = U->f32 ? 1 : 0;
+  FDMI_CHECK(H % p == 0 && W % p == 0 && B > 0 && L > 0, "dit: H, W must be multiples of the patch size");
+  FDMI_CHECK(in.keep > 0 && in.keep <= c.out_channels, "dit: out_keep must be 1 .. out_channels");
+  const bool modg = R.save && !U->loras.empty();   // the modulation vectors carry a gradient: a LoRA sits on the embedders
+  R.dit_geom[0] = B; R.dit_geom[1] = H; R.dit_geom[2] = W; R.dit_geom[3] = in.keep; R.dit_geom[4] = c.in_channels;
+
+  // ---- patches + positions ----
+  T* pt = R.mk((int64_t)B * Tn, c.in_channels * p * p);
+  FAIL_IF_NULL(pt);
+  R.x0 = pt;
+  if (!R.dry()) RET_IF(launch_patchify(in.x, pt->p, B, c.in_channels, H, W, p, f, st));
+  T* pe1 = dit_input(E, in.pos, Tn, D);
+  T* pe = R.mk((int64_t)B * Tn, D);
+  FAIL_IF_NULL(pe1); FAIL_IF_NULL(pe);
+  if (!R.dry()) RET_IF(E.l_copy2d(pe1->p, 0, 0, pe->p, (int64_t)Tn * D, 0, B, Tn * D, 0));   // every sample: the same [T][D] table
+  T* hid = dit_lin(E, pt, N.patch, pe);
+  FAIL_IF_NULL(hid);
+
+  // ---- per-sample vectors: timestep (+ pooled / size conditioning) embedding ----
+  T* te = R.mk(B, c.tdim);
+  FAIL_IF_NULL(te);
+  if (!R.dry())
+    RET_IF(U->f32 ? launch_timestep_embed32(in.t, Exec::F(te->p), B, c.tdim, 1, 0.f, st) : launch_timestep_embed(in.t, te->p, B, c.tdim, 1, 0.f, st));
+  T* emb = dit_embed(E, te, N.temb, false);
+  FAIL_IF_NULL(emb);
+
+  T* y = nullptr;
+  DitPingPong pp{R.arena, !R.save && !U->f32 && fdmi_tune_get(41) == 0};
+  if (c.kind == FDMI_DIT_PIXART) {
+    if (c.vec_dim > 0) {                                                                  // utils.py:75-102
+      FDMI_CHECK(in.vec != nullptr, "dit: vector conditioning required");
+      const int nv = c.n_vec > 0 ? c.n_vec : 1;
+      T* vb = dit_input(E, in.vec, B, c.vec_dim * nv);
+      FAIL_IF_NULL(vb);
+      std::vector<T*> parts;
+      for (int i = 0; i < nv; ++i) {
+        T* vi = vb;
+        if (nv > 1) {
+          vi = R.mk(B, c.vec_dim);
+          FAIL_IF_NULL(vi);
+          if (!R.dry()) RET_IF(E.l_copy2d(vb->p, vb->cols, i * c.vec_dim, vi->p, c.vec_dim, 0, B, c.vec_dim, 0));
+        }
+        T* a = dit_embed(E, vi, *N.addemb[i], false);
+        FAIL_IF_NULL(a);
+        parts.push_back(a);
+      }
+      emb = dit_cat_add(E, emb, parts);
+      FAIL_IF_NULL(emb);
+    }
+    T* se = dit_act(E, emb, DIT_SILU);
+    FAIL_IF_NULL(se);
+    T* mod6 = dit_lin(E, se, N.ada);                     // [B][6 D]: shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+    FAIL_IF_NULL(mod6);
+    // caption: [B * L][caption_channels] -> projection -> [B * L][D]
+    const int cw = c.caption_channels > 0 ? c.caption_channels : c.cross_dim;
+    T* cx = dit_input(E, in.ctx, (int64_t)B * L, cw);
+    FAIL_IF_NULL(cx);
+    const bool cx_grad = c.caption_channels > 0;
+    if (c.caption_channels > 0) {
+      T* c1 = dit_linear_gelu(E, cx, N.cap.l1, false);
+      FAIL_IF_NULL(c1);
+      cx = dit_lin(E, c1, N.cap.l2);
+      FAIL_IF_NULL(cx);
+    }
+    for (int b = 0; b < (int)in.lens.size(); ++b)
+      FDMI_CHECK(in.lens[b] > 0 && in.lens[b] <= L, "dit: key lengths must be 1 .. L");
+    int bi = 0;
+    for (auto& bp : N.blocks) {
+      DitBlockW& blk = *bp;
+      pp.enter(bi++);
+      T* mod = dit_add_table(E, mod6, blk.table, 6 * D);
+      FAIL_IF_NULL(mod);
+      T* n1 = dit_ln_mod(E, hid, mod, 0, D, Tn, c.norm_eps, modg);
+      FAIL_IF_NULL(n1);
+      T *q, *k, *v;
+      RET_IF(dit_qkv(E, n1, blk.at, D, &q, &k, &v));
+      T* o = E.attention(q, k, v, B, heads, Tn, Tn);
+      FAIL_IF_NULL(o);
+      hid = dit_linear_gate_res(E, o, blk.at.a1.o, mod, 2 * D, hid, Tn, modg);
+      FAIL_IF_NULL(hid);
+      q = E.linear(hid, blk.at.a2.q);                   // (ada_norm_single: no norm in front of the cross-attention)
+      k = dit_lin(E, cx, blk.at.a2.k, nullptr, cx_grad);
+      v = dit_lin(E, cx, blk.at.a2.v, nullptr, cx_grad);
+      FAIL_IF_NULL(q); FAIL_IF_NULL(k); FAIL_IF_NULL(v);
+      o = dit_cross_attention(E, q, k, v, B, heads, Tn, L, in.lens);
+      FAIL_IF_NULL(o);
+      hid = E.linear(o, blk.at.a2.o, hid);
+      FAIL_IF_NULL(hid);
+      T* n2 = dit_ln_mod(E, hid, mod, 3 * D, 4 * D, Tn, c.norm_eps, modg);
+      FAIL_IF_NULL(n2);
+      T* ff = dit_linear_gelu(E, n2, blk.ff1);
+      FAIL_IF_NULL(ff);
+      hid = dit_linear_gate_res(E, ff, blk.ff2, mod, 5 * D, hid, Tn, modg);
+      FAIL_IF_NULL(hid);
+      RET_IF(pp.leave());
+    }
+    pp.done();
+    T* fin = dit_add_table(E, emb, N.table, 2 * D);     // (shift, scale) = scale_shift_table[None] + embedded_timestep[:, None]
+    FAIL_IF_NULL(fin);
+    T* nf = dit_ln_mod(E, hid, fin, 0, D, Tn, 1e-6f, modg);
+    FAIL_IF_NULL(nf);
+    y = dit_lin(E, nf, N.proj_out);
+  } else {
+    FDMI_CHECK(in.vec != nullptr, "dit: pooled projections required");
+    FDMI_CHECK(in.lens.empty(), "dit: the joint attention takes no key mask");
+    T* vb = dit_input(E, in.vec, B, c.vec_dim);
+    FAIL_IF_NULL(vb);
+    T* ep = dit_embed(E, vb, N.text, false);
+    FAIL_IF_NULL(ep);
+    emb = dit_cat_add(E, emb, {ep});
+    FAIL_IF_NULL(emb);
+    T* se = dit_act(E, emb, DIT_SILU);
+    FAIL_IF_NULL(se);
+    T* cx = dit_input(E, in.ctx, (int64_t)B * L, c.caption_channels);
+    FAIL_IF_NULL(cx);
+    T* ctx = dit_lin(E, cx, N.ctx_emb, nullptr, false);
+    FAIL_IF_NULL(ctx);
+    const float eps = 1e-6f;
+    const int S = Tn + L;
+    int bi = 0;
+    for (auto& bp : N.mblocks) {
+      MmBlockW& blk = *bp;
+      pp.enter(bi++);
+      T* m = dit_lin(E, se, blk.n1);                    // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
+      T* mc = dit_lin(E, se, blk.n1c);                  // the same six for the context stream -- or (scale, shift) in the last block
+      FAIL_IF_NULL(m); FAIL_IF_NULL(mc);
+      T* n = dit_ln_mod(E, hid, m, 0, D, Tn, eps, modg);
+      T* nc = blk.pre_only ? dit_ln_mod(E, ctx, mc, D, 0, L, eps, modg) : dit_ln_mod(E, ctx, mc, 0, D, L, eps, modg);
+      FAIL_IF_NULL(n); FAIL_IF_NULL(nc);
+      T *qx, *kx, *vx, *qc, *kc, *vc, *q, *k, *v;
+      const bool fused = qkv_fusable(U, blk.x) && qkv_fusable(U, blk.c) && (R.dry() || (blk.x.qkv.w && blk.c.qkv.w));
+      if (fused) {   // [q | k | v] of both streams as two GEMMs, joined once
+        T* yx = E.linear_qkv(n, blk.x, D);
+        T* yc = E.linear_qkv(nc, blk.c, D);
+        FAIL_IF_NULL(yx); FAIL_IF_NULL(yc);
+        T* J = dit_join(E, yx, yc, B, Tn, L);
+        FAIL_IF_NULL(J);
+        q = R.view(J, 0, D); k = R.view(J, D, D); v = R.view(J, 2 * D, D);
+      } else {
+        qx = E.linear(n, blk.x.a1.q); kx = E.linear(n, blk.x.a1.k); vx = E.linear(n, blk.x.a1.v);
+        qc = E.linear(nc, blk.c.a1.q); kc = E.linear(nc, blk.c.a1.k); vc = E.linear(nc, blk.c.a1.v);
+        FAIL_IF_NULL(qx); FAIL_IF_NULL(kx); FAIL_IF_NULL(vx); FAIL_IF_NULL(qc); FAIL_IF_NULL(kc); FAIL_IF_NULL(vc);
+        q = dit_join(E, qx, qc, B, Tn, L); k = dit_join(E, kx, kc, B, Tn, L); v = dit_join(E, vx, vc, B, Tn, L);
+      }
+      FAIL_IF_NULL(q); FAIL_IF_NULL(k); FAIL_IF_NULL(v);
+      T* o = E.attention(q, k, v, B, heads, S, S);
+      FAIL_IF_NULL(o);
+      T *ox, *oc;
+      RET_IF(dit_split(E, o, B, Tn, L, !blk.pre_only, &ox, &oc));
+      hid = dit_linear_gate_res(E, ox, blk.x.a1.o, m, 2 * D, hid, Tn, modg);
+      FAIL_IF_NULL(hid);
+      T* n2 = dit_ln_mod(E, hid, m, 3 * D, 4 * D, Tn, eps, modg);
+      FAIL_IF_NULL(n2);
+      T* ff = dit_linear_gelu(E, n2, blk.ff1);
+      FAIL_IF_NULL(ff);
+      hid = dit_linear_gate_res(E, ff, blk.ff2, m, 5 * D, hid, Tn, modg);
+      FAIL_IF_NULL(hid);
+      if (!blk.pre_only) {
+        ctx = dit_linear_gate_res(E, oc, blk.c.a1.o, mc, 2 * D, ctx, L, modg);
+        FAIL_IF_NULL(ctx);
+        T* n2c = dit_ln_mod(E, ctx, mc, 3 * D, 4 * D, L, eps, modg);
+        FAIL_IF_NULL(n2c);
+        T* fc = dit_linear_gelu(E, n2c, blk.ffc1);
+        FAIL_IF_NULL(fc);
+        ctx = dit_linear_gate_res(E, fc, blk.ffc2, mc, 5 * D, ctx, L, modg);
+        FAIL_IF_NULL(ctx);
+      }
+      RET_IF(pp.leave());
+    }
+    pp.done();
+    T* mo = dit_lin(E, se, N.norm_out);                 // AdaLayerNormContinuous: (scale, shift)
+    FAIL_IF_NULL(mo);
+    T* nf = dit_ln_mod(E, hid, mo, D, 0, Tn, eps, modg);
+    FAIL_IF_NULL(nf);
+    y = dit_lin(E, nf, N.proj_out);
+  }
+  FAIL_IF_NULL(y);
+  R.out = y;
+  R.outC = y->cols;
+  if (!R.dry()) RET_IF(launch_unpatchify(y->p, in.out, B, c.out_channels, in.keep, H, W, p, f, st));
+  U->last_flops = E.flops;
+  return 0;
+}
+
+int run_dit_backward(fdmi_unet* U, Run& R, const float* grad_out, float* grad_x) {
+  FDMI_CHECK(R.save && R.out, "dit: backward without a saved forward in this slot");
+  const fdmi_dit_config& c = U->dcfg;
+  Exec E{U, R, R.st};
+  E.splitk_max_rows = 4096;
+  T* o = R.out;
+  bf16_t* g = E.grad_of(o);
+  FDMI_CHECK(g, "dit: workspace exhausted (grad)");
+  const int B = R.dit_geom[0], H = R.dit_geom[1], W = R.dit_geom[2], keep = R.dit_geom[3], f = U->f32 ? 1 : 0;
+  if (!R.dry()) RET_IF(launch_unpatchify_bwd(grad_out, g, B, c.out_channels, keep, H, W, c.patch_size, f, R.st));
+  o->ginit = true;
+  // replay in reverse; after an entry ran, the value and the gradient of what it produced are dead: recycle them (Run::recycle)
+  R.recycle = fdmi_tune_get(41) == 0;   // (A/B switch 41 = 1: plain bump allocation)
+  R.freelist.clear();
+  R.scoped.clear();
+  size_t idx = R.tape.size();
+  auto oi = R.tape_outs.rbegin();
+  for (auto it = R.tape.rbegin(); it != R.tape.rend(); ++it) {
+    --idx;
+    RET_IF((*it)(E));
+    for (auto& sc : R.scoped) R.rfree(sc.first, sc.second);
+    R.scoped.clear();
+    for (; oi != R.tape_outs.rend() && oi->first == idx; ++oi) {
+      T* t = oi->second;
+      const size_t bytes = (size_t)t->rows * t->cols * E.es();
+      if (t->own && t != R.x0) R.rfree(t->p, bytes);
+      if (t->g && !t->parent) R.rfree(t->g, bytes);
+    }
+  }
+  R.recycle = false;
+  if (grad_x) {
+    FDMI_CHECK(R.x0->g && R.x0->ginit, "dit: no gradient reached the input");
+    if (!R.dry()) RET_IF(launch_patchify_bwd(R.x0->g, grad_x, B, c.in_channels, H, W, c.patch_size, f, R.st));
+  }
+  R.save = false;
+  R.tape.clear();
+  U->last_flops = E.flops;
+  return 0;
+}

@@ -14,12 +14,14 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <vector>
 
 #include "../../include/fdmi.h"
 #include "ops.h"
+#include "dit_ops.h"
 
 namespace {
 
@@ -51,6 +53,8 @@ struct T {  // NHWC / token-major bf16 activation [rows][cols] (+ lazily allocat
   T* parent = nullptr;
   int col0 = 0;
   int64_t ldv = 0;
+  bool own = false;   // p was bump-allocated for this tensor (Run::mk): its storage may be recycled once its producer's backward ran
+  int64_t goff = 0;   // element offset of this view inside the parent's gradient buffer (column views: col0; row views: row0 * cols)
   int64_t ld() const { return ldv ? ldv : cols; }
   // a channel concatenation that is never materialised (Exec::cat): columns [0, c1) live at p (row stride c1), columns
   // [c1, cols) at p2 (row stride cols - c1).  Only groupnorm() and linear_w() (the ResNet block's norm1 and 1x1 shortcut, the two
@@ -140,7 +144,7 @@ struct Slot {
 };
 
 // ---- the frozen convolutional networks that sit beside the denoiser in the step, on the same executor ----
-enum { NET_UNET = 0, NET_VAE_DECODER = 1, NET_VGG_LPIPS = 3, NET_T2I_ADAPTER = 4 };
+enum { NET_UNET = 0, NET_VAE_DECODER = 1, NET_VGG_LPIPS = 3, NET_T2I_ADAPTER = 4, NET_DIT_PIXART = 5, NET_DIT_MMDIT = 6 };
 struct NetVae {   // diffusers AutoencoderKL: post_quant_conv + Decoder (vae/autoencoderKL.py:63-128 calls .decode)
   Weight post_quant, conv_in, conv_out;
   Norm norm_out, mid_gn;
@@ -160,6 +164,34 @@ struct AdapterBlockW {   // diffusers AdapterBlock: [AvgPool2d(2)] [1x1 in_conv]
 struct NetAdapter {
   Weight conv_in;
   std::vector<std::unique_ptr<AdapterBlockW>> body;
+};
+
+// ---- the transformer denoisers (dit_plan.h): PixArt-alpha's adaLN-single Transformer2D and SD3's MMDiT ----
+struct DitEmbW { LinearW l1, l2; };   // linear_2(act(linear_1(x))): timestep / vector / text embedders, the caption projection
+struct DitBlockW {                     // BasicTransformerBlock with norm_type = "ada_norm_single"
+  TBlockW at;                          // a1 = attn1 (q / k / v fused into one GEMM), a2 = attn2 (cross-attention over the caption)
+  LinearW ff1, ff2;
+  float* table = nullptr;              // scale_shift_table [6][D]
+};
+struct MmBlockW {                      // JointTransformerBlock
+  bool pre_only = false;               // the last block: the context stream only feeds the attention
+  LinearW n1, n1c;                     // norm1.linear / norm1_context.linear (AdaLayerNormZero / ...Continuous projections)
+  TBlockW x, c;                        // a1 = (to_q, to_k, to_v, to_out.0) / (add_q_proj, add_k_proj, add_v_proj, to_add_out)
+  LinearW ff1, ff2, ffc1, ffc2;
+};
+struct NetDit {
+  TransformerW tw;                     // (C, heads) for the shared fused-operand builders
+  LinearW patch;                       // pos_embed.proj: a k = stride convolution IS a linear map on the folded patches
+  DitEmbW temb;
+  std::vector<std::unique_ptr<DitEmbW>> addemb;   // PixArt: adaln_single.add_embedding (one, or one per concatenated vector)
+  LinearW ada;                         // PixArt: adaln_single.linear -> the six modulation vectors shared by every block
+  DitEmbW cap;                         // PixArt: caption_projection
+  DitEmbW text;                        // MMDiT: time_text_embed.text_embedder
+  LinearW ctx_emb, norm_out;           // MMDiT: context_embedder, norm_out.linear
+  float* table = nullptr;              // PixArt: the final scale_shift_table [2][D]
+  LinearW proj_out;
+  std::vector<std::unique_ptr<DitBlockW>> blocks;
+  std::vector<std::unique_ptr<MmBlockW>> mblocks;
 };
 
 struct Exec;
@@ -182,6 +214,40 @@ struct Run {
     zoff += bytes;
     return p;
   }
+  // Backward-time recycling (the transformer plans, dit_plan.h): once the tape entry that PRODUCED a tensor has run, nobody reads
+  // its value or its gradient again (every consumer's entry was recorded later, so it ran earlier) -- both buffers go to a free
+  // list keyed by size and come back as the gradient / scratch buffers of the layers below.  The identical layers of a
+  // transformer make the reuse near-perfect: a saved run needs about its forward footprint, not forward + backward.
+  bool recycle = false;
+  std::multimap<size_t, void*> freelist;
+  std::vector<std::pair<size_t, T*>> tape_outs;        // (tape index, tensor it produced)
+  std::vector<std::pair<void*, size_t>> scoped;        // scratch of the running tape entry
+  static size_t rnd(size_t b) { return (b + 255) & ~(size_t)255; }
+  void* ralloc(size_t bytes) {
+    bytes = rnd(bytes);
+    if (recycle) {
+      auto it = freelist.find(bytes);
+      if (it != freelist.end()) {
+        void* p = it->second;
+        freelist.erase(it);
+        return p;
+      }
+    }
+    return arena.alloc(bytes);
+  }
+  void rfree(void* p, size_t bytes) {
+    if (recycle && p) freelist.emplace(rnd(bytes), p);
+  }
+  void* tmp(size_t bytes) {   // scratch that dies with the running tape entry (plain bump allocation outside a recycling backward)
+    if (!recycle) return arena.alloc(bytes);
+    void* p = ralloc(bytes);
+    if (p) scoped.push_back({p, bytes});
+    return p;
+  }
+  void mark_out(std::initializer_list<T*> ts) {   // call right after tape.push_back: the tensors that entry produced
+    for (T* t : ts)
+      if (t) tape_outs.push_back({tape.size() - 1, t});
+  }
   T* x0 = nullptr;   // NHWC input (grad wrt the sample)
   T* out = nullptr;  // output tensor
   int outC = 0;
@@ -189,7 +255,8 @@ struct Run {
     tensors.emplace_back();
     T* t = &tensors.back();
     t->rows = rows; t->cols = cols; t->B = B; t->H = H; t->W = W;
-    t->p = (bf16_t*)arena.alloc((size_t)rows * cols * es);
+    t->p = (bf16_t*)arena.alloc(rnd((size_t)rows * cols * es));
+    t->own = true;
     return t->p ? t : nullptr;
   }
   // tensor header over caller-provided storage (no arena allocation)
@@ -204,12 +271,21 @@ struct Run {
     tensors.emplace_back();
     T* t = &tensors.back();
     t->rows = parent->rows; t->cols = cols; t->B = parent->B; t->H = parent->H; t->W = parent->W;
-    t->p = parent->p + col0; t->parent = parent; t->col0 = col0; t->ldv = parent->ld();
+    t->p = parent->p + col0; t->parent = parent; t->col0 = col0; t->ldv = parent->ld(); t->goff = col0;
+    return t;
+  }
+  // rows row0 .. row0 + rows of a (compact) `parent`, all columns: one sample's tokens (either precision)
+  T* rowview(T* parent, int64_t row0, int64_t rows) {
+    tensors.emplace_back();
+    T* t = &tensors.back();
+    t->rows = rows; t->cols = parent->cols; t->B = 1;
+    t->p = (bf16_t*)((char*)parent->p + (size_t)row0 * parent->cols * es); t->parent = parent; t->goff = row0 * parent->cols;
     return t;
   }
   bool dry() const { return arena.dry; }
   const float* gvec = nullptr;   // NET_VGG_LPIPS backward: d loss / d distance [B] (device, fp32)
   std::vector<T*> outs;          // NET_T2I_ADAPTER: the feature maps of the last forward
+  int dit_geom[5] = {0, 0, 0, 0, 0};   // transformer denoisers: B, H, W (latent), channels kept of the output, sample channels
 };
 
 }  // namespace
@@ -220,6 +296,8 @@ struct fdmi_unet {
   std::unique_ptr<NetVae> vae;
   std::unique_ptr<NetVgg> vgg;
   std::unique_ptr<NetAdapter> adp;
+  std::unique_ptr<NetDit> dit;
+  fdmi_dit_config dcfg{};
   // T2I-adapter residuals for the NEXT forward (one f32 NCHW tensor per down block, consumed once): UW:100-106
   std::vector<const float*> down_res;
   float down_res_scale = 1.f;
@@ -535,6 +613,7 @@ int set_param(fdmi_unet* U, const std::string& name, const float* src, int64_t n
       const int nb = (w.Cout > 0 && w.Cout < w.N) ? w.Cout : w.N;   // (a conv with padded output columns: the pad stays zero)
       hipLaunchKernelGGL(pack_vec_kernel, dim3(gridfor(nb)), dim3(256), 0, st, src, w.bias, nb, w.geglu ? 1 : 0);
       w.set |= 2;
+      U->fused_dirty = true;   // (a fused q / k / v GEMM carries the three biases concatenated)
       break;
     }
     case S_GAMMA:
@@ -595,6 +674,10 @@ void for_each_tblock(fdmi_unet* U, F fn) {
   if (U->mid_attn)
     for (auto& b : U->mid_attn->blocks) fn(*U->mid_attn, *b);
   for (auto& s : U->up) stage(*s);
+  if (U->dit) {   // the transformer denoisers' blocks hold the same fused-projection record(s)
+    for (auto& b : U->dit->blocks) fn(U->dit->tw, b->at);
+    for (auto& b : U->dit->mblocks) { fn(U->dit->tw, b->x); fn(U->dit->tw, b->c); }
+  }
 }
 // attn1's three projections can run as one GEMM when none of them or all of them carry a LoRA of one rank (bf16 plans;
 // A/B switch 17 = 1 keeps the three separate launches)
@@ -652,6 +735,15 @@ int build_fused_operands(fdmi_unet* U, hipStream_t st) {
         rc = -2;
       }
     }
+    if (w[0]->bias && w[1]->bias && w[2]->bias) {   // (attention_bias = True: the transformer denoisers)
+      if (!b.qkv.bias && (rc = dmalloc(U, &b.qkv.bias, (size_t)3 * C))) return;
+      for (int s = 0; s < 3 && !rc; ++s)
+        if (hipMemcpyAsync(b.qkv.bias + (size_t)s * C, w[s]->bias, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) {
+          fdmi_set_error("unet: copying the fused q/k/v bias failed");
+          rc = -2;
+        }
+      if (rc) return;
+    }
     // ... and with the three LoRA up-projections folded in (zero blocks off the diagonal: dmalloc clears)
     const Lora& lq = b.a1.q.lora;
     if (!rc && qkv_fusable(U, b) && lq.on && lora_foldable(U, lq) && lora_foldable(U, b.a1.k.lora) && lora_foldable(U, b.a1.v.lora)) {
@@ -675,6 +767,7 @@ struct Exec {
   double flops = 0;
   int ctx_mode = 0;  // 0: none, 1: fill the cross-attention K/V cache, 2: reuse it (FDMI_UNET_CTX_*)
   bool gn_epi = false;  // GroupNorm statistics in the producing GEMM's epilogue (see want_gn)
+  int splitk_max_rows = 0;  // > 0: only problems of at most this many rows may split K (the transformer denoisers, dit_plan.h)
 
   // ---- precision dispatch: an fp32 validation plan stores floats behind the same (opaque) bf16_t* handles and runs the
   // ref32.hip kernels; everything below picks the kernel family by U->f32 ----
@@ -705,10 +798,10 @@ struct Exec {
   bf16_t* grad_of(T* t) {  // lazily allocate the gradient buffer
     if (t->parent) {      // a column slice: the same columns of the parent's gradient
       bf16_t* pg = grad_of(t->parent);
-      t->g = pg ? pg + t->col0 : nullptr;
+      t->g = pg ? off(pg, t->goff) : nullptr;
       return t->g;
     }
-    if (!t->g) t->g = (bf16_t*)R.arena.alloc((size_t)t->rows * t->cols * es());
+    if (!t->g) t->g = (bf16_t*)R.ralloc((size_t)t->rows * t->cols * es());
     return t->g;
   }
   int gemm(GemmArgs& a) {
@@ -725,10 +818,10 @@ struct Exec {
       fprintf(stderr, "PLANGEMM mode=%d M=%d N=%d K=%d act=%d res=%d dgrad=%d atomic=%d kernel=%d BM=%d BN=%d splitk=%d\n", a.mode, a.M, a.N,
               a.K, a.act, a.residual ? 1 : 0, a.dgrad, a.accum_atomic, p.big, p.big ? 256 : p.BM, p.BN, p.splitk);
     }
-    if (!a.accum_atomic && a.splitk == 1) {  // let the launcher split K when the tile grid under-fills the chip
+    if (!a.accum_atomic && a.splitk == 1 && (!splitk_max_rows || a.M <= splitk_max_rows)) {  // let the launcher split K when the tile grid under-fills the chip
       const size_t wsb = gemm_ws_bytes(a);
       if (wsb) {
-        a.ws = (float*)R.arena.alloc(wsb);
+        a.ws = (float*)R.tmp(wsb);
         FDMI_CHECK(a.ws, "unet: workspace exhausted (split-K)");
         a.splitk = 0;
         U->hbm[HBM_SPLITK] += (double)wsb + 2.0 * a.M * a.N;   // what the finalize pass reads (fp32 slabs) and writes (bf16)
@@ -766,7 +859,9 @@ struct Exec {
   }
 
   int lora_refresh() {
-    if (R.dry() || f32()) return 0;   // (an fp32 plan reads the fp32 masters directly)
+    if (R.dry()) return 0;
+    for (Lora* l : U->loras) FDMI_CHECK(l->A && l->A_master, "unet: a declared LoRA was never bound (fdmi_unet_set_lora)");
+    if (f32()) return 0;   // (an fp32 plan reads the fp32 masters directly)
     if (U->cast_mode != fdmi_tune_get(17)) U->cast_dirty = true;
     if (U->cast_dirty) {
       U->cast_mode = fdmi_tune_get(17);  // (re)build the tile table of the one-launch refresh
@@ -914,6 +1009,7 @@ struct Exec {
         }
         return 0;
       });
+      R.mark_out({y, t});
     }
     return y;
   }
@@ -936,12 +1032,12 @@ struct Exec {
       NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.A3, 3 * r, C, nullptr, t3->p, 3 * r, nullptr, 0));
     }
     if (fold) {
-      GemmArgs a = rows_args(x->p, x->cols, x->rows, b.Wc3, 3 * C, C + 3 * r, nullptr, y->p, 3 * C, nullptr, 0);
+      GemmArgs a = rows_args(x->p, x->cols, x->rows, b.Wc3, 3 * C, C + 3 * r, b.qkv.bias, y->p, 3 * C, nullptr, 0);
       a.ldw = C + 3 * r; a.A2 = t3->p; a.lda2 = 3 * r; a.K1 = C;
       NULL_IF(gemm(a));
       flops -= 2.0 * x->rows * (3.0 * C) * (2.0 * r);   // (the zero blocks off the diagonal are not algorithmic work)
     } else {
-      NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.qkv.w, 3 * C, C, nullptr, y->p, 3 * C, nullptr, 0));
+      NULL_IF(gemm_rows(x->p, x->cols, x->rows, b.qkv.w, 3 * C, C, b.qkv.bias, y->p, 3 * C, nullptr, 0));
       if (lora)
         for (int s = 0; s < 3; ++s)
           NULL_IF(gemm_rows(t3->p + s * r, 3 * r, x->rows, l3[s]->B, C, r, nullptr, y->p + s * C, 3 * C, y->p + s * C, 3 * C));
@@ -979,6 +1075,7 @@ struct Exec {
         }
         return 0;
       });
+      R.mark_out({y, t3});
     }
     return y;
   }
@@ -1131,11 +1228,17 @@ struct Exec {
     return y;
   }
 
-  // vt_ext: caller-owned V^T buffer; vt_ready: it already holds the transposed V (cached context)
-  T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, bf16_t* vt_ext = nullptr, bool vt_ready = false) {
+  // the gradient of a tensor a consumer may have written through its parent (a row / column view): resolve it before testing
+  bool has_grad(T* t) {
+    if (t->parent && !t->g && t->parent->g) grad_of(t);
+    return t->g != nullptr;
+  }
+  // vt_ext: caller-owned V^T buffer; vt_ready: it already holds the transposed V (cached context); o_ext: write the output into
+  // this tensor (a row view of a larger one: per-sample launches of a masked cross-attention) instead of allocating it
+  T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, bf16_t* vt_ext = nullptr, bool vt_ready = false, T* o_ext = nullptr) {
     const int d = q->cols / H;
-    if (f32()) return attention32(q, k, v, Bn, H, Sq, Skv, d);
-    T* o = R.mk(q->rows, q->cols, q->B, q->H, q->W);
+    if (f32()) return attention32(q, k, v, Bn, H, Sq, Skv, d, o_ext);
+    T* o = o_ext ? o_ext : R.mk(q->rows, q->cols, q->B, q->H, q->W);
     const int64_t tr_kv = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Skv);
     const int64_t tr_q = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Sq);
     bf16_t* VT = vt_ext ? vt_ext : (bf16_t*)R.arena.alloc((size_t)tr_kv * 2);
@@ -1152,12 +1255,12 @@ struct Exec {
       NULL_IF(launch_attn_fwd(a, st));
     }
     if (R.save) {
-      R.tape.push_back([o, q, k, v, a, Bn, H, Sq, Skv, d, tr_q, tr_kv](Exec& E) -> int {
-        if (!o->g) return 0;
-        bf16_t* QT = (bf16_t*)E.R.arena.alloc((size_t)tr_q * 2);
-        bf16_t* dOT = (bf16_t*)E.R.arena.alloc((size_t)tr_q * 2);
-        bf16_t* KT = (bf16_t*)E.R.arena.alloc((size_t)tr_kv * 2);
-        float* delta = (float*)E.R.arena.alloc((size_t)Bn * H * Sq * 4);
+      R.tape.push_back([o, q, k, v, a, Bn, H, Sq, Skv, d, tr_q, tr_kv, vt_ext](Exec& E) -> int {
+        if (!E.has_grad(o)) return 0;
+        bf16_t* QT = (bf16_t*)E.R.tmp((size_t)tr_q * 2);
+        bf16_t* dOT = (bf16_t*)E.R.tmp((size_t)tr_q * 2);
+        bf16_t* KT = (bf16_t*)E.R.tmp((size_t)tr_kv * 2);
+        float* delta = (float*)E.R.tmp((size_t)Bn * H * Sq * 4);
         bf16_t *dq = E.grad_of(q), *dk = E.grad_of(k), *dv = E.grad_of(v);
         FDMI_CHECK(QT && dOT && KT && delta && dq && dk && dv, "unet: workspace exhausted (attn bwd)");
         E.flops += 2.0 * 4.0 * Bn * H * (double)Sq * Skv * d;  // algorithmic: 2x forward
@@ -1175,15 +1278,18 @@ struct Exec {
         }
         q->ginit = k->ginit = v->ginit = true;
         if (q->parent) q->parent->ginit = true;   // (the three slices of a fused projection are written together)
+        if (!vt_ext) E.R.rfree((void*)a.VT, (size_t)tr_kv * 2);   // (the forward's V^T and log-sum-exp die with this entry)
+        E.R.rfree(a.lse, (size_t)Bn * H * Sq * 4);
         return 0;
       });
+      if (!o_ext) R.mark_out({o});
     }
     return o;
   }
 
   // fp32 validation plan: materialised scores, exact-f32 MFMA products, fp32 softmax (ref32.hip)
-  T* attention32(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, int d) {
-    T* o = R.mk(q->rows, H * d, q->B, q->H, q->W);
+  T* attention32(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, int d, T* o_ext = nullptr) {
+    T* o = o_ext ? o_ext : R.mk(q->rows, H * d, q->B, q->H, q->W);
     float* sc = attn_scratch(Bn, H, Sq, Skv, 0);
     if (!o || !sc) return nullptr;
     const float scale = 1.f / sqrtf((float)d);
@@ -1193,7 +1299,7 @@ struct Exec {
                                 sc, R.sc32_elems, st));
     if (R.save) {
       R.tape.push_back([o, q, k, v, Bn, H, Sq, Skv, d, scale](Exec& E) -> int {
-        if (!o->g) return 0;
+        if (!E.has_grad(o)) return 0;
         float* sc2 = E.attn_scratch(Bn, H, Sq, Skv, 1);
         bf16_t *dq = E.grad_of(q), *dk = E.grad_of(k), *dv = E.grad_of(v);
         FDMI_CHECK(sc2 && dq && dk && dv, "unet: workspace exhausted (attn bwd)");
@@ -1204,6 +1310,7 @@ struct Exec {
         q->ginit = k->ginit = v->ginit = true;
         return 0;
       });
+      if (!o_ext) R.mark_out({o});
     }
     return o;
   }
@@ -1497,6 +1604,8 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   for (double& b : U->hbm) b = 0;
   R.tensors.clear();
   R.tape.clear();
+  R.tape_outs.clear();
+  R.recycle = false;
   R.arena.off = 0;
   R.es = U->f32 ? 4 : 2;
   R.sc32 = nullptr;
@@ -1774,6 +1883,10 @@ static void run_reset(fdmi_unet* U, Run& R, int flags) {
   for (double& b : U->hbm) b = 0;
   R.tensors.clear();
   R.tape.clear();
+  R.tape_outs.clear();
+  R.freelist.clear();
+  R.scoped.clear();
+  R.recycle = false;
   R.outs.clear();
   R.arena.off = 0;
   R.es = U->f32 ? 4 : 2;
@@ -1978,6 +2091,8 @@ int run_net_backward(fdmi_unet* U, Run& R, const float* grad_out, float* grad_x)
   return 0;
 }
 
+#include "dit_plan.h"
+
 int check_ready(fdmi_unet* U) {
   for (auto& kv : U->slots) {
     const Slot& s = kv.second;
@@ -2039,17 +2154,32 @@ int fdmi_unet_set_lora(fdmi_unet* U, const char* target, const float* A, const f
   const Weight& w = it->second->w;
   if (l.A_master != A || l.B_master != B) U->cast_dirty = true;
   l.A_master = A; l.B_master = B; l.A_grad = A_grad; l.B_grad = B_grad;
-  if (!l.on) {
+  FDMI_CHECK(!l.on || l.r == rank, "unet: LoRA rank changed");
+  if (!l.A) {
+    const bool declared = l.on;
     l.r = rank; l.in = w.K; l.out = w.N;
     RET_IF(dmalloc(U, &l.A, (size_t)rank * l.in));
     RET_IF(dmalloc(U, &l.AT, (size_t)rank * l.in));
     RET_IF(dmalloc(U, &l.B, (size_t)rank * l.out));
     RET_IF(dmalloc(U, &l.BT, (size_t)rank * l.out));
     l.on = true;
-    U->loras.push_back(&l);
+    if (!declared) U->loras.push_back(&l);
     U->fused_dirty = true;   // the folded [W | B] / [W^T | A^T] operands of this linear are built at the next forward
   }
-  FDMI_CHECK(l.r == rank, "unet: LoRA rank changed");
+  return 0;
+}
+int fdmi_unet_declare_lora(fdmi_unet* U, const char* target, int rank) {
+  FDMI_CHECK(U && target, "null argument");
+  auto it = U->lora_targets.find(target);
+  FDMI_CHECK(it != U->lora_targets.end(), std::string("unet: '") + target + "' is not a LoRA-capable linear");
+  FDMI_CHECK(rank > 0 && rank % 8 == 0, "unet: LoRA rank must be a positive multiple of 8");
+  Lora& l = it->second->lora;
+  FDMI_CHECK(!l.on || l.r == rank, "unet: LoRA rank changed");
+  if (!l.on) {
+    l.r = rank; l.in = it->second->w.K; l.out = it->second->w.N;
+    l.on = true;
+    U->loras.push_back(&l);
+  }
   return 0;
 }
 int fdmi_unet_ready(fdmi_unet* U) {
@@ -2182,6 +2312,60 @@ int fdmi_adapter_forward(fdmi_unet* U, int slot, const float* x, float* const* o
   R.arena.dry = false;
   R.st = (hipStream_t)stream;
   return run_adapter(U, R, x, outs, n_outs, B, H, W);
+}
+
+// ---- the transformer denoisers (dit_plan.h): same handle type, fdmi_unet_set_param / _set_lora / _ready / _destroy apply ----
+fdmi_unet* fdmi_dit_create(const fdmi_dit_config* cfg) {
+  if (!cfg) { fdmi_set_error("null config"); return nullptr; }
+  if (cfg->precision != 0 && cfg->precision != 1) {
+    fdmi_set_error("dit: precision must be 0 (bf16 MFMA) or 1 (fp32 validation mode)");
+    return nullptr;
+  }
+  auto* U = new fdmi_unet();
+  U->kind = cfg->kind == FDMI_DIT_MMDIT ? NET_DIT_MMDIT : NET_DIT_PIXART;
+  U->dcfg = *cfg;
+  U->cfg = fdmi_unet_config{};
+  U->cfg.precision = cfg->precision;
+  U->f32 = cfg->precision == 1;
+  if (build_dit(U)) { delete U; return nullptr; }
+  return U;
+}
+static bool is_dit(const fdmi_unet* U) { return U && (U->kind == NET_DIT_PIXART || U->kind == NET_DIT_MMDIT); }
+int64_t fdmi_dit_workspace_bytes(fdmi_unet* U, int B, int H, int W, int L, int masked, int flags) {
+  if (!is_dit(U)) return -1;
+  Run R;
+  R.arena.dry = true;
+  DitIn in{};
+  in.B = B; in.H = H; in.W = W; in.L = L; in.keep = 1;
+  in.vec = (const float*)(uintptr_t)256;
+  if (masked) in.lens.assign(B, L);   // (per-sample launches: a few more small buffers than the one-launch form)
+  if (run_dit(U, R, in, flags)) return -1;
+  if (flags & FDMI_UNET_SAVE) {
+    if (run_dit_backward(U, R, nullptr, (flags & FDMI_UNET_INPUT_GRAD) ? (float*)(uintptr_t)256 : nullptr)) return -1;
+  }
+  return (int64_t)R.arena.peak + (1 << 20);
+}
+int fdmi_dit_forward(fdmi_unet* U, int slot, const float* sample, const float* timestep, const float* ctx, const float* vector,
+                     const float* pos, const int32_t* key_lens, float* out, int B, int H, int W, int L, int out_keep,
+                     void* workspace, int64_t workspace_bytes, int flags, void* stream) {
+  FDMI_CHECK(is_dit(U) && slot >= 0 && slot < 8, "dit: bad plan / slot");
+  FDMI_CHECK(sample && timestep && ctx && pos && out && workspace, "dit: null argument");
+  Run& R = U->runs[slot];
+  R.arena.base = (char*)workspace;
+  R.arena.cap = (size_t)workspace_bytes;
+  R.arena.dry = false;
+  R.st = (hipStream_t)stream;
+  DitIn in{};
+  in.x = sample; in.t = timestep; in.ctx = ctx; in.vec = vector; in.pos = pos; in.out = out;
+  in.B = B; in.H = H; in.W = W; in.L = L; in.keep = out_keep;
+  if (key_lens) in.lens.assign(key_lens, key_lens + B);
+  return run_dit(U, R, in, flags);
+}
+int fdmi_dit_backward(fdmi_unet* U, int slot, const float* grad_out, float* grad_sample, void* stream) {
+  FDMI_CHECK(is_dit(U) && slot >= 0 && slot < 8 && grad_out, "dit: bad plan / slot / null grad");
+  Run& R = U->runs[slot];
+  R.st = (hipStream_t)stream;
+  return run_dit_backward(U, R, grad_out, grad_sample);
 }
 
 // ---- the frozen teacher's CFG loop without a host round trip between steps (FD:288-324) ----------------------------

@@ -11,6 +11,12 @@ memory, the stream, the autograd graph edges between those launches, the patch (
 the glue on per-sample vectors ([B, C]: adding the scale-shift tables, chunk / cat).  There is no torch compute path for
 the activations and no CPU fallback: without libfdmi.so every call raises.
 
+On the GPU a forward is ONE C-ABI call into the library's plan of the denoiser (include/fdmi.h: fdmi_dit_create / _forward /
+_backward -- csrc/dit_plan.h on the tape executor of the UNet plan): patch folding, the embedders, every block, the joint
+[latent | text] sequence of the MMDiT and the whole backward run from C++ with activations bump-allocated from one workspace;
+torch keeps ONE autograd edge per denoiser call (``_DitFn``).  ``FDMI_DIT_PLAN=0`` keeps the op-by-op composition below on the GPU
+(the A/B switch; it is also what the CPU host-logic tests drive through ``tests/fake_ops.py``).
+
 LoRA follows peft (examples/train_flash_pixart.py:237-256): y = W x + B(A x) on every module whose name ends in one of the
 target suffixes -- linears and the patch-embedding convolution alike (a k = stride convolution IS a linear map on the
 folded patches, so it runs as one)."""
@@ -24,6 +30,10 @@ import torch
 import torch.nn as nn
 
 from . import ops
+
+import ctypes as C
+import os
+import weakref
 
 BF16 = torch.bfloat16
 F32 = torch.float32
@@ -399,6 +409,7 @@ class _DenoiserBase(nn.Module):
         self._pos_cache = {}
         self.last_flops = 0.0
         self.step_flops = 0.0   # running sum of algorithmic MFMA flops (bench.py resets it)
+        self.plan_calls = 0     # forwards that ran as ONE fdmi_dit_forward (the tests assert the plan is the path that ran)
         for m in self.modules():
             if isinstance(m, MiLinear):
                 m._owner[0] = self
@@ -450,10 +461,11 @@ class _DenoiserBase(nn.Module):
     def lora_rank(self):
         return self.lora_r
 
-    def _reflatten_lora(self, device):
+    def _reflatten_lora(self, device, attach=True):
         """(Re)establish the invariant that every LoRA tensor is a view into one flat fp32 buffer and every LoRA ``.grad`` a
         view into one flat gradient buffer which the backward GEMMs accumulate into directly (after .to(device) / deepcopy /
-        load_state_dict).  Returns True when nothing had to move."""
+        load_state_dict).  Returns True when nothing had to move.  attach=False (the plan path, at every forward) only makes
+        sure the two flat buffers exist: ``.grad`` is attached by ``_attach_lora_grads`` at backward time."""
         named = [(n, p) for n, p in self.named_parameters() if ".lora_" in n]
         total = sum(p.numel() for _, p in named)
         flat = self._lora_flat
@@ -477,6 +489,8 @@ class _DenoiserBase(nn.Module):
         g = self._lora_grad
         if g is None or g.device != device:
             g = self._lora_grad = torch.zeros(total, dtype=torch.float32, device=device)
+        if not attach:
+            return ok
         off = 0
         views = {}
         for n, p in named:
@@ -496,6 +510,200 @@ class _DenoiserBase(nn.Module):
 
     def lora_flat_grad(self):
         return self._lora_grad
+
+    # ---- the C++ plan of this denoiser (include/fdmi.h fdmi_dit_*; same slot / workspace protocol as unet.py's _Plan) --------
+    _PLANS: Dict[int, object] = {}
+
+    def _use_plan(self, sample):
+        return sample.is_cuda and os.environ.get("FDMI_DIT_PLAN", "1") == "1"
+
+    def _plan(self):
+        p = _DenoiserBase._PLANS.get(id(self))
+        if p is None:
+            from .unet import _Plan
+            p = _Plan(self._dit_cfg(), create="fdmi_dit_create")
+            _DenoiserBase._PLANS[id(self)] = p
+            weakref.finalize(self, _DenoiserBase._drop_plan, id(self))
+        return p
+
+    @staticmethod
+    def _drop_plan(key):
+        p = _DenoiserBase._PLANS.pop(key, None)
+        if p is not None:
+            p.close()
+
+    def invalidate_plan(self):
+        """Call after changing frozen base weights in place (load_state_dict does it for you)."""
+        p = _DenoiserBase._PLANS.get(id(self))
+        if p is not None:
+            p.packed = False
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self.invalidate_plan()
+        return r
+
+    def _lora_modules(self):
+        return [(n, m) for n, m in self.named_modules() if isinstance(m, MiLinear) and m.rank]
+
+    def _ensure_packed(self, device):
+        from ._lib import check, i64, lib, ptr, stream_ptr
+        plan = self._plan()
+        L = lib()
+        if not plan.packed:
+            n = L.fdmi_unet_num_params(plan.handle)
+            expected = {}
+            buf = C.create_string_buffer(512)
+            ne = i64()
+            for i in range(n):
+                check(L.fdmi_unet_param_name(plan.handle, i, buf, 512, C.byref(ne)))
+                expected[buf.value.decode()] = ne.value
+            mine = {k: v for k, v in self.named_parameters() if ".lora_" not in k}
+            assert set(expected) == set(mine), (set(expected) ^ set(mine))
+            for name, p in mine.items():
+                assert p.is_cuda and p.dtype == torch.float32, f"{name}: parameters must be fp32 on the GPU"
+                t = p.detach().contiguous()
+                check(L.fdmi_unet_set_param(plan.handle, name.encode(), ptr(t), t.numel(), stream_ptr()))
+            torch.cuda.current_stream().synchronize()
+            check(L.fdmi_unet_ready(plan.handle))
+            plan.packed = True
+        if self.lora_r:
+            same = self._reflatten_lora(device, attach=False)
+            key = (self._lora_flat.data_ptr(), self._lora_grad.data_ptr())
+            if not (same and plan.lora_bound == key):
+                g, off = self._lora_grad, 0
+                grads = {}
+                for pn, p in self.named_parameters():      # (the flat buffers hold the LoRA tensors in named_parameters order)
+                    if ".lora_" in pn:
+                        grads[pn] = g[off:off + p.numel()]
+                        off += p.numel()
+                for name, m in self._lora_modules():
+                    a, b = m.lora_A.default.weight, m.lora_B.default.weight
+                    check(L.fdmi_unet_set_lora(plan.handle, name.encode(), ptr(a), ptr(b), ptr(grads[name + ".lora_A.default.weight"]),
+                                               ptr(grads[name + ".lora_B.default.weight"]), m.rank))
+                plan.lora_bound = key
+        return plan
+
+    def _attach_lora_grads(self):
+        """param.grad <- views of the flat gradient buffer the plan's backward accumulates into (zeroing it when the grads were
+        None: optimizer.zero_grad(set_to_none=True))"""
+        named = [(n, p) for n, p in self.named_parameters() if ".lora_" in n]
+        if any(p.grad is None for _, p in named):
+            self._lora_grad.zero_()
+        off = 0
+        for _, p in named:
+            v = self._lora_grad[off:off + p.numel()].view(p.shape)
+            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
+                p.grad = v
+            off += p.numel()
+
+    def _plan_call(self, sample, timestep, ctx, vector, pos, lens, keep):
+        """one denoiser call through the plan: sample [B, C, H, W], timestep [B], ctx [B, L, .], vector [B, .] or None, pos
+        [T, D] fp32, lens = per-sample valid keys (host ints) or None -> [B, keep, H, W] fp32"""
+        B = sample.shape[0]
+        dev = sample.device
+        if not torch.is_tensor(timestep):
+            timestep = torch.full((B,), float(timestep), device=dev)
+        t = timestep.to(device=dev, dtype=torch.float32).reshape(-1)
+        if t.numel() == 1:
+            t = t.expand(B)
+        t = t.contiguous()
+        lora = self.lora_parameters() if self.lora_r else []
+        need_grad = torch.is_grad_enabled() and (sample.requires_grad or any(p.requires_grad for p in lora))
+        x = sample.float().contiguous()
+        cx = ctx.float().contiguous()
+        vec = vector.float().contiguous() if vector is not None else None
+        args = (x, t, cx, vec, pos, tuple(lens) if lens is not None else None, keep)
+        if need_grad:
+            return _DitFn.apply(self, args, *([x] + lora))
+        out, _ = self._run_plan(args, 0)
+        return out
+
+    def _run_plan(self, args, flags):
+        from ._lib import check, lib, ptr, stream_ptr
+        from .unet import FDMI_UNET_INPUT_GRAD, FDMI_UNET_SAVE
+        x, t, cx, vec, pos, lens, keep = args
+        plan = self._ensure_packed(x.device)
+        L = lib()
+        B, _, H, W = x.shape
+        Lc = cx.shape[1]
+        save = bool(flags & FDMI_UNET_SAVE)
+        if save:
+            free = [s for s in range(1, 8) if s not in plan.busy]
+            if not free:
+                raise RuntimeError("fdmi: seven denoiser calls with saved activations are outstanding on this model "
+                                   "(call backward or release_saved())")
+            slot = free[0]
+            plan.busy.add(slot)
+            plan.gen[slot] = plan.gen.get(slot, 0) + 1
+            qflags = flags | (FDMI_UNET_INPUT_GRAD if x.requires_grad else 0)
+        else:
+            slot, qflags = 0, flags
+        need = L.fdmi_dit_workspace_bytes(plan.handle, B, H, W, Lc, int(lens is not None), qflags)
+        if need < 0:
+            raise RuntimeError("fdmi: " + L.fdmi_last_error().decode())
+        ws = plan.workspaces.get(slot)
+        if ws is None or ws.numel() < need or ws.device != x.device:
+            ws = torch.empty(need, dtype=torch.uint8, device=x.device)
+            plan.workspaces[slot] = ws
+        out = torch.empty(B, keep, H, W, dtype=torch.float32, device=x.device)
+        kl = (C.c_int32 * B)(*lens) if lens is not None else None
+        plan.enter(slot)
+        try:
+            check(L.fdmi_dit_forward(plan.handle, slot, ptr(x), ptr(t), ptr(cx), ptr(vec), ptr(pos), kl, ptr(out), B, H, W, Lc, keep,
+                                     ptr(ws), ws.numel(), flags, stream_ptr()))
+        finally:
+            plan.leave(slot)
+        self.last_flops = L.fdmi_unet_last_flops(plan.handle)
+        self.step_flops += self.last_flops
+        self.plan_calls += 1
+        return out, slot
+
+    def _run_plan_backward(self, slot, grad_out, needs_x, xshape, gen):
+        from ._lib import check, lib, ptr, stream_ptr
+        plan = self._plan()
+        L = lib()
+        if self.lora_r:
+            self._attach_lora_grads()
+        g = grad_out.float().contiguous()
+        gx = torch.empty(xshape, dtype=torch.float32, device=g.device) if needs_x else None
+        plan.enter(slot)
+        try:
+            check(L.fdmi_dit_backward(plan.handle, slot, ptr(g), ptr(gx), stream_ptr()))
+        finally:
+            plan.leave(slot)
+            plan.release(slot, gen)
+        self.last_flops = L.fdmi_unet_last_flops(plan.handle)
+        self.step_flops += self.last_flops
+        return gx
+
+    def release_saved(self):
+        """Drop saved-for-backward runs that will never be back-propagated (e.g. after an exception)."""
+        self._plan().busy.clear()
+
+
+class _DitFn(torch.autograd.Function):
+    """the ONE autograd edge of a denoiser call through the plan (as unet._UNetFn): x = the fp32 sample, *lora = the student's
+    LoRA tensors (their gradients are accumulated in place by the plan's backward: nothing is returned for them)"""
+
+    @staticmethod
+    def forward(ctx, mod, args, x, *lora):
+        from .unet import FDMI_UNET_SAVE
+        out, slot = mod._run_plan(args, FDMI_UNET_SAVE)
+        plan = mod._plan()
+        ctx.mod, ctx.slot, ctx.gen = mod, slot, plan.gen[slot]
+        weakref.finalize(ctx, plan.release, slot, ctx.gen)   # a graph dropped without backward gives its slot back
+        ctx.needs_x = x.requires_grad
+        ctx.nlora = len(lora)
+        ctx.xshape = x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        if ctx.mod._plan().gen.get(ctx.slot) != ctx.gen:
+            raise RuntimeError("fdmi: backward of a denoiser call whose saved activations were released (slot reused)")
+        gx = ctx.mod._run_plan_backward(ctx.slot, grad_out, ctx.needs_x, ctx.xshape, ctx.gen)
+        return (None, None, gx) + (None,) * ctx.nlora
 
 
 class MiTransformer2DModel(_DenoiserBase):
@@ -525,6 +733,7 @@ class MiTransformer2DModel(_DenoiserBase):
                                 out_channels=out_channels, num_layers=num_layers, heads=num_attention_heads,
                                 head_dim=attention_head_dim, inner_dim=D, cross_attention_dim=cross_attention_dim,
                                 caption_channels=caption_channels, norm_eps=norm_eps, tdim=timesteps_embedding_num_channels,
+                                attention_bias=bool(attention_bias),
                                 interpolation_scale=interpolation_scale if interpolation_scale is not None
                                 else max(sample_size // 64, 1))
         p = patch_size
@@ -555,6 +764,25 @@ class MiTransformer2DModel(_DenoiserBase):
         self.proj_out = MiLinear(p * p * out_channels, D)
         self._mask_cache = None
         self._init_base()
+
+    def _dit_cfg(self):
+        from ._lib import DitCfg
+        c, s = self.config_dict, DitCfg()
+        s.kind, s.in_channels, s.out_channels, s.patch_size = 1, c["in_channels"], c["out_channels"], c["patch_size"]
+        s.num_layers, s.heads, s.head_dim = c["num_layers"], c["heads"], c["head_dim"]
+        s.cross_dim, s.caption_channels, s.tdim = c["cross_attention_dim"], c["caption_channels"] or 0, c["tdim"]
+        s.vec_dim = self.vdim or 0
+        s.n_vec = self.n_vec if (self.vdim is not None and isinstance(self.adaln_single.add_embedding, nn.ModuleList)) else 0
+        s.attention_bias, s.norm_eps, s.precision = int(c["attention_bias"]), c["norm_eps"], int(self.dt == F32)
+        return s
+
+    def _pos32(self, h, w, device):
+        key = ("f32", h, w, str(device))
+        if key not in self._pos_cache:
+            c = self.config_dict
+            pe = sincos_pos_embed(c["inner_dim"], h, w, c["sample_size"] // c["patch_size"], c["interpolation_scale"])
+            self._pos_cache[key] = torch.from_numpy(pe).float().to(device).contiguous()
+        return self._pos_cache[key]
 
     # ---- forward ------------------------------------------------------------------------------------------------------
     def _pos(self, h, w, B, device):
@@ -612,6 +840,10 @@ class MiTransformer2DModel(_DenoiserBase):
         h, w = Hh // p, Ww // p
         T = h * w
         dev = sample.device
+        if self._use_plan(sample):      # ONE call into the library's plan of this denoiser (csrc/dit_plan.h)
+            assert C_in <= c["out_channels"]
+            return self._plan_call(sample, timestep, crossattn, vector, self._pos32(h, w, dev),
+                                   self._key_lens(mask, crossattn.shape[1]), C_in)
 
         # adaLN-single (TU:75-102): per-sample vectors [B, .]
         if not torch.is_tensor(timestep):
@@ -747,6 +979,26 @@ class MiSD3Transformer2DModel(_DenoiserBase):
         self.proj_out = MiLinear(p * p * out_channels, D)
         self._init_base()
 
+    def _dit_cfg(self):
+        from ._lib import DitCfg
+        c, s = self.config_dict, DitCfg()
+        s.kind, s.in_channels, s.out_channels, s.patch_size = 2, c["in_channels"], c["out_channels"], c["patch_size"]
+        s.num_layers, s.heads, s.head_dim = c["num_layers"], c["heads"], c["head_dim"]
+        s.cross_dim, s.caption_channels, s.tdim = c["inner_dim"], c["joint_attention_dim"], 256
+        s.vec_dim, s.n_vec, s.attention_bias, s.norm_eps, s.precision = c["pooled_projection_dim"], 0, 1, 1e-6, int(self.dt == F32)
+        return s
+
+    def _pos32(self, h, w, device):
+        buf = self.pos_embed.pos_embed
+        key = ("f32", h, w, str(device), buf.data_ptr(), buf._version)
+        if key not in self._pos_cache:
+            m = self.config_dict["pos_embed_max_size"]
+            assert h <= m and w <= m, "input larger than pos_embed_max_size"
+            top, left = (m - h) // 2, (m - w) // 2
+            pe = buf.reshape(m, m, -1)[top:top + h, left:left + w, :].reshape(h * w, -1)
+            self._pos_cache[key] = pe.to(device).float().contiguous()
+        return self._pos_cache[key]
+
     def _pos(self, h, w, B, device):
         buf = self.pos_embed.pos_embed
         key = (h, w, B, str(device), buf.data_ptr(), buf._version)
@@ -782,6 +1034,9 @@ class MiSD3Transformer2DModel(_DenoiserBase):
         T, L = h * w, crossattn.shape[1]
         dev = sample.device
         eps = 1e-6
+        if self._use_plan(sample):      # ONE call into the library's plan of this denoiser (csrc/dit_plan.h)
+            assert C_in <= c["out_channels"]
+            return self._plan_call(sample, timestep, crossattn, vector, self._pos32(h, w, dev), None, C_in)
 
         # CombinedTimestepTextProjEmbeddings: per-sample vectors [B, D]
         if not torch.is_tensor(timestep):

@@ -125,8 +125,8 @@ def unet_param_shapes(boc, down_types, up_types, layers_per_block, cross_dim, tl
 
 
 class _Plan:
-    def __init__(self, cfg: UNetCfg):
-        self.handle = _lib.lib().fdmi_unet_create(C.byref(cfg))
+    def __init__(self, cfg, create="fdmi_unet_create"):
+        self.handle = getattr(_lib.lib(), create)(C.byref(cfg))
         if not self.handle:
             raise RuntimeError("fdmi: " + _lib.lib().fdmi_last_error().decode())
         self.packed = False

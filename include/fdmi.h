@@ -288,6 +288,9 @@ int fdmi_unet_param_name(fdmi_unet* u, int64_t i, char* buf, int64_t buflen, int
 int fdmi_unet_set_param(fdmi_unet* u, const char* name, const float* data, int64_t numel, void* stream);
 int fdmi_unet_set_lora(fdmi_unet* u, const char* target /* e.g. "...attn1.to_q" */, const float* A /*[r][in]*/,
                        const float* B /*[out][r]*/, float* A_grad, float* B_grad, int rank);
+/* Declares that a LoRA pair of this rank WILL be bound to `target` (fdmi_unet_set_lora, same rank): workspace queries then account
+ * for its GEMMs and gradient buffers.  Touches no device memory -- a host can size its workspace before the adapters exist.   */
+int fdmi_unet_declare_lora(fdmi_unet* u, const char* target, int rank);
 int fdmi_unet_ready(fdmi_unet* u);   /* 0 when every parameter has been set */
 /* bytes of caller workspace one forward (+ backward when flags has SAVE) needs at this shape */
 int64_t fdmi_unet_workspace_bytes(fdmi_unet* u, int B, int H, int W, int L, int flags);
@@ -356,6 +359,48 @@ int fdmi_net_backward(fdmi_unet* n, int slot, const float* grad_out, float* grad
 int fdmi_adapter_out_shape(fdmi_unet* n, int level, int H, int W, int* C, int* h, int* w);
 int fdmi_adapter_forward(fdmi_unet* n, int slot, const float* x, float* const* outs, int n_outs, int B, int H, int W, void* workspace,
                          int64_t workspace_bytes, void* stream);
+
+/* ---------------- the transformer denoisers: PixArt-alpha's adaLN-single Transformer2D and SD3's MMDiT ----------------
+ * Replace DiffusersTransformer2DWrapper.forward (/root/reference/src/flash/models/transformers/tranformers.py:49-92, with the
+ * reference's AdaLayerNormSingle, transformers/utils.py:8-102) and DiffusersSD3Transformer2DWrapper.forward (tranformers.py:113-155)
+ * and their autograd backward.  Same handle type and executor as the UNet plan: fdmi_unet_set_param / _num_params / _param_name
+ * / _ready / _destroy / _last_flops work on it, and fdmi_unet_set_lora binds a LoRA pair to ANY linear by its module name (peft
+ * semantics; the examples' target lists -- examples/train_flash_pixart.py:237-256, train_flash_sd3.py:100-121 -- cover attention,
+ * feed-forward, the embedders, the adaLN projections and the patch embedding).  Parameters carry the wrappers' state_dict
+ * names ("pos_embed.proj.weight" [D][C][p][p], "adaln_single.linear.weight", "transformer_blocks.0.attn1.to_q.weight",
+ * "transformer_blocks.0.scale_shift_table", "scale_shift_table", "proj_out.weight"; MMDiT: "time_text_embed.text_embedder.linear_1.
+ * weight", "context_embedder.weight", "transformer_blocks.0.norm1.linear.weight", "transformer_blocks.0.attn.add_q_proj.weight",
+ * "norm_out.linear.weight", ...).  The positional table is an INPUT (pos [T][heads * head_dim] f32: the host crops / builds the
+ * sin-cos table once per resolution), not plan state.                                                                     */
+enum { FDMI_DIT_PIXART = 1, FDMI_DIT_MMDIT = 2 };
+typedef struct fdmi_dit_config {
+  int32_t kind;              /* FDMI_DIT_* */
+  int32_t in_channels, out_channels, patch_size;
+  int32_t num_layers, heads, head_dim;   /* inner width D = heads * head_dim */
+  int32_t cross_dim;         /* PixArt: cross_attention_dim (= D behind the caption projection) */
+  int32_t caption_channels;  /* PixArt: caption_projection input width (0: none, ctx is [B][L][cross_dim]); MMDiT: joint_attention_dim */
+  int32_t tdim;              /* width of the sinusoidal timestep embedding (256) */
+  int32_t vec_dim;           /* PixArt: projection_class_embeddings_input_dim (0: no vector conditioning); MMDiT: pooled_projection_dim */
+  int32_t n_vec;             /* PixArt: num_vector_conditionings with use_concat_vector_conditioning (vector is [B][n_vec * vec_dim]); 0: one add_embedding */
+  int32_t attention_bias;    /* PixArt: bias on to_q / to_k / to_v */
+  float norm_eps;            /* PixArt: norm_eps of the blocks (the final norm uses 1e-6; the MMDiT uses 1e-6 throughout) */
+  int32_t precision;         /* 0 = bf16 MFMA, 1 = fp32 validation kernels */
+} fdmi_dit_config;
+fdmi_unet* fdmi_dit_create(const fdmi_dit_config* cfg);   /* NULL on error */
+/* bytes of caller workspace one forward (+ backward with FDMI_UNET_SAVE, + d sample with FDMI_UNET_INPUT_GRAD) needs on a
+ * [B, in_channels, H, W] latent with L context tokens; masked != 0: the forward will carry key lengths */
+int64_t fdmi_dit_workspace_bytes(fdmi_unet* d, int B, int H, int W, int L, int masked, int flags);
+/* sample [B][in_channels][H][W] f32, timestep [B] f32, ctx [B][L][caption width] f32, vector [B][vector width] f32 (or NULL
+ * without vector conditioning), pos [(H/p)(W/p)][D] f32, key_lens: HOST int32 [B] = number of valid (leading) context tokens
+ * per sample, or NULL (PixArt's T5 padding mask, tranformers.py:75-77; the MMDiT takes none) -> out [B][out_keep][H][W] f32 =
+ * the first out_keep of the out_channels (the wrappers drop the learned-variance half: tranformers.py:91 / :154).
+ * flags: FDMI_UNET_SAVE keeps the tape for fdmi_dit_backward on the same slot (workspace untouched until then).            */
+int fdmi_dit_forward(fdmi_unet* d, int slot, const float* sample, const float* timestep, const float* ctx, const float* vector,
+                     const float* pos, const int32_t* key_lens, float* out, int B, int H, int W, int L, int out_keep,
+                     void* workspace, int64_t workspace_bytes, int flags, void* stream);
+/* grad_out [B][out_keep][H][W] f32 -> LoRA gradients ACCUMULATED (+=) into the bound buffers; grad_sample [B][in_channels][H][W]
+ * f32 or NULL */
+int fdmi_dit_backward(fdmi_unet* d, int slot, const float* grad_out, float* grad_sample, void* stream);
 
 /* The frozen teacher's classifier-free-guidance loop (flash_diffusion_model.py:288-324) as ONE call: for each of the n
  * steps  eps = unet([x | x], t_i, [ctx_cond | ctx_uncond])  (one forward on the 2B batch; the cross-attention K/V of the

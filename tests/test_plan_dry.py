@@ -274,3 +274,84 @@ def test_frozen_net_plans_count_the_flops_of_the_upstream_modules():
     assert abs(lpv - pad - ref_lp) < 2e-3 * ref_lp, (lpv, ref_lp, pad)
     adv = plan_flops(_net_cfg(4, 3, 0, [320, 640, 1280, 1280], 2), 1, 512, 512)
     assert abs(adv - ref_ad) < 1e-6 * ref_ad, (adv, ref_ad)
+
+
+# ---- the transformer denoisers' plans (csrc/dit_plan.h), walked the same way ------------------------------------------------
+def _dit_plan(kind, arch, lora):
+    from flash_diffusion_amd import dit
+    lib = _lib.lib()
+    with torch.device("meta"):
+        m = (dit.MiTransformer2DModel if kind == "pixart" else dit.MiSD3Transformer2DModel)(**arch)
+        if lora:
+            m.add_adapter(lora)
+    p = m._plan()
+    for n, mod in m._lora_modules():      # (no GPU here: declare the adapters instead of binding them)
+        assert lib.fdmi_unet_declare_lora(p.handle, n.encode(), mod.rank) == 0, lib.fdmi_last_error()
+    return m, p
+
+
+def _dit_query(p, B, HW, L, masked, flags):
+    lib = _lib.lib()
+    need = lib.fdmi_dit_workspace_bytes(p.handle, B, HW, HW, L, masked, flags)
+    assert need > 0, lib.fdmi_last_error()
+    return need, lib.fdmi_unet_last_flops(p.handle)
+
+
+@pytest.mark.parametrize("kind,arch_name", [("pixart", "TINY_PIXART"), ("pixart", "PIXART"), ("sd3", "TINY_SD3"), ("sd3", "SD3")])
+def test_dit_plan_registers_every_parameter_of_the_module(kind, arch_name):
+    import ctypes as C
+    from flash_diffusion_amd import workloads
+    m, p = _dit_plan(kind, getattr(workloads, arch_name), 0)
+    lib = _lib.lib()
+    buf, ne, names = C.create_string_buffer(512), C.c_int64(), set()
+    for i in range(lib.fdmi_unet_num_params(p.handle)):
+        assert lib.fdmi_unet_param_name(p.handle, i, buf, 512, C.byref(ne)) == 0
+        names.add((buf.value.decode(), ne.value))
+    assert names == {(k, v.numel()) for k, v in m.named_parameters()}
+
+
+@pytest.mark.parametrize("kind,arch_name,B,HW,L,r", [("pixart", "PIXART", 8, 128, 120, 64), ("sd3", "SD3", 4, 128, 333, 64)])
+def test_dit_plan_flops_and_workspace_at_the_benchmarked_shapes(kind, arch_name, B, HW, L, r):
+    """forward FLOPs against the architecture's closed form (projections + attention + feed-forward per block; the embedders and
+    per-sample vectors are noise at this size); a frozen forward needs two blocks' worth of workspace whatever the depth; a
+    saved run's backward recycles the forward's buffers (about the forward footprint, not twice it); LoRA adds its rank-r GEMMs"""
+    from flash_diffusion_amd import workloads
+    arch = getattr(workloads, arch_name)
+    m, p = _dit_plan(kind, arch, 0)
+    D, nl = arch["num_attention_heads"] * arch["attention_head_dim"], arch["num_layers"]
+    T = (HW // 2) ** 2
+    ws0, f0 = _dit_query(p, B, HW, L, 0, 0)
+    if kind == "pixart":
+        per = 2 * T * D * D * (4 + 2 + 8) + 4 * T * T * D + 4 * T * L * D + 2 * L * D * D * 2      # self, cross (q, out | k, v), ff
+        blocks = nl * per
+    else:
+        S = T + L
+        full = 2 * T * D * D * (4 + 8) + 2 * L * D * D * (4 + 8) + 4 * S * S * D
+        last = 2 * T * D * D * (4 + 8) + 2 * L * D * D * 3 + 4 * S * S * D
+        blocks = (nl - 1) * full + last
+    assert abs(f0 / B - blocks) < 0.01 * blocks, (f0 / B / 1e12, blocks / 1e12)
+    ws1, f1 = _dit_query(p, 2 * B, HW, L, 0, 0)
+    assert abs(f1 - 2 * f0) < 1e-6 * f0 and ws0 < 8 * 2 ** 30
+    wsS, _ = _dit_query(p, B, HW, L, 0, FDMI_UNET_SAVE)
+    wsG, _ = _dit_query(p, B, HW, L, 0, FDMI_UNET_SAVE | FDMI_UNET_INPUT_GRAD)
+    assert wsS > 4 * ws0 and wsG >= wsS and wsS < 80 * 2 ** 30
+    ml, pl = _dit_plan(kind, arch, r)
+    _, fl = _dit_query(pl, B, HW, L, 0, 0)
+    assert 1.01 * f0 < fl < 1.12 * f0
+    if kind == "pixart":
+        wsM, fM = _dit_query(p, B, HW, L, 1, 0)            # key lengths: per-sample cross-attention launches, same work
+        assert fM == f0 and abs(wsM - ws0) < 0.05 * ws0
+
+
+@pytest.mark.parametrize("kind,arch_name", [("pixart", "TINY_PIXART"), ("sd3", "TINY_SD3")])
+def test_dit_plan_walks_every_mode_at_toy_size(kind, arch_name):
+    from flash_diffusion_amd import workloads
+    arch = getattr(workloads, arch_name)
+    for lora in (0, 8):
+        for precision in ("bf16", "fp32"):
+            m, p = _dit_plan(kind, dict(arch, precision=precision), lora)
+            for masked in ((0, 1) if kind == "pixart" else (0,)):
+                for flags in (0, FDMI_UNET_SAVE, FDMI_UNET_SAVE | FDMI_UNET_INPUT_GRAD):
+                    ws, fl = _dit_query(p, 2, 16, 12, masked, flags)
+                    assert ws > 0 and fl > 0
+    assert _lib.lib().fdmi_dit_workspace_bytes(p.handle, 2, 15, 16, 12, 0, 0) < 0      # H not a multiple of the patch size

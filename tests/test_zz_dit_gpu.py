@@ -127,6 +127,7 @@ def _body_test_dit_frozen_forward_matches_reference_golden(name):
     assert out2.requires_grad
     assert rel_err(out2, g["out"]["frozen"]) < 2e-2, rel_err(out2, g["out"]["frozen"])
     assert rel_err(out2, out) < 1e-2, rel_err(out2, out)
+    assert m.plan_calls == 2, "the forwards must have run through the C++ plan (fdmi_dit_forward)"
 
 
 @pytest.mark.parametrize("name", list(DIT_CASES) + list(MMDIT_CASES))
@@ -152,6 +153,7 @@ def _body_test_dit_lora_step_matches_reference_golden(name):
         assert _cos(p.grad, ref) > 0.999 and rel_err(p.grad, ref) < 6e-2, (k, _cos(p.grad, ref), rel_err(p.grad, ref))
         n += 1
     assert n == len(g["grads"]) and n > 0
+    assert m.plan_calls == 1, "the step must have run through the C++ plan (fdmi_dit_forward / fdmi_dit_backward)"
 
 
 # ---- 256 x 192 variant of the 2-slot ring kernel (gemm4<BN=192>): the tile for N = 1152 / 1536 / 4608 / 6144 -----------------
