@@ -1889,6 +1889,7 @@ static void run_reset(fdmi_unet* U, Run& R, int flags) {
   R.recycle = false;
   R.outs.clear();
   R.arena.off = 0;
+  R.arena.peak = 0;   // (per run: the two-region block allocation of dit_plan.h rewinds to it)
   R.es = U->f32 ? 4 : 2;
   R.sc32 = nullptr;
   R.sc32_elems = 0;
