@@ -58,6 +58,8 @@ _SIGS = {
     "fdmi_dit_forward": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, vp, i64, i32, vp]),
     "fdmi_dit_backward": (i32, [vp, i32, vp, vp, vp]),
     "fdmi_unet_declare_lora": (i32, [vp, C.c_char_p, i32]),
+    "fdmi_dit_teacher_loop_scratch_bytes": (i64, [vp, i32, i32, i32]),
+    "fdmi_dit_teacher_loop": (i32, [vp, i32, vp, vp, i32, vp, vp, vp, vp, vp, i32, i32, i32, i32, vp, i64, vp, i64, vp]),
     "fdmi_unet_create": (vp, [C.POINTER(UNetCfg)]),
     "fdmi_unet_destroy": (None, [vp]),
     "fdmi_unet_num_params": (i64, [vp]),

@@ -190,6 +190,20 @@ __global__ __launch_bounds__(256) void vec_grad_add_kernel(const float* src, TO*
     *d = cvt_out<TO>(src[i] + (accumulate ? cvt_in(*d) : 0.f));
   }
 }
+// KV[b * (T + L) + s][0 .. 2D) = columns [D, 3D) of yx[b * T + s] (s < T) or of yc[b * L + s - T]: the keys and values of the MMDiT's
+// joint [latent | text] sequence out of the two streams' fused [q | k | v] projections (the queries stay where they are)
+__global__ __launch_bounds__(256) void kv_join_kernel(const bf16_t* yx, const bf16_t* yc, bf16_t* kv, int B, int T, int L, int D) {
+  const int S = T + L, cpr = (2 * D) >> 3;
+  const int64_t total = (int64_t)B * S * cpr;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int c = (int)(i % cpr) * 8;
+    const int64_t row = i / cpr;
+    const int s = (int)(row % S);
+    const int64_t b = row / S;
+    const bf16_t* src = s < T ? yx + (b * T + s) * 3 * D : yc + (b * L + (s - T)) * 3 * D;
+    *(u16x8*)(kv + row * 2 * D + c) = *(const u16x8*)(src + D + c);
+  }
+}
 }  // namespace
 
 #define DIT_LAUNCH(kernel, total, ...)                                                              \
@@ -227,4 +241,8 @@ int launch_add_table(const void* src, int src_cols, const float* table, void* ds
 int launch_vec_grad_add(const float* src, void* dst, int64_t ldd, int col0, int B, int C, int accumulate, int f32, hipStream_t st) {
   if (f32) { DIT_LAUNCH(vec_grad_add_kernel<float>, (int64_t)B * C, src, (float*)dst, ldd, col0, B, C, accumulate) }
   DIT_LAUNCH(vec_grad_add_kernel<bf16_t>, (int64_t)B * C, src, (bf16_t*)dst, ldd, col0, B, C, accumulate)
+}
+int launch_kv_join(const bf16_t* yx, const bf16_t* yc, bf16_t* kv, int B, int T, int L, int D, hipStream_t st) {
+  FDMI_CHECK(D % 8 == 0, "kv_join: D must be a multiple of 8");
+  DIT_LAUNCH(kv_join_kernel, (int64_t)B * (T + L) * (2 * D / 8), yx, yc, kv, B, T, L, D)
 }

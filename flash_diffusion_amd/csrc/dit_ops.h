@@ -13,3 +13,6 @@ int launch_unpatchify_bwd(const float* gimg, void* dtokens, int B, int oc, int k
 int launch_add_table(const void* src, int src_cols, const float* table, void* dst, int B, int n, int f32, hipStream_t st);
 // dst[b][col0 + c] (+)= src[b][c], c < C (src fp32 [B][C])
 int launch_vec_grad_add(const float* src, void* dst, int64_t ldd, int col0, int B, int C, int accumulate, int f32, hipStream_t st);
+// KV [B * (T + L)][2 D] = per sample [k | v of the T latent tokens ; k | v of the L text tokens] out of the fused projections
+// yx [B * T][3 D], yc [B * L][3 D] (bf16 plans)
+int launch_kv_join(const bf16_t* yx, const bf16_t* yc, bf16_t* kv, int B, int T, int L, int D, hipStream_t st);

@@ -645,6 +645,27 @@ int run_dit(fdmi_unet* U, Run& R, const DitIn& in, int flags) {
       FAIL_IF_NULL(n); FAIL_IF_NULL(nc);
       T *qx, *kx, *vx, *qc, *kc, *vc, *q, *k, *v;
       const bool fused = qkv_fusable(U, blk.x) && qkv_fusable(U, blk.c) && (R.dry() || (blk.x.qkv.w && blk.c.qkv.w));
+      T *ox = nullptr, *oc = nullptr;
+      if (fused && !R.save && !fdmi_tune_get(42)) {
+        // a run without a tape: only the keys and values are joined (one pass over 2 D of the 3 D columns); the queries stay in
+        // the two projections' outputs and each stream's attention output lands where its output projection reads it -- two
+        // attention launches over the same joint K / V (one V^T), no split pass.  (A/B switch 42 = 1: the joined form below.)
+        T* yx = E.linear_qkv(n, blk.x, D);
+        T* yc = E.linear_qkv(nc, blk.c, D);
+        FAIL_IF_NULL(yx); FAIL_IF_NULL(yc);
+        T* KV = R.mk((int64_t)B * S, 2 * D);
+        bf16_t* VT = (bf16_t*)R.arena.alloc((size_t)B * heads * attn_dvpad(c.head_dim) * attn_spad(S) * 2);
+        FAIL_IF_NULL(KV); FAIL_IF_NULL(VT);
+        E.U->hbm[HBM_COPY2D] += 2.0 * 2 * KV->rows * KV->cols;
+        if (!R.dry()) RET_IF(launch_kv_join(yx->p, yc->p, KV->p, B, Tn, L, D, st));
+        k = R.view(KV, 0, D); v = R.view(KV, D, D);
+        ox = E.attention(R.view(yx, 0, D), k, v, B, heads, Tn, S, VT, false);
+        FAIL_IF_NULL(ox);
+        if (!blk.pre_only) {
+          oc = E.attention(R.view(yc, 0, D), k, v, B, heads, L, S, VT, true);
+          FAIL_IF_NULL(oc);
+        }
+      } else {
       if (fused) {   // [q | k | v] of both streams as two GEMMs, joined once
         T* yx = E.linear_qkv(n, blk.x, D);
         T* yc = E.linear_qkv(nc, blk.c, D);
@@ -661,8 +682,8 @@ int run_dit(fdmi_unet* U, Run& R, const DitIn& in, int flags) {
       FAIL_IF_NULL(q); FAIL_IF_NULL(k); FAIL_IF_NULL(v);
       T* o = E.attention(q, k, v, B, heads, S, S);
       FAIL_IF_NULL(o);
-      T *ox, *oc;
       RET_IF(dit_split(E, o, B, Tn, L, !blk.pre_only, &ox, &oc));
+      }
       hid = dit_linear_gate_res(E, ox, blk.x.a1.o, m, 2 * D, hid, Tn, modg);
       FAIL_IF_NULL(hid);
       T* n2 = dit_ln_mod(E, hid, m, 3 * D, 4 * D, Tn, eps, modg);

@@ -353,11 +353,16 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
           gmv[0] = g0.x; gmv[1] = g0.y; gmv[2] = g0.z; gmv[3] = g0.w; gmv[4] = g1.x; gmv[5] = g1.y; gmv[6] = g1.z; gmv[7] = g1.w;
           btv[0] = b0.x; btv[1] = b0.y; btv[2] = b0.z; btv[3] = b0.w; btv[4] = b1.x; btv[5] = b1.y; btv[6] = b1.z; btv[7] = b1.w;
         }
+        u16x8 scv = {0, 0, 0, 0, 0, 0, 0, 0}, shv = scv;   // (one 16-byte load each: launch_ln checks the alignment)
+        if (a.scale) {
+          scv = *(const u16x8*)(a.scale + mrow + c0);
+          shv = *(const u16x8*)(a.shift + mrow + c0);
+        }
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           float v = (xv[s][e] - mean) * rstd;
           if (a.gamma) v = fmaf(v, gmv[e], btv[e]);
-          if (a.scale) v = fmaf(v, 1.f + bf2f(a.scale[mrow + c0 + e]), bf2f(a.shift[mrow + c0 + e]));
+          if (a.scale) v = fmaf(v, 1.f + bf2f(scv[e]), bf2f(shv[e]));
           o[e] = f2bf(v);
         }
         *(u16x8*)(a.y + row * a.C + c0) = o;
@@ -376,11 +381,12 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
           const float4 g0 = *(const float4*)(a.gamma + ch * 8), g1 = *(const float4*)(a.gamma + ch * 8 + 4);
           gmv[0] = g0.x; gmv[1] = g0.y; gmv[2] = g0.z; gmv[3] = g0.w; gmv[4] = g1.x; gmv[5] = g1.y; gmv[6] = g1.z; gmv[7] = g1.w;
         }
+        u16x8 scv = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (a.scale) scv = *(const u16x8*)(a.scale + mrow + ch * 8);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          const int c = ch * 8 + e;
           float gmul = gmv[e];
-          if (a.scale) gmul *= (1.f + bf2f(a.scale[mrow + c]));
+          if (a.scale) gmul *= (1.f + bf2f(scv[e]));
           dxh[s][e] = bf2f(d[e]) * gmul;
           const float xh = (xv[s][e] - mean) * rstd;
           s1 += dxh[s][e];
@@ -410,6 +416,8 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
 
 template <bool BWD>
 static int launch_ln(const LnArgs& a, hipStream_t st) {
+  FDMI_CHECK(((uintptr_t)a.scale & 15) == 0 && ((uintptr_t)a.shift & 15) == 0 && (!a.scale || (a.mod_ld & 7) == 0),
+             "layernorm: the modulation vectors must be 16-byte aligned (column blocks of a [B][k C] tensor, C % 8 == 0)");
   const int CPR = a.C >> 3;
   int lpr = 8;
   while (lpr < 64 && lpr * 5 < CPR) lpr <<= 1;

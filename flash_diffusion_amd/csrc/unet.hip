@@ -2371,6 +2371,62 @@ int fdmi_dit_backward(fdmi_unet* U, int slot, const float* grad_out, float* grad
 
 // ---- the frozen teacher's CFG loop without a host round trip between steps (FD:288-324) ----------------------------
 static size_t tl_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// ... for a transformer denoiser (the PixArt recipe's DPM-Solver++ loop, flash_diffusion_model.py:288-324; the SD3 recipe's
+// flow-matching Euler loop, flash_diffusion_sd3_model.py:282-314 -- x0 = the step's increment, a3 = a4 = 1)
+int64_t fdmi_dit_teacher_loop_scratch_bytes(fdmi_unet* U, int B, int H, int W) {
+  if (!is_dit(U) || B <= 0 || H <= 0 || W <= 0) return -1;
+  const size_t per = (size_t)U->dcfg.in_channels * H * W;
+  return (int64_t)(2 * tl_align(2 * B * per * 4) + tl_align(2 * (size_t)B * 4) + 2 * tl_align(B * per * 4));
+}
+int fdmi_dit_teacher_loop(fdmi_unet* U, int slot, float* x, const float* timesteps, int n, const float* ctx2, const float* vector2,
+                          const float* pos, const int32_t* key_lens2, const float* coeffs, int B, int H, int W, int L,
+                          void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream) {
+  FDMI_CHECK(is_dit(U) && slot >= 0 && slot < 8, "dit: bad plan / slot");
+  FDMI_CHECK(x && timesteps && ctx2 && pos && coeffs && workspace && scratch && n > 0, "dit teacher_loop: null argument");
+  FDMI_CHECK(U->dcfg.in_channels <= U->dcfg.out_channels, "dit teacher_loop: the update needs out_channels >= in_channels");
+  FDMI_CHECK(scratch_bytes >= fdmi_dit_teacher_loop_scratch_bytes(U, B, H, W), "dit teacher_loop: scratch too small");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t per = (size_t)U->dcfg.in_channels * H * W;
+  const int64_t nel = (int64_t)B * per;
+  char* sp = (char*)scratch;
+  float* xx = (float*)sp;            sp += tl_align(2 * nel * 4);
+  float* eps = (float*)sp;           sp += tl_align(2 * nel * 4);
+  float* tt = (float*)sp;            sp += tl_align(2 * (size_t)B * 4);
+  float* x0[2];
+  x0[0] = (float*)sp;                sp += tl_align(nel * 4);
+  x0[1] = (float*)sp;
+  Run& R = U->runs[slot];
+  R.arena.base = (char*)workspace;
+  R.arena.cap = (size_t)workspace_bytes;
+  R.arena.dry = false;
+  R.st = st;
+  DitIn in{};
+  in.x = xx; in.t = tt; in.ctx = ctx2; in.vec = vector2; in.pos = pos; in.out = eps;
+  in.B = 2 * B; in.H = H; in.W = W; in.L = L; in.keep = U->dcfg.in_channels;
+  if (key_lens2) in.lens.assign(key_lens2, key_lens2 + 2 * B);
+  double flops = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const float* a = coeffs + (size_t)i * 6;
+    FDMI_HIP(hipMemcpyAsync(xx, x, nel * 4, hipMemcpyDeviceToDevice, st));          // [x | x]
+    FDMI_HIP(hipMemcpyAsync(xx + nel, x, nel * 4, hipMemcpyDeviceToDevice, st));
+    uint32_t tbits;
+    memcpy(&tbits, &timesteps[i], 4);
+    FDMI_HIP(hipMemsetD32Async((hipDeviceptr_t)tt, (int)tbits, 2 * (size_t)B, st));
+    int rc = run_dit(U, R, in, 0);
+    if (rc) return rc;
+    flops += U->last_flops;
+    float* cur = x0[i & 1];
+    const float* prev = x0[(i & 1) ^ 1];
+    // x0 = a0 x + a1 eps_c + a2 eps_u ;  x = a3 x + a4 x0 + a5 x0_prev
+    rc = launch_axpby4(x, a[0], eps, a[1], eps + nel, a[2], nullptr, 0.f, cur, nel, st);
+    if (rc) return rc;
+    const bool use_prev = i > 0 && a[5] != 0.f;
+    rc = launch_axpby4(x, a[3], cur, a[4], use_prev ? prev : nullptr, use_prev ? a[5] : 0.f, nullptr, 0.f, x, nel, st);
+    if (rc) return rc;
+  }
+  U->last_flops = flops;
+  return 0;
+}
 int64_t fdmi_teacher_loop_scratch_bytes(fdmi_unet* U, int B, int H, int W) {
   if (!U || B <= 0 || H <= 0 || W <= 0) return -1;
   const size_t per_in = (size_t)U->cfg.in_channels * H * W, per_out = (size_t)U->cfg.out_channels * H * W;

@@ -681,6 +681,51 @@ class _DenoiserBase(nn.Module):
         """Drop saved-for-backward runs that will never be back-propagated (e.g. after an exception)."""
         self._plan().busy.clear()
 
+    teacher_loop_takes_mask = True
+
+    @torch.no_grad()
+    def teacher_loop(self, x, timesteps, crossattn2, vector2, coeffs, attention_mask=None):
+        """The frozen teacher's whole guidance loop in ONE C-ABI call (include/fdmi.h: fdmi_dit_teacher_loop): x [B, C, H, W] is
+        advanced through the steps `timesteps` (host floats) with the host coefficient rows `coeffs` ([n][6]: x0 = a0 x + a1 e_c
+        + a2 e_u; x = a3 x + a4 x0 + a5 x0_prev); crossattn2 [2B, L, .] / vector2 [2B, .] / attention_mask [2B, L] hold the
+        conditional rows first, then the unconditional ones.  Returns the new latent."""
+        from ._lib import check, lib, ptr, stream_ptr
+        assert x.is_cuda and not self.lora_r, "teacher_loop is for a frozen denoiser on the GPU"
+        c = self.config_dict
+        B, Cx, H, W = x.shape
+        assert Cx == c["in_channels"] and crossattn2.shape[0] == 2 * B and len(coeffs) == len(timesteps)
+        plan = self._ensure_packed(x.device)
+        L = lib()
+        n, Lc, p = len(timesteps), crossattn2.shape[1], c["patch_size"]
+        lens = self._key_lens(attention_mask, Lc) if attention_mask is not None else None
+        x = x.float().contiguous().clone()
+        enc = crossattn2.float().contiguous()
+        vec = vector2.float().contiguous() if vector2 is not None else None
+        pos = self._pos32(H // p, W // p, x.device)
+        need = L.fdmi_dit_workspace_bytes(plan.handle, 2 * B, H, W, Lc, int(lens is not None), 0)
+        sneed = L.fdmi_dit_teacher_loop_scratch_bytes(plan.handle, B, H, W)
+        if need < 0 or sneed < 0:
+            raise RuntimeError("fdmi: " + L.fdmi_last_error().decode())
+        ws = plan.workspaces.get(0)
+        if ws is None or ws.numel() < need or ws.device != x.device:
+            ws = plan.workspaces[0] = torch.empty(need, dtype=torch.uint8, device=x.device)
+        sc = plan.workspaces.get("teacher_loop")
+        if sc is None or sc.numel() < sneed or sc.device != x.device:
+            sc = plan.workspaces["teacher_loop"] = torch.empty(sneed, dtype=torch.uint8, device=x.device)
+        ts = (C.c_float * n)(*[float(t) for t in timesteps])
+        cf = (C.c_float * (6 * n))(*[float(v) for r in coeffs for v in r])
+        kl = (C.c_int32 * (2 * B))(*lens) if lens is not None else None
+        plan.enter(0)
+        try:
+            check(L.fdmi_dit_teacher_loop(plan.handle, 0, ptr(x), ts, n, ptr(enc), ptr(vec), ptr(pos), kl, cf, B, H, W, Lc, ptr(ws),
+                                          ws.numel(), ptr(sc), sc.numel(), stream_ptr()))
+        finally:
+            plan.leave(0)
+        self.last_flops = L.fdmi_unet_last_flops(plan.handle)
+        self.step_flops += self.last_flops
+        self.plan_calls += n
+        return x
+
 
 class _DitFn(torch.autograd.Function):
     """the ONE autograd edge of a denoiser call through the plan (as unet._UNetFn): x = the fp32 sample, *lora = the student's

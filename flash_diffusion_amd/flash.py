@@ -581,11 +581,16 @@ class FlashDiffusion(nn.Module):
                 one_call = (os.environ.get("FDMI_TEACHER_LOOP", "1") == "1" and cfg_cond is not None
                             and getattr(self, "batch_cfg", True) and hasattr(sch, "loop_coefficients")
                             and hasattr(self.teacher_denoiser, "teacher_loop") and not args and set(kwargs) <= {"device"}
-                            and set(cfg_cond["cond"]) <= {"crossattn", "vector"} and res is None)
-                if one_call:   # the whole loop inside the library (fdmi_teacher_loop; A/B switch: FDMI_TEACHER_LOOP=0)
+                            and res is None
+                            and set(cfg_cond["cond"]) <= ({"crossattn", "vector", "attention_mask"}
+                                                          if getattr(self.teacher_denoiser, "teacher_loop_takes_mask", False)
+                                                          else {"crossattn", "vector"})
+                            and (not hasattr(self.teacher_denoiser, "_use_plan") or self.teacher_denoiser._use_plan(x)))
+                if one_call:   # the whole loop inside the library (fdmi_teacher_loop / fdmi_dit_teacher_loop; A/B switch: FDMI_TEACHER_LOOP=0)
+                    kw = ({"attention_mask": cfg_cond["cond"]["attention_mask"]} if "attention_mask" in cfg_cond["cond"] else {})
                     x = self.teacher_denoiser.teacher_loop(x, [float(t) for t in sch.timesteps[si:]],
                                                            cfg_cond["cond"]["crossattn"], cfg_cond["cond"].get("vector"),
-                                                           sch.loop_coefficients(si, g))
+                                                           sch.loop_coefficients(si, g), **kw)
                 for it, t in enumerate(sch.timesteps[si:] if not one_call else []):
                     x_ = sch.scale_model_input(x, t)
                     e_c, e_u = self._teacher_cfg(x_, torch.full((B,), float(t), device=z.device), conditioning, uncond,

@@ -229,6 +229,17 @@ class FlashDiffusionSD3(nn.Module):
         if getattr(net, "per_sample", False) and getattr(self, "batch_cfg", True) \
                 and set(cond["cond"]) == set(uncond["cond"]):
             both = {"cond": {k: torch.cat([cond["cond"][k], uncond["cond"][k]], dim=0) for k in cond["cond"]}}
+        import os
+        if (both is not None and os.environ.get("FDMI_TEACHER_LOOP", "1") == "1" and hasattr(net, "teacher_loop")
+                and hasattr(sch, "step_delta") and not getattr(net, "lora_r", 0) and not torch.is_grad_enabled() and not args
+                and not kwargs and set(both["cond"]) <= {"crossattn", "vector"} and getattr(net, "_use_plan", lambda s: False)(x)
+                and x.shape[1] == net.config_dict["in_channels"] and len(timesteps) > 0):
+            # the whole loop inside the library (fdmi_dit_teacher_loop): x += dl (g e_c + (1 - g) e_u) per step
+            rows = []
+            for t in timesteps:
+                dl = sch.step_delta(t)          # (advances the scheduler's step index: once per step)
+                rows.append([0.0, g * dl, (1.0 - g) * dl, 1.0, 1.0, 0.0])
+            return net.teacher_loop(x, [float(t) for t in timesteps], both["cond"]["crossattn"], both["cond"].get("vector"), rows)
         for t in timesteps:
             tt = torch.full((B,), float(t), device=x.device)
             if both is not None:

@@ -402,6 +402,18 @@ int fdmi_dit_forward(fdmi_unet* d, int slot, const float* sample, const float* t
  * f32 or NULL */
 int fdmi_dit_backward(fdmi_unet* d, int slot, const float* grad_out, float* grad_sample, void* stream);
 
+/* The frozen teacher's guidance loop over a transformer denoiser as ONE call -- fdmi_teacher_loop (below) for the fdmi_dit_* plans:
+ * per step  eps = dit([x | x], t_i, [ctx_cond | ctx_uncond], [vector_cond | vector_uncond])  on the 2B batch, then
+ *           x0 = a0 x + a1 eps_cond + a2 eps_uncond ;  x = a3 x + a4 x0 + a5 x0_prev          with a = coeffs[i][0..5] (HOST).
+ * The PixArt recipe's DPM-Solver++ loop (flash_diffusion_model.py:288-324) has this form as the UNet's does; the SD3 recipe's
+ * flow-matching Euler loop (flash_diffusion_sd3_model.py:282-314: x += dt (g eps_c + (1 - g) eps_u)) is a0 = 0, a1 = g dt, a2 =
+ * (1 - g) dt, a3 = a4 = 1, a5 = 0.  x [B][in_channels][H][W] f32 is advanced in place (eps = the first in_channels output
+ * channels); key_lens2: HOST int32 [2B] or NULL; workspace as fdmi_dit_workspace_bytes(d, 2B, H, W, L, masked, 0).          */
+int64_t fdmi_dit_teacher_loop_scratch_bytes(fdmi_unet* d, int B, int H, int W);
+int fdmi_dit_teacher_loop(fdmi_unet* d, int slot, float* x, const float* timesteps, int n, const float* ctx2, const float* vector2,
+                          const float* pos, const int32_t* key_lens2, const float* coeffs, int B, int H, int W, int L,
+                          void* workspace, int64_t workspace_bytes, void* scratch, int64_t scratch_bytes, void* stream);
+
 /* The frozen teacher's classifier-free-guidance loop (flash_diffusion_model.py:288-324) as ONE call: for each of the n
  * steps  eps = unet([x | x], t_i, [ctx_cond | ctx_uncond])  (one forward on the 2B batch; the cross-attention K/V of the
  * constant context are computed at step 0 and reused),

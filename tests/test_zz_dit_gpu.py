@@ -665,3 +665,59 @@ def _body_test_plan_matches_the_op_by_op_composition(kind, masked):
     assert worst[0] > 0.995, worst
     tot = lambda d: torch.cat([v.flatten() for _, v in sorted(d.items())])
     assert rel_err(tot(a["grads"]), tot(b["grads"])) < 3e-2, rel_err(tot(a["grads"]), tot(b["grads"]))
+
+
+@pytest.mark.parametrize("kind", ["pixart", "sd3"])
+def test_dit_teacher_loop_single_call_matches_the_stepwise_loop(kind):
+    run_isolated(__name__, "_body_test_dit_teacher_loop_single_call_matches_the_stepwise_loop", (kind,))
+
+
+def _body_test_dit_teacher_loop_single_call_matches_the_stepwise_loop(kind):
+    """fdmi_dit_teacher_loop (the frozen transformer teacher's guidance loop as ONE C-ABI call: 2B-batched plan forwards, the
+    guidance and the scheduler update from a host coefficient table) against the step-by-step loops of flash.py (DPM-Solver++,
+    PixArt, ragged key mask) and flash_sd3.py (flow-matching Euler, MMDiT): same forwards, the update in two fused launches
+    instead of one."""
+    import types
+    from flash_diffusion_amd.dit import MiSD3Transformer2DModel, MiTransformer2DModel
+    torch.manual_seed(0)
+    net = (MiTransformer2DModel if kind == "pixart" else MiSD3Transformer2DModel)(**MID[kind]).cuda()
+    net.freeze()
+    B, HW, L, K, g = 2, 32, 16, 4, 4.5
+    gen = torch.Generator().manual_seed(3)
+    Cin = MID[kind]["in_channels"]
+    x = torch.randn(B, Cin, HW, HW, generator=gen).cuda()
+    ctx2 = torch.randn(2 * B, L, 192, generator=gen).cuda()
+    vec2 = torch.randn(2 * B, 128 if kind == "pixart" else 64, generator=gen).cuda()
+    if kind == "pixart":
+        from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+        mask2 = torch.tensor([[1] * n + [0] * (L - n) for n in (16, 9, 3, 16)]).cuda()
+        cond2 = {"cond": {"crossattn": ctx2, "vector": vec2, "attention_mask": mask2}}
+        sch = DPMSolverMultistepScheduler()
+        sch.set_timesteps(K)
+        cur = x
+        with torch.no_grad():
+            for t in sch.timesteps[1:]:
+                e_c, e_u = net(torch.cat([cur, cur]), torch.full((2 * B,), float(t), device="cuda"), cond2).chunk(2)
+                cur = sch.fused_cfg_step(e_c.contiguous(), e_u.contiguous(), g, t, cur)
+        calls = net.plan_calls
+        sch = DPMSolverMultistepScheduler()
+        sch.set_timesteps(K)
+        got = net.teacher_loop(x, [float(t) for t in sch.timesteps[1:]], ctx2, vec2, sch.loop_coefficients(1, g), attention_mask=mask2)
+        assert net.plan_calls == calls + K - 1
+    else:
+        from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlowMatchEulerDiscreteScheduler
+        cond = {"cond": {"crossattn": ctx2[:B], "vector": vec2[:B]}}
+        uncond = {"cond": {"crossattn": ctx2[B:], "vector": vec2[B:]}}
+        me = types.SimpleNamespace(batch_cfg=True)
+        outs = []
+        for one_call in ("0", "1"):
+            os.environ["FDMI_TEACHER_LOOP"] = one_call
+            sch = FlowMatchEulerDiscreteScheduler()
+            sch.set_timesteps(K)
+            with torch.no_grad():
+                outs.append(FlashDiffusionSD3._euler_cfg(me, net, sch, sch.timesteps, x, cond, uncond, g))
+        cur, got = outs
+        assert net.plan_calls == 2 * K
+    # (a GEMM over <= 4096 rows may split K with fp32 atomics: run-to-run differences at the level of single bf16 roundings)
+    assert got.shape == x.shape and rel_err(got, cur) < 5e-3, rel_err(got, cur)
+    assert rel_err(got, x) > 1e-2     # the loop moved the latent (and left the caller's tensor alone)
