@@ -86,6 +86,11 @@ struct Lora {
   bf16_t *A_dst = nullptr, *AT_dst = nullptr;
   int AT_ld = 0;
   int r = 0, in = 0, out = 0;
+  // rank of the bf16 operand copies A [rp][in] and B^T [rp][out]: ranks below 128 are padded with zero rows so that the rank-r
+  // products t = x A^T and dt = dy B run as N = 128 problems on the 256-row LDS-DMA kernels instead of the small-tile fallback
+  // (C4: 574 launches x 84 us per step on `gemm_kernel<128,64>`); t / dt are then [M][rp] buffers whose first r columns everything
+  // else reads (leading dimension rp).  fp32 plans: rp = r.
+  int rp = 0;
   bool on = false;
   // LoRA up-projection as extra K tiles of the base GEMM (round 3): Wc [out][in + r] = [W | B] so that y = [x | t] Wc^T is ONE
   // launch (no read-modify-write pass over y), and Wtc [in][out + r] = [W^T | A^T] so that dx = [dy | dt] Wtc^T is one launch as
@@ -115,6 +120,10 @@ struct TBlockW {
   // ... and, with the LoRA up-projections folded in: Wc3 [3C][C + 3r] = [Wqkv | blockdiag(B_q, B_k, B_v)], Wtc3 [C][3C + 3r] =
   // [Wqkv^T | A_q^T A_k^T A_v^T]
   bf16_t *Wc3 = nullptr, *Wtc3 = nullptr;
+  // ranks below 128: blockdiag(B_q^T, B_k^T, B_v^T) [3r][3C], so that dt3 = dy3 . blockdiag is ONE N = 3r GEMM on the LDS-DMA kernels
+  // instead of three N = r launches of the small-tile fallback (the zero blocks cost 3x the flops of a product that is a few
+  // per cent of the layer's; refreshed with the other LoRA copies)
+  bf16_t* BT3 = nullptr;
   // cross-attention K / V / V^T of a fixed context (FDMI_UNET_CTX_FILL / _REUSE), plan-owned
   bf16_t *ck = nullptr, *cv = nullptr, *cvt = nullptr;
   int64_t c_rows = 0, c_vt = 0;
@@ -888,8 +897,15 @@ struct Exec {
           l3[s]->AT_dst = b.AT3 + (size_t)s * r;
           l3[s]->AT_ld = 3 * r;
         }
+        if (r < 128 && !b.BT3) rc = dmalloc(U, &b.BT3, (size_t)3 * r * 3 * in);
       });
       RET_IF(rc);
+      std::map<const Lora*, std::pair<TBlockW*, int>> in_bt3;
+      for_each_tblock(U, [&](TransformerW& t, TBlockW& b) {
+        if (!b.BT3 || !qkv_fusable(U, b) || !b.a1.q.lora.on) return;
+        Lora* l3[3] = {&b.a1.q.lora, &b.a1.k.lora, &b.a1.v.lora};
+        for (int sI = 0; sI < 3; ++sI) in_bt3[l3[sI]] = {&b, sI};
+      });
       // the LoRA halves of the folded operands ride along as second destinations: A^T [in][r] -> Wtc[:, out:], B [out][r] ->
       // Wc[:, in:]; for a fused q / k / v block slice s lands at Wtc3[:, 3C + s r :] and Wc3[s C :, C + s r :]
       std::map<const Lora*, std::pair<TBlockW*, int>> in_qkv;
@@ -911,8 +927,16 @@ struct Exec {
           a2 = l->Wtc + l->out; a2ld = l->out + l->r;
           b2 = l->Wc + l->in; b2ld = l->in + l->r;
         }
+        bf16_t* bt2 = nullptr;   // B^T [r][out] also into its diagonal block of the block's [3r][3C] operand
+        int bt2ld = 0;
+        auto q3 = in_bt3.find(l);
+        if (q3 != in_bt3.end()) {
+          const int sI = q3->second.second, C = l->out;
+          bt2 = q3->second.first->BT3 + (size_t)sI * l->r * 3 * C + (size_t)sI * C;
+          bt2ld = 3 * C;
+        }
         add(l->A_master, l->A_dst, l->AT_dst, l->r, l->in, l->AT_ld, nullptr, 0, a2, a2ld);
-        add(l->B_master, l->B, l->BT, l->out, l->r, 0, b2, b2ld, nullptr, 0);
+        add(l->B_master, l->B, l->BT, l->out, l->r, 0, b2, b2ld, bt2, bt2ld);
       }
       if (U->cast_jobs) FDMI_HIP(hipFree(U->cast_jobs));
       U->cast_jobs = nullptr;
@@ -934,11 +958,13 @@ struct Exec {
     // (lora_foldable, built by build_lora_folded) and a problem the two-segment loaders take (M >= 256)
     const bool fold = lo && lora_foldable(U, *lo) && (R.dry() || lo->Wc != nullptr) && x->rows >= 256 && !x->p2;
     T* t = nullptr;
+    const int rp = lo ? ((!f32() && x->rows >= 256 && !x->p2 && !fdmi_tune_get(44)) ? lo->rp : lo->r) : 0;   // (A/B switch 44 = 1: N = r)
     if (lo) {
-      t = R.mk(x->rows, lo->r);
+      t = R.mk(x->rows, rp);
       if (!t) return nullptr;
       const bf16_t* LA = f32() ? (const bf16_t*)lo->A_master : lo->A;
-      NULL_IF(gemm_rows(x->p, x->cols, x->rows, LA, lo->r, lo->in, nullptr, t->p, lo->r, nullptr, 0));
+      NULL_IF(gemm_rows(x->p, x->cols, x->rows, LA, rp, lo->in, nullptr, t->p, rp, nullptr, 0));
+      flops -= 2.0 * x->rows * (double)(rp - lo->r) * lo->in;   // (the zero rows are not algorithmic work)
     }
     {
       GemmArgs a = rows_args(x->p, x->cols, x->rows, w.w, w.N, w.K, w.bias, y->p, w.N, residual ? residual->p : nullptr,
@@ -948,7 +974,7 @@ struct Exec {
       }
       if (fold) {
         a.W = lo->Wc; a.K = w.K + lo->r; a.ldw = a.K;
-        a.A2 = t->p; a.lda2 = lo->r; a.K1 = w.K;
+        a.A2 = t->p; a.lda2 = rp; a.K1 = w.K;
       }
       if (gn_rows > 0 && !lo) want_gn(a, gn_rows);   // (a LoRA delta is added to y afterwards: the sums would be stale)
       NULL_IF(gemm(a));
@@ -956,10 +982,10 @@ struct Exec {
     }
     if (lo && !fold) {
       const bf16_t* LB = f32() ? (const bf16_t*)lo->B_master : lo->B;
-      NULL_IF(gemm_rows(t->p, lo->r, x->rows, LB, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N));
+      NULL_IF(gemm_rows(t->p, rp, x->rows, LB, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N));
     }
     if (R.save) {
-      R.tape.push_back([x, y, residual, lo, t, need_dx, fold, &w](Exec& E) -> int {
+      R.tape.push_back([x, y, residual, lo, t, need_dx, fold, &w, rp](Exec& E) -> int {
         if (!y->g) return 0;  // no gradient reached this output
         if (residual) RET_IF(E.add_grad(residual, y->g, y->cols, 0, y->cols));
         if (need_dx && !fold) {
@@ -974,12 +1000,14 @@ struct Exec {
         }
         if (lo) {
           // dt = dy B ; dB += dy^T t ; dA += dt^T x ; dx += dt A
-          T* dt = E.R.mk(x->rows, lo->r);
+          T* dt = E.R.mk(x->rows, rp);
           FDMI_CHECK(dt, "unet: workspace exhausted (lora)");
-          if (E.f32())
+          if (E.f32()) {
             RET_IF(E.gemm_rows_strided(y->g, w.N, x->rows, lo->B_master, lo->r, lo->out, 1, lo->r, dt->p, lo->r, nullptr, 0));
-          else
-            RET_IF(E.gemm_rows(y->g, w.N, x->rows, lo->BT, lo->r, lo->out, nullptr, dt->p, lo->r, nullptr, 0));
+          } else {
+            RET_IF(E.gemm_rows(y->g, w.N, x->rows, lo->BT, rp, lo->out, nullptr, dt->p, rp, nullptr, 0));
+            E.flops -= 2.0 * x->rows * (double)(rp - lo->r) * lo->out;
+          }
           // dB += dy^T t and dA += dt^T x straight from the row-major operands (wgrad.hip): no transposed copies
           E.flops += 2.0 * x->rows * lo->r * ((double)lo->out + lo->in);
           if (!E.R.dry()) {
@@ -987,8 +1015,8 @@ struct Exec {
               RET_IF(launch_wgrad_tn32(F(y->g), w.N, F(t->p), lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
               RET_IF(launch_wgrad_tn32(F(dt->p), lo->r, F(x->p), x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
             } else {
-              RET_IF(launch_wgrad_tn(y->g, w.N, t->p, lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
-              RET_IF(launch_wgrad_tn(dt->p, lo->r, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
+              RET_IF(launch_wgrad_tn(y->g, w.N, t->p, rp, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
+              RET_IF(launch_wgrad_tn(dt->p, rp, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
             }
           }
           if (need_dx && fold) {   // dx (+)= [dy | dt] [W^T | A^T]^T: the base input gradient and the LoRA one in ONE launch
@@ -996,7 +1024,7 @@ struct Exec {
             FDMI_CHECK(dx, "unet: workspace exhausted (grad)");
             GemmArgs d = rows_args(y->g, w.N, x->rows, lo->Wtc, w.K, w.N + lo->r, nullptr, dx, x->cols, x->ginit ? dx : nullptr,
                                    x->cols);
-            d.ldw = w.N + lo->r; d.A2 = dt->p; d.lda2 = lo->r; d.K1 = w.N;
+            d.ldw = w.N + lo->r; d.A2 = dt->p; d.lda2 = rp; d.K1 = w.N;
             RET_IF(E.gemm(d));
             x->ginit = true;
           } else if (need_dx) {
@@ -1004,7 +1032,7 @@ struct Exec {
             if (E.f32())
               RET_IF(E.gemm_rows_strided(dt->p, lo->r, x->rows, lo->A_master, lo->in, lo->r, 1, lo->in, dx, x->cols, dx, x->cols));
             else
-              RET_IF(E.gemm_rows(dt->p, lo->r, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
+              RET_IF(E.gemm_rows(dt->p, rp, x->rows, lo->AT, lo->in, lo->r, nullptr, dx, x->cols, dx, x->cols));
           }
         }
         return 0;
@@ -1055,8 +1083,13 @@ struct Exec {
         if (lora) {   // per slice s: dt_s = dy_s B_s ; dB_s += dy_s^T t_s ; dA_s += dt_s^T x ; then dx += [dt_q | dt_k | dt_v] A3
           T* dt3 = E.R.mk(x->rows, 3 * r);
           FDMI_CHECK(dt3, "unet: workspace exhausted (lora)");
-          for (int s = 0; s < 3; ++s)
-            RET_IF(E.gemm_rows(y->g + s * C, 3 * C, x->rows, l3[s]->BT, r, C, nullptr, dt3->p + s * r, 3 * r, nullptr, 0));
+          if (r < 128 && (E.R.dry() || b.BT3) && x->rows >= 256 && !fdmi_tune_get(44)) {   // one N = 3r GEMM over blockdiag(B^T)
+            RET_IF(E.gemm_rows(y->g, 3 * C, x->rows, b.BT3, 3 * r, 3 * C, nullptr, dt3->p, 3 * r, nullptr, 0));
+            E.flops -= 2.0 * x->rows * (3.0 * r) * (2.0 * C);   // (the zero blocks are not algorithmic work)
+          } else {
+            for (int s = 0; s < 3; ++s)
+              RET_IF(E.gemm_rows(y->g + s * C, 3 * C, x->rows, l3[s]->BT, r, C, nullptr, dt3->p + s * r, 3 * r, nullptr, 0));
+          }
           E.flops += 3 * 2.0 * x->rows * r * (2.0 * C);
           if (!E.R.dry()) {
             for (int s = 0; s < 3; ++s) {
@@ -2159,10 +2192,11 @@ int fdmi_unet_set_lora(fdmi_unet* U, const char* target, const float* A, const f
   if (!l.A) {
     const bool declared = l.on;
     l.r = rank; l.in = w.K; l.out = w.N;
-    RET_IF(dmalloc(U, &l.A, (size_t)rank * l.in));
+    l.rp = (!U->f32 && rank < 128) ? 128 : rank;
+    RET_IF(dmalloc(U, &l.A, (size_t)l.rp * l.in));    // (rows r .. rp stay zero: dmalloc clears, the refresh writes r rows)
     RET_IF(dmalloc(U, &l.AT, (size_t)rank * l.in));
     RET_IF(dmalloc(U, &l.B, (size_t)rank * l.out));
-    RET_IF(dmalloc(U, &l.BT, (size_t)rank * l.out));
+    RET_IF(dmalloc(U, &l.BT, (size_t)l.rp * l.out));
     l.on = true;
     if (!declared) U->loras.push_back(&l);
     U->fused_dirty = true;   // the folded [W | B] / [W^T | A^T] operands of this linear are built at the next forward
@@ -2178,6 +2212,7 @@ int fdmi_unet_declare_lora(fdmi_unet* U, const char* target, int rank) {
   FDMI_CHECK(!l.on || l.r == rank, "unet: LoRA rank changed");
   if (!l.on) {
     l.r = rank; l.in = it->second->w.K; l.out = it->second->w.N;
+    l.rp = (!U->f32 && rank < 128) ? 128 : rank;
     l.on = true;
     U->loras.push_back(&l);
   }

@@ -20,6 +20,7 @@ struct TnArgs {
   int64_t M; int N1, N2;
   float* C; int64_t ldc;
   int rows_per_split;   // multiple of TN_BK
+  int ct;               // 1: the result is stored transposed, C[n2][n1] (the launcher swapped the operands: see launch_wgrad_tn)
 };
 
 // byte offset of element (row, k) of an [rows][64] bf16 image: 16-byte chunk k>>3 stored at slot (k>>3) ^ ((row>>1)&7)
@@ -110,7 +111,7 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int n1 = n1_0 + w1 * 32 + f1 * 16 + g * 4 + r;
-        if (n1 < a.N1 && n2 < a.N2) atomicAdd(a.C + (int64_t)n1 * a.ldc + n2, acc[f1][f2][r]);
+        if (n1 < a.N1 && n2 < a.N2) atomicAdd(a.ct ? a.C + (int64_t)n2 * a.ldc + n1 : a.C + (int64_t)n1 * a.ldc + n2, acc[f1][f2][r]);
       }
     }
 }
@@ -122,13 +123,23 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
   FDMI_CHECK(X && Y && C && M > 0 && N1 > 0 && N2 > 0, "wgrad_tn: empty problem / null operand");
   FDMI_CHECK((N1 % 8) == 0 && (N2 % 8) == 0 && (ldx % 8) == 0 && (ldy % 8) == 0, "wgrad_tn: widths and leading dims must be multiples of 8");
   FDMI_CHECK(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0, "wgrad_tn: operands must be 16-B aligned");
+  int ct = 0;
+  // The tile is 64 (first operand) x 128 (second): a product with a narrow SECOND operand (dB = dY^T t: N2 = the LoRA rank) would
+  // fill half of every tile with zeros and walk the wide operand in 64-column tiles.  It runs with the operands swapped --
+  // t^T dY, the wide operand in 128-column tiles -- and stores its result transposed (round 4; C4: 586 launches, 54 ms per step).
+  if (N2 <= TN_BN1 && N1 >= TN_BN2 && !fdmi_tune_get(43)) {
+    const bf16_t* tp = X; X = Y; Y = tp;
+    const int64_t tl = ldx; ldx = ldy; ldy = tl;
+    const int tn = N1; N1 = N2; N2 = tn;
+    ct = 1;
+  }
   const int t1 = cdiv(N1, TN_BN1), t2 = cdiv(N2, TN_BN2);
   const int64_t slabs = (M + TN_BK - 1) / TN_BK;
   // ~4 blocks per CU: enough row splits to fill the chip, at least 4 slabs each so the atomics stay a small tail
   int64_t splits = (1024 + (int64_t)t1 * t2 - 1) / ((int64_t)t1 * t2);   // (512 ... 2048 blocks measure the same on C2; 256 is slower)
   if (splits > (slabs + 3) / 4) splits = (slabs + 3) / 4;
   if (splits < 1) splits = 1;
-  TnArgs a{X, ldx, Y, ldy, M, N1, N2, C, ldc, (int)(((slabs + splits - 1) / splits) * TN_BK)};
+  TnArgs a{X, ldx, Y, ldy, M, N1, N2, C, ldc, (int)(((slabs + splits - 1) / splits) * TN_BK), ct};
   const int nz = (int)((M + a.rows_per_split - 1) / a.rows_per_split);
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(st, PROF_WGRAD_TN, 2.0 * (double)M * N1 * N2);
