@@ -3,9 +3,9 @@
 // The LoRA gradients contract over the ROWS of two row-major activations (dB = dY^T t, dA = dt^T x): both operands have the
 // reduction index slow.  The NT kernels (gemm*.hip) want it fast, so the plan used to materialise four transposed copies per
 // LoRA linear (transpose2d: 449 launches and ~10 GB of HBM traffic per C2 step at 1.8 TB/s, round-1 profile) before two
-// split-K GEMMs.  This kernel reads X and Y as they are: a 64-row slab of each is loaded with coalesced 16-byte reads and
-// scattered into LDS TRANSPOSED (2-byte writes) into exactly the [index][64 k] image with the 16-byte-chunk XOR swizzle that
-// gemm.hip's fragment reads expect; the MFMA loop is that kernel's.  Developer knob 16 until its first GPU run.
+// split-K GEMMs.  This kernel reads X and Y as they are: a 64-row slab of each is loaded with coalesced 16-byte reads, transposed
+// in registers in 8 x 8 blocks and written as whole 16-byte chunks into exactly the [index][64 k] LDS image with the
+// 16-byte-chunk XOR swizzle that gemm.hip's fragment reads expect; the MFMA loop is that kernel's.
 //
 // grid (N2 tiles of 128, N1 tiles of 64, row splits); 256 threads = 4 waves as 2 (n1) x 2 (n2), wave tile 32 x 64.
 #include "ops.h"
@@ -38,40 +38,42 @@ __global__ __launch_bounds__(256) void wgrad_tn_kernel(TnArgs a) {
   if (m_beg >= m_end) return;
   const int nk = (int)((m_end - m_beg + TN_BK - 1) / TN_BK);
 
-  // loader: chunk q = tid + 256 * i of a [64 m][BN / 8 chunks] slab; X: 2 chunks per thread, Y: 4
-  constexpr int XI = TN_BK * (TN_BN1 / 8) / 256, YI = TN_BK * (TN_BN2 / 8) / 256;
-  uint4 xr[XI], yr[YI];
+  // staging (round 4): a thread owns ONE 8 (rows m) x 8 (columns n) block of the slab -- wave 0 the 64 blocks of X's 64 x 64
+  // slab, waves 1 / 2 the two 64-column halves of Y's 64 x 128 slab (wave 3 only multiplies; with several blocks per CU the
+  // SIMDs even out).  It loads the block's 8 rows with 16-byte reads (a wave instruction = 8 rows x 128 B), transposes the 8 x 8
+  // 16-bit elements in registers (two ALU ops per output dword) and writes 8 whole 16-byte chunks of the image -- chunk
+  // (index n, k-chunk br) holds k = 8 br .. 8 br + 7 of index n -- instead of 64 2-byte scatter writes whose bank conflicts
+  // bound the kernel (C4: 586 launches x 92 us per step at 0.8 TB/s).  Lane -> (br = lane & 7, column block lane >> 3): the 16
+  // lanes of an LDS write group then cover two image rows with all eight swizzled slots each, i.e. 2 x 128 B without conflicts.
+  const int sw = wave;
+  const int br = lane & 7, bc = (sw == 2 ? 8 : 0) + (lane >> 3);
+  const bf16_t* sbase = sw == 0 ? a.X : a.Y;
+  const int64_t sld = sw == 0 ? a.ldx : a.ldy;
+  const int sn0 = (sw == 0 ? n1_0 : n2_0) + bc * 8;
+  const bool scol_ok = sw < 3 && sn0 < (sw == 0 ? a.N1 : a.N2);   // (widths are multiples of 8: a column block is in or out as a whole)
+  char* const simg = sw == 0 ? sx : sy;
+  uint4 rr[8];
   auto load = [&](int kt) {
-    const int64_t m0 = m_beg + (int64_t)kt * TN_BK;
+    const int64_t m0 = m_beg + (int64_t)kt * TN_BK + br * 8;
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int q = tid + 256 * i, m = q / (TN_BN1 / 8), c = q % (TN_BN1 / 8);
-      const int n = n1_0 + c * 8;
-      xr[i] = (m0 + m < m_end && n < a.N1) ? *(const uint4*)(a.X + (m0 + m) * a.ldx + n) : make_uint4(0, 0, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < YI; ++i) {
-      const int q = tid + 256 * i, m = q / (TN_BN2 / 8), c = q % (TN_BN2 / 8);
-      const int n = n2_0 + c * 8;
-      yr[i] = (m0 + m < m_end && n < a.N2) ? *(const uint4*)(a.Y + (m0 + m) * a.ldy + n) : make_uint4(0, 0, 0, 0);
-    }
-  };
-  auto scatter = [&](char* img, const uint4& v, int row0, int k) {   // 8 values of one source row -> 8 image rows, column k
-    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-    for (int e = 0; e < 8; ++e)
-      *(bf16_t*)(img + img_off(row0 + e, k)) = (bf16_t)(e & 1 ? w[e >> 1] >> 16 : w[e >> 1] & 0xffffu);
+    for (int i = 0; i < 8; ++i)
+      rr[i] = (scol_ok && m0 + i < m_end) ? *(const uint4*)(sbase + (m0 + i) * sld + sn0) : make_uint4(0, 0, 0, 0);
   };
   auto store = [&]() {
+    if (sw == 3) return;
+    uint32_t w[8][4];
 #pragma unroll
-    for (int i = 0; i < XI; ++i) {
-      const int q = tid + 256 * i;
-      scatter(sx, xr[i], (q % (TN_BN1 / 8)) * 8, q / (TN_BN1 / 8));
-    }
+    for (int i = 0; i < 8; ++i) { w[i][0] = rr[i].x; w[i][1] = rr[i].y; w[i][2] = rr[i].z; w[i][3] = rr[i].w; }
 #pragma unroll
-    for (int i = 0; i < YI; ++i) {
-      const int q = tid + 256 * i;
-      scatter(sy, yr[i], (q % (TN_BN2 / 8)) * 8, q / (TN_BN2 / 8));
+    for (int e = 0; e < 8; ++e) {            // column e of the block -> image row n, its 8 k values = rows 0 .. 7 of the block
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t lo = w[2 * q][e >> 1], hi = w[2 * q + 1][e >> 1];
+        o[q] = (e & 1) ? ((lo >> 16) | (hi & 0xffff0000u)) : ((lo & 0xffffu) | (hi << 16));
+      }
+      const int n = bc * 8 + e;
+      *(uint4*)(simg + ((n * 8 + (br ^ ((n >> 1) & 7))) << 4)) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   };
 
@@ -124,10 +126,11 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
   FDMI_CHECK((N1 % 8) == 0 && (N2 % 8) == 0 && (ldx % 8) == 0 && (ldy % 8) == 0, "wgrad_tn: widths and leading dims must be multiples of 8");
   FDMI_CHECK(((uintptr_t)X % 16) == 0 && ((uintptr_t)Y % 16) == 0, "wgrad_tn: operands must be 16-B aligned");
   int ct = 0;
-  // The tile is 64 (first operand) x 128 (second): a product with a narrow SECOND operand (dB = dY^T t: N2 = the LoRA rank) would
-  // fill half of every tile with zeros and walk the wide operand in 64-column tiles.  It runs with the operands swapped --
-  // t^T dY, the wide operand in 128-column tiles -- and stores its result transposed (round 4; C4: 586 launches, 54 ms per step).
-  if (N2 <= TN_BN1 && N1 >= TN_BN2 && !fdmi_tune_get(43)) {
+  // The tile is 64 (first operand) x 128 (second).  A product with a narrow SECOND operand (dB = dY^T t: N2 = a LoRA rank of 64)
+  // leaves half of every tile empty; running it with the operands swapped (t^T dY, result stored transposed) fills the tiles but
+  // turns the epilogue's atomics into a strided pattern, and that costs more than the empty half: 115 vs 42 us at M = 32768,
+  // N1 = 1152, N2 = 64 (profiles/r4_wgrad_tn_rates.txt).  The swap therefore stays a developer switch (knob 43 = 1), off by default.
+  if (N2 <= TN_BN1 && N1 >= TN_BN2 && fdmi_tune_get(43)) {
     const bf16_t* tp = X; X = Y; Y = tp;
     const int64_t tl = ldx; ldx = ldy; ldy = tl;
     const int tn = N1; N1 = N2; N2 = tn;

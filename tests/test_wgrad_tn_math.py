@@ -1,7 +1,7 @@
 """CPU: the index bookkeeping of the TN weight-gradient kernel (csrc/wgrad.hip) restated in numpy on top of the MFMA operand
 convention the validated NT kernels use (gemm.hip: a fragment = 8 consecutive k of index lane & 15, k-block lane >> 4; lane (g, j)
 of the 16x16 result holds first-operand indices g*4 .. g*4+3 and second-operand index j): the transposing scatter of a 64-row
-slab into the swizzled [index][64 k] LDS image, the fragment reads at that image's addresses, the wave / fragment -> (n1, n2)
+slab (8 x 8 blocks, one per thread, transposed in registers: round 4) into the swizzled [index][64 k] LDS image, the fragment reads at that image's addresses, the wave / fragment -> (n1, n2)
 mapping of the epilogue, zero fill past M / N1 / N2 and the row splits -- against X^T Y.  It restates the index math (the kernel
 itself runs in tests/test_zz_dit_gpu.py on the GPU): a change to one must be mirrored in the other."""
 import numpy as np
@@ -28,13 +28,24 @@ def emulate(M, N1, N2, rows_per_split, seed=0):
                 for kt in range((m_end - m_beg + BK - 1) // BK):
                     m0 = m_beg + kt * BK
                     sx, sy = np.zeros(BN1 * 64), np.zeros(BN2 * 64)    # images indexed by byte offset / 2
-                    for img, src, n0, N, BN in ((sx, X, n1_0, N1, BN1), (sy, Y, n2_0, N2, BN2)):
-                        for q in range(BK * (BN // 8)):                 # chunk q: source row m = q / (BN/8), columns c*8 .. +7
-                            m, c = q // (BN // 8), q % (BN // 8)
-                            n = n0 + c * 8
-                            v = src[m0 + m, n:n + 8] if (m0 + m < m_end and n < N) else np.zeros(8)
-                            for e in range(8):
-                                img[img_off(c * 8 + e, m) // 2] = v[e]
+                    for tid in range(256):                               # staging: one 8 (rows) x 8 (columns) block per thread
+                        sw, lane = tid >> 6, tid & 63
+                        if sw == 3:
+                            continue                                     # (the fourth wave only multiplies)
+                        br, bc = lane & 7, (8 if sw == 2 else 0) + (lane >> 3)
+                        img, src, n0, N = (sx, X, n1_0, N1) if sw == 0 else (sy, Y, n2_0, N2)
+                        sn0 = n0 + bc * 8
+                        rr = np.zeros((8, 8))                            # the block's 8 rows as loaded (zero past M / N)
+                        for i in range(8):
+                            m = m0 + br * 8 + i
+                            if sn0 < N and m < m_end:
+                                rr[i] = src[m, sn0:sn0 + 8]
+                        for e in range(8):                               # register transpose: column e -> one 16-byte chunk
+                            n = bc * 8 + e
+                            base = ((n * 8 + (br ^ ((n >> 1) & 7))) << 4) // 2
+                            assert base == img_off(n, br * 8) // 2
+                            for q in range(4):                           # dword q = (row 2q | row 2q + 1 << 16)
+                                img[base + 2 * q], img[base + 2 * q + 1] = rr[2 * q, e], rr[2 * q + 1, e]
                     for wave in range(4):
                         w1, w2 = wave >> 1, wave & 1
                         for ks in range(2):
