@@ -2,7 +2,9 @@
 """Work list of a UNet forward (+ backward) as the planner sees it, without a GPU: every GEMM / conv of a workspace-query walk with
 the kernel, tile and split-K the launcher would pick (FDMI_PLAN_LOG=1), grouped by problem, with algorithmic GFLOP and share.
 
-  python scripts/plan_report.py [sd15|sdxl] [B] [hw] [--save]        (defaults: sd15 32 64 = one teacher CFG forward of C2)"""
+  python scripts/plan_report.py [sd15|sdxl|pixart|sd3] [B] [hw] [--save] [--lora r]
+  (defaults: sd15 32 64 = one teacher CFG forward of C2; pixart / sd3: the transformer plans, --lora r declares rank-r adapters on
+  the examples' target modules, --save walks the taped forward and its backward)"""
 import collections
 import os
 import re
@@ -16,22 +18,35 @@ import torch
 from flash_diffusion_amd import _lib
 from flash_diffusion_amd.unet import MiUNet2DConditionModel
 from flash_diffusion_amd import workloads
-arch, B, hw, flags = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-with torch.device("meta"):
-    m = MiUNet2DConditionModel(**getattr(workloads, arch.upper()))
-assert _lib.lib().fdmi_unet_workspace_bytes(m._plan().handle, B, hw, hw, 77, flags) > 0
+arch, B, hw, flags, lora = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+L = _lib.lib()
+if arch in ("pixart", "sd3"):      # the transformer denoisers' plans (csrc/dit_plan.h); --lora r declares the adapters (no GPU needed)
+    from flash_diffusion_amd import dit
+    with torch.device("meta"):
+        m = (dit.MiTransformer2DModel if arch == "pixart" else dit.MiSD3Transformer2DModel)(**getattr(workloads, arch.upper()))
+        if lora:
+            m.add_adapter(lora)
+    p = m._plan()
+    for n, mod in m._lora_modules():
+        assert L.fdmi_unet_declare_lora(p.handle, n.encode(), mod.rank) == 0, L.fdmi_last_error()
+    assert L.fdmi_dit_workspace_bytes(p.handle, B, hw, hw, 120 if arch == "pixart" else 333, 0, flags & 1) > 0
+else:
+    with torch.device("meta"):
+        m = MiUNet2DConditionModel(**getattr(workloads, arch.upper()))
+    assert L.fdmi_unet_workspace_bytes(m._plan().handle, B, hw, hw, 77, flags) > 0
 """
 
 
 def main():
-    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    args = [a for i, a in enumerate(sys.argv[1:], 1) if not a.startswith("--") and sys.argv[i - 1] != "--lora"]
     arch = args[0] if args else "sd15"
     B = int(args[1]) if len(args) > 1 else 32
     hw = int(args[2]) if len(args) > 2 else 64
     flags = 1 if "--save" in sys.argv else 8
     env = dict(os.environ, FDMI_PLAN_LOG="1")
-    err = subprocess.run([sys.executable, "-c", CHILD % ROOT, arch, str(B), str(hw), str(flags)], env=env, capture_output=True,
-                         text=True, check=True).stderr
+    lora = int(sys.argv[sys.argv.index("--lora") + 1]) if "--lora" in sys.argv else 0
+    err = subprocess.run([sys.executable, "-c", CHILD % ROOT, arch, str(B), str(hw), str(flags), str(lora)], env=env,
+                         capture_output=True, text=True, check=True).stderr
     rows = collections.Counter()
     for l in err.splitlines():
         if l.startswith("PLANGEMM"):

@@ -482,3 +482,42 @@ def test_full_size_parameter_counts_match_the_published_models():
     n_pix = sum(1 for n, m in pix.named_modules() if isinstance(m, dit.MiLinear)
                 and any(n == t or n.endswith("." + t) for t in dit.PIXART_LORA_TARGETS))
     assert n_pix == 293      # 28 blocks x 10 linears + patch conv + 2 + 6 + 2 embedder linears + adaLN + proj_out
+
+
+@pytest.mark.parametrize("kind", ["pixart", "sd3"])
+def test_plan_path_lora_buffers(kind):
+    """the host side of the C++ plan path (dit._DenoiserBase): `_reflatten_lora(attach=False)` -- what every plan forward calls --
+    makes the flat parameter / gradient buffers exist without touching `.grad`; `_attach_lora_grads` -- what the plan's backward
+    calls -- points `.grad` at views of the flat gradient buffer (in named_parameters order: the order `_ensure_packed` binds the
+    pairs in) and zeroes it when the gradients were None (optimizer.zero_grad(set_to_none=True)), but keeps accumulated values
+    otherwise; the plan binds exactly the modules that carry a LoRA pair, under their module names"""
+    from flash_diffusion_amd import dit
+    from flash_diffusion_amd.workloads import TINY_PIXART, TINY_SD3
+    torch.manual_seed(0)
+    m = (dit.MiTransformer2DModel(**TINY_PIXART) if kind == "pixart" else dit.MiSD3Transformer2DModel(**TINY_SD3))
+    m.add_adapter(8, init_std_b=0.02)
+    lora = [(n, p) for n, p in m.named_parameters() if ".lora_" in n]
+    before = {n: p.detach().clone() for n, p in lora}
+    assert m._reflatten_lora(torch.device("cpu"), attach=False) is False          # first call: the tensors move into the flat buffer
+    assert m._reflatten_lora(torch.device("cpu"), attach=False) is True           # ... and stay there
+    assert all(p.grad is None for _, p in lora)
+    assert all(torch.equal(p.detach(), before[n]) for n, p in lora)
+    flat, g = m.lora_flat(), m.lora_flat_grad()
+    assert flat.numel() == g.numel() == sum(p.numel() for _, p in lora)
+    off = 0
+    for n, p in lora:                                                            # parameters are views, in named_parameters order
+        assert p.data_ptr() == flat.data_ptr() + 4 * off
+        off += p.numel()
+    g.fill_(3.0)                                                                  # stale values of an earlier step
+    m._attach_lora_grads()                                                        # grads were None: the buffer is zeroed first
+    off = 0
+    for n, p in lora:
+        assert p.grad is not None and p.grad.shape == p.shape and p.grad.data_ptr() == g.data_ptr() + 4 * off
+        off += p.numel()
+    assert float(g.abs().max()) == 0.0
+    g.fill_(2.0)                                                                  # what a backward accumulated
+    m._attach_lora_grads()                                                        # grads attached already: nothing is cleared
+    assert float(g.min()) == 2.0
+    mods = dict(m._lora_modules())
+    assert set(mods) == {n.split(".lora_")[0] for n, _ in lora} and all(v.rank == 8 for v in mods.values())
+    assert not m._use_plan(torch.zeros(1))                                        # CPU tensors never take the plan path
