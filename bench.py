@@ -174,6 +174,8 @@ with torch.device("meta"):
     m = MiUNet2DConditionModel(**workloads.SD15)
     if lora:
         m.add_adapter(lora)
+for t in (m._lora_targets if lora else []):      # (no GPU in this walk: the adapters are declared, not bound)
+    assert _lib.lib().fdmi_unet_declare_lora(m._plan().handle, t.encode(), lora) == 0
 assert _lib.lib().fdmi_unet_workspace_bytes(m._plan().handle, B, 64, 64, 77, flags) > 0
 """
 
