@@ -85,6 +85,7 @@ def emulate(M, N1, N2, rows_per_split, seed=0):
     return np.abs(C - X.T @ Y).max()
 
 
-@pytest.mark.parametrize("M,N1,N2,rps", [(128, 64, 128, 64), (200, 64, 128, 128), (77, 128, 320, 64), (130, 72, 40, 192)])
+@pytest.mark.parametrize("M,N1,N2,rps", [(128, 64, 128, 64), (200, 64, 128, 128), (77, 128, 320, 64), (130, 72, 40, 192),
+                                         (200, 192, 64, 128), (100, 136, 8, 64)])   # (the rank-64 / rank-8 dB shapes: a half-empty second tile)
 def test_tn_kernel_bookkeeping_equals_xt_y(M, N1, N2, rps):
     assert emulate(M, N1, N2, rps) == 0.0
