@@ -139,7 +139,8 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
   const int t1 = cdiv(N1, TN_BN1), t2 = cdiv(N2, TN_BN2);
   const int64_t slabs = (M + TN_BK - 1) / TN_BK;
   // ~4 blocks per CU: enough row splits to fill the chip, at least 4 slabs each so the atomics stay a small tail
-  int64_t splits = (1024 + (int64_t)t1 * t2 - 1) / ((int64_t)t1 * t2);   // (512 ... 2048 blocks measure the same on C2; 256 is slower)
+  const int64_t want = fdmi_tune_get(45) > 0 ? fdmi_tune_get(45) : 1024;   // blocks to aim for (developer knob 45: scripts/wgrad_rates.py)
+  int64_t splits = (want + (int64_t)t1 * t2 - 1) / ((int64_t)t1 * t2);   // (512 ... 2048 blocks measure the same on C2; 256 is slower)
   if (splits > (slabs + 3) / 4) splits = (slabs + 3) / 4;
   if (splits < 1) splits = 1;
   TnArgs a{X, ldx, Y, ldy, M, N1, N2, C, ldc, (int)(((slabs + splits - 1) / splits) * TN_BK), ct};
