@@ -309,9 +309,23 @@ def main():
     # multi-process path on a single-GPU box -- the driver's runs use nccl (= RCCL) with one GPU per rank
     backend = os.environ.get("FDMI_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local % torch.cuda.device_count() if backend != "nccl" else local)
+    comm_note = None
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend, rank=rank, world_size=world)
+    elif os.environ.get("FDMI_BENCH_SINGLE_RANK_GROUP", "1") == "1":
+        # N = 1 still runs the step's one collective -- the all-reduce of the flat LoRA gradient on the comm stream -- through a
+        # process group of ONE rank (RCCL), so that the line's "comm" block measures the code path the N-GPU job runs
+        # (VERDICT r4 item 6).  A failure to create the group is reported in the block, not fatal.
+        try:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+            sk.close()
+            dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)
+        except Exception as e:     # noqa: BLE001
+            comm_note = f"single-rank {backend} group not created: {type(e).__name__}: {e}"
     if world != args.gpus:
         sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
 
@@ -367,6 +381,7 @@ def main():
     pipe.finish()
     model.student_denoiser.step_flops = model.teacher_denoiser.step_flops = 0.0
     flops = [0.0]
+    pipe.comm_timing = True       # events around every gradient exchange and around the main stream's waits for it
     barrier()
     t0 = time.perf_counter()
     run(args.steps, flops)
@@ -383,6 +398,21 @@ def main():
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     step_flops = flops[0] / args.steps
+    # ---- the gradient exchange of the timed steps: ONE all-reduce of the flat fp32 LoRA gradient per step on the comm
+    # stream; "exposed_ms" = mean time the main stream waited for exchange + AdamW (0 when the next teacher loop hides them) ----
+    rep = pipe.comm_report()
+    pipe.comm_timing = False
+    comm = {"backend": (dist.get_backend() if dist.is_initialized() else None),
+            "ranks_seen": (dist.get_world_size() if dist.is_initialized() else 0),
+            "collective": "all_reduce(sum) of the flat fp32 LoRA gradient, 1/world folded into the fused AdamW",
+            "payload_bytes": rep["payload_bytes"], "exchanges_timed": rep["exchanges"],
+            "allreduce_ms": rep["allreduce_ms"], "exposed_ms": rep["exposed_ms"],
+            "exposed_is": "mean main-stream wait on the comm stream's (all-reduce + AdamW) event per step, HIP events",
+            "note": comm_note}
+    if world > 1:     # slowest rank's figures
+        t = torch.tensor([rep["allreduce_ms"] or 0.0, rep["exposed_ms"] or 0.0], device="cuda", dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        comm["allreduce_ms_max_over_ranks"], comm["exposed_ms_max_over_ranks"] = float(t[0]), float(t[1])
 
     # ---- roofline leg: per-launch HIP events on the launch stream, one extra (untimed) step.  EVERY rank runs the
     # step (it contains the gradient all-reduce: a collective only rank 0 entered would hang the job); only rank 0
@@ -574,14 +604,16 @@ def main():
                        "dev_switches": {k: os.environ[k] for k in ("FDMI_TUNE", "FDMI_TEACHER_LOOP", "FDMI_CFG_DEDUP",
                                                                    "FDMI_NO_CTX_CACHE", "FDMI_TEACHER_STREAM",
                                                                    "FDMI_DEFER_BACKWARD") if os.environ.get(k)}},
-            "roofline": roofline, "cpu_baseline": cpu, "parity": parity_record() if headline else None,
+            "roofline": roofline, "cpu_baseline": cpu, "comm": comm, "parity": parity_record() if headline else None,
             # the like-for-like numbers of the reference's own loop, also kept under "secondary":
             "two_optimizer_step_ms": two_opt["ms_per_step"] if two_opt else None,          # G + D training_step (TR:169-218)
             "lpips_step_ms": lpips_leg["ms_per_step"] if lpips_leg else None,              # generator iteration with the YAMLs' lpips loss
             "secondary": {"sampler": sampler, "two_optimizer_step": two_opt, "lpips_step": lpips_leg},
         }
         print(json.dumps(line))
-    if world > 1:
+    if os.environ.get("FDMI_BENCH_DUMP_LORA"):     # (tests/test_multigpu_rccl_gpu.py: the replicas must be identical after the run)
+        torch.save(model.student_denoiser.lora_flat().detach().cpu(), f"{os.environ['FDMI_BENCH_DUMP_LORA']}.rank{rank}.pt")
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

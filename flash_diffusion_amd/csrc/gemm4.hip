@@ -22,7 +22,11 @@ namespace {
 // the transformer denoisers' 1152 / 1536 / 4608 / 6144 (PixArt, SD3): 56 KB per tile, 110 flop/B, wave tile 64 x 96.
 // GN: the epilogue also accumulates the consumer's GroupNorm statistics (GemmArgs::gn_stats); a separate instantiation, so the
 // default kernels are instruction-identical with and without the feature
-template <int MODE, bool GEGLU, int BN, bool GN = false>
+// DEV: developer instantiation (scripts/rowbench.py, scripts/kbench.py through knob 40 = GemmArgs::dev) -- timing ablations with
+// WRONG results (16: A re-read from its first tile; 32: no epilogue) and experiments (0x800: conv K order (channel chunk, tap)
+// instead of (tap, channel chunk); bits 16-18 / 20-27: start the blocks in 2 ... 7 phase groups, group i delayed by i * n us).
+// The production instantiations (DEV = false) contain none of it.
+template <int MODE, bool GEGLU, int BN, bool GN = false, bool DEV = false>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256;
@@ -35,6 +39,16 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, j = lane & 15;
+  if constexpr (DEV) {   // phase stagger: desynchronise the blocks' K-loop / epilogue phases across the chip
+    const int ph = (a.dev >> 16) & 7, dl = (a.dev >> 20) & 0xff;
+    if (ph > 1) {
+      const int mine = (int)((blockIdx.x >> 3) % ph) * dl;
+      for (int i = 0; i < mine; ++i) __builtin_amdgcn_s_sleep(32);   // ~2048 clocks ~ 1 us
+    }
+  }
+  const bool ctap = DEV && MODE == GEMM_CONV && (a.dev & 0x800);   // K tile t = (channel chunk t / taps, tap t % taps)
+  int tapi = 0;                 // (ctap) the tap of the tile to issue next
+  const bf16_t* wrow = nullptr; // (ctap) W row n0+lr at k = 0
 
   // ---- persistent work loop: item = (tile, k-split); block b takes items b, b+G, b+2G, ... ----
   const int tilesN = a.N / BN, tilesM = a.M / BM;
@@ -107,14 +121,20 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
         abase = a.A2 + (int64_t)(it.m0 + lr) * a.lda2 + (it.kbeg - a.K1) + c8;
         astep = 64 * a.lda2;
       } else {
-        abase = a.A + (int64_t)(((a.dev & 16) ? 0 : it.m0) + lr) * a.lda + it.kbeg + c8;   // (dev & 16: timing ablation, A from L2)
+        abase = a.A + (int64_t)(((DEV && (a.dev & 16)) ? 0 : it.m0) + lr) * a.lda + it.kbeg + c8;   // (dev & 16: timing ablation, A from L2)
         astep = 64 * a.lda;
       }
       akpos = it.kbeg;
       arow = it.m0 + lr;
     } else {
-      const int tap = it.kbeg / a.Cin;
+      int tap = it.kbeg / a.Cin;
       cc = it.kbeg - tap * a.Cin;
+      if (ctap) {
+        const int t0 = it.kbeg >> 6, ntap = a.KH * a.KW;
+        tap = t0 % ntap;
+        cc = (t0 / ntap) << 6;
+        tapi = tap;
+      }
       ky = tap / a.KW;
       kx = tap - ky * a.KW;
       const int hw = a.Hout * a.Wout;
@@ -132,6 +152,10 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
     }
     wbase = a.W + (int64_t)(it.n0 + lr) * a.ldw + it.kbeg + c8;
     wstep = 64 * a.ldw;
+    if (ctap) {
+      wrow = a.W + (int64_t)(it.n0 + lr) * a.ldw + c8;
+      wbase = wrow + tapi * a.Cin + cc;
+    }
   };
   const unsigned lds0 = (unsigned)(uintptr_t)((LDS_AS char*)smem);
   int iv = blockIdx.x, ikt = 0, ink = 0, islot = 0;
@@ -166,7 +190,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
         glds16(abase + i * astep, sa + 512 * 16 * i);
       } else {
         glds16(ap[i], sa + 512 * 16 * i);
-        ap[i] += ((aok >> i) & 1u) << 6;
+        if (!ctap) ap[i] += ((aok >> i) & 1u) << 6;
       }
     } else {
       glds16(wbase + (i - AR) * wstep, sa + BM * 128 + 512 * 16 * (i - AR));
@@ -180,6 +204,14 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
         abase = a.A2 + (int64_t)arow * a.lda2 + c8;
         astep = 64 * a.lda2;
       }
+    } else if (ctap) {   // next tile: the next tap of the same channel chunk, then the next chunk
+      if (++tapi == a.KH * a.KW) {
+        tapi = 0;
+        cc += 64;
+      }
+      ky = tapi / a.KW;
+      kx = tapi - ky * a.KW;
+      retap();
     } else {
       cc += 64;
       if (cc >= a.Cin) {  // next tile starts a new filter tap (uniform: Cin % 64 == 0)
@@ -191,7 +223,8 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
         retap();
       }
     }
-    wbase += wstep ? 64 : 0;
+    if (ctap) wbase = wstep ? wrow + tapi * a.Cin + cc : wbase;
+    else wbase += wstep ? 64 : 0;
     islot ^= 1;
     ++ikt;
   };
@@ -261,18 +294,18 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       cslot ^= 1;
     }
     // the next item's first tile is landing meanwhile
-    if (!(MODE == GEMM_ROW && (a.dev & 32)))   // (timing ablation of scripts/rowbench.py: the K loop alone)
+    if (!(DEV && (a.dev & 32)))   // (timing ablation of scripts/rowbench.py: the K loop alone)
       tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN, true, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);   // (whole tiles only)
   }
   wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
 }
 
-template <int MODE, bool GEGLU, int BN, bool GN = false>
+template <int MODE, bool GEGLU, int BN, bool GN = false, bool DEV = false>
 int launch4_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
   constexpr int smem = 2 * (256 + BN) * 128;
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN, DEV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int items = (a.M / 256) * (a.N / BN) * (a.splitk > 1 ? a.splitk : 1);
@@ -288,7 +321,7 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a));
-  FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN>), grid, dim3(512), smem, stream, a);
+  FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN, DEV>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -310,10 +343,15 @@ int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
     FDMI_CHECK(a.act != ACT_GEGLU, "gemm4: the 256 x 192 tile has no GEGLU epilogue");
     return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 192>(a, stream) : launch4_t<GEMM_CONV, false, 192>(a, stream);
   }
+  // developer instantiations: only the plain 256 x 320 row / conv / GEGLU kernels, only when a developer bit asks for one
+  const bool dev = (a.dev & (16 | 32 | 0x800)) != 0 || ((a.dev >> 16) & 7) > 1;
   if (a.act == ACT_GEGLU) {
     FDMI_CHECK(a.mode == GEMM_ROW && a.splitk <= 1 && !a.accum_atomic, "gemm4: GEGLU needs a plain row GEMM");
+    if (dev) return launch4_t<GEMM_ROW, true, 320, false, true>(a, stream);
     return launch4_t<GEMM_ROW, true, 320>(a, stream);
   }
+  if (dev && !a.gn_stats)
+    return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 320, false, true>(a, stream) : launch4_t<GEMM_CONV, false, 320, false, true>(a, stream);
   if (a.gn_stats)
     return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 320, true>(a, stream) : launch4_t<GEMM_CONV, false, 320, true>(a, stream);
   return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 320>(a, stream) : launch4_t<GEMM_CONV, false, 320>(a, stream);

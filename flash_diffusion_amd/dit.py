@@ -23,6 +23,7 @@ folded patches, so it runs as one)."""
 from __future__ import annotations
 
 import math
+import weakref
 from typing import Dict, List, Optional, Sequence, Union
 
 import numpy as np
@@ -585,17 +586,9 @@ class _DenoiserBase(nn.Module):
         return plan
 
     def _attach_lora_grads(self):
-        """param.grad <- views of the flat gradient buffer the plan's backward accumulates into (zeroing it when the grads were
-        None: optimizer.zero_grad(set_to_none=True))"""
-        named = [(n, p) for n, p in self.named_parameters() if ".lora_" in n]
-        if any(p.grad is None for _, p in named):
-            self._lora_grad.zero_()
-        off = 0
-        for _, p in named:
-            v = self._lora_grad[off:off + p.numel()].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                p.grad = v
-            off += p.numel()
+        """param.grad <- views of the flat gradient buffer the plan's backward accumulates into (ops.attach_flat_grads: zeroed
+        where the grads were None: optimizer.zero_grad(set_to_none=True))"""
+        ops.attach_flat_grads([p for n, p in self.named_parameters() if ".lora_" in n], self._lora_grad)
 
     def _plan_call(self, sample, timestep, ctx, vector, pos, lens, keep):
         """one denoiser call through the plan: sample [B, C, H, W], timestep [B], ctx [B, L, .], vector [B, .] or None, pos
@@ -684,7 +677,7 @@ class _DenoiserBase(nn.Module):
     teacher_loop_takes_mask = True
 
     @torch.no_grad()
-    def teacher_loop(self, x, timesteps, crossattn2, vector2, coeffs, attention_mask=None):
+    def teacher_loop(self, x, timesteps, crossattn2, vector2, coeffs, attention_mask=None, attention_mask_lens=None):
         """The frozen teacher's whole guidance loop in ONE C-ABI call (include/fdmi.h: fdmi_dit_teacher_loop): x [B, C, H, W] is
         advanced through the steps `timesteps` (host floats) with the host coefficient rows `coeffs` ([n][6]: x0 = a0 x + a1 e_c
         + a2 e_u; x = a3 x + a4 x0 + a5 x0_prev); crossattn2 [2B, L, .] / vector2 [2B, .] / attention_mask [2B, L] hold the
@@ -697,7 +690,7 @@ class _DenoiserBase(nn.Module):
         plan = self._ensure_packed(x.device)
         L = lib()
         n, Lc, p = len(timesteps), crossattn2.shape[1], c["patch_size"]
-        lens = self._key_lens(attention_mask, Lc) if attention_mask is not None else None
+        lens = self._key_lens(attention_mask, Lc, attention_mask_lens) if attention_mask is not None else None
         x = x.float().contiguous().clone()
         enc = crossattn2.float().contiguous()
         vec = vector2.float().contiguous() if vector2 is not None else None
@@ -840,18 +833,30 @@ class MiTransformer2DModel(_DenoiserBase):
             self._pos_cache[key] = pe.unsqueeze(0).expand(B, -1, -1).reshape(B * h * w, -1).contiguous()
         return self._pos_cache[key]
 
-    def _key_lens(self, mask, L) -> Optional[List[int]]:
+    def _key_lens(self, mask, L, host_lens=None) -> Optional[List[int]]:
+        """per-sample key prefix lengths of a padding mask (TW:75-77), or None when nothing is masked.  `host_lens` (the optional
+        conditioning entry "attention_mask_lens": host integers the conditioner already knows from its tokenizer) avoids the
+        device -> host read.  Otherwise the mask is read on EVERY call except when it is the very same tensor object, unmodified,
+        as in the previous call (held by weak reference; ADVICE r4: an address is not an identity -- the caching allocator hands
+        a freed block to the next batch's mask -- so a (data_ptr, version, shape) key could reuse another batch's lengths)."""
         if mask is None:
             return None
-        key = (mask.data_ptr(), mask._version, tuple(mask.shape))
-        if self._mask_cache is None or self._mask_cache[0] != key:
-            m = (mask.detach().to("cpu") != 0)
-            lens = m.sum(dim=1).tolist()
-            for b, n in enumerate(lens):
-                if n == 0 or not bool(m[b, :n].all()):
-                    raise NotImplementedError("attention_mask must keep a non-empty prefix of the keys (tokenizer padding)")
-            self._mask_cache = (key, None if all(n == L for n in lens) else lens)
-        return self._mask_cache[1]
+        if host_lens is not None:
+            lens = [int(n) for n in host_lens]
+            if len(lens) != mask.shape[0] or any(n < 1 or n > L for n in lens):
+                raise ValueError(f"attention_mask_lens {lens} does not describe a [{mask.shape[0]}, {L}] prefix mask")
+            return None if all(n == L for n in lens) else lens
+        c = self._mask_cache
+        if c is not None and c[0]() is mask and c[1] == mask._version:
+            return c[2]
+        m = (mask.detach().to("cpu") != 0)
+        lens = m.sum(dim=1).tolist()
+        for b, n in enumerate(lens):
+            if n == 0 or not bool(m[b, :n].all()):
+                raise NotImplementedError("attention_mask must keep a non-empty prefix of the keys (tokenizer padding)")
+        lens = None if all(n == L for n in lens) else lens
+        self._mask_cache = (weakref.ref(mask), mask._version, lens)
+        return lens
 
     def _attn(self, a: _Attention, xq, xkv, B, Sq, Skv, lens, residual=None, gate=None):
         q = a.to_q(xq).view(B, Sq, -1)
@@ -869,7 +874,7 @@ class MiTransformer2DModel(_DenoiserBase):
         assert isinstance(conditioning, dict), "conditionings must be a dictionary"                 # TW:69
         cnd = conditioning["cond"]
         vector, crossattn, concat = cnd.get("vector", None), cnd.get("crossattn", None), cnd.get("concat", None)
-        mask = cnd.get("attention_mask", None)
+        mask, mask_lens = cnd.get("attention_mask", None), cnd.get("attention_mask_lens", None)
         ops._dev(sample)      # device tensors only: there is no CPU fallback
         c = self.config_dict
         C_in = sample.shape[1]
@@ -888,7 +893,7 @@ class MiTransformer2DModel(_DenoiserBase):
         if self._use_plan(sample):      # ONE call into the library's plan of this denoiser (csrc/dit_plan.h)
             assert C_in <= c["out_channels"]
             return self._plan_call(sample, timestep, crossattn, vector, self._pos32(h, w, dev),
-                                   self._key_lens(mask, crossattn.shape[1]), C_in)
+                                   self._key_lens(mask, crossattn.shape[1], mask_lens), C_in)
 
         # adaLN-single (TU:75-102): per-sample vectors [B, .]
         if not torch.is_tensor(timestep):
@@ -914,7 +919,7 @@ class MiTransformer2DModel(_DenoiserBase):
         ctx = crossattn.to(self.dt).reshape(B * L, -1).contiguous()
         if self.caption_projection is not None:
             ctx = self.caption_projection.linear_2(_linear_gelu(self.caption_projection.linear_1, ctx))
-        lens = self._key_lens(mask, L)
+        lens = self._key_lens(mask, L, mask_lens)
 
         eps = c["norm_eps"]
         for blk in self.transformer_blocks:

@@ -129,6 +129,8 @@ class TensorConditioner(nn.Module):
                 cond[k] = torch.zeros_like(batch[k]) if drop else batch[k]
         if batch.get("attention_mask", None) is not None:   # T5 key mask of the PixArt path (TW:75): never dropped
             cond["attention_mask"] = batch["attention_mask"]
+            if batch.get("attention_mask_lens", None) is not None:     # its host-side prefix lengths (no device read per step)
+                cond["attention_mask_lens"] = batch["attention_mask_lens"]
         return {"cond": cond}
 
 
@@ -294,7 +296,7 @@ class FlashDiffusion(nn.Module):
         self.terms: Dict[str, Any] = {}
         self.fixed_start_idx: Optional[int] = None     # benchmark: pin the teacher-step count
         self.fixed_guidance: Optional[float] = None
-        self.shared_start_rng: Optional[torch.Generator] = None   # data-parallel training: see share_start_idx()
+        self.shared_start_seed: Optional[int] = None   # data-parallel training: see share_start_idx()
 
     # ---- helpers -----------------------------------------------------------------------------------
     def share_start_idx(self, seed: Optional[int]):
@@ -302,8 +304,16 @@ class FlashDiffusion(nn.Module):
         for the rank that drew the longest teacher loop.  With a host generator seeded IDENTICALLY on every rank (the trainer
         broadcasts rank 0's seed once) all ranks draw the same index from the same pmf at every step -- no communication in the
         step, and each rank's marginal distribution of start indices is the reference's.  Noise, guidance scale and GAN draws
-        stay per rank.  seed=None switches back to per-rank draws."""
-        self.shared_start_rng = None if seed is None else torch.Generator().manual_seed(int(seed))
+        stay per rank.  seed=None switches back to per-rank draws.  The generator of a forward is derived from (seed, the model's
+        forward counter FD:181) and holds no state between forwards, so a rank-local extra draw (validation or sample logging on
+        rank 0 only) cannot make the ranks drift apart.  DEVIATION from the reference, on by default in
+        TrainingPipeline when world > 1: the global batch of an optimizer step sees ONE start timestep instead of `world`."""
+        self.shared_start_seed = None if seed is None else int(seed)
+
+    def _shared_start_generator(self):
+        if getattr(self, "shared_start_seed", None) is None:
+            return None
+        return torch.Generator().manual_seed((self.shared_start_seed * 1000003 + int(self.iter_steps)) % (2 ** 62))
 
     def freeze(self):
         self.eval()
@@ -336,7 +346,7 @@ class FlashDiffusion(nn.Module):
         if self.fixed_start_idx is not None:
             start_idx = torch.tensor([self.fixed_start_idx])
         else:
-            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self.shared_start_rng)
+            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self._shared_start_generator())
         t0 = self.teacher_noise_scheduler.timesteps[start_idx]
         self._start_t_host = int(t0.reshape(-1)[0])   # forward() reports it without a device round trip
         return start_idx, t0.to(device).repeat(num_samples)
@@ -352,7 +362,9 @@ class FlashDiffusion(nn.Module):
     def _cat_cond(cond, uncond):
         if cond is None or uncond is None or set(cond["cond"]) != set(uncond["cond"]):
             return None
-        return {"cond": {k: torch.cat([cond["cond"][k], uncond["cond"][k]], dim=0) for k in cond["cond"]}}
+        # ("attention_mask_lens": host integers beside a key mask -- lists concatenate)
+        return {"cond": {k: (torch.cat([cond["cond"][k], uncond["cond"][k]], dim=0) if torch.is_tensor(cond["cond"][k])
+                             else list(cond["cond"][k]) + list(uncond["cond"][k])) for k in cond["cond"]}}
 
     def _adapter_residuals(self, inputs, scale):
         """FD:207-218 / 820-829: list of residual tensors (scaled), or None without an adapter"""
@@ -582,12 +594,12 @@ class FlashDiffusion(nn.Module):
                             and getattr(self, "batch_cfg", True) and hasattr(sch, "loop_coefficients")
                             and hasattr(self.teacher_denoiser, "teacher_loop") and not args and set(kwargs) <= {"device"}
                             and res is None
-                            and set(cfg_cond["cond"]) <= ({"crossattn", "vector", "attention_mask"}
+                            and set(cfg_cond["cond"]) <= ({"crossattn", "vector", "attention_mask", "attention_mask_lens"}
                                                           if getattr(self.teacher_denoiser, "teacher_loop_takes_mask", False)
                                                           else {"crossattn", "vector"})
                             and (not hasattr(self.teacher_denoiser, "_use_plan") or self.teacher_denoiser._use_plan(x)))
                 if one_call:   # the whole loop inside the library (fdmi_teacher_loop / fdmi_dit_teacher_loop; A/B switch: FDMI_TEACHER_LOOP=0)
-                    kw = ({"attention_mask": cfg_cond["cond"]["attention_mask"]} if "attention_mask" in cfg_cond["cond"] else {})
+                    kw = {k: cfg_cond["cond"][k] for k in ("attention_mask", "attention_mask_lens") if k in cfg_cond["cond"]}
                     x = self.teacher_denoiser.teacher_loop(x, [float(t) for t in sch.timesteps[si:]],
                                                            cfg_cond["cond"]["crossattn"], cfg_cond["cond"].get("vector"),
                                                            sch.loop_coefficients(si, g), **kw)
@@ -710,7 +722,8 @@ class FlashDiffusion(nn.Module):
             noisy_real = sch.add_noise(real, noise, ts)
         x = torch.cat([noisy_fake, noisy_real], dim=0)
         if conditioning is not None:
-            conditioning = {"cond": {k: torch.cat([v, v], dim=0) for k, v in conditioning["cond"].items()}}
+            conditioning = {"cond": {k: (torch.cat([v, v], dim=0) if torch.is_tensor(v) else list(v) + list(v))
+                                     for k, v in conditioning["cond"].items()}}
         t2 = torch.cat([ts, ts], dim=0).float()
         feat = self.disc_backbone(sample=x, timestep=t2, conditioning=conditioning,
                                   down_intrablock_additional_residuals=self._dup(res), return_intermediate=True)

@@ -175,13 +175,18 @@ class FlashDiffusionSD3(nn.Module):
         self.draws: Optional[Draws] = None      # tests inject the reference's random draws here
         self.last_draws: Optional[Draws] = None
         self.fixed_start_idx: Optional[int] = None     # benchmark: pin the teacher-step count (as FlashDiffusion)
-        self.shared_start_rng: Optional[torch.Generator] = None   # data-parallel training: FlashDiffusion.share_start_idx
+        self.shared_start_seed: Optional[int] = None   # data-parallel training: FlashDiffusion.share_start_idx
         self.fixed_guidance: Optional[float] = None
         self.terms: Dict[str, Any] = {}
 
     def share_start_idx(self, seed: Optional[int]):
         """one start index for all data-parallel ranks per step (FlashDiffusion.share_start_idx: identically seeded host generators)"""
-        self.shared_start_rng = None if seed is None else torch.Generator().manual_seed(int(seed))
+        self.shared_start_seed = None if seed is None else int(seed)
+
+    def _shared_start_generator(self):
+        if self.shared_start_seed is None:
+            return None
+        return torch.Generator().manual_seed((self.shared_start_seed * 1000003 + int(self.iter_steps)) % (2 ** 62))
 
     def freeze(self):
         self.eval()
@@ -362,7 +367,7 @@ class FlashDiffusionSD3(nn.Module):
         if self.fixed_start_idx is not None:
             start_idx = torch.tensor([self.fixed_start_idx])
         else:
-            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self.shared_start_rng)
+            start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self._shared_start_generator())
         si = int(start_idx)
         t_host = sch.timesteps[si].reshape(1).repeat(B)                  # host values: no device round trip in the step
         start_t = t_host.to(z.device)
@@ -419,7 +424,7 @@ class FlashDiffusionSD3(nn.Module):
         else:
             l_distill = _DistillLoss.apply(student_output, teacher_output.detach(), self.distill_loss_type == "l1")
         loss = l_distill * self.distill_loss_scale[K_step]
-        self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": g}
+        self.terms = {"distill": l_distill.detach(), "K_step": K_step, "guidance": g, "n_teacher_steps": K - si}
         if self.use_dmd_loss:
             l_dmd = self._dmd_loss(d, student_output, cond, cond, uncond, K_step)
             self.terms["dmd"] = l_dmd.detach()

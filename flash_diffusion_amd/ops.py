@@ -548,3 +548,25 @@ def axpby(x0, c0, x1=None, c1=0.0, x2=None, c2=0.0, x3=None, c3=0.0, out=None):
         out = torch.empty_like(x0)
     check(lib().fdmi_axpby4(ptr(x0), c0, ptr(x1), c1, ptr(x2), c2, ptr(x3), c3, ptr(out), x0.numel(), stream_ptr()))
     return out
+
+
+def attach_flat_grads(params, flat_grad):
+    """param.grad <- views of the flat gradient buffer the plans' backward accumulates into.  A parameter whose .grad is None
+    (optimizer.zero_grad(set_to_none=True), or never set) starts from zero: the WHOLE buffer in one launch when that holds for
+    every parameter (the normal step), only that parameter's slice otherwise -- gradients other parameters already accumulated
+    stay.  A .grad that is some other tensor is copied into its slice first, so accumulation semantics hold."""
+    params = list(params)
+    none = [p.grad is None for p in params]
+    if params and all(none):
+        flat_grad.zero_()
+    off = 0
+    for p, was_none in zip(params, none):
+        v = flat_grad[off:off + p.numel()].view(p.shape)
+        if was_none:
+            if not all(none):
+                v.zero_()
+            p.grad = v
+        elif p.grad.data_ptr() != v.data_ptr():
+            v.copy_(p.grad)
+            p.grad = v
+        off += p.numel()

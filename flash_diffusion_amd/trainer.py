@@ -162,6 +162,12 @@ class TrainingPipeline(nn.Module):
         self.overlap = overlap
         self.reduced_grad_hook = None   # callable(optimizer, grad_scale): see _reduce_and_step
         self._comm_stream = None
+        # comm_timing = True (bench.py): HIP events around every gradient exchange on the stream it runs on, and around the
+        # main stream's wait for the exchange + optimizer step (comm_report() reads them after a device synchronisation)
+        self.comm_timing = False
+        self._comm_events: List[Any] = []     # (start, stop) of each all-reduce
+        self._wait_events: List[Any] = []     # (before, after) of each main-stream wait on `_pending`
+        self.comm_payload_bytes = 0
         self._pending = None      # event recorded on the comm stream after the deferred optimizer step
         self._deferred = None     # (loss, optimizer index) whose backward + step the next before_student hook issues
         self.global_rank = torch.distributed.get_rank() if torch.distributed.is_initialized() else 0
@@ -281,8 +287,28 @@ class TrainingPipeline(nn.Module):
     # ---- gradient exchange + optimizer step ---------------------------------------------------------
     def _wait_pending(self):
         if self._pending is not None and torch.cuda.is_available():
-            torch.cuda.current_stream().wait_event(self._pending)
+            cur = torch.cuda.current_stream()
+            if self.comm_timing:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(cur)
+                cur.wait_event(self._pending)
+                e1.record(cur)
+                self._wait_events.append((e0, e1))
+            else:
+                cur.wait_event(self._pending)
             self._pending = None
+
+    def comm_report(self, reset=True):
+        """{"allreduce_ms", "exposed_ms", "exchanges", "payload_bytes"}: mean duration of a gradient exchange on its stream and the
+        mean time the main stream stood still waiting for exchange + optimizer step (what the step pays for data parallelism when
+        the overlap with the next teacher loop fails), over the steps since the last reset.  Call after a device synchronisation."""
+        ar = [a.elapsed_time(b) for a, b in self._comm_events]
+        ex = [a.elapsed_time(b) for a, b in self._wait_events]
+        rec = {"exchanges": len(ar), "allreduce_ms": sum(ar) / len(ar) if ar else None,
+               "exposed_ms": sum(ex) / len(ex) if ex else None, "waits": len(ex), "payload_bytes": self.comm_payload_bytes}
+        if reset:
+            self._comm_events, self._wait_events = [], []
+        return rec
 
     def _defer_ok(self):
         """the backward of a forward may wait for the next forward's hook: GPU, overlap on, a model that calls the hook
@@ -322,8 +348,13 @@ class TrainingPipeline(nn.Module):
         ctx = torch.cuda.stream(side) if side is not None else _null()
         with ctx:
             if self.distributed:
+                ev = None
+                if self.comm_timing and torch.cuda.is_available():
+                    ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                    ev[0].record(torch.cuda.current_stream())
                 if isinstance(opt, FusedAdamW) and opt.flat_grad is not None:
                     torch.distributed.all_reduce(opt.flat_grad)
+                    self.comm_payload_bytes = opt.flat_grad.numel() * opt.flat_grad.element_size()
                 else:
                     grads = [p.grad for g in opt.param_groups for p in g["params"] if p.grad is not None]
                     if grads:
@@ -331,6 +362,10 @@ class TrainingPipeline(nn.Module):
                         torch.distributed.all_reduce(flat)
                         for g, f in zip(grads, torch._utils._unflatten_dense_tensors(flat, grads)):
                             g.copy_(f)
+                        self.comm_payload_bytes = flat.numel() * flat.element_size()
+                if ev is not None:   # (the synchronous all_reduce made the current stream wait for the collective's stream)
+                    ev[1].record(torch.cuda.current_stream())
+                    self._comm_events.append(ev)
                 if isinstance(opt, FusedAdamW):
                     opt.grad_scale = 1.0 / self.world
                 else:

@@ -15,7 +15,7 @@ from typing import Dict, List, Optional, Sequence, Union
 import torch
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, ops
 from ._lib import check, f32, i32, i64, ptr, stream_ptr, vp
 
 FDMI_UNET_SAVE, FDMI_UNET_INTERMEDIATE, FDMI_UNET_INPUT_GRAD = 1, 2, 4
@@ -412,16 +412,8 @@ class MiUNet2DConditionModel(nn.Module):
         plan.lora_bound = key
 
     def _attach_lora_grads(self):
-        """param.grad <- views of the flat grad buffer (zeroing it when grads were None)."""
-        params = self.lora_parameters()
-        if any(p.grad is None for p in params):
-            self._lora_grad.zero_()
-        off = 0
-        for p in params:
-            v = self._lora_grad[off:off + p.numel()].view(p.shape)
-            if p.grad is None or p.grad.data_ptr() != v.data_ptr():
-                p.grad = v
-            off += p.numel()
+        """param.grad <- views of the flat grad buffer (ops.attach_flat_grads: zeroed where the grads were None)."""
+        ops.attach_flat_grads(self.lora_parameters(), self._lora_grad)
 
     # ---- reference wrapper contract (unet.py:66-127) -------------------------------------------------
     def freeze(self):

@@ -93,6 +93,7 @@ def synthetic_batch(B, hw, ctx_dim, device="cuda", seed=1234, L=77, vector_dim=0
         b["vector"] = torch.randn(B, vector_dim, generator=g).to(device)
     if attention_mask:                                      # "mask of ones" for the PixArt T5 context
         b["attention_mask"] = torch.ones(B, L, dtype=torch.long, device=device)
+        b["attention_mask_lens"] = [L] * B                  # what a tokenizer knows on the host: no device read per step
     return b
 
 

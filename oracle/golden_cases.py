@@ -480,16 +480,48 @@ FULLSTEP_CASES = {
 }
 
 
+# ---- the same three recipes with ALL FOUR teacher CFG steps (K = [4], start index 0: the second-order
+# DPM-Solver++ 2M state FD:288-324 / the flow-matching Euler loop over four sigmas FD3:281-314) at B = 2 with per-sample content
+# (PixArt: two DIFFERENT T5 key lengths, TW:75-77) -- the loop BASELINE.json configs[2..4] run, at their real widths.  The start
+# index comes from the reference's own draw: a one-mode mixture centred on index 0 and the seed whose multinomial lands there
+# (as the C2 fixture does).  64x64 latents (FULLSTEP4_HW): the fp32 host tape of the G-step -- two student samples plus the four
+# samples the GAN term sends through the frozen backbone with grad -- is 4x the B = 1 fixture's per token; at 128x128 it exceeds the
+# 62 GB of the authoring container (tried: PixArt, the smallest, failed in _gan_loss).  The benchmarked 128x128 shapes at the
+# benchmarked batch are covered on the GPU by tests/test_batch_invariance_gpu.py.
+_FS4 = dict(_FS_COMMON, K=[4], timestep_distribution="mixture", mixture_num_components=4, mixture_var=0.5,
+            mode_probs=[[1.0, 0.0, 0.0, 0.0]])
+FULLSTEP4_CASES = {
+    "step4_sdxl": ("fd", dict(_FS4, guidance_scale_min=3.0, guidance_scale_max=13.0), 81),
+    "step4_pixart": ("fd", dict(_FS4, guidance_scale_min=2.0, guidance_scale_max=9.0, ucg_keys=["text"], use_empty_prompt=True), 82),
+    "step4_sd3": ("fd3", dict(_FS4, guidance_scale_min=3.0, guidance_scale_max=7.0), 83),
+}
+FULLSTEP4_B = 2
+FULLSTEP4_HW = {"step4_sdxl": 64, "step4_pixart": 64, "step4_sd3": 64}
+FULLSTEP4_KEY_LENS = (100, 57)          # PixArt: per-sample T5 prefix lengths of the conditional prompts
+FULLSTEP_CASES_ALL = dict(FULLSTEP_CASES, **FULLSTEP4_CASES)
+
+
+def _fs_base(name):
+    return name.replace("step4_", "step_")
+
+
 def fullstep_head(name):
     """the PatchGAN head of the example: SDXL on the teacher's mid-block features [B, 1280, 32, 32] (train_flash_sdxl.py:238-267),
     PixArt / SD3 on the prediction itself (train_flash_pixart.py:277-325: five strided stages; train_flash_sd3.py:145-183: four)"""
     nn = torch.nn
+    four = name.startswith("step4_")
+    name = _fs_base(name)
     if name == "step_sdxl":
         c, f, n = 1280, 256, 3
     elif name == "step_pixart":
         c, f, n = 4, 64, 5
     else:
         c, f, n = 16, 64, 4
+    if four and name != "step_sd3":
+        # 64x64 latents (FULLSTEP4_HW): the examples' heads are sized for 128x128 -- their last 4x4 / stride-1 convolution would
+        # meet a 2x2 map -- so the SDXL and PixArt heads drop their last strided stage (same widths otherwise; SD3's fits as is)
+        assert FULLSTEP4_HW["step4_" + name[5:]] == 64
+        n -= 1
     layers = [nn.Conv2d(c, f, 4, 2, 1, bias=False), nn.SiLU(True)]
     for i in range(1, n):
         layers += [nn.Conv2d(f << (i - 1), f << i, 4, 2, 1, bias=False), nn.GroupNorm(4, f << i), nn.SiLU(True)]
@@ -501,6 +533,7 @@ def fullstep_oracle(name, lora_rank):
     """empty fp32 oracle denoiser of the case (the `make` default of build_fullstep_models)"""
     from . import dit_cpu, mmdit_cpu
     from .unet_cpu import sdxl_config
+    name = _fs_base(name)
     if name == "step_sdxl":
         m = UNet2DConditionRef(sdxl_config())
         if lora_rank:
@@ -531,21 +564,31 @@ def build_fullstep_models(name, device="cpu", make=None):
     return teacher, student, disc
 
 
-def fullstep_inputs(name, device="cpu"):
-    """(batch, conditioner or text-embedding pipeline) of the case -- hashed, unit-variance, identical on host and GPU"""
+def fullstep_inputs(name, device="cpu", B=None, hw=None):
+    """(batch, conditioner or text-embedding pipeline) of the case -- hashed, unit-variance, identical on host and GPU.  The
+    `step4_*` cases: B = FULLSTEP4_B samples at FULLSTEP4_HW latents; B / hw override both (the GPU batch-invariance tests tile
+    the fixture's batch to the benchmarked one)."""
     from .flash_ref import TensorConditioner
+    four = name.startswith("step4_")
+    B = B or (FULLSTEP4_B if four else 1)
+    hw = hw or (FULLSTEP4_HW[name] if four else 128)
+    name = _fs_base(name)
     if name == "step_sdxl":
-        return {"image": _hu((1, 4, 128, 128), 21, device), "crossattn": _hu((1, 77, 2048), 22, device),
-                "vector": _hu((1, 2816), 23, device), "text": ["a"]}, TensorConditioner()
+        return {"image": _hu((B, 4, hw, hw), 21, device), "crossattn": _hu((B, 77, 2048), 22, device),
+                "vector": _hu((B, 2816), 23, device), "text": ["a"] * B}, TensorConditioner()
     if name == "step_pixart":
-        mask = torch.ones(1, 120, dtype=torch.long, device=device)
+        mask = torch.ones(B, 120, dtype=torch.long, device=device)
         mask[:, 100:] = 0
-        empty = torch.zeros(1, 120, dtype=torch.long, device=device)
+        if four:
+            for i in range(B):
+                mask[i] = 0
+                mask[i, :FULLSTEP4_KEY_LENS[i % len(FULLSTEP4_KEY_LENS)]] = 1
+        empty = torch.zeros(B, 120, dtype=torch.long, device=device)
         empty[:, :1] = 1
-        return {"image": _hu((1, 4, 128, 128), 21, device), "text": ["a"], "crossattn": _hu((1, 120, 4096), 22, device),
-                "crossattn_empty": _hu((1, 120, 4096), 24, device), "attention_mask": mask, "attention_mask_empty": empty,
-                "vector": _hu((1, 768), 23, device)}, PromptTableConditioner()
+        return {"image": _hu((B, 4, hw, hw), 21, device), "text": ["a"] * B, "crossattn": _hu((B, 120, 4096), 22, device),
+                "crossattn_empty": _hu((B, 120, 4096), 24, device), "attention_mask": mask, "attention_mask_empty": empty,
+                "vector": _hu((B, 768), 23, device)}, PromptTableConditioner()
     from .flash_sd3_ref import EmbeddingPipeline
-    pipe = EmbeddingPipeline(_hu((1, 333, 4096), 22, device), _hu((1, 2048), 23, device), _hu((1, 333, 4096), 24, device),
-                             _hu((1, 2048), 25, device))
-    return {"image": _hu((1, 16, 128, 128), 21, device), "text": ["a"]}, pipe
+    pipe = EmbeddingPipeline(_hu((B, 333, 4096), 22, device), _hu((B, 2048), 23, device), _hu((B, 333, 4096), 24, device),
+                             _hu((B, 2048), 25, device))
+    return {"image": _hu((B, 16, hw, hw), 21, device), "text": ["a"] * B}, pipe

@@ -336,13 +336,28 @@ def make_fullstep_golden(names=None):
     from . import dit_cpu, unet_cpu
     from .flash_ref import FlashConfigRef, FlashDiffusionRef
     from .flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
-    from .golden_cases import FULLSTEP_CASES, build_fullstep_models, fullstep_inputs
+    from .flash_ref import timestep_pmf
+    from .golden_cases import FULLSTEP4_HW, FULLSTEP_CASES, FULLSTEP_CASES_ALL, build_fullstep_models, fullstep_inputs
     from .sched_cpu import FlowMatchEulerDiscreteSchedulerRef
     unet_cpu.FUSED_ATTENTION = True
     dit_cpu.FUSED_ATTENTION = True
     for name in (names or FULLSTEP_CASES):
-        kind, kw, seed = FULLSTEP_CASES[name]
+        kind, kw, seed = FULLSTEP_CASES_ALL[name]
         t0 = time.time()
+        four = name.startswith("step4_")
+        if four:
+            # `step4_*`: all four teacher steps.  The reference draws the start index (FD:167 / FD3:177, after
+            # `randn_like(z)`): take the first seed >= the case's whose draw is index 0.  FDMI_STEP4_HW=<n> overrides the latent size.
+            if os.environ.get("FDMI_STEP4_HW"):
+                FULLSTEP4_HW[name] = int(os.environ["FDMI_STEP4_HW"])
+            z0 = fullstep_inputs(name)[0]["image"]
+            pmf = timestep_pmf(FlashConfigRef(**{k: v for k, v in kw.items() if k not in ("ucg_keys", "use_empty_prompt")}), 4, 0)
+            for s in range(seed, seed + 100):
+                torch.manual_seed(s)
+                torch.randn_like(z0)
+                if int(torch.multinomial(pmf, 1)) == 0:
+                    seed = s
+                    break
 
         def build(real):
             teacher, student, disc = build_fullstep_models(name)
@@ -376,6 +391,10 @@ def make_fullstep_golden(names=None):
             assert torch.equal(keep[k], out2[k]), (name, k)
         assert float(out2["loss"][0]) == losses[0], (name, float(out2["loss"][0]), losses[0])
         blob = {"step": np.int64(0), "start_timestep": np.float64(start_t), "seed": np.int64(seed)}
+        if four:
+            assert int(ora.last_draws.values["start_idx"]) == 0, ora.last_draws.values["start_idx"]   # all four teacher steps
+            blob["B"] = np.int64(batch2["image"].shape[0])
+            blob["hw"] = np.int64(batch2["image"].shape[-1])
         for k, v in ora.last_draws.values.items():
             blob["draw:" + k] = v.numpy()
         for k, v in keep.items():
@@ -399,6 +418,60 @@ def make_fullstep_golden(names=None):
               "KiB", flush=True)
         del ora, out2, grads
         gc.collect()
+
+
+
+def make_bf16_anchor(tag):
+    """The reference's OWN training precision as a yardstick: the pinned oracle replays a full-width step
+    fixture's draws under `torch.autocast("cpu", bfloat16)` -- PyTorch's implementation of the `precision="bf16-mixed"` the
+    reference trains with (examples/train_flash_sd.py:405) -- and the distances of that run to the fixture's fp32 run are stored
+    in tests/golden/<tag>_bf16ref.npz.  The GPU tests hold the HIP bf16 path to 1.5 x these distances instead of to bars derived
+    from its own history.  Forward only (outputs and loss terms).  tag: c2_sd15_r128_n4[_b16] or step4_{sdxl,pixart,sd3}."""
+    import time
+    from . import dit_cpu, unet_cpu
+    from .flash_ref import Draws, FlashConfigRef, FlashDiffusionRef
+    from .flash_sd3_ref import FlashDiffusionSD3Ref, FlashSD3ConfigRef
+    from .golden_cases import (C2_KW, FULLSTEP_CASES_ALL, build_c2_models, build_fullstep_models, c2_batch, fullstep_inputs)
+    from .sched_cpu import FlowMatchEulerDiscreteSchedulerRef
+    unet_cpu.FUSED_ATTENTION = True
+    dit_cpu.FUSED_ATTENTION = True
+    blob = np.load(os.path.join(OUT, tag + ".npz"))
+    draws = {k[5:]: torch.from_numpy(blob[k]) for k in blob.files if k.startswith("draw:")}
+    t0 = time.time()
+    if tag.startswith("c2_"):
+        B = int(blob["B"]) if "B" in blob.files else 2
+        teacher, student, disc = build_c2_models()
+        m = FlashDiffusionRef(FlashConfigRef(**C2_KW), student_denoiser=student, teacher_denoiser=teacher,
+                              teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=TensorConditioner(), discriminator=disc)
+        batch, call = c2_batch(B=B), (lambda mm, b: mm(b, step=0, device="cpu"))
+    else:
+        kind, kw, _ = FULLSTEP_CASES_ALL[tag]
+        teacher, student, disc = build_fullstep_models(tag)
+        batch, cond = fullstep_inputs(tag, hw=int(blob["hw"]) if "hw" in blob.files else None)
+        if kind == "fd":
+            m = FlashDiffusionRef(FlashConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                                  teacher_noise_scheduler=SCHEDS["dpm"](), conditioner=cond, discriminator=disc)
+            call = lambda mm, b: mm(b, step=0, device="cpu")
+        else:
+            m = FlashDiffusionSD3Ref(FlashSD3ConfigRef(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                                     teacher_noise_scheduler=FlowMatchEulerDiscreteSchedulerRef(), discriminator=disc, pipeline=cond)
+            call = lambda mm, b: mm(b, step=0)
+    m.draws = Draws(draws)
+    with torch.no_grad(), torch.autocast("cpu", dtype=torch.bfloat16):
+        out = call(m, batch)
+
+    def rel(a, b):
+        a, b = a.detach().double(), torch.from_numpy(b).double()
+        return float((a - b).norm() / (b.norm() + 1e-30))
+    rec = {"teacher_output_rel": rel(out["teacher_output"].float(), blob["out:teacher_output"]),
+           "student_output_rel": rel(out["student_output"].float(), blob["out:student_output"]),
+           "loss_rel": abs(float(out["loss"][0]) - float(blob["loss:0"])) / abs(float(blob["loss:0"]))}
+    for k, v in getattr(m, "terms", {}).items():
+        if "term:" + k in blob.files and k not in ("K_step", "guidance") and float(blob["term:" + k]) != 0:
+            rec["term_rel:" + k] = abs(float(v) - float(blob["term:" + k])) / abs(float(blob["term:" + k]))
+    np.savez(os.path.join(OUT, tag + "_bf16ref.npz"), **{k: np.float64(v) for k, v in rec.items()},
+             mode=np.array("torch.autocast(cpu, bfloat16), no_grad, oracle restatement (bit-pinned to the reference class)"))
+    print(tag, "reference bf16-mixed vs its fp32 run:", {k: f"{v:.3e}" for k, v in rec.items()}, f"{time.time() - t0:.0f} s", flush=True)
 
 
 def make_c2_golden(B=2):
@@ -521,7 +594,12 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "full":
         make_fullsize_golden(sys.argv[2:] or None)
     elif len(sys.argv) > 1 and sys.argv[1] == "fullstep":
+        import resource                  # an allocation beyond the host's memory should fail here, not take the container down
+        resource.setrlimit(resource.RLIMIT_AS, (int(os.environ.get("FDMI_GOLDEN_MEM_GB", "58")) << 30,) * 2)
         make_fullstep_golden(sys.argv[2:] or None)
+    elif len(sys.argv) > 1 and sys.argv[1] == "bf16anchor":
+        for tag in sys.argv[2:] or ("c2_sd15_r128_n4", "c2_sd15_r128_n4_b16", "step4_sdxl", "step4_pixart", "step4_sd3"):
+            make_bf16_anchor(tag)
     elif len(sys.argv) > 1 and sys.argv[1] == "c2":
         make_c2_golden(int(sys.argv[2]) if len(sys.argv) > 2 else 2)
     elif len(sys.argv) > 1 and sys.argv[1] == "gan":

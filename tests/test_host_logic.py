@@ -214,9 +214,14 @@ def _start_idx_worker(rank, world, port, q, share):
                             **({} if share is None else {"share_start_idx": share}))
     assert pipe.share_start_idx == (True if share is None else share)
     idx = []
-    for _ in range(24):
+    for i in range(24):
         torch.randn(3)                                          # the ranks' global RNG streams drift apart, as noise draws do
+        m.iter_steps += 1                                       # what forward() does first (FD:181)
         idx.append(int(m._get_timesteps(Draws(), 2, 8, 0, "cpu")[0]))
+        if rank == 0 and i % 5 == 2:
+            # a rank-LOCAL extra draw (sample logging / validation on rank 0 only): the shared index is a function of (seed,
+            # forward counter) and holds no generator state, so the ranks cannot drift apart
+            m._get_timesteps(Draws(), 2, 8, 0, "cpu")
     q.put((rank, idx))
     dist.barrier()
     dist.destroy_process_group()
