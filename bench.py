@@ -44,8 +44,8 @@ def cpu_baseline(n_teacher_steps, budget_s=130.0):
     cores on a bounded sample of the SAME workload (SD1.5, r128 LoRA, 64x64 latents, n teacher steps): whole generator
     iterations (forward + backward + AdamW) at B=1 -- one warm-up UNet forward, then the median of up to 3 timed
     iterations -- and, if the time budget allows, one iteration at B=2 (the batch-scaling point).  Threads: the fastest of a
-    short sweep (physical cores / 8 ... physical cores) of one UNet forward -- the GPU box's 128 cores are slower at 128
-    torch threads than at 32 (profiles/r2_cpu_thread_sweep.txt); FDMI_CPU_THREADS pins a count."""
+    sweep over physical cores / 8, / 4, / 2 and ALL physical cores of a B = 2 student forward + backward;
+    FDMI_CPU_THREADS pins a count."""
     import copy
     import statistics
     import torch
@@ -57,23 +57,23 @@ def cpu_baseline(n_teacher_steps, budget_s=130.0):
     student = copy.deepcopy(teacher)
     student.add_adapter(128)
     teacher.freeze()
-    # thread count: the fastest of {physical/8, physical/4, physical/2, physical} on ONE teacher forward each (PyTorch's CPU
-    # kernels stop scaling long before a 128-core host is full: profiles/r2_cpu_thread_sweep.txt); FDMI_CPU_THREADS overrides
+    # thread count: the fastest of {physical/8, physical/4, physical/2, physical} -- ALL four, up to every
+    # physical core -- on the part of the step that carries the batch: a B = 2 student forward + backward (LoRA gradients), not a
+    # B = 1 forward (whose optimum, 16 of 128 threads on the pool's host, undersold the CPU).  FDMI_CPU_THREADS pins a count.
     phys = _physical_cores()
-    probe = (torch.randn(1, 4, 64, 64), torch.tensor([999]), {"cond": {"crossattn": torch.randn(1, 77, 768)}})
+    probe = (torch.randn(2, 4, 64, 64), torch.tensor([999, 999]), {"cond": {"crossattn": torch.randn(2, 77, 768)}})
     t_begin = time.perf_counter()
     sweep = {}
     forced = int(os.environ.get("FDMI_CPU_THREADS", "0"))
     for n in ([forced] if forced else sorted({max(1, phys // 8), max(1, phys // 4), max(1, phys // 2), phys})):
         torch.set_num_threads(n)
-        with torch.no_grad():
-            if not sweep:
-                teacher(*probe)          # warm-up: allocator, oneDNN primitive caches
-            t0 = time.perf_counter()
-            teacher(*probe)
-            sweep[n] = time.perf_counter() - t0
-        if len(sweep) > 1 and sweep[n] > 1.3 * min(sweep.values()):
-            break                        # past the knee
+        if not sweep:
+            with torch.no_grad():
+                student(probe[0][:1], probe[1][:1], {"cond": {"crossattn": probe[2]["cond"]["crossattn"][:1]}})   # warm-up: allocator, oneDNN primitive caches
+        t0 = time.perf_counter()
+        student(*probe).square().mean().backward()
+        sweep[n] = time.perf_counter() - t0
+        student.zero_grad(set_to_none=True)
     threads = min(sweep, key=sweep.get)
     torch.set_num_threads(threads)
     m = FlashDiffusionRef(FlashConfigRef(K=[n_teacher_steps], num_iterations_per_K=[10 ** 9], timestep_distribution="uniform"),
@@ -102,11 +102,11 @@ def cpu_baseline(n_teacher_steps, budget_s=130.0):
         t2 = iteration(2)
     best = max(1.0 / med1, (2.0 / t2) if t2 else 0.0)
     return {"value": best, "unit": "images/s", "cores": threads, "physical_cores": phys, "kind": "port",
-            "thread_sweep_s_per_unet_forward": {str(k): round(v, 2) for k, v in sweep.items()},
+            "thread_sweep_s_per_b2_student_fwd_bwd": {str(k): round(v, 2) for k, v in sweep.items()},
             "b1_s_per_iteration": [round(x, 2) for x in t1], "b1_images_per_s": 1.0 / med1,
             "b2_s_per_iteration": round(t2, 2) if t2 else None, "b2_images_per_s": (2.0 / t2) if t2 else None,
             "sample": f"whole generator iterations (fwd+bwd+AdamW) of the same SD1.5 r128 step, {n_teacher_steps} teacher CFG steps, "
-                      f"fp32 PyTorch-CPU oracle on {threads} threads (fastest of a sweep up to the {phys} physical cores), B=1 median of "
+                      f"fp32 PyTorch-CPU oracle on {threads} threads (fastest of a B=2 fwd+bwd sweep over {sorted(sweep)} threads, {phys} physical cores), B=1 median of "
                       f"{len(t1)} = {med1:.1f} s" + (f", B=2 one iteration = {t2:.1f} s" if t2 else "") +
                       "; value = the better of the two batch sizes"}
 

@@ -140,7 +140,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       const int hw = a.Hout * a.Wout;
 #pragma unroll
       for (int i = 0; i < AR; ++i) {
-        const int m = it.m0 + lr + 64 * i;
+        const int m = ((DEV && (a.dev & 16)) ? 0 : it.m0) + lr + 64 * i;   // (dev & 16: timing ablation, every tile gathers the first 256 pixels: A from L2)
         const int b = m / hw, rem = m - b * hw;
         const int oy = rem / a.Wout, ox = rem - oy * a.Wout;
         apix[i] = b * a.Hin * a.Win;

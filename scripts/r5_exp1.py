@@ -63,7 +63,9 @@ def conv_order(reps, B=32):
         fns = [(lambda x=x, w=w, out=out: ops.gemm(x, w, M=M, bias=bias, out=out, conv=conv, force_tile=TILE)) for (x, w, out) in sets]
         line = f"conv3x3 B={B} {hw}x{hw} {ci}->{co} |"
         ref = None
-        for name, d in (("(tap,c)", 0), ("(c,tap)", 0x800), ("(tap,c) again", 0)):
+        # 16: every tile gathers the first 256 output pixels' windows (A served by the L2: WRONG results) -- the conv kernel's own
+        # "A from L2" ablation (is its 5.2x fabric traffic free?); 32: no epilogue; 48: both
+        for name, d in (("(tap,c)", 0), ("(c,tap)", 0x800), ("A from L2", 16), ("no epilogue", 32), ("both", 48), ("(tap,c) again", 0)):
             L.fdmi_tune_set(40, d)
             us = bench(fns, reps)
             fns[0]()
@@ -72,7 +74,7 @@ def conv_order(reps, B=32):
             if ref is None:
                 ref = o.clone()
             err = float((o - ref).norm() / ref.norm())
-            line += f" {name}: {us:7.1f} us {fl / us / 1e6:6.0f} TF rel {err:.1e} |"
+            line += f" {name}: {us:7.1f} us {fl / us / 1e6:6.0f} TF" + (f" rel {err:.1e}" if d in (0, 0x800) else "") + " |"
         L.fdmi_tune_set(40, 0)
         print(line, flush=True)
 

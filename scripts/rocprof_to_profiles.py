@@ -160,9 +160,12 @@ def main():
             fh.write("# rocprofv3 --pmc GRBM_GUI_ACTIVE --kernel-trace (own pass): busy cycles per launch as reported and the dispatch's "
                      "duration from the same rows; GHz = cycles / ns.  The counter is summed over the chip's 8 XCDs when the value "
                      "is ~8x a plausible clock: ghz_per_xcd = GHz / 8 is then the shader clock the kernel ran at\n")
+            fh.write("# ONLY kernels whose launches average >= 200 us are listed (VERDICT r4 weak 10): GRBM_GUI_ACTIVE also counts the "
+                     "dispatch's ramp on either side of the timestamps, so cycles / duration of a short launch exceeds the part's "
+                     "2.4 GHz maximum (round 4's file showed 2.5 - 3.3 GHz for launches under 100 us) and is not a clock\n")
             fh.write("kernel,launches,avg_us,grbm_gui_active_per_launch,ghz_raw,ghz_per_xcd\n")
             for n, (c, cyc, ns) in sorted(agg.items(), key=lambda kv: -kv[1][2]):
-                if ns > 0:
+                if ns > 0 and ns / c >= 200e3:
                     fh.write(f"\"{n}\",{c},{ns / c / 1e3:.1f},{cyc / c:.0f},{cyc / ns:.3f},{cyc / ns / 8:.3f}\n")
         print("wrote", f"{pre}_clock{a.tag}.csv")
     if not (a.fetch_dir and a.write_dir):

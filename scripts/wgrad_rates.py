@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """GPU dev tool: us per launch of `wgrad_tn` (C[n1][n2] += sum_m X[m][n1] Y[m][n2]) at the LoRA weight-gradient shapes of C2 / C4 / C5,
-for each value of the developer knobs given on the command line (43: operand swap, 45: blocks the row split aims for):
+for each value of the developer knobs given on the command line (43: operand swap of the old kernel, 45: blocks the row split aims
+for, 46: 1 = round 4's register-transposing kernel, 0 = round 5's streaming kernel):
 
   python scripts/wgrad_rates.py                 # defaults
   python scripts/wgrad_rates.py 45=512,2048,4096 43=0,1
@@ -17,7 +18,7 @@ import torch  # noqa: E402
 from flash_diffusion_amd import _lib, ops  # noqa: E402
 
 SHAPES = [(32768, 1152, 64), (32768, 64, 1152), (32768, 4608, 64), (32768, 64, 4608), (65536, 320, 128), (65536, 128, 320),
-          (16384, 640, 128), (16384, 1536, 64), (4096, 1280, 128)]
+          (16384, 640, 128), (16384, 128, 640), (16384, 1536, 64), (4096, 1280, 128), (4096, 128, 1280), (1232, 128, 768)]
 
 
 def rate(M, N1, N2, reps=20):
@@ -48,9 +49,9 @@ def main():
         for k, v in zip(keys, combo):
             _lib.lib().fdmi_tune_set(k, v)
         res = [rate(*s) for s in SHAPES]
-        assert all(e < 2e-2 for _, e in res), res
         print(" ".join(f"{k}={v}" for k, v in zip(keys, combo)) or "defaults", " ".join(f"{u:7.1f}" for u, _ in res),
-              f"(max rel err {max(e for _, e in res):.1e})", flush=True)
+              f"(max rel err {max(e for _, e in res):.1e})" + ("  WRONG RESULT at " + str([s for s, (_, e) in zip(SHAPES, res) if e >= 2e-2])
+                                                              if any(e >= 2e-2 for _, e in res) else ""), flush=True)
 
 
 if __name__ == "__main__":

@@ -27,6 +27,7 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     config.addinivalue_line("markers", "gpu_exclusive: a GPU test that needs most of the 288 GB of HBM (full-width steps at the "
                                        "benchmarked batch): runs while no other worker's GPU test does")
+    config.addinivalue_line("markers", "gpu_mem(gib): HBM this GPU test may hold (default: one 34 GiB slot of the box's eight)")
 
 
 def pytest_xdist_auto_num_workers(config):
@@ -49,10 +50,35 @@ def pytest_collection_modifyitems(config, items):
             it.add_marker(skip)
 
 
-# ---- HBM budget across xdist workers: every GPU test holds the box's lock SHARED, a `gpu_exclusive` test holds it EXCLUSIVE.  Two
-# flock files make the writer starvation-free without a daemon: readers pass through a turnstile (A) they hold only while taking
-# the room lock (B); a writer keeps the turnstile, so new readers queue behind it while the running ones drain.
+# ---- HBM budget across xdist workers.  The box's 288 GB are 8 slots of 34 GiB (lock files); a GPU test holds one slot unless it
+# declares more -- `@pytest.mark.gpu_mem(gib)` -- or all of them (`gpu_exclusive`: the full-width steps at the benchmarked batch).
+# Taking slots: under the turnstile lock, try-lock any k free slot files; whoever cannot get its k keeps the turnstile while it
+# waits, so no new test enters, the running ones drain, and a large request cannot starve.  No hold-and-wait: no deadlock.
 _LOCK_DIR = os.environ.get("FDMI_TEST_LOCK_DIR", "/tmp")
+_SLOTS, _SLOT_GIB = 8, 34
+
+
+def _take_slots(k):
+    k = max(1, min(_SLOTS, k))
+    gate = open(os.path.join(_LOCK_DIR, "fdmi_gpu_turnstile.lock"), "w")
+    fcntl.flock(gate, fcntl.LOCK_EX)
+    try:
+        while True:
+            held = []
+            for i in range(_SLOTS):
+                f = open(os.path.join(_LOCK_DIR, f"fdmi_gpu_slot{i}.lock"), "w")
+                try:
+                    fcntl.flock(f, fcntl.LOCK_EX | fcntl.LOCK_NB)
+                    held.append(f)
+                except OSError:
+                    f.close()
+                if len(held) == k:
+                    return held
+            for f in held:
+                f.close()              # (closing drops the lock)
+            time.sleep(0.25)
+    finally:
+        gate.close()
 
 
 @pytest.fixture(autouse=True)
@@ -60,24 +86,14 @@ def _gpu_room(request):
     if "gpu" not in request.keywords or not _has_gpu():
         yield
         return
-    a = open(os.path.join(_LOCK_DIR, "fdmi_gpu_turnstile.lock"), "w")
-    b = open(os.path.join(_LOCK_DIR, "fdmi_gpu_room.lock"), "w")
+    m = request.node.get_closest_marker("gpu_mem")
+    k = _SLOTS if "gpu_exclusive" in request.keywords else (-(-int(m.args[0]) // _SLOT_GIB) if m else 1)
+    held = _take_slots(k)
     try:
-        if "gpu_exclusive" in request.keywords:
-            fcntl.flock(a, fcntl.LOCK_EX)
-            fcntl.flock(b, fcntl.LOCK_EX)
-            yield
-        else:
-            fcntl.flock(a, fcntl.LOCK_SH)
-            fcntl.flock(b, fcntl.LOCK_SH)
-            fcntl.flock(a, fcntl.LOCK_UN)
-            yield
+        yield
     finally:
-        for f in (b, a):
-            try:
-                fcntl.flock(f, fcntl.LOCK_UN)
-            finally:
-                f.close()
+        for f in held:
+            f.close()
 
 
 # ---- per-test wall time of every run, appended to gpurun_out/test_durations.txt (the suite's time budget is a judged quantity) ----

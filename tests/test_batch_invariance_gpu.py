@@ -8,9 +8,15 @@ the LoRA gradient (the mean over identical copies).  HIP path against HIP path, 
 l2 + DMD + lsgan with the example's own PatchGAN head (the step the C3 / C4 / C5 bench lines time), the same random draws tiled.
 This needs no B = 8 oracle and catches tile / split-K / masking choices that only trigger at the bench shape.
 
-Tolerance: a different tiling changes the fp32 summation order only, which flips a bf16 rounding now and then -- far below the
-distance of bf16 to fp32 (measured on the first run: see profiles/r5_parity_batch_invariance.txt).  Bars: outputs rel. Frobenius
-1e-2, loss terms 1e-2, global LoRA-gradient cosine > 0.999 and norm within 2 %."""
+SDXL runs l2 + DMD without the GAN term: at B = 8 and 128x128 the student's tape (113 GiB), the teacher's workspace and the GAN
+term's taped pass of 16 samples through the frozen backbone do not fit 288 GB together -- `bench.py --arch sdxl` (C3) times the
+l2 generator iteration; PixArt (C4) and SD3 (C5: the bench's own DMD + GAN step) run all three terms.
+
+Tolerance: a different tiling changes the fp32 summation order only, which flips bf16 roundings that then propagate through 4 x 2
+teacher evaluations -- measured on the first run (profiles/r5_parity_batch_invariance.txt): teacher output 9.4 - 9.6e-3, student
+output 3.1 - 5.1e-3, loss terms <= 1.9e-4, LoRA-gradient cosine 0.99999 -- a quarter to a half of the distance bf16 keeps from fp32
+on the same models (tests/test_step4_parity_gpu.py); a wrong tile or mask at the bench shape is an O(1) error.  Bars: teacher
+output 2e-2, student output 1e-2 (rel. Frobenius), loss terms 1e-2, global LoRA-gradient cosine > 0.999 and norm within 2 %."""
 import os
 
 import pytest
@@ -41,47 +47,53 @@ def _tile(v, k):
     return torch.cat([v] * k, dim=0)
 
 
-def _body(name):
+def _run(name, B, draws):
+    """one step at batch B (the two fixture samples tiled) in a freshly built model -> (outputs, loss terms, loss, flat LoRA gradient,
+    draws), everything on the host; the models and their workspaces are released on return"""
     from flash_diffusion_amd.flash import Draws
     from oracle.golden_cases import fullstep_inputs
     from tests.test_step4_parity_gpu import _build
-    kind, model = _build(name, "bf16")
-    B2, B = 2, BENCH_BATCH[name]
+    kind, model = _build(name, "bf16", head=(name != "step4_sdxl"))
+    B2 = 2
     k = B // B2
-    batch2, cond = fullstep_inputs(name, "cuda", B=B2, hw=128)
+    batch, cond = fullstep_inputs(name, "cuda", B=B2, hw=128)
+    if k > 1:
+        batch = {q: (_tile(v, k) if torch.is_tensor(v) else list(v) * k) for q, v in batch.items()}
+        if kind != "fd":     # the SD3 step takes its text embeddings from the pipeline stand-in: (prompt, negative, pooled, negative pooled)
+            e = cond.e
+            cond = type(cond)(_tile(e[0], k), _tile(e[2], k), _tile(e[1], k), _tile(e[3], k))
+        # the same draws for the tiled batch: per-sample tensors repeat with the samples, scalars stay
+        draws = Draws({q: (_tile(v, k) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B2 else v) for q, v in draws.items()})
+    assert batch["image"].shape == (B, batch["image"].shape[1], 128, 128)
+    m = model(cond)
+    m.fixed_start_idx = 0                     # all four teacher steps, as the bench pins them
+    m.draws = draws
+    out = m(batch, step=0, device="cuda") if kind == "fd" else m(batch, step=0)
+    assert m.terms["n_teacher_steps"] == 4
+    out["loss"][0].backward()
+    torch.cuda.synchronize()
+    grads = torch.cat([p.grad.detach().float().flatten() for n, p in m.student_denoiser.named_parameters()
+                       if ".lora_" in n and p.grad is not None]).cpu()
+    terms = {t: float(v) for t, v in m.terms.items() if t not in ("K_step", "guidance", "n_teacher_steps")}
+    keep = {q: out[q].detach().float().cpu() for q in ("teacher_output", "student_output", "noisy_sample")}
+    return keep, terms, float(out["loss"][0]), grads, {q: (v.detach().cpu() if torch.is_tensor(v) else v) for q, v in m.last_draws.values.items()}
 
-    def step(batch, draws, cond):
-        m = model(cond)
-        m.fixed_start_idx = 0                     # all four teacher steps, as the bench pins them
-        m.draws = draws
-        m.student_denoiser.zero_grad(set_to_none=True)
-        out = m(batch, step=0, device="cuda") if kind == "fd" else m(batch, step=0)
-        assert m.terms["n_teacher_steps"] == 4
-        out["loss"][0].backward()
-        torch.cuda.synchronize()
-        grads = torch.cat([p.grad.detach().float().flatten() for n, p in m.student_denoiser.named_parameters()
-                           if ".lora_" in n and p.grad is not None])
-        terms = {t: float(v) for t, v in m.terms.items() if t not in ("K_step", "guidance", "n_teacher_steps")}
-        keep = {q: out[q].detach().float().clone() for q in ("teacher_output", "student_output", "noisy_sample")}
-        return keep, terms, float(out["loss"][0]), grads, m.last_draws
 
+def _body(name):
+    import gc
+    B2, B = 2, BENCH_BATCH[name]
     torch.manual_seed(4242)
-    o2, t2, l2, g2, d2 = step(batch2, None, cond)
-    # the same draws for the tiled batch: per-sample tensors repeat with the samples, scalars stay
-    tiled = {q: (_tile(v, k) if torch.is_tensor(v) and v.dim() >= 1 and v.shape[0] == B2 else v) for q, v in d2.values.items()}
-    batch = {q: (_tile(v, k) if torch.is_tensor(v) else list(v) * k) for q, v in batch2.items()}
-    assert batch["image"].shape == (B, batch2["image"].shape[1], 128, 128)
-    if kind != "fd":     # the SD3 step takes its text embeddings from the pipeline stand-in: (prompt, negative, pooled, negative pooled)
-        e = cond.e
-        cond = type(cond)(_tile(e[0], k), _tile(e[2], k), _tile(e[1], k), _tile(e[3], k))
-    oB, tB, lB, gB, _ = step(batch, Draws(tiled), cond)
-    errs = {q: max(rel_err(oB[q][i::B2][j], o2[q][i]) for i in range(B2) for j in range(k)) for q in o2}
+    o2, t2, l2, g2, d2 = _run(name, B2, None)
+    gc.collect()
+    torch.cuda.empty_cache()                  # the B = 2 run's plan workspaces go back before the bench-size run allocates its own
+    oB, tB, lB, gB, _ = _run(name, B, d2)
+    errs = {q: max(rel_err(oB[q][i::B2][j], o2[q][i]) for i in range(B2) for j in range(B // B2)) for q in o2}
     terr = {q: abs(tB[q] - t2[q]) / max(abs(t2[q]), 1e-12) for q in t2 if t2[q] != 0}
     lerr = abs(lB - l2) / abs(l2)
     cos, nr = _cos(gB, g2), float(gB.norm() / g2.norm())
     log(f"{name}: B={B} (tiled) vs B={B2} at 128x128, 4 teacher steps, bf16: " + " ".join(f"{q}={v:.3e}" for q, v in errs.items())
         + f" loss_rel={lerr:.3e} terms={ {q: f'{v:.1e}' for q, v in terr.items()} } LoRA-grad cosine={cos:.6f} norm ratio={nr:.4f} "
         f"({gB.numel() / 1e6:.1f} M gradient elements)")
-    assert errs["noisy_sample"] < 1e-6 and errs["teacher_output"] < 1e-2 and errs["student_output"] < 1e-2, errs
+    assert errs["noisy_sample"] < 1e-6 and errs["teacher_output"] < 2e-2 and errs["student_output"] < 1e-2, errs
     assert lerr < 1e-2 and all(v < 1e-2 for v in terr.values()), (lerr, terr)
     assert cos > 0.999 and abs(nr - 1) < 0.02, (cos, nr)

@@ -43,6 +43,7 @@ def _cos(a, b):
 
 
 # ---- 1d: full-size forwards ------------------------------------------------------------------------------------------------------
+@pytest.mark.gpu_mem(60)
 @pytest.mark.parametrize("name", ["full_sdxl", "full_pixart", "full_sd3"])
 def test_full_size_forward_B1_matches_the_fp32_oracle(name):
     run_isolated(__name__, "_forward_body", (name,), timeout=900)
@@ -119,7 +120,23 @@ def _check_projected_grads(tag, m, blob, g, fp32):
             (worst_n_big, worst_p_big, full)
 
 
-def _check_outputs(tag, m, g, out, fp32, bf16_bars=(5e-2, 1e-2, 3e-2)):
+ANCHOR_FACTOR = 1.5
+
+
+def bf16_anchor_bars(tag, floor=(4e-3, 2e-3, 2e-3), term_floor=5e-3):
+    """((teacher, student, loss) bars, {loss term: bar}, the reference's own figures) of the bf16 production mode: ANCHOR_FACTOR x the
+    deviation of the REFERENCE's precision mode on this very fixture -- tests/golden/<tag>_bf16ref.npz holds the distance of the
+    pinned oracle's `torch.autocast(bfloat16)` run (the reference trains with precision="bf16-mixed",
+    examples/train_flash_sd.py:405) to its fp32 run (oracle/make_golden.py::make_bf16_anchor) -- never below a small floor (a
+    fixture on which the autocast run happens to land on the fp32 loss says nothing about achievable accuracy).  VERDICT r4 item
+    1c: bars anchored to the reference's precision class instead of to this path's own history."""
+    a = np.load(os.path.join(GOLDEN_DIR, tag + "_bf16ref.npz"))
+    ref = (float(a["teacher_output_rel"]), float(a["student_output_rel"]), float(a["loss_rel"]))
+    terms = {k[9:]: max(ANCHOR_FACTOR * float(a[k]), term_floor) for k in a.files if k.startswith("term_rel:")}
+    return tuple(max(ANCHOR_FACTOR * r, f) for r, f in zip(ref, floor)), terms, ref
+
+
+def _check_outputs(tag, m, g, out, fp32, bf16_bars=(5e-2, 1e-2, 3e-2), term_bars=None):
     assert out["start_timestep"] == g["start_timestep"]
     errs = {k: rel_err(out[k], g["out"][k]) for k in ("teacher_output", "student_output", "noisy_sample")}
     lerr = []
@@ -133,14 +150,19 @@ def _check_outputs(tag, m, g, out, fp32, bf16_bars=(5e-2, 1e-2, 3e-2)):
     o_t, o_s, l_tol = (1e-4, 1e-4, 1e-3) if fp32 else bf16_bars
     assert errs["noisy_sample"] < 1e-6 and errs["teacher_output"] <= o_t and errs["student_output"] <= o_s, errs
     assert lerr[0] <= l_tol and lerr[1] <= l_tol, lerr
-    assert all(v <= l_tol for v in terr.values()), terr
+    if term_bars is not None and not fp32:      # every loss term against its own anchored bar
+        assert all(v <= term_bars.get(k, l_tol) for k, v in terr.items()), (terr, term_bars)
+    else:
+        assert all(v <= l_tol for v in terr.values()), terr
 
 
+@pytest.mark.gpu_mem(60)
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_c2_shaped_step_matches_reference_golden(precision):
     run_isolated(__name__, "_c2_body", (precision,), timeout=900)
 
 
+@pytest.mark.gpu_mem(100)
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_c2_step_at_its_own_batch_matches_reference_golden(precision):
     """BASELINE.json configs[1] at B = 16 -- the 2B = 32-row teacher and 16-row student shapes bench.py times (VERDICT r3 item
@@ -177,7 +199,12 @@ def _c2_body(precision, B=2):
     out = m(c2_batch("cuda", B=B), step=0, device="cuda")
     assert m.terms["n_teacher_steps"] == 4                  # the headline's four teacher CFG steps
     assert tuple(out["student_output"].shape) == (B, 4, 64, 64)
-    _check_outputs(f"{tag} [{precision}]", m, g, out, precision == "fp32")
+    bars, tbars = (5e-2, 1e-2, 3e-2), None
+    if precision == "bf16":     # anchored to the reference's own bf16-mixed deviation on this fixture
+        bars, tbars, ref = bf16_anchor_bars(tag)
+        log(f"step {tag} [bf16]: reference bf16-mixed deviation teacher {ref[0]:.3e} student {ref[1]:.3e} loss {ref[2]:.3e} -> bars "
+            f"{bars[0]:.3e} / {bars[1]:.3e} / {bars[2]:.3e}, terms { {k: f'{v:.1e}' for k, v in tbars.items()} }")
+    _check_outputs(f"{tag} [{precision}]", m, g, out, precision == "fp32", bars, tbars)
     out["loss"][0].backward()
     torch.cuda.synchronize()
     _check_projected_grads(f"{tag} [{precision}]", m, blob, g, precision == "fp32")
@@ -188,6 +215,7 @@ def _have(name):
     return os.path.exists(os.path.join(GOLDEN_DIR, name + ".npz"))
 
 
+@pytest.mark.gpu_mem(200)           # (the fp32 validation mode of the SDXL step: twice the bf16 tape, beside 2 x 10 GB of fp32 weights)
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("name", ["step_sdxl", "step_pixart", "step_sd3"])
 def test_full_width_step_matches_reference_golden(name, precision):
@@ -243,6 +271,7 @@ def _fullstep_body(name, precision):
     _check_projected_grads(f"{name} [{precision}]", m, blob, g, precision == "fp32")
 
 
+@pytest.mark.gpu_mem(60)
 def test_c1_full_size_step_bf16():
     run_isolated(__name__, "_c1_bf16_body", (), timeout=900)
 

@@ -71,3 +71,27 @@ def test_attach_flat_grads_zeroes_only_what_was_none():
     p[0].grad = torch.full((4,), 5.0)                               # a foreign .grad tensor: its content moves into the slice
     ops.attach_flat_grads(p, flat)
     assert torch.equal(flat[:4], torch.full((4,), 5.0)) and p[0].grad.data_ptr() == flat.data_ptr()
+
+
+def test_milpips_takes_the_lpips_package_state_dict_with_its_duplicate_lins():
+    """flash.py (FD:102-103): `MiLPIPS.load_state_dict(lpips.LPIPS(net="vgg").state_dict())`.  lpips 0.1.4 registers its five linear
+    layers twice -- as attributes lin0 .. lin4 AND in the ModuleList `lins` -- so its state_dict carries every
+    `lin{k}.model.1.weight` a second time as `lins.{k}.model.1.weight`.  The package is absent from the image (VERDICT r4 missing
+    5): a state_dict FABRICATED with that key set (the oracle's restatement of the architecture + the duplicates) must load with
+    strict=True, land in the right tensors, and a key that is really foreign must still be refused."""
+    from flash_diffusion_amd.nets import MiLPIPS
+    from oracle.vae_cpu import LPIPSRef, seeded_net_init_
+    ref = seeded_net_init_(LPIPSRef(), 5)
+    sd = dict(ref.state_dict())
+    for k in range(5):
+        sd[f"lins.{k}.model.1.weight"] = sd[f"lin{k}.model.1.weight"]          # the same tensors, as lpips exposes them
+    assert sum(k.startswith("lins.") for k in sd) == 5
+    m = MiLPIPS(precision="fp32")
+    res = m.load_state_dict(sd)                                                # strict
+    assert not res.missing_keys and not res.unexpected_keys
+    own = m.state_dict()
+    assert set(own) == {k for k in sd if not k.startswith("lins.")}
+    for k, v in own.items():
+        assert torch.equal(v.cpu().float().reshape(-1), sd[k].float().reshape(-1)), k
+    with pytest.raises(RuntimeError):
+        m.load_state_dict(dict(sd, **{"net.slice9.0.weight": torch.zeros(1)}))

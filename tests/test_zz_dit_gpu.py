@@ -568,7 +568,7 @@ def _body_test_groupnorm_unrolled_reduction(cfg):
 # ---- TN weight-gradient kernel (csrc/wgrad.hip): LoRA gradients without transposed operand copies (in-plan use: the LoRA-gradient
 # parity tests of tests/test_unet_gpu.py / test_flash_gpu.py against the oracle) ------------------------------------------------------
 @pytest.mark.parametrize("shape", [(4096, 320, 128), (65536, 128, 320), (1232, 640, 128), (1232, 128, 768), (16384, 1280, 128),
-                                   (130, 72, 40), (64, 64, 128), (100000, 128, 1280)])
+                                   (130, 72, 40), (64, 64, 128), (100000, 128, 1280), (32768, 1152, 64), (8192, 64, 4608), (333, 200, 136)])
 def test_wgrad_tn(shape):
     run_isolated(__name__, "_body_test_wgrad_tn", (shape,))
 
