@@ -12,9 +12,11 @@ static inline int nblocks(int64_t total, int cap = 8192) {
 }
 
 // y[m][c] = res[m][c] + gate[m / rows_per_batch][c] * x[m][c]   (res may be null: the backward's dy = gate * dout)
+// res32 / y32 (round 5): the residual's fp32 master is read instead of `res`, and the fp32 result is stored beside the bf16 one --
+// the transformer denoisers' residual stream stays in fp32 (gemm.h, GemmArgs::residual32)
 __global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* x, const bf16_t* gate, int64_t gate_ld,
                                                             const bf16_t* res, bf16_t* y, int64_t rows, int C,
-                                                            int rows_per_batch) {
+                                                            int rows_per_batch, const float* res32, float* y32) {
   const int CPR = C >> 3;
   const int64_t total = rows * CPR;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -23,6 +25,22 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const bf16_t* x, con
     const u16x8 xv = *(const u16x8*)(x + m * C + c0);
     const u16x8 gv = *(const u16x8*)(gate + (m / rows_per_batch) * gate_ld + c0);
     u16x8 rv = {0, 0, 0, 0, 0, 0, 0, 0}, o;
+    if (res32) {   // (uniform)
+      const float4 r0 = *(const float4*)(res32 + m * C + c0), r1 = *(const float4*)(res32 + m * C + c0 + 4);
+      const float rf[8] = {r0.x, r0.y, r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+      float v[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[e] = fmaf(bf2f(gv[e]), bf2f(xv[e]), rf[e]);
+        o[e] = f2bf(v[e]);
+      }
+      if (y32) {
+        *(float4*)(y32 + m * C + c0) = make_float4(v[0], v[1], v[2], v[3]);
+        *(float4*)(y32 + m * C + c0 + 4) = make_float4(v[4], v[5], v[6], v[7]);
+      }
+      *(u16x8*)(y + m * C + c0) = o;
+      continue;
+    }
     if (res) rv = *(const u16x8*)(res + m * C + c0);
 #pragma unroll
     for (int e = 0; e < 8; ++e) o[e] = f2bf(fmaf(bf2f(gv[e]), bf2f(xv[e]), bf2f(rv[e])));
@@ -96,10 +114,11 @@ __global__ __launch_bounds__(256) void batch_colsum_kernel(const bf16_t* dy, con
 }
 
 int launch_gate_residual(const bf16_t* x, const bf16_t* gate, int64_t gate_ld, const bf16_t* res, bf16_t* y,
-                         int64_t rows, int C, int rows_per_batch, hipStream_t st) {
+                         int64_t rows, int C, int rows_per_batch, hipStream_t st, const float* res32, float* y32) {
   FDMI_CHECK(C % 8 == 0 && gate_ld % 8 == 0 && rows_per_batch > 0, "gate_residual: C and gate_ld must be multiples of 8");
+  FDMI_CHECK(!y32 || res32, "gate_residual: an fp32 output needs the fp32 residual");
   hipLaunchKernelGGL(gate_residual_kernel, dim3(nblocks(rows * (C >> 3))), dim3(256), 0, st, x, gate, gate_ld, res, y,
-                     rows, C, rows_per_batch);
+                     rows, C, rows_per_batch, res32, y32);
   FDMI_HIP(hipGetLastError());
   return 0;
 }

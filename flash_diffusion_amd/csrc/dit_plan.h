@@ -108,9 +108,16 @@ int build_dit(fdmi_unet* U) {
 // ops (forward + recorded backward), on top of Exec
 // ---------------------------------------------------------------------------------------------
 static inline int DF(const Exec& E) { return E.f32() ? 1 : 0; }
-static T* dit_lin(Exec& E, T* x, LinearW& L, T* residual = nullptr, bool need_dx = true) {
-  return E.linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr, need_dx);
+static T* dit_lin(Exec& E, T* x, LinearW& L, T* residual = nullptr, bool need_dx = true, bool out32 = false) {
+  return E.linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr, need_dx, 0, out32);
 }
+// The hidden state of the latent stream is a RESIDUAL STREAM IN FP32 in bf16 plans (round 5): in the reference's bf16-mixed run the
+// patch embedding adds the fp32 position table and every block adds gate * (bf16 sub-layer output) to it, so type promotion keeps
+// it in fp32 (the context stream of the MMDiT stays bf16 there, and here).  Rounded to bf16 after each of its ~56 adds the stream
+// put the 28-block PixArt teacher at 4x the reference's own bf16 deviation (tests/golden/step4_pixart_bf16ref.npz).  T::p32
+// carries the fp32 master from the patch embedding on: LayerNorm reads it, the residual GEMM epilogues / gate_residual add into it
+// and store it beside the bf16 shadow `p` that GEMM A operands and the backward read.  Developer switch 49 = 1: bf16 stream.
+static inline bool dit_stream32(const Exec& E) { return !E.f32() && !fdmi_tune_get(49); }
 // the gradient of an op's single input: written in place when nothing has reached x yet, staged and added otherwise
 template <typename Fw>
 static int dit_dx(Exec& E, T* x, Fw write) {
@@ -228,7 +235,7 @@ static T* dit_ln_mod(Exec& E, T* x, T* mod, int shift_col, int scale_col, int rp
     DIT_NULL(E.f32() ? launch_layernorm32_fwd(Exec::F(x->p), nullptr, nullptr, Exec::F(mod->p) + shift_col, Exec::F(mod->p) + scale_col, ld,
                                               rpb, Exec::F(y->p), x->rows, C, eps, E.st, stats)
                      : launch_layernorm_fwd(x->p, nullptr, nullptr, mod->p + shift_col, mod->p + scale_col, ld, rpb, y->p, x->rows, C, eps,
-                                            E.st, stats));
+                                            E.st, stats, x->p32));
   if (R.save) {
     R.tape.push_back([x, y, mod, shift_col, scale_col, rpb, eps, mod_grad, stats, ld, C](Exec& E) -> int {
       if (!y->g) return 0;
@@ -238,7 +245,8 @@ static T* dit_ln_mod(Exec& E, T* x, T* mod, int shift_col, int scale_col, int rp
       if (!E.R.dry())
         RET_IF(E.f32() ? launch_layernorm32_bwd(Exec::F(x->p), Exec::F(y->g), nullptr, Exec::F(mod->p) + scale_col, ld, rpb, Exec::F(dx),
                                                 x->rows, C, eps, x->ginit ? 1 : 0, E.st)
-                       : launch_layernorm_bwd(x->p, y->g, nullptr, mod->p + scale_col, ld, rpb, dx, x->rows, C, eps, x->ginit ? 1 : 0, E.st));
+                       : launch_layernorm_bwd(x->p, y->g, nullptr, mod->p + scale_col, ld, rpb, dx, x->rows, C, eps, x->ginit ? 1 : 0, E.st,
+                                              x->p32));
       x->ginit = true;
       if (mod_grad) {
         const int B = (int)(x->rows / rpb);
@@ -265,10 +273,11 @@ static T* dit_gate_res(Exec& E, T* y, T* mod, int gate_col, T* res, int rpb, boo
   const int C = y->cols;
   T* o = R.mk(y->rows, C);
   DIT_NULL(!o);
+  if (res->p32) DIT_NULL(!R.mk32(o));   // the fp32 residual stream goes on
   const int64_t ld = mod->cols;
   if (!R.dry())
     DIT_NULL(E.f32() ? launch_gate_residual32(Exec::F(y->p), Exec::F(mod->p) + gate_col, ld, Exec::F(res->p), Exec::F(o->p), y->rows, C, rpb, E.st)
-                     : launch_gate_residual(y->p, mod->p + gate_col, ld, res->p, o->p, y->rows, C, rpb, E.st));
+                     : launch_gate_residual(y->p, mod->p + gate_col, ld, res->p, o->p, y->rows, C, rpb, E.st, res->p32, o->p32));
   if (R.save) {
     R.tape.push_back([y, o, mod, gate_col, res, rpb, mod_grad, ld, C](Exec& E) -> int {
       if (!o->g) return 0;
@@ -320,6 +329,11 @@ static T* dit_linear_gate_res(Exec& E, T* x, LinearW& L, T* mod, int gate_col, T
     a.rowvec_ld = mod->cols;
     a.rows_per_batch = rpb;
     a.rowvec_mul = 1;
+    if (res->p32) {   // the fp32 residual stream goes on
+      DIT_NULL(!E.R.mk32(y));
+      a.residual = nullptr; a.residual32 = res->p32; a.ldr32 = res->cols;
+      a.C32 = y->p32; a.ldc32 = L.w.N;
+    }
     DIT_NULL(E.gemm(a));
     return y;
   }
@@ -529,7 +543,7 @@ int run_dit(fdmi_unet* U, Run& R, const DitIn& in, int flags) {
   T* pe = R.mk((int64_t)B * Tn, D);
   FAIL_IF_NULL(pe1); FAIL_IF_NULL(pe);
   if (!R.dry()) RET_IF(E.l_copy2d(pe1->p, 0, 0, pe->p, (int64_t)Tn * D, 0, B, Tn * D, 0));   // every sample: the same [T][D] table
-  T* hid = dit_lin(E, pt, N.patch, pe);
+  T* hid = dit_lin(E, pt, N.patch, pe, true, dit_stream32(E));   // (the start of the fp32 residual stream: dit_stream32)
   FAIL_IF_NULL(hid);
 
   // ---- per-sample vectors: timestep (+ pooled / size conditioning) embedding ----
@@ -745,6 +759,7 @@ int run_dit_backward(fdmi_unet* U, Run& R, const float* grad_out, float* grad_x)
       T* t = oi->second;
       const size_t bytes = (size_t)t->rows * t->cols * E.es();
       if (t->own && t != R.x0) R.rfree(t->p, bytes);
+      if (t->p32) R.rfree(t->p32, (size_t)t->rows * t->cols * 4);
       if (t->g && !t->parent) R.rfree(t->g, bytes);
     }
   }

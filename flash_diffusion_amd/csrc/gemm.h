@@ -27,12 +27,24 @@ struct GemmArgs {
   int rowvec_mul = 0;             // 1: the row vector MULTIPLIES: v = (alpha*acc + bias[n]) * rowvec[m / rows_per_batch][n] + residual[m][n]
                                   // (the adaLN gate of the transformer denoisers; not with ACT_GEGLU)
   const bf16_t* residual = nullptr; int64_t ldr = 0;
+  // fp32 residual stream (round 5: the transformer denoisers' hidden state; the reference's bf16-mixed run keeps it in fp32 -- the
+  // fp32 position table / scale_shift_table promote it -- and rounding it to bf16 after each of the ~56 residual adds of a 28-block
+  // DiT cost 4x the reference's own bf16 deviation): residual32[m][n] (fp32) is ADDED like `residual`, and the fp32 value of the
+  // result is ALSO stored to C32[m][n] beside the bf16 store to C (the shadow the next GEMM's A operand reads).  ACT_NONE only,
+  // N, ldr32, ldc32 multiples of 8; run by the R32 instantiations of gemm3 / gemm4<192>, the small-tile kernel and the finalize
+  // kernel (gemm_r32_ok).
+  const float* residual32 = nullptr; int64_t ldr32 = 0;
+  float* C32 = nullptr; int64_t ldc32 = 0;
   int act = ACT_NONE;             // ACT_GEGLU: N pre-activation columns in 16-wide (value|gate)
                                   // interleave -> N/2 output columns
   bf16_t* preact = nullptr; int64_t ldp = 0;   // optional save of the pre-activation (GEGLU bwd)
   void* C = nullptr; int64_t ldc = 0; int out_f32 = 0;
   float alpha = 1.f;
   int splitk = 1; float* ws = nullptr;  // splitk>1: raw f32 partial sums accumulate into ws[M][N]
+  // set by launch_gemm (round 5): one zeroed counter per output tile -- the 256-row kernels then reduce the split-K slabs INSIDE the
+  // launch (the block that writes a tile's last slab sums all of them in slab order and runs the epilogue; gemm_tile.h::
+  // splitk_last_arriver) instead of leaving them to gemm_finalize_kernel
+  int* sk_tickets = nullptr;
   int accum_atomic = 0;           // C is f32 and receives atomicAdd(alpha*acc) (wgrad accumulation)
   int force_tile = 0;             // 0 auto; else (BM<<16 | BN)
   int use_glds = 1;               // LDS-DMA staging (1) or register staging (0)
@@ -72,5 +84,7 @@ bool gemm_a2_ok(const GemmArgs& a);
 // true when launch_gemm will run this problem on a kernel whose epilogue accumulates GemmArgs::gn_stats (a 256-row tile
 // without split-K, full tiles inside one sample, 8-column-aligned operands); a.gn_* and a.ws-availability as at launch
 bool gemm_gn_ok(const GemmArgs& a, bool ws_available);
+// true when this problem's epilogue can carry the fp32 residual stream (GemmArgs::residual32 / C32)
+bool gemm_r32_ok(const GemmArgs& a);
 // algorithmic flops of one launch (2*M*N*K)
 static inline double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }

@@ -56,6 +56,11 @@ __device__ __forceinline__ void epi_store(const GemmArgs& a, int act, int64_t m,
         if (nout + r < Nout) v[r] += bf2f(rs[r]);
     }
   }
+  if (a.residual32) {   // the fp32 residual stream (gemm.h): N, ldr32 % 8 == 0 (gemm_r32_ok), whole 4-column groups
+    const float4 t = *(const float4*)(a.residual32 + m * a.ldr32 + nout);
+    v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+  }
+  if (a.C32) *(float4*)(a.C32 + m * a.ldc32 + nout) = make_float4(v[0], v[1], v[2], v[3]);
   if (act == ACT_SILU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
@@ -549,6 +554,14 @@ bool gemm_a2_ok(const GemmArgs& a) {
   return gemm3_eligible(a);   // (whenever the 256 x 320 / 256 x 192 kernel is eligible, so is the 256-row ring kernel)
 }
 
+bool gemm_r32_ok(const GemmArgs& a) {
+  if (a.f32 || a.mode != GEMM_ROW || a.act != ACT_NONE || a.out_f32 || a.accum_atomic || a.preact || a.gn_stats) return false;
+  if ((a.N & 7) || (a.ldc & 7) || (a.residual && (a.ldr & 7)) || (a.rowvec && (a.rowvec_ld & 7))) return false;
+  if (a.residual32 && ((a.ldr32 & 7) || ((uintptr_t)a.residual32 & 15))) return false;
+  if (a.C32 && ((a.ldc32 & 7) || ((uintptr_t)a.C32 & 15))) return false;
+  return true;
+}
+
 bool gemm_gn_ok(const GemmArgs& a, bool ws_available) {
   if (a.f32) return false;
   if (!a.gn_stats || a.gn_cpg < 8 || a.gn_G < 1 || a.gn_G > 32 || a.N != a.gn_cpg * a.gn_G) return false;
@@ -569,6 +582,7 @@ size_t gemm_ws_bytes(const GemmArgs& a) {
 
 // developer aid: FDMI_GEMM_LOG=1 prints a histogram of the launched problems at exit
 #include <map>
+#include <mutex>
 #include <tuple>
 #include <cstdlib>
 namespace {
@@ -584,6 +598,32 @@ struct GemmLog {
     }
   }
 } g_gemm_log;
+}  // namespace
+
+// ---- in-launch split-K reduction: per-stream ticket regions ---------------------------------------------------------------------
+// One counter per output tile of a launch, zero between launches (the tile's reducer resets it).  Two launches that run at the same
+// time must not share counters: launches of ONE stream are serialised by the stream, so every stream gets its own region of a
+// static device array (first come, first served; a 17th stream falls back to the finalize kernel).  The library allocates nothing.
+namespace {
+constexpr int SK_STREAMS = 16, SK_TICKETS = 4096;
+__device__ int g_sk_tickets[SK_STREAMS * SK_TICKETS];
+std::mutex g_sk_mu;
+hipStream_t g_sk_stream[SK_STREAMS];
+int g_sk_nstreams = 0;
+int* g_sk_base = nullptr;
+int* sk_ticket_region(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_sk_mu);
+  if (!g_sk_base && hipGetSymbolAddress((void**)&g_sk_base, HIP_SYMBOL(g_sk_tickets)) != hipSuccess) {
+    (void)hipGetLastError();
+    g_sk_base = nullptr;
+    return nullptr;
+  }
+  for (int i = 0; i < g_sk_nstreams; ++i)
+    if (g_sk_stream[i] == st) return g_sk_base + i * SK_TICKETS;
+  if (g_sk_nstreams == SK_STREAMS) return nullptr;
+  g_sk_stream[g_sk_nstreams] = st;
+  return g_sk_base + (g_sk_nstreams++) * SK_TICKETS;
+}
 }  // namespace
 
 int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
@@ -605,6 +645,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.act == ACT_GEGLU) FDMI_CHECK((a.N % 32) == 0, "geglu: N must be a multiple of 32");
   if (a.rowvec_mul) FDMI_CHECK(a.rowvec != nullptr && a.act != ACT_GEGLU, "gemm: rowvec_mul needs a row vector and is not available with GEGLU");
   if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
+  if (a.residual32 || a.C32) FDMI_CHECK(gemm_r32_ok(a), "gemm: the fp32 residual stream (residual32 / C32) needs a plain row GEMM, ACT_NONE, bf16 C, 8-aligned N and leading dims");
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic);
   if (a.A2) FDMI_CHECK(p.big != 0, "gemm: a second A segment is read by the LDS-DMA kernels only (forced tile?)");
   if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
@@ -618,6 +659,21 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     FDMI_CHECK(a.ws != nullptr, "gemm: split-K needs a workspace of splitk*M*N floats");
   }
   if (a.gn_stats) FDMI_CHECK(gemm_gn_ok(a_in, a_in.ws != nullptr || a_in.accum_atomic), "gemm: gn_stats requested for a problem whose kernel cannot accumulate them (ask gemm_gn_ok first)");
+  // In-launch reduction of the split-K slabs by the 256-row kernels (gemm_tile.h::splitk_arrive): correct and deterministic, but
+  // MEASURED SLOWER on the C2 step than the finalize kernel it replaces -- the tile's last block re-reads the slabs alone while
+  // the finalize kernel spreads the same bytes over every CU: in-process A/B 178.4 ms (finalize kernel) vs 182.7 ms (in-launch up to
+  // 4 slabs) vs 184.0 ms (up to 8), profiles/r5_knob_ab_inlaunch_splitk.txt.  OFF by default; knob 48 = n reduces up to n slabs in the
+  // launch (the A/B switch the parity tests flip).
+  a.sk_tickets = nullptr;
+  {
+    const int sk_max = fdmi_tune_get(48) > 0 ? fdmi_tune_get(48) : 0;
+    const int tiles = p.big ? cdiv(a.M, 256) * cdiv(a.N, p.BN) : 0;
+    const int64_t items = (int64_t)tiles * a.splitk;     // (a block of the persistent kernels takes ceil(items / 256) of them)
+    if (p.big && a.splitk > 1 && a.splitk <= sk_max && !a.accum_atomic && a.act != ACT_GEGLU && !(a.dev & (16 | 32 | 0x800)) &&
+        !a.residual32 && !a.C32 &&
+        tiles <= SK_TICKETS && (items + 247) / 248 <= 12)
+      a.sk_tickets = sk_ticket_region(stream);
+  }
   if (g_gemm_log.on)
     ++g_gemm_log.n[std::make_tuple(a.mode, a.M, a.N, a.K, a.act, (a.residual ? 1 : 0) | (a.preact ? 2 : 0) | (a.accum_atomic ? 4 : 0) | (a.out_f32 ? 8 : 0) | (a.dgrad ? 16 : 0),
                                    p.big ? p.big * 1000 + p.BN : p.BM * 1000 + p.BN, a.splitk)];
@@ -631,7 +687,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   else
     rc = a.use_glds ? launch_tile<GEMM_CONV, true>(a, p.BM, p.BN, stream) : launch_tile<GEMM_CONV, false>(a, p.BM, p.BN, stream);
   if (rc) return rc;
-  if (a.splitk > 1 && !a.accum_atomic) {
+  if (a.splitk > 1 && !a.accum_atomic && !a.sk_tickets) {
     const int64_t total = (int64_t)a.M * ((a.N + 3) >> 2);
     int blocks = (int)((total + 255) / 256);
     if (blocks > 4096) blocks = 4096;

@@ -31,7 +31,9 @@ __device__ __forceinline__ void wait_vm() {
 }
 
 // GN: the epilogue also accumulates the consumer's GroupNorm statistics (GemmArgs::gn_stats); separate instantiations
-template <int BN, int MODE, bool GN = false>
+// SKR: in-launch split-K reduction (GemmArgs::sk_tickets, gemm_tile.h::splitk_last_arriver), its own instantiation (see gemm4.hip)
+// R32: the fp32-residual-stream epilogue (GemmArgs::residual32 / C32, gemm_tile.h::tile_epilogue_r32), its own instantiation
+template <int BN, int MODE, bool GN = false, bool SKR = false, bool R32 = false>
 __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256;
@@ -45,6 +47,9 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int g = lane >> 4, j = lane & 15;
+  if constexpr (SKR) {
+    if (tid == 0) ((volatile SkList*)(smem + 3 * (BM + BN) * 128))->n = 0;   // (ordered before its first use by the K loops' barriers)
+  }
 
   // ---- persistent work loop: item = (tile, k-split); block b takes items b, b+G, b+2G, ... ----
   const int tilesN = (a.N + BN - 1) / BN, tilesM = (a.M + BM - 1) / BM;
@@ -232,7 +237,10 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     __builtin_amdgcn_s_setprio(0);
   };
 
-  auto epilogue = [&](const Item& it) { tile_epilogue<NF, MF, 2, GN, false, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j); };
+  auto epilogue = [&](const Item& it) {
+    if constexpr (R32) tile_epilogue_r32<NF, MF>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+    else tile_epilogue<NF, MF, 2, GN, false, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+  };
 
   // ---- flattened 3-stage ring across items: counted vmcnt, one raw barrier per K tile ----
   int inflight = 0;
@@ -264,18 +272,34 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
       --inflight;
     }
     epilogue(it);
+    if constexpr (SKR)   // in-launch split-K reduction: this item's slab is stored -- hand off (gemm_tile.h)
+      splitk_arrive(a, (it.m0 / BM) * tilesN + it.n0 / BN, it.m0, it.n0, smem + 3 * STAGE);
     // make the waitcnt pass see an empty VM scoreboard at the back-edge: otherwise it protects the
     // epilogue's pending loads/stores with a vmcnt(0) inside every K iteration (draining the ring)
     __builtin_amdgcn_s_waitcnt(0);
   }
+  if constexpr (SKR) {   // the tiles whose last slab this block wrote: sum the slabs in slab order, run the real epilogue
+    __syncthreads();
+    const SkList* l = (const SkList*)(smem + 3 * STAGE);
+    const int nred = l->n;
+    if (nred > 0) {
+      if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+      for (int i = 0; i < nred; ++i) {
+        const int mw = l->m0[i] + wm * 64, nw = l->n0[i] + wn * (BN / 2);
+        splitk_sum_slabs<NF, MF, false>(a, mw, nw, acc, g, j);
+        tile_epilogue<NF, MF, 2, false, false, MODE == GEMM_ROW, true>(a, mw, nw, 0, acc, g, j);
+      }
+    }
+  }
 }
 
-template <int BN, int MODE, bool GN = false>
+template <int BN, int MODE, bool GN = false, bool SKR = false, bool R32 = false>
 int launch3_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
-  constexpr int smem = 3 * (256 + BN) * 128;
+  constexpr int smem = 3 * (256 + BN) * 128 + (SKR ? SK_LDS_BYTES : 0);   // (+ the split-K reducer's tile list behind the ring)
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm3_kernel<BN, MODE, GN>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm3_kernel<BN, MODE, GN, SKR, R32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int items = cdiv(a.M, 256) * cdiv(a.N, BN) * (a.splitk > 1 ? a.splitk : 1);
@@ -291,7 +315,7 @@ int launch3_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);   // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, PROF_GEMM3 + MODE * 2 + (BN == 160 ? 0 : 1), gemm_flops(a));
-  FDMI_KLAUNCH(prof, (gemm3_kernel<BN, MODE, GN>), grid, dim3(512), smem, stream, a);
+  FDMI_KLAUNCH(prof, (gemm3_kernel<BN, MODE, GN, SKR, R32>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -312,6 +336,15 @@ int gemm3_pick_bn(const GemmArgs& a) {
   return ((double)cdiv(a.N, 160) * 160 / a.N <= (double)cdiv(a.N, 128) * 128 / a.N) ? 160 : 128;
 }
 int launch_gemm3(const GemmArgs& a, int BN, hipStream_t stream) {
+  if (a.residual32 || a.C32) {   // the fp32 residual stream: its own instantiation (row GEMMs only: gemm_r32_ok)
+    FDMI_CHECK(a.mode == GEMM_ROW && !a.sk_tickets, "gemm3: the fp32 residual stream needs a row GEMM");
+    return BN == 160 ? launch3_t<160, GEMM_ROW, false, false, true>(a, stream) : launch3_t<128, GEMM_ROW, false, false, true>(a, stream);
+  }
+  if (a.sk_tickets) {   // in-launch split-K reduction: the SKR instantiations
+    FDMI_CHECK(a.splitk > 1 && !a.gn_stats, "gemm3: in-launch split-K reduction needs a split problem without GroupNorm sums");
+    if (a.mode == GEMM_ROW) return BN == 160 ? launch3_t<160, GEMM_ROW, false, true>(a, stream) : launch3_t<128, GEMM_ROW, false, true>(a, stream);
+    return BN == 160 ? launch3_t<160, GEMM_CONV, false, true>(a, stream) : launch3_t<128, GEMM_CONV, false, true>(a, stream);
+  }
   if (a.gn_stats) {
     if (a.mode == GEMM_ROW) return BN == 160 ? launch3_t<160, GEMM_ROW, true>(a, stream) : launch3_t<128, GEMM_ROW, true>(a, stream);
     return BN == 160 ? launch3_t<160, GEMM_CONV, true>(a, stream) : launch3_t<128, GEMM_CONV, true>(a, stream);

@@ -26,7 +26,10 @@ namespace {
 // WRONG results (16: A re-read from its first tile; 32: no epilogue) and experiments (0x800: conv K order (channel chunk, tap)
 // instead of (tap, channel chunk); bits 16-18 / 20-27: start the blocks in 2 ... 7 phase groups, group i delayed by i * n us).
 // The production instantiations (DEV = false) contain none of it.
-template <int MODE, bool GEGLU, int BN, bool GN = false, bool DEV = false>
+// SKR: in-launch split-K reduction (GemmArgs::sk_tickets, gemm_tile.h::splitk_last_arriver) -- its own instantiation: the second
+// epilogue's live ranges pushed a spill into the production conv kernel's K loop when it was compiled into it
+// R32: the fp32-residual-stream epilogue (GemmArgs::residual32 / C32, gemm_tile.h::tile_epilogue_r32) -- its own instantiation too
+template <int MODE, bool GEGLU, int BN, bool GN = false, bool DEV = false, bool SKR = false, bool R32 = false>
 __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int BM = 256;
@@ -45,6 +48,9 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       const int mine = (int)((blockIdx.x >> 3) % ph) * dl;
       for (int i = 0; i < mine; ++i) __builtin_amdgcn_s_sleep(32);   // ~2048 clocks ~ 1 us
     }
+  }
+  if constexpr (SKR) {
+    if (tid == 0) ((volatile SkList*)(smem + 2 * STAGE))->n = 0;   // (ordered before its first use by the K loops' barriers)
   }
   const bool ctap = DEV && MODE == GEMM_CONV && (a.dev & 0x800);   // K tile t = (channel chunk t / taps, tap t % taps)
   int tapi = 0;                 // (ctap) the tap of the tile to issue next
@@ -294,18 +300,36 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
       cslot ^= 1;
     }
     // the next item's first tile is landing meanwhile
-    if (!(DEV && (a.dev & 32)))   // (timing ablation of scripts/rowbench.py: the K loop alone)
+    if constexpr (R32)
+      tile_epilogue_r32<NF, MF>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+    else if (!(DEV && (a.dev & 32)))   // (timing ablation of scripts/rowbench.py: the K loop alone)
       tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN, true, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);   // (whole tiles only)
+    if constexpr (SKR)   // in-launch split-K reduction: this item's slab is stored -- hand off (gemm_tile.h)
+      splitk_arrive(a, (it.m0 / BM) * tilesN + it.n0 / BN, it.m0, it.n0, smem + 2 * STAGE);
   }
   wait_vmcnt<0>();  // no LDS-DMA may still be in flight when the workgroup's LDS is released
+  if constexpr (SKR) {   // the tiles whose last slab this block wrote: sum the slabs in slab order, run the real epilogue
+    __syncthreads();
+    const SkList* l = (const SkList*)(smem + 2 * STAGE);
+    const int nred = l->n;
+    if (nred > 0) {
+      if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      __syncthreads();
+      for (int i = 0; i < nred; ++i) {
+        const int mw = l->m0[i] + wm * 64, nw = l->n0[i] + wn * (BN / 2);
+        splitk_sum_slabs<NF, MF, true>(a, mw, nw, acc, g, j);
+        tile_epilogue<NF, MF, 0, false, true, MODE == GEMM_ROW, true>(a, mw, nw, 0, acc, g, j);
+      }
+    }
+  }
 }
 
-template <int MODE, bool GEGLU, int BN, bool GN = false, bool DEV = false>
+template <int MODE, bool GEGLU, int BN, bool GN = false, bool DEV = false, bool SKR = false, bool R32 = false>
 int launch4_t(const GemmArgs& a, hipStream_t stream) {
   static bool attr_set = false;
-  constexpr int smem = 2 * (256 + BN) * 128;
+  constexpr int smem = 2 * (256 + BN) * 128 + (SKR ? SK_LDS_BYTES : 0);   // (+ the split-K reducer's tile list behind the ring)
   if (!attr_set) {
-    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN, DEV>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
+    FDMI_HIP(hipFuncSetAttribute((const void*)gemm4_kernel<MODE, GEGLU, BN, GN, DEV, SKR, R32>, hipFuncAttributeMaxDynamicSharedMemorySize, smem));
     attr_set = true;
   }
   const int items = (a.M / 256) * (a.N / BN) * (a.splitk > 1 ? a.splitk : 1);
@@ -321,7 +345,7 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) fdmi_prof_begin(stream, (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a));
-  FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN, DEV>), grid, dim3(512), smem, stream, a);
+  FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN, DEV, SKR, R32>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
   return 0;
@@ -335,10 +359,22 @@ bool gemm4_eligible(const GemmArgs& a, int BN) {
   if (BN == 192 && a.act == ACT_GEGLU) return false;
   if (a.mode == GEMM_CONV && ((a.Cin & 63) != 0 || a.Hout > 2048 || a.Wout > 2048)) return false;
   if (a.act == ACT_GEGLU && (a.mode != GEMM_ROW || a.accum_atomic || fdmi_tune_get(9))) return false;
+  if ((a.residual32 || a.C32) && BN != 192) return false;   // (the fp32 residual stream: the transformer denoisers' 256 x 192 tile only)
   return true;
 }
 int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
   FDMI_CHECK((a.M & 255) == 0 && (a.N % BN) == 0 && (a.K & 63) == 0, "gemm4: whole 256 x BN x 64 tiles only (its epilogue has no bounds checks)");
+  if (a.residual32 || a.C32) {   // the fp32 residual stream: its own instantiation
+    FDMI_CHECK(BN == 192 && a.mode == GEMM_ROW && !a.sk_tickets, "gemm4: the fp32 residual stream runs on the 256 x 192 row kernel");
+    return launch4_t<GEMM_ROW, false, 192, false, false, false, true>(a, stream);
+  }
+  if (a.sk_tickets) {   // in-launch split-K reduction: the SKR instantiations (launch_gemm sets the tickets only for plain problems)
+    FDMI_CHECK(a.splitk > 1 && a.act != ACT_GEGLU && !a.gn_stats, "gemm4: in-launch split-K reduction needs a plain split problem");
+    if (BN == 192) return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 192, false, false, true>(a, stream)
+                                             : launch4_t<GEMM_CONV, false, 192, false, false, true>(a, stream);
+    return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 320, false, false, true>(a, stream)
+                              : launch4_t<GEMM_CONV, false, 320, false, false, true>(a, stream);
+  }
   if (BN == 192) {
     FDMI_CHECK(a.act != ACT_GEGLU, "gemm4: the 256 x 192 tile has no GEGLU epilogue");
     return a.mode == GEMM_ROW ? launch4_t<GEMM_ROW, false, 192>(a, stream) : launch4_t<GEMM_CONV, false, 192>(a, stream);

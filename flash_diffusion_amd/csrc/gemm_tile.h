@@ -211,8 +211,8 @@ __device__ __forceinline__ void wait_vmcnt() {
 // of a per-sample vector; the terms are added in the general epilogue's order, so the results are bit-identical), hoists every pointer product out of the loops (one 64-bit pointer per lane,
 // row-fragment steps by addition, column pairs as immediate offsets) and keeps the residual one column pair ahead: ~40
 // instructions per 16-byte store.  Whole tiles, 8-column-aligned operands, bf16 output, no activation (epi_fast_ok).
-__device__ __forceinline__ bool epi_fast_ok(const GemmArgs& a) {
-  return !a.accum_atomic && a.splitk <= 1 && a.act == ACT_NONE && !a.out_f32 && !a.preact && a.alpha == 1.f &&
+__device__ __forceinline__ bool epi_fast_ok(const GemmArgs& a) {   // (a reduced split-K tile takes the general epilogue)
+  return !a.accum_atomic && a.splitk <= 1 && !a.residual32 && !a.C32 && a.act == ACT_NONE && !a.out_f32 && !a.preact && a.alpha == 1.f &&
          (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
          (!a.rowvec || ((a.rowvec_ld & 7) == 0 && !a.rowvec_mul && (a.rows_per_batch & 63) == 0));
 }
@@ -500,13 +500,217 @@ __device__ __forceinline__ void tile_epilogue_fast_geglu(const GemmArgs& a, int 
   }
 }
 
+
+// ---- in-launch split-K reduction (round 5; cdna_hip_programming.md, "In-launch split-K reduction") --------------------------------
+// Every block of a tile's `splitk` items writes its fp32 slab (tile_epilogue's split path), then the workgroup hands off ONCE:
+// every wave waits for its slab stores, the workgroup meets, thread 0 releases at agent scope (L2 write-back: the slabs of a tile
+// may come from different XCDs) and draws a ticket; the block that draws splitk - 1 is the tile's reducer: thread 0 acquires at
+// agent scope, resets the ticket for the next launch and tells the workgroup through 4 bytes of LDS behind the ring.  The reducer
+// then sums the slabs in slab order -- its own included, read back from memory, so the result does not depend on which block
+// came last (bit-identical to gemm_finalize_kernel's sum) -- into its accumulators and runs the ordinary epilogue (FINAL).
+// Nobody ever WAITS for another block (no spinning: two such kernels on two streams cannot starve each other of CUs).
+// Order matters on ROCm 7.2: fence FIRST, then the ticket; the asm waits restate what the compiler may drop around the fence.
+// The acquire side runs once, before the block's reductions (after its last item): every slab it will read was released before
+// the ticket it drew last.
+// The reduction itself runs AFTER the kernel's persistent loop (SkList below): a reducer inlined into the loop lengthened live
+// ranges across the K loop -- a spill reload there drains the whole LDS-DMA ring once per K tile (scripts/kloop_spill_audit.py) --
+// and an out-of-line reducer made hipcc keep the accumulators in scratch.  In the loop only this hand-off happens: thread 0 appends
+// the tile to a short list in LDS (behind the ring) when its block drew the last ticket.
+struct SkList { int n; int pad[3]; int m0[12]; int n0[12]; };   // 112 bytes; launch_gemm bounds the items per block by 12
+constexpr int SK_LDS_BYTES = 128;
+__device__ __forceinline__ void splitk_arrive(const GemmArgs& a, int tile, int m0, int n0, char* lds) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int old = __hip_atomic_fetch_add(a.sk_tickets + tile, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == a.splitk - 1) {
+      __hip_atomic_store(a.sk_tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch on this stream
+      volatile SkList* l = (volatile SkList*)lds;
+      const int k = l->n;
+      l->m0[k] = m0;
+      l->n0[k] = n0;
+      l->n = k + 1;
+    }
+  }
+}
+// the reducer's sums: acc[nf][mf] := slab_0 + slab_1 + ... (this wave's fragment positions; rows mw + mf*16 + j, columns nw + nf*16 + g*4)
+template <int NF, int MF, bool FULL>
+__device__ __forceinline__ void splitk_sum_slabs(const GemmArgs& a, int mw, int nw, f32x4 (&acc)[NF][MF], int g, int j) {
+  const int64_t sstride = (int64_t)a.M * a.N;
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t m = mw + mf * 16 + j;
+      const int n = nw + nf * 16 + g * 4;
+      f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (FULL || (m < a.M && n < a.N)) {
+        const float* p = a.ws + m * a.N + n;
+        if (FULL || (n + 3 < a.N && (a.N & 3) == 0)) {
+          int s = 0;
+          for (; s + 2 <= a.splitk; s += 2) {   // two slabs in flight, summed in slab order
+            const float4 t0 = *(const float4*)(p + s * sstride), t1 = *(const float4*)(p + (s + 1) * sstride);
+            v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w;
+            v[0] += t1.x; v[1] += t1.y; v[2] += t1.z; v[3] += t1.w;
+          }
+          if (s < a.splitk) {
+            const float4 t0 = *(const float4*)(p + s * sstride);
+            v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w;
+          }
+        } else {
+          for (int s = 0; s < a.splitk; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (n + r < a.N) v[r] += p[s * sstride + r];
+        }
+      }
+      acc[nf][mf] = v;
+    }
+}
+
+// ---- epilogue of the fp32-residual-stream GEMMs (GemmArgs::residual32 / C32; the R32 instantiations of gemm3 / gemm4) --------------
+// v = (alpha acc + bias) (* | +) rowvec + residual (bf16) + residual32 (fp32); C32 <- v (fp32), C <- bf16(v).  8 columns per lane
+// after the fragment-pair swap (16-byte bf16 stores, 2 x 16-byte fp32 loads / stores), bounds-checked; split-K slabs as usual.
+template <int NF, int MF>
+__device__ __forceinline__ void tile_epilogue_r32(const GemmArgs& a, int mw, int nw, int z, f32x4 (&acc)[NF][MF], int g, int j) {
+  if (a.splitk > 1) {
+    float* slab = a.ws + (int64_t)z * a.M * a.N;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int mf = 0; mf < MF; ++mf) {
+        const int64_t m = mw + mf * 16 + j;
+        const int n = nw + nf * 16 + g * 4;
+        if (m < a.M && n < a.N) *(float4*)(slab + m * a.N + n) = make_float4(acc[nf][mf][0], acc[nf][mf][1], acc[nf][mf][2], acc[nf][mf][3]);
+      }
+    return;
+  }
+  // column pair outer, row fragment inner (bias / per-sample row vector of a column group fetched once); every operand access is a
+  // whole 16-byte (bf16) or 2 x 16-byte (fp32) vector -- gemm_r32_ok guarantees the alignments
+  const bool rvec = a.rowvec != nullptr, rmul = a.rowvec_mul != 0;
+  const bf16_t* const vrow = rvec ? a.rowvec + (int64_t)(mw / a.rows_per_batch) * a.rowvec_ld : nullptr;   // (a 64-row wave tile lies in one sample when rows_per_batch % 64 == 0; else per row below)
+  const bool vuni = rvec && (a.rows_per_batch & 63) == 0;
+  auto finish8 = [&](int64_t m, int n, float (&v)[8], const float (&b8)[8], const float (&r8)[8]) {
+#pragma unroll
+    for (int r = 0; r < 8; ++r) v[r] = fmaf(v[r], a.alpha, b8[r]);
+    if (rvec) {
+      float q8[8];
+      if (vuni) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) q8[r] = r8[r];
+      } else {
+        const u16x8 t = *(const u16x8*)(a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) q8[r] = bf2f(t[r]);
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] = rmul ? v[r] * q8[r] : v[r] + q8[r];
+    }
+    if (a.residual) {
+      const u16x8 t = *(const u16x8*)(a.residual + m * a.ldr + n);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) v[r] += bf2f(t[r]);
+    }
+    if (a.residual32) {
+      const float4 t0 = *(const float4*)(a.residual32 + m * a.ldr32 + n), t1 = *(const float4*)(a.residual32 + m * a.ldr32 + n + 4);
+      v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+    }
+    if (a.C32) {
+      float* c = a.C32 + m * a.ldc32 + n;
+      *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
+      *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    uint4 pk;
+    pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+    *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
+  };
+  auto finish = [&](int64_t m, int n, float* v, int nc) {   // the odd fragment: 4 consecutive columns n .. of row m
+    for (int r = 0; r < nc; ++r) v[r] *= a.alpha;
+    if (a.bias)
+      for (int r = 0; r < nc; ++r) v[r] += a.bias[n + r];
+    if (a.rowvec) {
+      const bf16_t* rv = a.rowvec + (m / a.rows_per_batch) * a.rowvec_ld + n;
+      for (int r = 0; r < nc; ++r) v[r] = a.rowvec_mul ? v[r] * bf2f(rv[r]) : v[r] + bf2f(rv[r]);
+    }
+    if (a.residual) {
+      const bf16_t* rs = a.residual + m * a.ldr + n;
+      for (int r = 0; r < nc; ++r) v[r] += bf2f(rs[r]);
+    }
+    if (a.residual32) {
+      const float* rs = a.residual32 + m * a.ldr32 + n;
+      for (int r = 0; r < nc; r += 4) {
+        const float4 t = *(const float4*)(rs + r);
+        v[r] += t.x; v[r + 1] += t.y; v[r + 2] += t.z; v[r + 3] += t.w;
+      }
+    }
+    if (a.C32) {
+      float* c = a.C32 + m * a.ldc32 + n;
+      for (int r = 0; r < nc; r += 4) *(float4*)(c + r) = make_float4(v[r], v[r + 1], v[r + 2], v[r + 3]);
+    }
+    bf16_t* c = (bf16_t*)a.C + m * a.ldc + n;
+    for (int r = 0; r < nc; r += 4) {
+      uint2 pk;
+      pk.x = pack2bf(v[r], v[r + 1]);
+      pk.y = pack2bf(v[r + 2], v[r + 3]);
+      *(uint2*)(c + r) = pk;
+    }
+  };
+#pragma unroll
+  for (int pr = 0; pr < NF / 2; ++pr) {
+    const int nf = 2 * pr;
+    const int n = nw + (nf + (g & 1)) * 16 + (g >> 1) * 8;
+    const bool nok = n < a.N;
+    float b8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, r8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.bias && nok) {
+      const float4 b0 = *(const float4*)(a.bias + n), b1 = *(const float4*)(a.bias + n + 4);
+      b8[0] = b0.x; b8[1] = b0.y; b8[2] = b0.z; b8[3] = b0.w; b8[4] = b1.x; b8[5] = b1.y; b8[6] = b1.z; b8[7] = b1.w;
+    }
+    if (vuni && nok) {
+      const u16x8 t = *(const u16x8*)(vrow + n);
+#pragma unroll
+      for (int r = 0; r < 8; ++r) r8[r] = bf2f(t[r]);
+    }
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t m = mw + mf * 16 + j;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) SWAP16(acc[nf][mf][r], acc[nf + 1][mf][r]);
+      if (m < a.M && nok) {
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          v[r] = acc[nf][mf][r];
+          v[4 + r] = acc[nf + 1][mf][r];
+        }
+        finish8(m, n, v, b8, r8);
+      }
+    }
+  }
+  if constexpr ((NF & 1) != 0) {
+#pragma unroll
+    for (int mf = 0; mf < MF; ++mf) {
+      const int64_t m = mw + mf * 16 + j;
+      const int n = nw + (NF - 1) * 16 + g * 4;
+      if (m < a.M && n < a.N) {
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = acc[NF - 1][mf][r];
+        finish(m, n, v, 4);
+      }
+    }
+  }
+}
+
 // epilogue of one wave: rows mw + mf*16 + j, columns nw + nf*16 + g*4 .. +3; z = split-K slab index
 // EPI selects the compiled paths: 0 = everything but GEGLU, 1 = GEGLU only, 2 = all
 // GN: also accumulate the consumer's GroupNorm statistics (full tiles, `wide` layout, no split-K: gemm_gn_ok)
 // FULL: the caller guarantees whole tiles (M % 256 == 0, N % BN == 0: gemm4's eligibility) -- no per-lane bounds checks
 // PF: fetch the residual one column pair ahead of its use (16 more live registers: the row-GEMM kernels have them in their
 // epilogue, the conv kernels -- whose gather state stays live across items -- do not, and their long K loops need it least)
-template <int NF, int MF, int EPI = 2, bool GN = false, bool FULL = false, bool PF = false>
+// FINAL: `acc` holds the sums over ALL split-K slabs (in-launch reduction): run the real epilogue although a.splitk > 1
+template <int NF, int MF, int EPI = 2, bool GN = false, bool FULL = false, bool PF = false, bool FINAL = false>
 __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw, int z, f32x4 (&acc)[NF][MF], int g, int j) {
   if (EPI != 1 && a.accum_atomic) {
 #pragma unroll
@@ -526,7 +730,7 @@ __device__ __forceinline__ void tile_epilogue(const GemmArgs& a, int mw, int nw,
   // wide (8 columns per lane) path needs 8-element alignment of every row pointer involved
   const bool wide = (a.N & 7) == 0 && (a.ldc & 7) == 0 && (!a.residual || (a.ldr & 7) == 0) &&
                     (!a.rowvec || (a.rowvec_ld & 7) == 0) && (!a.preact || (a.ldp & 7) == 0);
-  if (EPI != 1 && a.splitk > 1) {  // raw partial sums -> this split's fp32 slab (plain stores, deterministic)
+  if (EPI != 1 && a.splitk > 1 && !FINAL) {  // raw partial sums -> this split's fp32 slab (plain stores, deterministic)
     float* slab = a.ws + (int64_t)z * a.M * a.N;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)

@@ -285,6 +285,7 @@ struct LnArgs {
   const bf16_t* shift; const bf16_t* scale; int64_t mod_ld; int rows_per_batch;
   bf16_t* y; int64_t rows; int C; float eps; int accumulate;
   float* stats;  // fwd, optional: [rows][2] = (mean, rstd) for the adaLN parameter gradients (dit.hip batch_colsum)
+  const float* x32;  // optional: the fp32 master of x (the transformer denoisers' residual stream, round 5): read instead of x
 };
 
 // LPR lanes cooperate on one row (LPR = 8..64, a power of two chosen so each lane holds <= 5 chunks of
@@ -312,11 +313,18 @@ __global__ __launch_bounds__(256) void ln_kernel(LnArgs a) {
   for (int s = 0; s < MAXC; ++s) {
     const int ch = sub + LPR * s;
     if (ch < CPR) {
-      const u16x8 v = *(const u16x8*)(a.x + rrow * a.C + ch * 8);
+      if (a.x32) {   // (uniform)
+        const float4 v0 = *(const float4*)(a.x32 + rrow * a.C + ch * 8), v1 = *(const float4*)(a.x32 + rrow * a.C + ch * 8 + 4);
+        xv[s][0] = v0.x; xv[s][1] = v0.y; xv[s][2] = v0.z; xv[s][3] = v0.w; xv[s][4] = v1.x; xv[s][5] = v1.y; xv[s][6] = v1.z; xv[s][7] = v1.w;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        xv[s][e] = bf2f(v[e]);
-        sum += xv[s][e];
+        for (int e = 0; e < 8; ++e) sum += xv[s][e];
+      } else {
+        const u16x8 v = *(const u16x8*)(a.x + rrow * a.C + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xv[s][e] = bf2f(v[e]);
+          sum += xv[s][e];
+        }
       }
     }
   }
@@ -435,17 +443,19 @@ static int launch_ln(const LnArgs& a, hipStream_t st) {
 
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, const bf16_t* shift,
                          const bf16_t* scale, int64_t mod_ld, int rows_per_batch, bf16_t* y,
-                         int64_t rows, int C, float eps, hipStream_t st, float* stats) {
+                         int64_t rows, int C, float eps, hipStream_t st, float* stats, const float* x32) {
   FDMI_CHECK(C % 8 == 0 && C <= 2560, "layernorm: C must be a multiple of 8 and <= 2560");
   FDMI_CHECK(!scale || (shift && rows_per_batch > 0 && mod_ld % 8 == 0), "layernorm: adaLN modulate needs shift, scale, rows_per_batch");
-  LnArgs a{x, nullptr, gamma, beta, shift, scale, mod_ld, rows_per_batch, y, rows, C, eps, 0, stats};
+  FDMI_CHECK(((uintptr_t)x32 & 15) == 0, "layernorm: the fp32 input must be 16-byte aligned");
+  LnArgs a{x, nullptr, gamma, beta, shift, scale, mod_ld, rows_per_batch, y, rows, C, eps, 0, stats, x32};
   return launch_ln<false>(a, st);
 }
 
 int launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const bf16_t* scale,
                          int64_t mod_ld, int rows_per_batch, bf16_t* dx, int64_t rows, int C,
-                         float eps, int accumulate, hipStream_t st) {
+                         float eps, int accumulate, hipStream_t st, const float* x32) {
   FDMI_CHECK(C % 8 == 0 && C <= 2560, "layernorm: C must be a multiple of 8 and <= 2560");
-  LnArgs a{x, dy, gamma, nullptr, nullptr, scale, mod_ld, rows_per_batch, dx, rows, C, eps, accumulate, nullptr};
+  FDMI_CHECK(((uintptr_t)x32 & 15) == 0, "layernorm: the fp32 input must be 16-byte aligned");
+  LnArgs a{x, dy, gamma, nullptr, nullptr, scale, mod_ld, rows_per_batch, dx, rows, C, eps, accumulate, nullptr, x32};
   return launch_ln<true>(a, st);
 }

@@ -19,10 +19,10 @@ int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, 
                          const bf16_t* x2 = nullptr, int C1 = 0);
 int launch_layernorm_fwd(const bf16_t* x, const float* gamma, const float* beta, const bf16_t* shift,
                          const bf16_t* scale, int64_t mod_ld, int rows_per_batch, bf16_t* y,
-                         int64_t rows, int C, float eps, hipStream_t st, float* stats = nullptr);
+                         int64_t rows, int C, float eps, hipStream_t st, float* stats = nullptr, const float* x32 = nullptr);
 int launch_layernorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, const bf16_t* scale,
                          int64_t mod_ld, int rows_per_batch, bf16_t* dx, int64_t rows, int C,
-                         float eps, int accumulate, hipStream_t st);
+                         float eps, int accumulate, hipStream_t st, const float* x32 = nullptr);   // x32: the fp32 master of x, read instead of it
 
 // ---- attn.hip ----
 __host__ __device__ static inline int attn_spad(int S) { return (S + 63) & ~63; }      // padded sequence length
@@ -93,7 +93,7 @@ int launch_adamw(float* p, const float* g, float* m, float* v, int64_t n, float 
 // ---- dit.hip: adaLN-single DiT element-wise kernels ----
 // y = res + gate[m / rows_per_batch] * x  (res may be null)
 int launch_gate_residual(const bf16_t* x, const bf16_t* gate, int64_t gate_ld, const bf16_t* res, bf16_t* y,
-                         int64_t rows, int C, int rows_per_batch, hipStream_t st);
+                         int64_t rows, int C, int rows_per_batch, hipStream_t st, const float* res32 = nullptr, float* y32 = nullptr);
 int launch_gelu_tanh(const bf16_t* x, bf16_t* y, int64_t n, hipStream_t st);
 int launch_gelu_tanh_bwd(const bf16_t* x, const bf16_t* dy, bf16_t* dx, int64_t n, hipStream_t st);
 // out1[b][c] = sum_r dy ; out0[b][c] = sum_r dy * f(x)  (f = LayerNorm normalisation from stats[rows][2], identity if null)

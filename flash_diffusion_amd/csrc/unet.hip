@@ -61,6 +61,9 @@ struct T {  // NHWC / token-major bf16 activation [rows][cols] (+ lazily allocat
   // readers of the up path's [h | skip]) accept such a tensor; its gradient buffer g is an ordinary [rows][cols] one.
   bf16_t* p2 = nullptr;
   int c1 = 0;
+  // fp32 master copy of the values (bf16 plans, round 5): the transformer denoisers' residual stream.  `p` stays the bf16 shadow
+  // every GEMM operand / backward kernel reads; LayerNorm and the residual adds read and write p32 (Run::mk32, Exec::linear_w)
+  float* p32 = nullptr;
 };
 
 struct Weight {
@@ -267,6 +270,10 @@ struct Run {
     t->p = (bf16_t*)arena.alloc(rnd((size_t)rows * cols * es));
     t->own = true;
     return t->p ? t : nullptr;
+  }
+  float* mk32(T* t) {   // the fp32 master of a bf16 tensor (T::p32)
+    t->p32 = (float*)arena.alloc(rnd((size_t)t->rows * t->cols * 4));
+    return t->p32;
   }
   // tensor header over caller-provided storage (no arena allocation)
   T* wrap(bf16_t* p, int64_t rows, int cols) {
@@ -951,9 +958,13 @@ struct Exec {
   // y = x W^T + b (+ residual) (+ LoRA)
   T* linear(T* x, LinearW& L, T* residual = nullptr) { return linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr); }
   // gn_rows > 0: the output feeds a GroupNorm over samples of gn_rows rows (want_gn)
-  T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true, int gn_rows = 0) {
+  // out32 / a residual that carries an fp32 master (T::p32): the output gets one too -- v = ... + residual32 in fp32, stored to
+  // y->p32 beside the bf16 y->p (GemmArgs::residual32 / C32: the transformer denoisers' residual stream)
+  T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true, int gn_rows = 0, bool out32 = false) {
     T* y = R.mk(x->rows, w.N, x->B, x->H, x->W);
     if (!y) return nullptr;
+    const bool r32 = !f32() && (out32 || (residual && residual->p32));
+    if (r32 && !R.mk32(y)) return nullptr;
     // LoRA up-projection folded into the base GEMM: y = [x | t] [W | B]^T (+ bias, residual) -- needs the folded operands
     // (lora_foldable, built by build_lora_folded) and a problem the two-segment loaders take (M >= 256)
     const bool fold = lo && lora_foldable(U, *lo) && (R.dry() || lo->Wc != nullptr) && x->rows >= 256 && !x->p2;
@@ -977,12 +988,18 @@ struct Exec {
         a.A2 = t->p; a.lda2 = rp; a.K1 = w.K;
       }
       if (gn_rows > 0 && !lo) want_gn(a, gn_rows);   // (a LoRA delta is added to y afterwards: the sums would be stale)
+      if (r32) {
+        a.C32 = y->p32; a.ldc32 = w.N;
+        if (residual && residual->p32) { a.residual = nullptr; a.residual32 = residual->p32; a.ldr32 = residual->cols; }
+      }
       NULL_IF(gemm(a));
       y->gn = a.gn_stats;
     }
     if (lo && !fold) {
       const bf16_t* LB = f32() ? (const bf16_t*)lo->B_master : lo->B;
-      NULL_IF(gemm_rows(t->p, rp, x->rows, LB, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N));
+      GemmArgs a2 = rows_args(t->p, rp, x->rows, LB, lo->out, lo->r, nullptr, y->p, w.N, y->p, w.N);
+      if (r32) { a2.residual = nullptr; a2.residual32 = y->p32; a2.ldr32 = w.N; a2.C32 = y->p32; a2.ldc32 = w.N; }
+      NULL_IF(gemm(a2));
     }
     if (R.save) {
       R.tape.push_back([x, y, residual, lo, t, need_dx, fold, &w, rp](Exec& E) -> int {

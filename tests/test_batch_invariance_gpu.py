@@ -8,9 +8,10 @@ the LoRA gradient (the mean over identical copies).  HIP path against HIP path, 
 l2 + DMD + lsgan with the example's own PatchGAN head (the step the C3 / C4 / C5 bench lines time), the same random draws tiled.
 This needs no B = 8 oracle and catches tile / split-K / masking choices that only trigger at the bench shape.
 
-SDXL runs l2 + DMD without the GAN term: at B = 8 and 128x128 the student's tape (113 GiB), the teacher's workspace and the GAN
-term's taped pass of 16 samples through the frozen backbone do not fit 288 GB together -- `bench.py --arch sdxl` (C3) times the
-l2 generator iteration; PixArt (C4) and SD3 (C5: the bench's own DMD + GAN step) run all three terms.
+SDXL runs the l2 generator iteration `bench.py --arch sdxl` (C3) times, without the DMD and GAN terms: at B = 8 and 128x128 the
+student's tape (113 GiB), the teacher loop's workspace (68 GiB) and a second teacher run slot for the DMD term (67 GiB) or the GAN
+term's taped pass of 16 samples through the frozen backbone do not fit 288 GB together.  PixArt (C4) and SD3 (C5: the bench's own
+DMD + GAN step) run all three terms.
 
 Tolerance: a different tiling changes the fp32 summation order only, which flips bf16 roundings that then propagate through 4 x 2
 teacher evaluations -- measured on the first run (profiles/r5_parity_batch_invariance.txt): teacher output 9.4 - 9.6e-3, student
@@ -53,7 +54,7 @@ def _run(name, B, draws):
     from flash_diffusion_amd.flash import Draws
     from oracle.golden_cases import fullstep_inputs
     from tests.test_step4_parity_gpu import _build
-    kind, model = _build(name, "bf16", head=(name != "step4_sdxl"))
+    kind, model = _build(name, "bf16", head=(name != "step4_sdxl"), dmd=(name != "step4_sdxl"))
     B2 = 2
     k = B // B2
     batch, cond = fullstep_inputs(name, "cuda", B=B2, hw=128)

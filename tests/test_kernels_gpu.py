@@ -763,3 +763,81 @@ def test_lean_and_line_wide_epilogues_store_what_the_general_one_stores(case):
     if has_gn:
         for knob in (256, 0):
             close(f"epi_gn_sums{case}[{knob}]", sums[knob], sums[64], tol_el=1e-5, tol_fro=1e-5)
+
+
+# ---- in-launch split-K reduction (round 5; gemm_tile.h::splitk_arrive, launch_gemm's knob 48) -----------------------------------------
+def _lib():
+    from flash_diffusion_amd._lib import lib
+    return lib()
+
+
+@pytest.mark.parametrize("tile", [(256 << 16) | 320, (256 << 16) | 160, (256 << 16) | 128, (256 << 16) | 192])
+@pytest.mark.parametrize("sk", [2, 3, 4])
+def test_inlaunch_splitk_reduction_equals_the_finalize_kernel(tile, sk):
+    """developer switch 48 = n: the 256-row kernels reduce up to n split-K slabs inside the launch (the block that stores a tile's last
+    slab sums them in slab order and runs the epilogue) -- OFF by default, the finalize kernel measured faster on the step
+    (profiles/r5_knob_ab_inlaunch_splitk.txt).  The switched path equals the reference with every epilogue term, is bit-identical
+    from run to run (the sum does not depend on which block came last) and stays within one bf16 ulp of the finalize-kernel path
+    (same slab sums, the finalize kernel spells its epilogue arithmetic differently)"""
+    ops, L = _ops(), _lib()
+    BN = tile & 0xffff
+    M, N, K, rpb = 1024, 3 * BN, 2560, 256
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, rowvec, res = rnd(N, seed=3), b16(rnd(M // rpb, N, seed=4)), b16(rnd(M, N, seed=5))
+    ref = 0.5 * (A.float() @ W.float().t()) + bias + rowvec.float().repeat_interleave(rpb, 0) + res.float()
+    kw = dict(bias=bias.cuda(), rowvec=rowvec.cuda(), rows_per_batch=rpb, residual=res.cuda(), alpha=0.5, splitk=sk, force_tile=tile)
+    Ad, Wd = A.cuda(), W.cuda()
+    try:
+        L.fdmi_tune_set(48, 0)
+        fin = ops.gemm(Ad, Wd, **kw)
+        L.fdmi_tune_set(48, 4)
+        out = ops.gemm(Ad, Wd, **kw)
+        close(f"inlaunch_sk{sk}_{tile:x}", out, ref)
+        for _ in range(5):
+            assert torch.equal(out, ops.gemm(Ad, Wd, **kw))
+        d = (out.float() - fin.float()).abs()
+        assert float((d > 2 ** -7 * fin.float().abs().clamp_min(1e-3)).float().mean()) == 0.0 and float((d > 0).float().mean()) < 0.02
+        out = ops.gemm(Ad, Wd, act=ops.ACT_SILU, **kw)
+        close(f"inlaunch_sk{sk}_silu_{tile:x}", out, F.silu(ref))
+    finally:
+        L.fdmi_tune_set(48, 0)
+
+
+def test_inlaunch_splitk_reduction_conv_and_two_streams():
+    """a 3x3 convolution with split-K 2 (the 16x16 level of the C2 teacher: M = 8192, N = 1280, K = 11520 at sk = 2) through the
+    in-launch reduction, and two streams launching such GEMMs at the same time -- every stream has its own ticket region"""
+    ops, L = _ops(), _lib()
+    L.fdmi_tune_set(48, 4)
+    try:
+        _inlaunch_conv_two_streams(ops)
+    finally:
+        L.fdmi_tune_set(48, 0)
+
+
+def _inlaunch_conv_two_streams(ops):
+    B, hw, ci, co = 8, 16, 640, 640
+    x = b16(rnd(B, hw, hw, ci, seed=1))
+    w = b16(rnd(co, 9 * ci, seed=2, scale=(9 * ci) ** -0.5))
+    bias = rnd(co, seed=3)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().view(co, 3, 3, ci).permute(0, 3, 1, 2), bias, padding=1).permute(0, 2, 3, 1).reshape(-1, co)
+    conv = dict(Hin=hw, Win=hw, Cin=ci, Hout=hw, Wout=hw, KH=3, KW=3, stride=1, pad=1)
+    M = B * hw * hw
+    xd, wd, bd = x.cuda(), w.cuda(), bias.cuda()
+    for tile in ((256 << 16) | 320, (256 << 16) | 160):
+        out = ops.gemm(xd, wd, M=M, bias=bd, conv=conv, splitk=2, force_tile=tile)
+        close(f"inlaunch_conv_{tile:x}", out, ref)
+    A, W = b16(rnd(2048, 1280, seed=7)).cuda(), b16(rnd(640, 1280, seed=8, scale=1280 ** -0.5)).cuda()
+    want = ops.gemm(A, W, splitk=4, force_tile=(256 << 16) | 320)
+    want_c = ops.gemm(xd, wd, M=M, bias=bd, conv=conv, splitk=2, force_tile=(256 << 16) | 320)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    outs = []
+    for it in range(20):
+        with torch.cuda.stream(s1):
+            o1 = ops.gemm(A, W, splitk=4, force_tile=(256 << 16) | 320)
+        with torch.cuda.stream(s2):
+            o2 = ops.gemm(xd, wd, M=M, bias=bd, conv=conv, splitk=2, force_tile=(256 << 16) | 320)
+        outs.append((o1, o2))
+    torch.cuda.synchronize()
+    for o1, o2 in outs:
+        assert torch.equal(o1, want) and torch.equal(o2, want_c)

@@ -33,7 +33,7 @@ def test_full_width_four_teacher_steps_B2_matches_reference_golden(name, precisi
     run_isolated(__name__, "_body", (name, precision), timeout=1500)
 
 
-def _build(name, precision, head=True):
+def _build(name, precision, head=True, dmd=True):
     from flash_diffusion_amd import workloads
     from flash_diffusion_amd.dit import MiSD3Transformer2DModel, MiTransformer2DModel
     from flash_diffusion_amd.flash import FlashDiffusion, FlashDiffusionConfig
@@ -42,6 +42,8 @@ def _build(name, precision, head=True):
     from flash_diffusion_amd.unet import MiUNet2DConditionModel
     from oracle.golden_cases import FULLSTEP_CASES_ALL, FULLSTEP_LORA_RANK, build_fullstep_models
     kind, kw, _ = FULLSTEP_CASES_ALL[name]
+    if not dmd:           # (tests/test_batch_invariance_gpu.py, SDXL at B = 8: the l2 generator iteration `bench.py --arch sdxl` times)
+        kw = dict(kw, use_dmd_loss=False)
     cls, arch = {"sdxl": (MiUNet2DConditionModel, workloads.SDXL), "pixart": (MiTransformer2DModel, workloads.PIXART),
                  "sd3": (MiSD3Transformer2DModel, workloads.SD3)}[name.split("_")[1]]
 
