@@ -161,6 +161,17 @@ def parity_record():
         if m:
             rec["fp32_gate" if m.group(1) == "fp32" else "bf16"] = {"loss_rel": float(m.group(4)), "teacher_output_rel": float(m.group(2)),
                                                                   "student_output_rel": float(m.group(3))}
+    # the yardstick for the bf16 record: the REFERENCE's own precision mode on the same fixture -- the pinned
+    # oracle under torch.autocast(bfloat16) (= precision="bf16-mixed", examples/train_flash_sd.py:405) against its fp32 run,
+    # tests/golden/c2_sd15_r128_n4_b16_bf16ref.npz (oracle/make_golden.py::make_bf16_anchor); the GPU tests hold the HIP path to 1.5 x it
+    try:
+        import numpy as np
+        a = np.load(os.path.join(ROOT, "tests", "golden", "c2_sd15_r128_n4_b16_bf16ref.npz"))
+        rec["reference_bf16_mixed"] = {"loss_rel": float(a["loss_rel"]), "teacher_output_rel": float(a["teacher_output_rel"]),
+                                       "student_output_rel": float(a["student_output_rel"]),
+                                       "is": "the reference's own bf16-mixed run (CPU autocast of the pinned oracle) vs the same fp32 fixture"}
+    except (OSError, KeyError, ValueError):
+        pass
     return rec if ("bf16" in rec or "fp32_gate" in rec) else None
 
 

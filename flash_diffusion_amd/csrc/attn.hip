@@ -920,11 +920,9 @@ template <int KS, int DB>
 struct Attn32Lds {
   static constexpr int KA = 64 * 128, VT = DB * 32 * 128, KB = KS > 4 ? 64 * 32 : 0, STAGE = KA + VT + KB;
 };
-// PRIO (round-5 experiment, developer knob 47; only the d = 40 instantiation is built with it): 1 = raise the wave's issue priority
-// (s_setprio 3) while it issues the MFMAs of K Q^T / V^T P and drop it for the exponentials -- with three waves of three different
-// workgroups on a SIMD, the wave that has matrix work then wins the issue port and the others' exp / cvt fill the MFMA shadows; 2 =
-// the same with scheduling barriers that pin the priority switches to the MFMA groups
-template <int KS, int DB, bool ONES, bool MT, int PRIO = 0>
+// (round 5: raising the wave's issue priority with s_setprio around the MFMA groups, with and without scheduling barriers, changed
+// nothing: 912 vs 910 vs 918 us at B = 32, d = 40 -- profiles/r5_attn_setprio.txt; the variants were removed)
+template <int KS, int DB, bool ONES, bool MT>
 __global__ __launch_bounds__(256, (MT && ONES && KS < 5) ? 3 : 2) void attn_fwd32_kernel(const AttnArgs a) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   using L = Attn32Lds<KS, DB>;
@@ -1180,29 +1178,16 @@ __global__ __launch_bounds__(256, (MT && ONES && KS < 5) ? 3 : 2) void attn_fwd3
     union { uint4 u; bf16x8 v; } p0, p1;
     p0.u = pb0;
     p1.u = pb1;
-    if (PRIO) {
-      if (PRIO == 2) __builtin_amdgcn_sched_barrier(0);
-      __builtin_amdgcn_s_setprio(3);
-    }
 #pragma unroll
     for (int db = 0; db < DB; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB]), p0.v, o[db]);
 #pragma unroll
     for (int db = 0; db < DB; ++db) o[db] = MFMA32(*(const bf16x8*)(base + db * 4096 + vofs[2 * KB + 1]), p1.v, o[db]);
-    if (PRIO) {
-      __builtin_amdgcn_s_setprio(0);
-      if (PRIO == 2) __builtin_amdgcn_sched_barrier(0);
-    }
   };
   auto fast = [&](auto slot_tag, int t) __attribute__((always_inline)) {
     constexpr int SLOT = decltype(slot_tag)::value;
     const char* base = smem + SLOT * STAGEB;
-    if (PRIO) __builtin_amdgcn_s_setprio(3);
     f32x16 s0 = qk_block(base, 0);
     f32x16 s1 = qk_block(base, 1);
-    if (PRIO) {
-      __builtin_amdgcn_s_setprio(0);
-      if (PRIO == 2) __builtin_amdgcn_sched_barrier(0);
-    }
     half(base, std::integral_constant<int, 0>{}, s0, s1);
     half(base, std::integral_constant<int, 1>{}, s1, s1);
   };
@@ -1748,8 +1733,6 @@ static int launch_attn_fwd32(const AttnArgs& a, hipStream_t st) {
   if (set_smem(attn_fwd32_kernel<KS_, DB_, ON_, MT_>, 2 * Attn32Lds<KS_, DB_>::STAGE)) return -2;
     ATTN32_ALL(ATTN32_SET)
 #undef ATTN32_SET
-    if (set_smem(attn_fwd32_kernel<3, 2, true, true, 1>, 2 * Attn32Lds<3, 2>::STAGE)) return -2;
-    if (set_smem(attn_fwd32_kernel<3, 2, true, true, 2>, 2 * Attn32Lds<3, 2>::STAGE)) return -2;
     once32 = true;
   }
   const bool prof = fdmi_prof_on();
@@ -1758,11 +1741,8 @@ static int launch_attn_fwd32(const AttnArgs& a, hipStream_t st) {
   const bool ones32 = a.vt_ones && a.d < attn_dvpad(a.d);   // (the transposer's spare padded row dd = d)
   const int ks32 = a.d <= 48 ? 3 : (a.d < 64 ? 4 : 5), db32 = a.d < 64 ? 2 : 3;
   const bool mt32 = a.d < 16 * ks32;                         // spare k slot for the running maximum
-  const int prio = (ks32 == 3 && db32 == 2 && ones32 && mt32) ? fdmi_tune_get(47) : 0;   // (experiment: the d = 40 instantiation only)
-  if (prio == 1) FDMI_KLAUNCH(prof, (attn_fwd32_kernel<3, 2, true, true, 1>), g32, dim3(256), (2 * Attn32Lds<3, 2>::STAGE), st, a);
-  if (prio == 2) FDMI_KLAUNCH(prof, (attn_fwd32_kernel<3, 2, true, true, 2>), g32, dim3(256), (2 * Attn32Lds<3, 2>::STAGE), st, a);
 #define ATTN32_GO(KS_, DB_, ON_, MT_)                                                                                             \
-  if (!prio && ks32 == KS_ && db32 == DB_ && ones32 == ON_ && mt32 == MT_)                                                                 \
+  if (ks32 == KS_ && db32 == DB_ && ones32 == ON_ && mt32 == MT_)                                                                 \
     FDMI_KLAUNCH(prof, (attn_fwd32_kernel<KS_, DB_, ON_, MT_>), g32, dim3(256), (2 * Attn32Lds<KS_, DB_>::STAGE), st, a);
   ATTN32_ALL(ATTN32_GO)
 #undef ATTN32_GO

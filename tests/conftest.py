@@ -3,6 +3,17 @@ import os
 import sys
 import time
 
+# ---- host threads per test process.  The GPU tests compute CPU oracles with torch / OpenMP; several xdist workers (and the isolated
+# interpreters they spawn) that each start one OpenMP thread per logical core thrash the host: round 5's first 6-worker run took
+# LONGER than one process (1500 s against 881 s: tests of 5 s took 100 s).  Every test process therefore gets cores / workers threads
+# (at most 32: the CPU oracle is fastest at 16 - 32 threads on the pool's 128-core host, profiles/r2_cpu_thread_sweep.txt), set through
+# the environment BEFORE torch is imported so that the spawned interpreters inherit it.
+_WORKERS = int(os.environ.get("PYTEST_XDIST_WORKER_COUNT", "0") or 0)
+_THREADS = max(1, min(32, (os.cpu_count() or 8) // max(1, 2 * max(1, _WORKERS)) if (os.cpu_count() or 8) > 16
+                      else (os.cpu_count() or 8) // max(1, _WORKERS)))
+for _k in ("OMP_NUM_THREADS", "MKL_NUM_THREADS"):
+    os.environ.setdefault(_k, str(_THREADS))
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -13,6 +24,7 @@ if ROOT not in sys.path:
 def _has_gpu():
     try:
         import torch
+        torch.set_num_threads(int(os.environ.get("OMP_NUM_THREADS", _THREADS)))
         return torch.cuda.is_available()
     except Exception:
         return False
@@ -37,7 +49,7 @@ def pytest_xdist_auto_num_workers(config):
     if os.environ.get("FDMI_TEST_WORKERS"):
         return int(os.environ["FDMI_TEST_WORKERS"])
     if _has_gpu():
-        return max(1, min(6, (os.cpu_count() or 2) // 8))
+        return max(1, min(4, (os.cpu_count() or 2) // 16))
     return max(1, min(3, (os.cpu_count() or 2) // 3))
 
 

@@ -215,7 +215,7 @@ def _have(name):
     return os.path.exists(os.path.join(GOLDEN_DIR, name + ".npz"))
 
 
-@pytest.mark.gpu_mem(200)           # (the fp32 validation mode of the SDXL step: twice the bf16 tape, beside 2 x 10 GB of fp32 weights)
+@pytest.mark.gpu_mem(130)           # (the fp32 validation mode of the SDXL step: twice the bf16 tape, beside 2 x 10 GB of fp32 weights)
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 @pytest.mark.parametrize("name", ["step_sdxl", "step_pixart", "step_sd3"])
 def test_full_width_step_matches_reference_golden(name, precision):
