@@ -24,7 +24,8 @@ namespace {
 // default kernels are instruction-identical with and without the feature
 // DEV: developer instantiation (scripts/rowbench.py, scripts/kbench.py through knob 40 = GemmArgs::dev) -- timing ablations with
 // WRONG results (16: A re-read from its first tile; 32: no epilogue) and experiments (0x800: conv K order (channel chunk, tap)
-// instead of (tap, channel chunk); bits 16-18 / 20-27: start the blocks in 2 ... 7 phase groups, group i delayed by i * n us).
+// instead of (tap, channel chunk); bits 16-18 / 20-27: start the blocks in 2 ... 7 phase groups, group i delayed by i * n us: the
+// K = 320 GEGLU launch gains 13 % in isolation, 0.1 - 0.4 ms on the C2 step -- profiles/r5_knob_ab_geglu_stagger.txt -- not adopted).
 // The production instantiations (DEV = false) contain none of it.
 // SKR: in-launch split-K reduction (GemmArgs::sk_tickets, gemm_tile.h::splitk_last_arriver) -- its own instantiation: the second
 // epilogue's live ranges pushed a spill into the production conv kernel's K loop when it was compiled into it
