@@ -367,7 +367,7 @@ static T* dit_cross_attention(Exec& E, T* q, T* k, T* v, int B, int H, int Sq, i
     T* kb = R.rowview(k, (int64_t)b * L, n);
     T* vb = R.rowview(v, (int64_t)b * L, n);
     T* ob = R.rowview(o, (int64_t)b * Sq, Sq);
-    DIT_NULL(!E.attention(qb, kb, vb, 1, H, Sq, n, nullptr, false, ob));
+    DIT_NULL(!E.attention(qb, kb, vb, 1, H, Sq, n, nullptr, false, ob, L));
   }
   if (R.save) {   // (pushed last = replayed first: the masked keys' gradient rows are zero, the per-sample launches fill the rest)
     R.tape.push_back([o, k, v](Exec& E) -> int {

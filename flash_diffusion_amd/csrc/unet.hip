@@ -1285,11 +1285,15 @@ struct Exec {
   }
   // vt_ext: caller-owned V^T buffer; vt_ready: it already holds the transposed V (cached context); o_ext: write the output into
   // this tensor (a row view of a larger one: per-sample launches of a masked cross-attention) instead of allocating it
-  T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, bf16_t* vt_ext = nullptr, bool vt_ready = false, T* o_ext = nullptr) {
+  // skv_cap: size the key-side scratch (V^T, K^T) for this many keys instead of Skv -- the per-sample launches of a masked
+  // cross-attention pass the unmasked length, so that a real run allocates exactly what the workspace query (which walks the plan
+  // with every key valid) allocated and the backward's size-keyed free list sees the same sequence of sizes
+  T* attention(T* q, T* k, T* v, int Bn, int H, int Sq, int Skv, bf16_t* vt_ext = nullptr, bool vt_ready = false, T* o_ext = nullptr,
+               int skv_cap = 0) {
     const int d = q->cols / H;
     if (f32()) return attention32(q, k, v, Bn, H, Sq, Skv, d, o_ext);
     T* o = o_ext ? o_ext : R.mk(q->rows, q->cols, q->B, q->H, q->W);
-    const int64_t tr_kv = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Skv);
+    const int64_t tr_kv = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(skv_cap > Skv ? skv_cap : Skv);
     const int64_t tr_q = (int64_t)Bn * H * attn_dvpad(d) * attn_spad(Sq);
     bf16_t* VT = vt_ext ? vt_ext : (bf16_t*)R.arena.alloc((size_t)tr_kv * 2);
     float* lse = R.save ? (float*)R.arena.alloc((size_t)Bn * H * Sq * 4) : nullptr;
