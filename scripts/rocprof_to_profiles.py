@@ -68,7 +68,8 @@ def bucket(name):
     if m:
         return f"gemm_kernel<{m.group(1)},{m.group(2)},{'conv' if m.group(3) == '1' else 'row'}>"
     for k, b in (("attn_fwd32_kernel", "attn_fwd_kernel"), ("attn_bwd_dq32_kernel", "attn_bwd_dq_kernel"),
-                 ("attn_bwd_dkv32_kernel", "attn_bwd_dkv_kernel")):      # the 32x32x16 family shares the bench's attention buckets
+                 ("attn_bwd_dkv32_kernel", "attn_bwd_dkv_kernel"),       # the 32x32x16 family shares the bench's attention buckets
+                 ("wgrad_tn2_kernel", "wgrad_tn_kernel")):               # round 5's streaming kernel: the same bench bucket
         if k in name:
             return b
     for k in ("attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel", "wgrad_tn_kernel"):
