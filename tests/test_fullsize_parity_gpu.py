@@ -116,7 +116,9 @@ def _check_projected_grads(tag, m, blob, g, fp32):
     if fp32:
         assert worst_n <= 1e-2 and worst_p <= 1e-2 and all(r <= 1e-2 for r, _ in full.values()), (worst_n, worst_p, full)
     else:
-        assert worst_n_big <= 0.04 and worst_p_big <= 0.12 and all(c > 0.999 for _, c in full.values()), \
+        # (worst-of-many statistics with run-to-run noise -- float atomics reorder, bf16 roundings flip: measured over rounds 3 - 5
+        # norms 0.7 - 2.4 %, projections 3.4 - 7.3 %, cosines of the tensors stored in full 0.9996 - 1.0000)
+        assert worst_n_big <= 0.06 and worst_p_big <= 0.15 and all(c > 0.998 for _, c in full.values()), \
             (worst_n_big, worst_p_big, full)
 
 
