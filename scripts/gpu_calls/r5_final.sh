@@ -2,7 +2,7 @@
 # Round-5 closing GPU call: the whole GPU suite as the driver runs it, smoke(), then the C3 / C4 / C5 bench lines of the closing tree on
 # ONE box (the C2 line and its profile: scripts/profile_c2.sh 5, the call before this one).
 set -u
-out=gpurun_out/r5final
+out=gpurun_out/r5final2
 mkdir -p "$out"
 cd "$(dirname "$0")/../.." || exit 1
 export TMPDIR=/tmp

@@ -111,7 +111,7 @@ def test_step_matches_reference_golden(name):
             assert abs(got - ref) <= term_bar(name, k) * abs(ref), (k, got, ref, term_bar(name, k))   # on its own
     out["loss"][step].backward()
     torch.cuda.synchronize()
-    n, worst_cos, worst_ratio = 0, 1.0, 0.0
+    n, worst_cos, worst_cos_big, worst_ratio = 0, 1.0, 1.0, 0.0
     flat_a, flat_b, detail = [], [], []
     gmax = max(float(v.norm()) for v in g["grads"].values())
     for pn, p in m.named_parameters():
@@ -136,9 +136,10 @@ def test_step_matches_reference_golden(name):
         # residual of cancelling contributions is only held to the tolerance when it carries >= 5 % of the largest gradient norm
         if float(ref.norm()) >= 0.05 * gmax:
             worst_ratio = max(worst_ratio, abs(r - 1))
+            worst_cos_big = min(worst_cos_big, c)
         n += 1
     gcos = cos(torch.cat(flat_a), torch.cat(flat_b))
-    log(f"{name}: {n} grad tensors, global cosine {gcos:.4f}, worst cosine {worst_cos:.4f}, worst |norm ratio - 1| {worst_ratio:.3e}"
+    log(f"{name}: {n} grad tensors, global cosine {gcos:.4f}, worst cosine {worst_cos:.4f} (tensors >= 5 % of the largest norm: {worst_cos_big:.4f}), worst |norm ratio - 1| {worst_ratio:.3e}"
         + (" " + " ".join(detail) if n <= 8 else ""))
     # The worst of 262 per-tensor cosines is a noisy statistic on this tiny model -- the float atomics of the GroupNorm sums and the
     # weight gradients reorder from run to run, a bf16 rounding flips, and the smallest gradient tensors move: 0.9914 / 0.9890 / 0.9796 for
