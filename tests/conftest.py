@@ -40,6 +40,11 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu_exclusive: a GPU test that needs most of the 288 GB of HBM (full-width steps at the "
                                        "benchmarked batch): runs while no other worker's GPU test does")
     config.addinivalue_line("markers", "gpu_mem(gib): HBM this GPU test may hold (default: one 34 GiB slot of the box's eight)")
+    if _has_gpu():
+        # On a GPU box the HIP library is the product: load it in THIS process too (under xdist the controller runs no test and
+        # would otherwise never map libfdmi.so), and let a missing / unloadable library stop the run before any test is collected.
+        from flash_diffusion_amd import _lib
+        _lib.lib()
 
 
 def pytest_xdist_auto_num_workers(config):
