@@ -622,7 +622,7 @@ def main():
             "secondary": {"sampler": sampler, "two_optimizer_step": two_opt, "lpips_step": lpips_leg},
         }
         print(json.dumps(line))
-    if os.environ.get("FDMI_BENCH_DUMP_LORA"):     # (tests/test_multigpu_rccl_gpu.py: the replicas must be identical after the run)
+    if os.environ.get("FDMI_BENCH_DUMP_LORA"):     # (tests/test_zzz_multigpu_rccl_gpu.py: the replicas must be identical after the run)
         torch.save(model.student_denoiser.lora_flat().detach().cpu(), f"{os.environ['FDMI_BENCH_DUMP_LORA']}.rank{rank}.pt")
     if dist.is_initialized():
         dist.destroy_process_group()

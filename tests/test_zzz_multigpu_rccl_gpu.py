@@ -88,7 +88,12 @@ def _c_abi_two_ranks(tmp_path, world=2):
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     procs = [subprocess.Popen([sys.executable, "-c", _CABI_RANK.format(root=ROOT), str(r), str(world), path], cwd=ROOT, env=env,
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for r in range(world)]
-    res = [p.communicate(timeout=600) for p in procs]
+    try:
+        res = [p.communicate(timeout=600) for p in procs]
+    finally:
+        for p in procs:          # (a rank that died leaves its peer waiting in the communicator's bootstrap: never leak it)
+            if p.poll() is None:
+                p.kill()
     for p, (so, se) in zip(procs, res):
         assert p.returncode == 0 and "CABI-RANK-OK" in so, se[-4000:]
 
