@@ -20,6 +20,12 @@ sqrt(abar_t) x + sqrt(1-abar_t) eps for *any* integer timestep.  For timesteps
 on the current schedule this is identical to upstream DPMSolverMultistep's
 sigma-indexed add_noise; off-schedule timesteps (DMD / GAN draws, FD:418, 524)
 are only well defined under the DDPM form, which is what T-FD exercises.
+
+PARITY UNPINNED: diffusers is not installed and the reference holds no golden
+values for its schedulers, so this restatement of the published algorithms could
+not be checked against the reference's own dependency (DESIGN.md section 2 says
+the same; the steps built on it are pinned only against the reference's
+FlashDiffusion class running over THESE schedulers).
 """
 from __future__ import annotations
 
