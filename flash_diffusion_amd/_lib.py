@@ -33,6 +33,12 @@ class GemmDesc(C.Structure):
     ]
 
 
+class WgradProblem(C.Structure):
+    """fdmi_wgrad_problem (include/fdmi.h)"""
+    _fields_ = [("X", C.c_void_p), ("ldx", C.c_int64), ("Y", C.c_void_p), ("ldy", C.c_int64), ("M", C.c_int64),
+                ("N1", C.c_int32), ("N2", C.c_int32), ("C", C.c_void_p), ("ldc", C.c_int64)]
+
+
 class UNetCfg(C.Structure):
     _fields_ = [("in_channels", i32), ("out_channels", i32), ("n_levels", i32), ("block_out", i32 * 4),
                 ("down_attn", i32 * 4), ("up_attn", i32 * 4), ("layers_per_block", i32), ("tlayers", i32 * 4),
@@ -96,6 +102,7 @@ _SIGS = {
     "fdmi_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
     "fdmi_gemm_a2_ok": (i32, [C.POINTER(GemmDesc)]),
     "fdmi_wgrad_tn": (i32, [vp, i64, vp, i64, i64, i32, i32, vp, i64, vp]),
+    "fdmi_wgrad_tn_group": (i32, [vp, i32, vp]),
     "fdmi_gemm_gn_ok": (i32, [C.POINTER(GemmDesc), i32, i32]),
     "fdmi_gemm_gn": (i32, [C.POINTER(GemmDesc), vp, i32, i32, vp]),
     "fdmi_groupnorm_apply": (i32, [vp, vp, vp, vp, vp, i32, i32, i32, i32, f32, i32, vp]),

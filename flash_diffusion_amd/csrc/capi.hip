@@ -1,6 +1,7 @@
 // extern "C" surface of libfdmi.so (op-level entry points).  See include/fdmi.h.
 #include "../../include/fdmi.h"
 #include "ops.h"
+#include "wgrad.h"
 
 static thread_local std::string g_err;
 void fdmi_set_error(const std::string& msg) { g_err = msg; }
@@ -114,6 +115,14 @@ int fdmi_gemm_plan(const fdmi_gemm_desc* d, int32_t* kernel, int32_t* BM, int32_
 int fdmi_wgrad_tn(const void* X, int64_t ldx, const void* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
                   void* stream) {
   return launch_wgrad_tn((const bf16_t*)X, ldx, (const bf16_t*)Y, ldy, M, N1, N2, C, ldc, (hipStream_t)stream);
+}
+int fdmi_wgrad_tn_group(const fdmi_wgrad_problem* problems, int n, void* stream) {
+  FDMI_CHECK(problems != nullptr && n >= 1 && n <= WGRAD_GROUP_MAX, "wgrad_tn_group: 1 ... 6 problems");
+  WgradProblem pr[WGRAD_GROUP_MAX];
+  for (int i = 0; i < n; ++i)
+    pr[i] = WgradProblem{(const bf16_t*)problems[i].X, problems[i].ldx, (const bf16_t*)problems[i].Y, problems[i].ldy, problems[i].M,
+                         problems[i].N1, problems[i].N2, problems[i].C, problems[i].ldc};
+  return launch_wgrad_tn_group(pr, n, (hipStream_t)stream);
 }
 static GemmArgs gemm_gn_args_from(const fdmi_gemm_desc* d, float* gn_stats, int gn_rows, int gn_G) {
   GemmArgs a = gemm_args_from(d);

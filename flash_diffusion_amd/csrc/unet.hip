@@ -20,6 +20,7 @@
 #include <vector>
 
 #include "../../include/fdmi.h"
+#include "wgrad.h"
 #include "ops.h"
 #include "dit_ops.h"
 
@@ -1032,8 +1033,9 @@ struct Exec {
               RET_IF(launch_wgrad_tn32(F(y->g), w.N, F(t->p), lo->r, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
               RET_IF(launch_wgrad_tn32(F(dt->p), lo->r, F(x->p), x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
             } else {
-              RET_IF(launch_wgrad_tn(y->g, w.N, t->p, rp, x->rows, lo->out, lo->r, lo->B_grad, lo->r, E.st));
-              RET_IF(launch_wgrad_tn(dt->p, rp, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in, E.st));
+              const WgradProblem wp[2] = {{y->g, w.N, t->p, rp, x->rows, lo->out, lo->r, lo->B_grad, lo->r},
+                                          {dt->p, rp, x->p, x->cols, x->rows, lo->r, lo->in, lo->A_grad, lo->in}};
+              RET_IF(launch_wgrad_tn_group(wp, 2, E.st));   // (dB, dA) in one launch
             }
           }
           if (need_dx && fold) {   // dx (+)= [dy | dt] [W^T | A^T]^T: the base input gradient and the LoRA one in ONE launch
@@ -1109,10 +1111,12 @@ struct Exec {
           }
           E.flops += 3 * 2.0 * x->rows * r * (2.0 * C);
           if (!E.R.dry()) {
+            WgradProblem wp[6];   // the six products of the three slices in one launch
             for (int s = 0; s < 3; ++s) {
-              RET_IF(launch_wgrad_tn(y->g + s * C, 3 * C, t3->p + s * r, 3 * r, x->rows, C, r, l3[s]->B_grad, r, E.st));
-              RET_IF(launch_wgrad_tn(dt3->p + s * r, 3 * r, x->p, x->cols, x->rows, r, C, l3[s]->A_grad, C, E.st));
+              wp[2 * s] = WgradProblem{y->g + s * C, 3 * C, t3->p + s * r, 3 * r, x->rows, C, r, l3[s]->B_grad, r};
+              wp[2 * s + 1] = WgradProblem{dt3->p + s * r, 3 * r, x->p, x->cols, x->rows, r, C, l3[s]->A_grad, C};
             }
+            RET_IF(launch_wgrad_tn_group(wp, 6, E.st));
           }
           if (fold) {   // dx (+)= [dy_q dy_k dy_v | dt_q dt_k dt_v] [Wqkv^T | A_q^T A_k^T A_v^T]^T, one launch
             GemmArgs d = rows_args(y->g, 3 * C, x->rows, b.Wtc3, C, 3 * C + 3 * r, nullptr, dx, x->cols, x->ginit ? dx : nullptr, x->cols);

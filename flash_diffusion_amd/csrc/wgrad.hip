@@ -10,6 +10,7 @@
 // grid (N2 tiles of 128, N1 tiles of 64, row splits); 256 threads = 4 waves as 2 (n1) x 2 (n2), wave tile 32 x 64.
 #include "ops.h"
 #include "gemm_tile.h"   // glds16 (LDS-DMA from inline asm), wait_vmcnt, g_zero16b
+#include "wgrad.h"
 
 namespace {
 
@@ -153,16 +154,17 @@ struct Tn2 {
 };
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 
+// one block's work: tile (bx = column tile of the second operand, by = of the first), row split bz of problem `a`
 template <int BN1, bool CT>
-__global__ __launch_bounds__(256) void wgrad_tn2_kernel(TnArgs a) {
+__device__ __forceinline__ void tn2_block(const TnArgs& a, const int bx, const int by, const int bz) {
   using T = Tn2<BN1>;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int w1 = wave / T::W2, w2 = wave % T::W2;
   const int g = lane >> 4, c = lane & 15;
-  const int n2_0 = blockIdx.x * T::BN2, n1_0 = blockIdx.y * BN1;
-  const int64_t m_beg = (int64_t)blockIdx.z * a.rows_per_split;
+  const int n2_0 = bx * T::BN2, n1_0 = by * BN1;
+  const int64_t m_beg = (int64_t)bz * a.rows_per_split;
   const int64_t m_end = min(a.M, m_beg + a.rows_per_split);
   if (m_beg >= m_end) return;
   const int nk = (int)((m_end - m_beg + T::BK - 1) / T::BK);
@@ -266,6 +268,56 @@ __global__ __launch_bounds__(256) void wgrad_tn2_kernel(TnArgs a) {
 }
 
 template <int BN1, bool CT>
+__global__ __launch_bounds__(256) void wgrad_tn2_kernel(TnArgs a) {
+  tn2_block<BN1, CT>(a, blockIdx.x, blockIdx.y, blockIdx.z);
+}
+
+// ---- several products in ONE launch (round 5, the "grouped LoRA launches" of VERDICT r4): the weight gradients of one LoRA-carrying
+// linear (dB, dA) or of a fused q/k/v projection (3 x (dB, dA)) are independent, ~20 us each, and each alone cannot both fill the
+// chip and keep its atomics small (every row split adds N1 x N2 fp32 atomics: 86 splits to reach 256 blocks at M = 65536, 320 x
+// 128).  As one launch the group fills the chip TOGETHER: the row split is chosen for the group (equal rows per block across the
+// problems, about one block per CU in total), so each problem runs with several times fewer splits.  blockIdx.z runs over the
+// problems' row splits back to back (zend = exclusive prefix ends); the grid's x / y are the largest tile counts of the group and
+// a block outside its problem's tile range leaves at once.  The problems share BN1 (the narrow operand's tile); the operand
+// order of the MFMA / the store (`ct`) is per problem (a uniform branch over two instantiations of the block body).
+constexpr int TN_GROUP_MAX = 6;
+struct TnGroup {
+  TnArgs p[TN_GROUP_MAX];
+  int zend[TN_GROUP_MAX], t1[TN_GROUP_MAX], t2[TN_GROUP_MAX];
+  int n;
+};
+
+template <int BN1>
+__global__ __launch_bounds__(256) void wgrad_tn2_group_kernel(TnGroup gr) {
+  const int z = blockIdx.z;
+  int p = 0;
+#pragma unroll
+  for (int i = 0; i + 1 < TN_GROUP_MAX; ++i)
+    if (i + 1 < gr.n && z >= gr.zend[i]) p = i + 1;
+  p = __builtin_amdgcn_readfirstlane(p);
+  const int zb = z - (p ? gr.zend[p - 1] : 0);
+  if ((int)blockIdx.x >= gr.t2[p] || (int)blockIdx.y >= gr.t1[p]) return;
+  const TnArgs& a = gr.p[p];
+  if (a.ct) tn2_block<BN1, true>(a, blockIdx.x, blockIdx.y, zb);
+  else tn2_block<BN1, false>(a, blockIdx.x, blockIdx.y, zb);
+}
+
+template <int BN1>
+int launch_tn2_group(const TnGroup& gr, dim3 grid, double flops, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    FDMI_HIP(hipFuncSetAttribute((const void*)wgrad_tn2_group_kernel<BN1>, hipFuncAttributeMaxDynamicSharedMemorySize, Tn2<BN1>::SMEM));
+    attr_set = true;
+  }
+  const bool prof = fdmi_prof_on();
+  if (prof) fdmi_prof_begin(st, PROF_WGRAD_TN, flops);
+  FDMI_KLAUNCH(prof, (wgrad_tn2_group_kernel<BN1>), grid, dim3(256), Tn2<BN1>::SMEM, st, gr);
+  if (prof) fdmi_prof_end(st);
+  FDMI_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int BN1, bool CT>
 int launch_tn2(const TnArgs& a, dim3 grid, hipStream_t st) {
   static bool attr_set = false;
   if (!attr_set) {
@@ -343,4 +395,75 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
   return 0;
+}
+
+int launch_wgrad_tn_group(const WgradProblem* pr, int n, hipStream_t st) {
+  FDMI_CHECK(pr && n >= 1 && n <= WGRAD_GROUP_MAX, "wgrad_tn_group: 1 ... 6 problems");
+  static_assert(WGRAD_GROUP_MAX == TN_GROUP_MAX, "group sizes");
+  bool group = n > 1 && !fdmi_tune_get(46) && fdmi_tune_get(47) != 1;
+  TnGroup gr{};
+  int bn1 = 0;
+  double flops = 0;
+  for (int i = 0; i < n && group; ++i) {
+    const WgradProblem& q = pr[i];
+    FDMI_CHECK(q.X && q.Y && q.C && q.M > 0 && q.N1 > 0 && q.N2 > 0, "wgrad_tn: empty problem / null operand");
+    FDMI_CHECK((q.N1 % 8) == 0 && (q.N2 % 8) == 0 && (q.ldx % 8) == 0 && (q.ldy % 8) == 0, "wgrad_tn: widths and leading dims must be multiples of 8");
+    FDMI_CHECK(((uintptr_t)q.X % 16) == 0 && ((uintptr_t)q.Y % 16) == 0, "wgrad_tn: operands must be 16-B aligned");
+    TnArgs& a = gr.p[i];
+    if (q.N2 < q.N1) a = TnArgs{q.Y, q.ldy, q.X, q.ldx, q.M, q.N2, q.N1, q.C, q.ldc, 0, 1};   // the narrow operand first (launch_wgrad_tn)
+    else a = TnArgs{q.X, q.ldx, q.Y, q.ldy, q.M, q.N1, q.N2, q.C, q.ldc, 0, 0};
+    const int b = a.N1 <= 64 ? 64 : 128;
+    if (i == 0) bn1 = b;
+    else if (b != bn1) group = false;
+    gr.t1[i] = cdiv(a.N1, b);
+    gr.t2[i] = cdiv(a.N2, 128);
+    flops += 2.0 * (double)q.M * q.N1 * q.N2;
+  }
+  if (group) {
+    // products of very different widths do not share a launch well: (dB, dA) of PixArt's feed-forward projections -- 36 against 9
+    // column tiles -- measured 105 us as a group against 94.5 us one by one, while equal or nearly equal widths gain 1.05 - 2.1x
+    // (profiles/r5_wgrad_group_rates.txt)
+    int64_t tmin = INT64_MAX, tmax = 0;
+    for (int i = 0; i < n; ++i) {
+      const int64_t t = (int64_t)gr.t1[i] * gr.t2[i];
+      tmin = t < tmin ? t : tmin;
+      tmax = t > tmax ? t : tmax;
+    }
+    if (tmax >= 4 * tmin) group = false;
+  }
+  if (!group) {
+    for (int i = 0; i < n; ++i) {
+      const int rc = launch_wgrad_tn(pr[i].X, pr[i].ldx, pr[i].Y, pr[i].ldy, pr[i].M, pr[i].N1, pr[i].N2, pr[i].C, pr[i].ldc, st);
+      if (rc) return rc;
+    }
+    return 0;
+  }
+  // ONE row split for the group: the smallest number of 64-row slabs per block (>= 8: the ring's fill and the tile's atomics must
+  // stay a tail) with which the whole group is at most one resident set of blocks -- 256 (the 128-wide tile: one block per CU) or
+  // 512 (the 64-wide one: two per CU); a few blocks more than that and the last ones would run alone
+  const int64_t want = fdmi_tune_get(45) > 0 ? fdmi_tune_get(45) : (bn1 == 64 ? 512 : 256);
+  int64_t work = 0;
+  for (int i = 0; i < n; ++i) work += (int64_t)gr.t1[i] * gr.t2[i] * ((gr.p[i].M + 63) / 64);
+  int64_t spb = (work + want - 1) / want;
+  if (spb < 8) spb = 8;
+  auto blocks_at = [&](int64_t s) {
+    int64_t b = 0;
+    for (int i = 0; i < n; ++i) b += (int64_t)gr.t1[i] * gr.t2[i] * (((gr.p[i].M + 63) / 64 + s - 1) / s);
+    return b;
+  };
+  int64_t max_slabs = 0;
+  for (int i = 0; i < n; ++i) max_slabs = (gr.p[i].M + 63) / 64 > max_slabs ? (gr.p[i].M + 63) / 64 : max_slabs;
+  while (spb < max_slabs && blocks_at(spb) > want) spb += spb / 32 > 0 ? spb / 32 : 1;   // (at max_slabs every tile is one block: the floor)
+  int gx = 1, gy = 1, z = 0;
+  for (int i = 0; i < n; ++i) {
+    gr.p[i].rows_per_split = (int)(spb * 64);
+    z += (int)((gr.p[i].M + gr.p[i].rows_per_split - 1) / gr.p[i].rows_per_split);
+    gr.zend[i] = z;
+    if (gr.t2[i] > gx) gx = gr.t2[i];
+    if (gr.t1[i] > gy) gy = gr.t1[i];
+  }
+  gr.n = n;
+  FDMI_CHECK(z <= 65535, "wgrad_tn_group: too many row splits");
+  const dim3 grid(gx, gy, z);
+  return bn1 == 64 ? launch_tn2_group<64>(gr, grid, flops, st) : launch_tn2_group<128>(gr, grid, flops, st);
 }

@@ -118,6 +118,20 @@ def tune(key):
     return lib().fdmi_tune_value(key)
 
 
+def wgrad_tn_group(problems):
+    """[(X, Y, out), ...] (at most 6, bf16 operands): every out += X^T @ Y as wgrad_tn does, in ONE launch (fdmi_wgrad_tn_group)"""
+    from ._lib import WgradProblem
+    import ctypes as C
+    arr = (WgradProblem * len(problems))()
+    for q, (X, Y, out) in zip(arr, problems):
+        unit = lambda t: t.shape[1] == 1 or t.stride(1) == 1
+        assert Y.shape[0] == X.shape[0] and unit(X) and unit(Y) and unit(out) and out.dtype == torch.float32 and not _f32(X)
+        q.X, q.ldx, q.Y, q.ldy, q.M = X.data_ptr(), X.stride(0), Y.data_ptr(), Y.stride(0), X.shape[0]
+        q.N1, q.N2, q.C, q.ldc = X.shape[1], Y.shape[1], out.data_ptr(), out.stride(0)
+    check(lib().fdmi_wgrad_tn_group(C.cast(arr, C.c_void_p), len(problems), stream_ptr()))
+    return [o for _, _, o in problems]
+
+
 def wgrad_tn(X, Y, out):
     """out[N1, N2] (f32, accumulated) += X[M, N1]^T @ Y[M, N2]: both operands row-major bf16, contraction over the rows"""
     M = X.shape[0]

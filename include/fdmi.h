@@ -93,6 +93,16 @@ int fdmi_groupnorm_apply(const void* x, const float* gamma, const float* beta, c
  * C[n1][n2] += sum_m X[m][n1] * Y[m][n2], C fp32 [N1][ldc] accumulated with atomics (caller zeroes it once per step).  */
 int fdmi_wgrad_tn(const void* X, int64_t ldx, const void* Y, int64_t ldy, int64_t M, int N1, int N2, float* C, int64_t ldc,
                   void* stream);
+/* Up to 6 such products in ONE launch (the (dB, dA) pair of a LoRA-carrying linear, the three pairs of a fused q/k/v
+ * projection): the group fills the GPU together, so each product runs with fewer row splits and fewer fp32 atomics than alone.
+ * Same operand rules per problem as fdmi_wgrad_tn; results as if the products ran one after the other.                     */
+typedef struct fdmi_wgrad_problem {
+  const void* X; int64_t ldx;
+  const void* Y; int64_t ldy;
+  int64_t M; int32_t N1, N2;
+  float* C; int64_t ldc;
+} fdmi_wgrad_problem;
+int fdmi_wgrad_tn_group(const fdmi_wgrad_problem* problems, int n, void* stream);
 
 /* ---------------- normalisation (NHWC / token-major bf16, fp32 statistics) -------------------- */
 int fdmi_groupnorm_fwd(const void* x, const float* gamma, const float* beta, float* stats /*[B][G][2]*/,

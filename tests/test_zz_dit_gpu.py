@@ -590,6 +590,62 @@ def _body_test_wgrad_tn(shape):
     assert err <= 2e-5 * scale + 1e-4, (err, scale)       # fp32 accumulation of exact bf16 products, split / atomic order
 
 
+# grouped launches (fdmi_wgrad_tn_group): the (dB, dA) pair of one LoRA linear, the three pairs of a fused q/k/v projection (operands are
+# column slices of shared [M, 3C] / [M, 3r] buffers), pairs with different widths, a tiny-M pair, groups whose narrow tiles differ or
+# whose widths differ 4x (both fall back to single launches) and a group of one
+WGRAD_GROUPS = {"pair_r128": [(16384, 640, 128), (16384, 128, 640)],
+                "qkv_r128": "qkv:65536:320:128", "qkv_r64": "qkv:8192:1152:64",
+                "pair_ff_r64": [(8192, 4608, 64), (8192, 64, 1152)],     # (36 against 9 column tiles: launched one by one)
+                "pair_out_r64": [(8192, 1152, 64), (8192, 64, 1152)],
+                "pair_ctx": [(1232, 320, 128), (1232, 128, 768)],
+                "ragged": [(130, 72, 40), (333, 40, 200), (64, 64, 128)],
+                "mixed_tiles": [(4096, 320, 128), (4096, 64, 320)],
+                "single": [(4096, 128, 320)]}
+
+
+@pytest.mark.parametrize("name", sorted(WGRAD_GROUPS))
+def test_wgrad_tn_group(name):
+    run_isolated(__name__, "_body_test_wgrad_tn_group", (name,))
+
+
+def _body_test_wgrad_tn_group(name):
+    """every product of a group against torch in fp64 on the same bf16 values (accumulating into non-zero C), and against the same
+    products launched one by one (developer switch 47 = 1): the two differ only in the row split, i.e. in fp32 summation order"""
+    ops = _ops()
+    spec = WGRAD_GROUPS[name]
+    probs = []
+    if isinstance(spec, str):                     # the fused q/k/v layout of csrc/unet.hip::linear_qkv's backward
+        _, M, C, r = spec.split(":")
+        M, C, r = int(M), int(C), int(r)
+        dy, t3, dt3, x = (b16(rnd(M, 3 * C, seed=1)).cuda(), b16(rnd(M, 3 * r, seed=2)).cuda(), b16(rnd(M, 3 * r, seed=3)).cuda(),
+                          b16(rnd(M, C, seed=4)).cuda())
+        for s in range(3):
+            probs.append((dy[:, s * C:(s + 1) * C], t3[:, s * r:(s + 1) * r]))
+            probs.append((dt3[:, s * r:(s + 1) * r], x))
+    else:
+        for i, (M, N1, N2) in enumerate(spec):
+            probs.append((b16(rnd(M, N1 + 8, seed=10 + i)).cuda()[:, 8:], b16(rnd(M, N2, seed=20 + i)).cuda()))
+    C0 = [rnd(X.shape[1], Y.shape[1], seed=30 + i) for i, (X, Y) in enumerate(probs)]
+    outs = [c.clone().cuda() for c in C0]
+    ops.wgrad_tn_group([(X, Y, o) for (X, Y), o in zip(probs, outs)])
+    torch.cuda.synchronize()
+    from flash_diffusion_amd import _lib
+    _lib.lib().fdmi_tune_set(47, 1)
+    try:
+        singles = [c.clone().cuda() for c in C0]
+        ops.wgrad_tn_group([(X, Y, o) for (X, Y), o in zip(probs, singles)])
+        torch.cuda.synchronize()
+    finally:
+        _lib.lib().fdmi_tune_set(47, 0)
+    for i, ((X, Y), c0, o, o1) in enumerate(zip(probs, C0, outs, singles)):
+        ref = c0.double() + X.double().cpu().t() @ Y.double().cpu()
+        scale = ref.abs().max().item()
+        err = (o.double().cpu() - ref).abs().max().item()
+        assert err <= 2e-5 * scale + 1e-4, (name, i, err, scale)
+        err1 = (o.double().cpu() - o1.double().cpu()).abs().max().item()
+        assert err1 <= 4e-5 * scale + 2e-4, (name, i, err1, scale)
+
+
 # ---- the C++ plans against the op-by-op composition of the same module, at a size where the workspace matters ----------------
 MID = {"pixart": dict(sample_size=64, num_layers=3, attention_head_dim=32, in_channels=4, out_channels=8, patch_size=2, attention_bias=True,
                       num_attention_heads=4, cross_attention_dim=128, activation_fn="gelu-approximate", num_embeds_ada_norm=1000,
