@@ -157,3 +157,19 @@ def test_developer_knobs_cover_the_keys_in_use():
         assert L.fdmi_tune_set(k, 3) == 0 and L.fdmi_tune_value(k) == 3
         assert L.fdmi_tune_set(k, 0) == 0
     assert L.fdmi_tune_set(64, 1) != 0 and L.fdmi_tune_value(64) == 0 and L.fdmi_tune_value(-1) == 0
+
+
+def test_grouped_weight_gradient_entry_point_validates_before_any_launch():
+    """fdmi_wgrad_tn_group (round 5): argument errors are reported through the return code and fdmi_last_error before any device
+    work -- a null array, an empty or over-long group, and a problem that breaks fdmi_wgrad_tn's operand rules (checked per
+    problem) -- so a host binding can probe it on a machine without a GPU"""
+    import ctypes as C
+    from flash_diffusion_amd import _lib
+    L = _lib.lib()
+    arr = (_lib.WgradProblem * 7)()
+    assert C.sizeof(_lib.WgradProblem) == 64                    # fdmi_wgrad_problem: 4 pointers / int64 + 2 int32 + pointer + int64
+    assert L.fdmi_wgrad_tn_group(None, 2, None) != 0 and b"wgrad_tn_group" in L.fdmi_last_error()
+    assert L.fdmi_wgrad_tn_group(C.cast(arr, C.c_void_p), 0, None) != 0
+    assert L.fdmi_wgrad_tn_group(C.cast(arr, C.c_void_p), 7, None) != 0 and b"1 ... 6" in L.fdmi_last_error()
+    # two problems with null operands: the per-problem check names the single-product kernel's rule
+    assert L.fdmi_wgrad_tn_group(C.cast(arr, C.c_void_p), 2, None) != 0 and b"null operand" in L.fdmi_last_error()
