@@ -81,12 +81,12 @@ __global__ __launch_bounds__(256) void gelu_tanh_kernel(const bf16_t* x, const b
 // grid (row chunks of RCH, B, ceil(C/8/256)); a thread owns one 8-channel chunk and walks the rows of its chunk.
 constexpr int BCS_RCH = 64;
 __global__ __launch_bounds__(256) void batch_colsum_kernel(const bf16_t* dy, const bf16_t* x, const float* stats,
-                                                           float* out0, float* out1, int rows_per_batch, int C) {
+                                                           float* out0, float* out1, int rows_per_batch, int C, int rch) {
   const int ch = blockIdx.z * 256 + threadIdx.x;
   if (ch >= (C >> 3)) return;
   const int b = blockIdx.y;
-  const int r0 = blockIdx.x * BCS_RCH;
-  const int r1 = min(r0 + BCS_RCH, rows_per_batch);
+  const int r0 = blockIdx.x * rch;
+  const int r1 = min(r0 + rch, rows_per_batch);
   float s0[8], s1[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
@@ -141,8 +141,9 @@ int launch_batch_colsum(const bf16_t* dy, const bf16_t* x, const float* stats, f
   FDMI_CHECK(!out0 || x, "batch_colsum: out0 needs x");
   if (out0) FDMI_HIP(hipMemsetAsync(out0, 0, (size_t)B * C * sizeof(float), st));
   if (out1) FDMI_HIP(hipMemsetAsync(out1, 0, (size_t)B * C * sizeof(float), st));
-  hipLaunchKernelGGL(batch_colsum_kernel, dim3(cdiv(rows_per_batch, BCS_RCH), B, cdiv(C >> 3, 256)), dim3(256), 0, st, dy,
-                     x, stats, out0, out1, rows_per_batch, C);
+  const int rch = fdmi_det() ? rows_per_batch : BCS_RCH;   // deterministic mode: one block per (sample, column chunk) = one contributor
+  hipLaunchKernelGGL(batch_colsum_kernel, dim3(cdiv(rows_per_batch, rch), B, cdiv(C >> 3, 256)), dim3(256), 0, st, dy,
+                     x, stats, out0, out1, rows_per_batch, C, rch);
   FDMI_HIP(hipGetLastError());
   return 0;
 }

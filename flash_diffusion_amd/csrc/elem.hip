@@ -386,8 +386,9 @@ __global__ __launch_bounds__(256) void silu_bwd_kernel(const bf16_t* x, const bf
   GRID_STRIDE(i, n) dx[i] = f2bf(bf2f(dy[i]) * dsilu_f(bf2f(x[i])));
 }
 // out0[c] += sum_r dy[r][c] ; out1[c] += sum_r dy[r][c] * xhat[r][c]   (xhat from GroupNorm stats when given)
+// det (fdmi_det(), common.h): the launcher runs ONE block per 64 columns and the block's four row lanes are combined in lane order
 __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, const bf16_t* x, const float* stats, float* out0,
-                                                     float* out1, int64_t rows, int C, int HW, int G, float eps) {
+                                                     float* out1, int64_t rows, int C, int HW, int G, float eps, int det) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rlane = threadIdx.x >> 6;
   float s0 = 0.f, s1 = 0.f;
@@ -407,8 +408,21 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* dy, const bf1
         s1 += d * xh;
       }
     }
-    atomicAdd(out0 + c, s0);
-    if (out1) atomicAdd(out1 + c, s1);
+    if (!det) {
+      atomicAdd(out0 + c, s0);
+      if (out1) atomicAdd(out1 + c, s1);
+    }
+  }
+  if (det) {
+    __shared__ float cpart[4][64][2];
+    cpart[rlane][threadIdx.x & 63][0] = s0;
+    cpart[rlane][threadIdx.x & 63][1] = s1;
+    __syncthreads();
+    if (rlane == 0 && c < C) {
+      const int l = threadIdx.x & 63;
+      out0[c] += ((cpart[0][l][0] + cpart[1][l][0]) + cpart[2][l][0]) + cpart[3][l][0];
+      if (out1) out1[c] += ((cpart[0][l][1] + cpart[1][l][1]) + cpart[2][l][1]) + cpart[3][l][1];
+    }
   }
 }
 // distillation loss (FD:368-382): out += sum |s-t|^p / n  (p = 2: l2, p = 1: l1)
@@ -478,13 +492,15 @@ int launch_colsum(const bf16_t* dy, const bf16_t* x, const float* stats, float* 
   int gy = (int)((rows + 63) / 64);
   if (gy > 256) gy = 256;
   if (gy < 1) gy = 1;
-  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, st, dy, x, stats, out0, out1, rows, C, HW, G, eps);
+  const int det = fdmi_det() ? 1 : 0;
+  if (det) gy = 1;
+  hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(C, 64), gy), dim3(256), 0, st, dy, x, stats, out0, out1, rows, C, HW, G, eps, det);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
 int launch_distill_loss(const float* s, const float* t, int64_t n, int l1, float* out, hipStream_t st) {
   FDMI_HIP(hipMemsetAsync(out, 0, sizeof(float), st));
-  hipLaunchKernelGGL(distill_loss_kernel, dim3(nblocks(n, 256)), dim3(256), 0, st, s, t, n, l1, out);
+  hipLaunchKernelGGL(distill_loss_kernel, dim3(fdmi_det() ? 1 : nblocks(n, 256)), dim3(256), 0, st, s, t, n, l1, out);   // (deterministic mode: one block = one contributor)
   FDMI_HIP(hipGetLastError());
   return 0;
 }
@@ -496,7 +512,7 @@ int launch_dmd_loss(const float* s, const float* noisy, const float* real, const
                     hipStream_t st) {
   FDMI_HIP(hipMemsetAsync(loss, 0, sizeof(float), st));
   hipLaunchKernelGGL(dmd_weight_kernel, dim3(B), dim3(256), 0, st, s, noisy, real, ia, ma, w, per);
-  hipLaunchKernelGGL(dmd_grad_kernel, dim3(nblocks((int64_t)B * per, 256)), dim3(256), 0, st, real, fake, kb, w, grad, loss, B,
+  hipLaunchKernelGGL(dmd_grad_kernel, dim3(fdmi_det() ? 1 : nblocks((int64_t)B * per, 256)), dim3(256), 0, st, real, fake, kb, w, grad, loss, B,
                      per);
   FDMI_HIP(hipGetLastError());
   return 0;

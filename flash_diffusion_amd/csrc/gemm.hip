@@ -651,6 +651,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
   if (p.big == 2) FDMI_CHECK(gemm4_eligible(a, p.BN), "gemm: 256x320 / 256x192 tile not applicable to this problem");
   a.splitk = p.splitk;
+  if (a.accum_atomic && fdmi_det()) a.splitk = 1;   // deterministic mode: one contributor per element of the atomic accumulation
   {  // every split must own at least one K tile (slabs of empty splits would stay uninitialised)
     const int kt = cdiv(a.K, 64);
     while (a.splitk > 1 && (a.splitk - 1) * cdiv(kt, a.splitk) >= kt) --a.splitk;

@@ -228,6 +228,9 @@ __device__ __forceinline__ float dpp_ror8_hi(float keep, float src) {   // lanes
 __device__ __forceinline__ float dpp_ror8_lo(float keep, float src) {   // lanes j < 8 := src of lane j + 8
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x128, 0xF, 0x3, false));
 }
+#ifndef FDMI_EPI_RD
+#define FDMI_EPI_RD 4   // residual chunks (16 bytes each) in flight per lane in the lean epilogue (compile-time experiment switch)
+#endif
 // the epilogue's walk as compile-time tables: unit k = (first pair, double?), micro-step i = one 16-byte residual chunk in
 // processing order (unit, row fragment, row of a double) -- the residual ring below is addressed by micro-step
 template <int NP, int MF, int PHASE>
@@ -260,7 +263,7 @@ __device__ __forceinline__ void tile_epilogue_fast(const GemmArgs& a, int mw, in
   // units: a double (pairs P, P + 1: line-wide) or a single pair.  PHASE 0: doubles from pair 0; 1: pair 0 single, doubles from
   // pair 1; 2: every pair single (A/B switch)
   using Wk = EpiWalk<NP, MF, PHASE>;
-  constexpr int NU = Wk::NU, NS = Wk::micro_count(), RD = 4;   // RD: residual chunks in flight per lane
+  constexpr int NU = Wk::NU, NS = Wk::micro_count(), RD = FDMI_EPI_RD;   // RD: residual chunks in flight per lane
   const int h = j >> 3, jr = j & 7;
   const int col0 = nw + (g & 1) * 16 + (g >> 1) * 8;           // single pair pr: this lane's 8 columns start at col0 + 32 pr, row j
   const int colT = col0 + 32 * h;                              // double (P, P + 1): columns colT + 32 P, rows jr and jr + 8

@@ -131,12 +131,9 @@ __global__ __launch_bounds__(256) void bf16_to_f32_kernel(const bf16_t* x, float
 // (their channel L2 norm + 1e-10), the squared difference is weighted by the non-negative 1x1 "lin" layer and averaged over
 // the pixels of the sample:  out[b] += (1 / HW) * sum_rows sum_c w[c] * (n0[c] - n1[c])^2.
 // One wave per row; lane l owns channels l, l + 64, ... (C <= 512: at most 8 per lane, kept in registers).
+// (row term shared by the production kernel and its deterministic twin: the wave's sum over channels of w (n0 - n1)^2)
 template <typename TT>
-__global__ __launch_bounds__(256) void lpips_level_fwd_kernel(const TT* f0, const TT* f1, const float* w, float* out, int64_t rows,
-                                                              int HW, int C) {
-  const int lane = threadIdx.x & 63;
-  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (row >= rows) return;
+__device__ __forceinline__ float lpips_row_term(const TT* f0, const TT* f1, const float* w, int64_t row, int C, int lane) {
   float a[8], b[8];
   float sa = 0.f, sb = 0.f;
 #pragma unroll
@@ -159,8 +156,29 @@ __global__ __launch_bounds__(256) void lpips_level_fwd_kernel(const TT* f0, cons
       acc = fmaf(w[c] * d, d, acc);
     }
   }
-  acc = wave_sum(acc);
+  return wave_sum(acc);
+}
+template <typename TT>
+__global__ __launch_bounds__(256) void lpips_level_fwd_kernel(const TT* f0, const TT* f1, const float* w, float* out, int64_t rows,
+                                                              int HW, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float acc = lpips_row_term(f0, f1, w, row, C, lane);
   if (lane == 0) atomicAdd(out + row / HW, acc / (float)HW);
+}
+// deterministic twin (fdmi_det(), common.h): one block per sample, wave v takes rows v, v + 4, ... in order, the four waves' sums are
+// added in wave order by the sample's only writer
+template <typename TT>
+__global__ __launch_bounds__(256) void lpips_level_fwd_det_kernel(const TT* f0, const TT* f1, const float* w, float* out, int HW, int C) {
+  __shared__ float part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x;
+  float tot = 0.f;
+  for (int r = wave; r < HW; r += 4) tot += lpips_row_term(f0, f1, w, (int64_t)b * HW + r, C, lane) / (float)HW;
+  if (lane == 0) part[wave] = tot;
+  __syncthreads();
+  if (threadIdx.x == 0) out[b] += ((part[0] + part[1]) + part[2]) + part[3];
 }
 // gradient wrt f0 (the student's features; f1 is the no-grad teacher side), accumulated into df0 (the feature tensor also feeds
 // the next VGG stage): with n0 = f0 / (s + eps), s = |f0|, g = gout[b] / HW * 2 w (n0 - n1):
@@ -309,13 +327,15 @@ int launch_bf16_to_f32(const bf16_t* x, float* y, int64_t n, hipStream_t st) { N
 
 int launch_lpips_level_fwd(const bf16_t* f0, const bf16_t* f1, const float* w, float* out, int64_t rows, int HW, int C, hipStream_t st) {
   FDMI_CHECK(C <= 512, "lpips_level: at most 512 channels");
-  hipLaunchKernelGGL(lpips_level_fwd_kernel<bf16_t>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, f0, f1, w, out, rows, HW, C);
+  if (fdmi_det()) hipLaunchKernelGGL(lpips_level_fwd_det_kernel<bf16_t>, dim3((unsigned)(rows / HW)), dim3(256), 0, st, f0, f1, w, out, HW, C);
+  else hipLaunchKernelGGL(lpips_level_fwd_kernel<bf16_t>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, f0, f1, w, out, rows, HW, C);
   FDMI_HIP(hipGetLastError());
   return 0;
 }
 int launch_lpips_level_fwd32(const float* f0, const float* f1, const float* w, float* out, int64_t rows, int HW, int C, hipStream_t st) {
   FDMI_CHECK(C <= 512, "lpips_level: at most 512 channels");
-  hipLaunchKernelGGL(lpips_level_fwd_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, f0, f1, w, out, rows, HW, C);
+  if (fdmi_det()) hipLaunchKernelGGL(lpips_level_fwd_det_kernel<float>, dim3((unsigned)(rows / HW)), dim3(256), 0, st, f0, f1, w, out, HW, C);
+  else hipLaunchKernelGGL(lpips_level_fwd_kernel<float>, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, st, f0, f1, w, out, rows, HW, C);
   FDMI_HIP(hipGetLastError());
   return 0;
 }

@@ -140,6 +140,99 @@ __global__ __launch_bounds__(256) void gn_reduce_kernel(GnArgs a, int rows_per_b
   if (tid < a.G * 2) atomicAdd(dst + (int64_t)b * a.G * 2 + tid, sred[tid >> 1][tid & 1]);
 }
 
+// Deterministic twin of gn_reduce_kernel (fdmi_det(), common.h): ONE block per sample walks all HW rows with the same thread ->
+// (channel chunk, row lane) assignment, every thread's sums run in row order, and the block's reduction is ORDERED: the per-thread
+// partial sums of a slot go to LDS and the 2 G reducer threads add the contributions to their (group, component) in thread order,
+// element order -- no LDS atomics, no global atomics (the block is the sample's only contributor).  A test mode: ~B blocks per launch.
+template <bool BWD>
+__global__ __launch_bounds__(256) void gn_reduce_det_kernel(GnArgs a) {
+  __shared__ float part[256][16];   // s0[8], s1[8] of each thread for the current slot
+  __shared__ int pc0[256];          // first channel of the thread's chunk (-1: idle in this slot)
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x;
+  const int CPR = a.C >> 3, cpg = a.C / a.G;
+  const int R = CPR <= 256 ? 256 / CPR : 1;
+  const int nslot = (CPR + 255) >> 8;
+  const float inv_n = 1.f / ((float)a.HW * cpg);
+  float tot = 0.f;                  // reducer thread t < 2 G: the running sum of (group t >> 1, component t & 1)
+  for (int s = 0; s < nslot; ++s) {
+    int chunk, roff;
+    bool active = true;
+    if (CPR <= 256) {
+      chunk = tid % CPR;
+      roff = tid / CPR;
+      active = roff < R;
+    } else {
+      chunk = tid + 256 * s;
+      roff = 0;
+      active = chunk < CPR;
+    }
+    float s0[8], s1[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s0[e] = s1[e] = 0.f;
+    if (active) {
+      const int c0 = chunk * 8;
+      int64_t xld;
+      const bf16_t* xp = gn_xsrc(a, c0, xld);
+      float mean[8], rstd[8], gm[8], bt[8];
+      if (BWD) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int gi = (c0 + e) / cpg;
+          const float sm = a.stats[((int64_t)b * a.G + gi) * 2 + 0] * inv_n;
+          const float sq = a.stats[((int64_t)b * a.G + gi) * 2 + 1] * inv_n;
+          mean[e] = sm;
+          rstd[e] = rsqrtf(fmaxf(sq - sm * sm, 0.f) + a.eps);
+          gm[e] = a.gamma[c0 + e];
+          bt[e] = a.beta[c0 + e];
+        }
+      }
+      for (int r = roff; r < a.HW; r += R) {
+        const int64_t row = (int64_t)b * a.HW + r;
+        const u16x8 xv = *(const u16x8*)(xp + row * xld);
+        if (!BWD) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float v = bf2f(xv[e]);
+            s0[e] += v;
+            s1[e] += v * v;
+          }
+        } else {
+          const u16x8 dv = *(const u16x8*)(a.dy + row * a.C + c0);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float xh = (bf2f(xv[e]) - mean[e]) * rstd[e];
+            float dz = bf2f(dv[e]);
+            if (a.silu) dz *= dsilu_f(gm[e] * xh + bt[e]);
+            const float dxh = dz * gm[e];
+            s0[e] += dxh;
+            s1[e] += dxh * xh;
+          }
+        }
+      }
+    }
+    __syncthreads();   // (the previous slot's reducers are done with part / pc0)
+    pc0[tid] = active ? chunk * 8 : -1;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      part[tid][e] = s0[e];
+      part[tid][8 + e] = s1[e];
+    }
+    __syncthreads();
+    if (tid < a.G * 2) {
+      const int gi = tid >> 1, comp = tid & 1;
+      for (int t = 0; t < 256; ++t) {
+        const int c0 = pc0[t];
+        if (c0 < 0 || (c0 + 7) / cpg < gi || c0 / cpg > gi) continue;
+        for (int e = 0; e < 8; ++e)
+          if ((c0 + e) / cpg == gi) tot += part[t][comp * 8 + e];
+      }
+    }
+  }
+  float* dst = BWD ? a.bstats : a.stats;
+  if (tid < a.G * 2) dst[(int64_t)b * a.G * 2 + tid] += tot;   // (the only contributor of this sample's sums)
+}
+
 // apply pass: thread t owns channel chunk t % CPR for rows t / CPR, +R, +2R, ... of its row block, so
 // the per-channel affine coefficients (mean/rstd/gamma/beta -> a, b) are derived ONCE per thread and
 // the row loop is a 16-byte load, 8 fmas (+SiLU) and a 16-byte store.
@@ -253,7 +346,8 @@ int launch_groupnorm_fwd(const bf16_t* x, const float* gamma, const float* beta,
   const int rpb = gn_rows_per_block(B, HW);
   if (!stats_ready) {
     if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(stats, 0, (size_t)B * G * 2 * sizeof(float), st));
-    hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+    if (fdmi_det()) hipLaunchKernelGGL(gn_reduce_det_kernel<false>, dim3(B), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(gn_reduce_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   }
   hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
@@ -268,7 +362,8 @@ int launch_groupnorm_bwd(const bf16_t* x, const bf16_t* dy, const float* gamma, 
   GnArgs a{x, dy, gamma, beta, (float*)stats, bstats, dx, B, HW, C, G, eps, silu, accumulate, x2, x2 ? C1 : 0};
   if (!stats_zeroed) FDMI_HIP(hipMemsetAsync(bstats, 0, (size_t)B * G * 2 * sizeof(float), st));
   const int rpb = gn_rows_per_block(B, HW);
-  hipLaunchKernelGGL(gn_reduce_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
+  if (fdmi_det()) hipLaunchKernelGGL(gn_reduce_det_kernel<true>, dim3(B), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL(gn_reduce_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(cdiv(HW, rpb), B), dim3(256), 0, st, a, rpb);
   FDMI_HIP(hipGetLastError());
   return 0;

@@ -1657,7 +1657,7 @@ int run_forward(fdmi_unet* U, Run& R, const float* x, const float* t, const floa
   E.ctx_mode = (flags & FDMI_UNET_CTX_REUSE) ? 2 : ((flags & FDMI_UNET_CTX_FILL) ? 1 : 0);
   // GroupNorm statistics from the producing GEMM's epilogue (A/B switch: FDMI_TUNE=14=1 turns it off).  Adapter residuals are
   // added in place AFTER their tensor was produced, so a forward that carries them keeps the reduce kernel everywhere.
-  E.gn_epi = fdmi_tune_get(14) == 0 && U->down_res.empty() && !U->f32;
+  E.gn_epi = fdmi_tune_get(14) == 0 && !fdmi_det() && U->down_res.empty() && !U->f32;
   U->last_gn = U->last_gn_epi = 0;
   for (double& b : U->hbm) b = 0;
   R.tensors.clear();
@@ -1971,7 +1971,7 @@ int run_vae_decoder(fdmi_unet* U, Run& R, const float* z, float* out, int B, int
   NetVae& V = *U->vae;
   const fdmi_net_config& c = U->ncfg;
   Exec E{U, R, R.st};
-  E.gn_epi = fdmi_tune_get(14) == 0 && !U->f32;
+  E.gn_epi = fdmi_tune_get(14) == 0 && !fdmi_det() && !U->f32;
   run_reset(U, R, flags);
   int n_norms = 2 * 2 + 1 + 1;
   for (auto& st : V.up) n_norms += 2 * (int)st->res.size();

@@ -357,9 +357,10 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
     // splits 39.7 / 25.5 / 24.7 us; the wide products, 36 column tiles at M = 32768: 4 splits 78 us, 15 splits 66 us)
     const int64_t tiles = (int64_t)t1 * t2;
     int64_t want = fdmi_tune_get(45) > 0 ? fdmi_tune_get(45) : 256;
+    if (fdmi_det()) want = 1;   // deterministic mode: ONE row split per tile (a tile's atomics then have a single contributor)
     // the 64-wide kernel fits two blocks per CU: 512 blocks when each still streams >= 2048 rows (the widest products: M = 32768,
     // 4608 x 64: 15 splits 66.7 us, 8 splits 78.9 us; at 1152 x 64 it is the other way round: 57 splits 28.3 us, 29 splits 23.5 us)
-    if (!fdmi_tune_get(45) && bn1 == 64 && slabs * 64 / ((512 + tiles - 1) / tiles) >= 2048) want = 512;
+    if (!fdmi_tune_get(45) && !fdmi_det() && bn1 == 64 && slabs * 64 / ((512 + tiles - 1) / tiles) >= 2048) want = 512;
     int64_t splits = (want + tiles - 1) / tiles;
     if (splits > (slabs + 7) / 8) splits = (slabs + 7) / 8;
     if (splits < 1) splits = 1;
@@ -383,7 +384,7 @@ int launch_wgrad_tn(const bf16_t* X, int64_t ldx, const bf16_t* Y, int64_t ldy, 
   const int t1 = cdiv(N1, TN_BN1), t2 = cdiv(N2, TN_BN2);
   const int64_t slabs = (M + TN_BK - 1) / TN_BK;
   // ~4 blocks per CU: enough row splits to fill the chip, at least 4 slabs each so the atomics stay a small tail
-  const int64_t want = fdmi_tune_get(45) > 0 ? fdmi_tune_get(45) : 1024;   // blocks to aim for (developer knob 45: scripts/wgrad_rates.py)
+  const int64_t want = fdmi_det() ? 1 : fdmi_tune_get(45) > 0 ? fdmi_tune_get(45) : 1024;   // blocks to aim for (developer knob 45: scripts/wgrad_rates.py; deterministic mode: one split)
   int64_t splits = (want + (int64_t)t1 * t2 - 1) / ((int64_t)t1 * t2);   // (512 ... 2048 blocks measure the same on C2; 256 is slower)
   if (splits > (slabs + 3) / 4) splits = (slabs + 3) / 4;
   if (splits < 1) splits = 1;
@@ -441,7 +442,7 @@ int launch_wgrad_tn_group(const WgradProblem* pr, int n, hipStream_t st) {
   // ONE row split for the group: the smallest number of 64-row slabs per block (>= 8: the ring's fill and the tile's atomics must
   // stay a tail) with which the whole group is at most one resident set of blocks -- 256 (the 128-wide tile: one block per CU) or
   // 512 (the 64-wide one: two per CU); a few blocks more than that and the last ones would run alone
-  const int64_t want = fdmi_tune_get(45) > 0 ? fdmi_tune_get(45) : (bn1 == 64 ? 512 : 256);
+  const int64_t want = fdmi_det() ? 1 : fdmi_tune_get(45) > 0 ? fdmi_tune_get(45) : (bn1 == 64 ? 512 : 256);   // (deterministic mode: every tile one block)
   int64_t work = 0;
   for (int i = 0; i < n; ++i) work += (int64_t)gr.t1[i] * gr.t2[i] * ((gr.p[i].M + 63) / 64);
   int64_t spb = (work + want - 1) / want;

@@ -13,6 +13,7 @@ previous step's gradient all-reduce + AdamW with it.
 Random draws go through `Draws` so tests can inject the exact values the reference consumed."""
 from __future__ import annotations
 
+import logging
 from copy import deepcopy
 from dataclasses import dataclass, field
 from typing import Any, Dict, List, Optional
@@ -30,6 +31,19 @@ from . import ops
 
 
 # ----------------------------------------------------------------------------------------------------
+_log = logging.getLogger(__name__)
+_torch_disc_warned = False
+
+
+def _warn_torch_discriminator(reason: str) -> None:
+    """The discriminator head stays a torch module (its convolutions run on torch's ROCm kernels, not libfdmi.so): log it once."""
+    global _torch_disc_warned
+    if not _torch_disc_warned:
+        _torch_disc_warned = True
+        _log.warning("flash_diffusion_amd: the discriminator head is NOT on the HIP path and runs as the caller's torch module (%s)", reason)
+
+
+
 @dataclass
 class FlashDiffusionConfig:
     """Field-for-field mirror of the reference FlashDiffusionConfig (flash_diffusion_config.py:9-105),
@@ -247,11 +261,16 @@ class FlashDiffusion(nn.Module):
         self.conditioner = conditioner
         if isinstance(discriminator, nn.Sequential) and not hasattr(discriminator, "convert"):
             from .discriminator import MiDiscriminator
-            try:   # run the reference's PatchGAN heads on the HIP kernels; anything exotic stays a plain module
-                if all(isinstance(m, (nn.Conv2d, nn.SiLU, nn.GroupNorm, nn.Flatten)) for m in discriminator):
+            # run the reference's PatchGAN heads on the HIP kernels; anything exotic stays the caller's torch module -- and says so
+            # ONCE (a head that silently trained on MIOpen was indistinguishable from one on libfdmi.so)
+            if all(isinstance(m, (nn.Conv2d, nn.SiLU, nn.GroupNorm, nn.Flatten)) for m in discriminator):
+                try:
                     discriminator = MiDiscriminator.convert(discriminator)
-            except Exception:
-                pass
+                except Exception as e:   # an unsupported layer geometry (MiDiscriminator.convert raises with the reason)
+                    _warn_torch_discriminator(f"MiDiscriminator.convert failed: {e!r}")
+            else:
+                _warn_torch_discriminator("layers outside Conv2d / SiLU / GroupNorm / Flatten: " + ", ".join(
+                    sorted({type(m).__name__ for m in discriminator if not isinstance(m, (nn.Conv2d, nn.SiLU, nn.GroupNorm, nn.Flatten))})))
         if getattr(discriminator, "precision", None) is not None and \
                 getattr(student_denoiser, "config_dict", {}).get("precision") == "fp32":
             discriminator.precision = "fp32"   # an fp32 validation student: the head runs the validation kernels too

@@ -118,6 +118,37 @@ def tune(key):
     return lib().fdmi_tune_value(key)
 
 
+DETERMINISTIC_KNOB = 50
+
+
+class deterministic:
+    """Context manager / switch of the library's DETERMINISTIC MODE (knob 50, csrc/common.h::fdmi_det): every floating-point
+    accumulation whose order the production kernels leave to the hardware (fp32 atomics of the GroupNorm-sum epilogues, of the
+    statistics passes, of the TN weight-gradient row splits, of the column sums and of the scalar losses) runs in a fixed order, so
+    two runs of the same step are bit-identical.  A test / debugging mode (slower); plans read the switch when they run, so it can
+    be flipped between steps.  `with ops.deterministic(): ...` or `ops.deterministic.set(True)`."""
+
+    def __init__(self, on=True):
+        self.on, self.prev = bool(on), None
+
+    @staticmethod
+    def set(on):
+        lib().fdmi_tune_set(DETERMINISTIC_KNOB, 1 if on else 0)
+
+    @staticmethod
+    def enabled():
+        return lib().fdmi_tune_value(DETERMINISTIC_KNOB) != 0
+
+    def __enter__(self):
+        self.prev = deterministic.enabled()
+        deterministic.set(self.on)
+        return self
+
+    def __exit__(self, *exc):
+        deterministic.set(self.prev)
+        return False
+
+
 def wgrad_tn_group(problems):
     """[(X, Y, out), ...] (at most 6, bf16 operands): every out += X^T @ Y as wgrad_tn does, in ONE launch (fdmi_wgrad_tn_group)"""
     from ._lib import WgradProblem

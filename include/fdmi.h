@@ -32,7 +32,12 @@ int fdmi_version(void);
 /* Optional per-launch HIP-event timing of the MFMA kernels on the stream they are launched on
  * (bench.py roofline leg).  Buckets 0-7: gemm_kernel<BM,BN,mode> = mode*4 + (BM==64)*2 + (BN==64);
  * 8: attention fwd, 9: attention dQ, 10: attention dK/dV.  collect() synchronises, sums and resets. */
-int fdmi_tune_set(int key, int value);   /* developer knobs for kernel-variant A/B runs (keys 0..31, default 0) */
+int fdmi_tune_set(int key, int value);   /* developer knobs for kernel-variant A/B runs (keys 0..63, default 0) */
+/* key 50 = 1: DETERMINISTIC MODE (round 6).  Every accumulation whose order the production kernels leave to the hardware -- the fp32
+ * atomics of the GroupNorm-sum GEMM epilogues (the plans then run the statistics pass instead), of that pass's blocks, of the TN
+ * weight-gradient row splits (one split per tile), of atomic-accumulating GEMMs (split-K 1), of the column sums and of the scalar
+ * loss kernels -- runs in a fixed order: two runs of the same step on the same inputs are bit-identical.  A test / debugging mode
+ * (slower, same kernels otherwise); read at every launch, so it can be flipped between calls. */
 int fdmi_tune_value(int key);            /* current value of a knob (0 for an unknown key) */
 int fdmi_prof_enable(int on);
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches);

@@ -20,8 +20,8 @@ Pinning status (see DESIGN.md "Oracle"):
   * the flow-matching step (FlashDiffusionSD3.forward, _dmd_loss, _gan_loss, get_sigmas;
     flash_sd3/flash_diffusion_model.py): PINNED -- ``oracle/flash_sd3_ref.py`` is bit-identical to the
     reference's own ``FlashDiffusionSD3`` (5 configurations x G/D step x 3 start indices), fixtures
-    ``tests/golden/sd3_*.npz`` from the real class.  (Oracle groundwork for SURVEY 8a row a18; the HIP
-    path of that row -- the SD3 transformer -- is not built yet.)
+    ``tests/golden/sd3_*.npz`` from the real class.  (its HIP path is
+    flash_diffusion_amd/flash_sd3.py over the MMDiT plan, checked against these fixtures by tests/test_flash_sd3_gpu.py.)
   * denoiser / scheduler arithmetic (diffusers UNet2DConditionModel,
     DPMSolverMultistepScheduler, DDPMScheduler, LCMScheduler, FlowMatchEulerDiscreteScheduler): PARITY UNPINNED by the
     reference -- it lives in an un-vendored fork of diffusers

@@ -86,7 +86,7 @@ def _forward_body(name):
 
 
 # ---- 1c / 1b: full-size steps ----------------------------------------------------------------------------------------------------
-def _check_projected_grads(tag, m, blob, g, fp32):
+def _check_projected_grads(tag, m, blob, g, fp32, det=False):
     from oracle.golden_cases import c1_grad_probe
     names = [str(n) for n in blob["gradnames"]]
     params = {pn: p for pn, p in m.named_parameters()}
@@ -118,7 +118,9 @@ def _check_projected_grads(tag, m, blob, g, fp32):
     else:
         # (worst-of-many statistics with run-to-run noise -- float atomics reorder, bf16 roundings flip: measured over rounds 3 - 5
         # norms 0.7 - 2.4 %, projections 3.4 - 7.3 %, cosines of the tensors stored in full 0.9996 - 1.0000)
-        assert worst_n_big <= 0.06 and worst_p_big <= 0.15 and all(c > 0.998 for _, c in full.values()), \
+        # Deterministic mode (round 6, ops.deterministic()): the step repeats bit for bit, the bars are the ones from BEFORE that allowance
+        nb, pb, cb = (0.04, 0.12, 0.999) if det else (0.06, 0.15, 0.998)
+        assert worst_n_big <= nb and worst_p_big <= pb and all(c > cb for _, c in full.values()), \
             (worst_n_big, worst_p_big, full)
 
 
@@ -168,6 +170,14 @@ def test_c2_shaped_step_matches_reference_golden(precision):
     run_isolated(__name__, "_c2_body", (precision,), timeout=900)
 
 
+@pytest.mark.gpu_mem(60)
+def test_c2_shaped_step_in_deterministic_mode_meets_the_tight_bars():
+    """the same bf16 step in the library's deterministic mode (ordered reductions, ops.deterministic(); bit-identical run to run:
+    tests/test_deterministic_gpu.py) against the bars from before round 5's run-to-run allowances: anchored loss floor 2e-3 (was
+    raised to 1e-2), projected gradient bars 0.04 / 0.12 / 0.999 (0.06 / 0.15 / 0.998) -- VERDICT r5 item 5"""
+    run_isolated(__name__, "_c2_body", ("bf16", 2, True), timeout=900)
+
+
 @pytest.mark.gpu_mem(100)
 @pytest.mark.parametrize("precision", ["bf16", "fp32"])
 def test_c2_step_at_its_own_batch_matches_reference_golden(precision):
@@ -176,8 +186,9 @@ def test_c2_step_at_its_own_batch_matches_reference_golden(precision):
     run_isolated(__name__, "_c2_body", (precision, 16), timeout=1200)
 
 
-def _c2_body(precision, B=2):
-    from flash_diffusion_amd import workloads
+def _c2_body(precision, B=2, det=False):
+    from flash_diffusion_amd import ops, workloads
+    ops.deterministic.set(det)
     from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig, TensorConditioner
     from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
     from flash_diffusion_amd.unet import MiUNet2DConditionModel
@@ -207,13 +218,13 @@ def _c2_body(precision, B=2):
     assert tuple(out["student_output"].shape) == (B, 4, 64, 64)
     bars, tbars = (5e-2, 1e-2, 3e-2), None
     if precision == "bf16":     # anchored to the reference's own bf16-mixed deviation on this fixture
-        bars, tbars, ref = bf16_anchor_bars(tag)
-        log(f"step {tag} [bf16]: reference bf16-mixed deviation teacher {ref[0]:.3e} student {ref[1]:.3e} loss {ref[2]:.3e} -> bars "
+        bars, tbars, ref = bf16_anchor_bars(tag, floor=(4e-3, 2e-3, 2e-3) if det else (4e-3, 2e-3, 1e-2))
+        log(f"step {tag} [bf16{', deterministic' if det else ''}]: reference bf16-mixed deviation teacher {ref[0]:.3e} student {ref[1]:.3e} loss {ref[2]:.3e} -> bars "
             f"{bars[0]:.3e} / {bars[1]:.3e} / {bars[2]:.3e}, terms { {k: f'{v:.1e}' for k, v in tbars.items()} }")
-    _check_outputs(f"{tag} [{precision}]", m, g, out, precision == "fp32", bars, tbars)
+    _check_outputs(f"{tag} [{precision}{', deterministic' if det else ''}]", m, g, out, precision == "fp32", bars, tbars)
     out["loss"][0].backward()
     torch.cuda.synchronize()
-    _check_projected_grads(f"{tag} [{precision}]", m, blob, g, precision == "fp32")
+    _check_projected_grads(f"{tag} [{precision}{', deterministic' if det else ''}]", m, blob, g, precision == "fp32", det)
 
 
 # ---- 1a: full-width B = 1 STEPS of C3 / C4 / C5 -------------------------------------------------------------------------

@@ -59,7 +59,16 @@ def test_tiny_forward_matches_oracle(hw, B):
     assert e < 3e-2 and em < 3e-2 and ef < 3e-2
 
 
-def test_tiny_backward_lora_and_input_grad():
+@pytest.mark.parametrize("mode", ["production", "deterministic"])
+def test_tiny_backward_lora_and_input_grad(mode):
+    """deterministic: the library's ordered-reduction mode (ops.deterministic(), round 6) -- the step repeats bit for bit there, so the
+    per-tensor bar is the one from before round 5's run-to-run allowance (8e-2 instead of 1.5e-1)"""
+    from flash_diffusion_amd import ops
+    with ops.deterministic(mode == "deterministic"):
+        _tiny_backward_body(mode == "deterministic")
+
+
+def _tiny_backward_body(det):
     o = seeded_init_(UNet2DConditionRef(tiny_config()), 1)
     o.add_adapter(8)
     seeded_init_(o, 2)
@@ -90,11 +99,11 @@ def test_tiny_backward_lora_and_input_grad():
             fb.append(ograds[k].float().flatten())
             # the worst of 256 tensors is a noisy statistic (5.8e-2 ... 8.6e-2 over six runs of rounds 3 - 5: the float atomics reorder,
             # a bf16 rounding flips): the per-tensor bar is for gross errors, the norm-weighted error below is the stable one
-            assert er < 1.5e-1, (k, er)
+            assert er < (8e-2 if det else 1.5e-1), (k, er)
         else:
             assert p.grad is None
     glob = rel_err(torch.cat(fa), torch.cat(fb))
-    log(f"tiny bwd: {n} LoRA grads, worst rel err {worst:.3e}, all tensors as one vector {glob:.3e}")
+    log(f"tiny bwd{' [deterministic]' if det else ''}: {n} LoRA grads, worst rel err {worst:.3e}, all tensors as one vector {glob:.3e}")
     assert n == len(ograds) and glob < 5e-2, glob
     # second backward accumulates (+=) like torch
     out2 = m(x.cuda(), t.cuda(), _cuda(cond))
@@ -252,7 +261,14 @@ def _set_knob(k, v):
     _lib.lib().fdmi_tune_set(k, v)
 
 
-def test_folded_lora_and_virtual_concat_match_the_oracle_and_the_unfolded_plan():
+@pytest.mark.parametrize("mode", ["production", "deterministic"])
+def test_folded_lora_and_virtual_concat_match_the_oracle_and_the_unfolded_plan(mode):
+    from flash_diffusion_amd import ops
+    with ops.deterministic(mode == "deterministic"):
+        _folded_body(mode == "deterministic")
+
+
+def _folded_body(det):
     o = seeded_init_(UNet2DConditionRef(_wide_cfg()), 1)
     o.add_adapter(64)
     seeded_init_(o, 2)
@@ -283,10 +299,11 @@ def test_folded_lora_and_virtual_concat_match_the_oracle_and_the_unfolded_plan()
     worst = max(rel_err(grads[k], ograds[k]) for k in grads)
     e0, ex0 = rel_err(out0, ref), rel_err(dx0, xo.grad)
     worst0 = max(rel_err(grads0[k], ograds[k]) for k in grads0)
-    log(f"wide r64 folded: fwd {e:.3e} dx {ex:.3e} worst LoRA grad {worst:.3e} | unfolded: fwd {e0:.3e} dx {ex0:.3e} worst {worst0:.3e} | "
+    log(f"wide r64{' [deterministic]' if det else ''} folded: fwd {e:.3e} dx {ex:.3e} worst LoRA grad {worst:.3e} | unfolded: fwd {e0:.3e} dx {ex0:.3e} worst {worst0:.3e} | "
         f"folded vs unfolded: fwd {rel_err(out, out0):.3e} dx {rel_err(dx, dx0):.3e}")
-    assert len(grads) == len(ograds) and e < 3e-2 and ex < 6e-2 and worst < 1e-1     # (worst-of-many: 4.5e-2 / 4.7e-2 measured)
-    assert e0 < 3e-2 and ex0 < 6e-2 and worst0 < 1e-1
+    wbar = 8e-2 if det else 1e-1                  # (worst-of-many: 4.5e-2 / 4.7e-2 measured; deterministic mode: the pre-round-5 bar)
+    assert len(grads) == len(ograds) and e < 3e-2 and ex < 6e-2 and worst < wbar
+    assert e0 < 3e-2 and ex0 < 6e-2 and worst0 < wbar
     # the folded forward accumulates base and LoRA products in ONE fp32 accumulator (no bf16 rounding of y in between): it is
     # at least as close to the oracle as the unfolded one, and the two agree to bf16 resolution
     assert rel_err(out, out0) < 2e-2 and e < 1.25 * e0 + 1e-3
