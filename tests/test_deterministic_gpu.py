@@ -205,3 +205,81 @@ def test_deterministic_statistics_and_sums_agree_with_the_production_kernels():
         e_dx = float((res[True][2].float() - res[False][2].float()).abs().max() / res[False][2].float().abs().max())
         log(f"groupnorm B={B} HW={HW} C={C}: statistics rel diff {e_s:.2e}, output max diff {e_y:.2e}, dx rel diff {e_dx:.2e}")
         assert e_s < 1e-5 and e_y <= 0.0625 and e_dx < 2e-2, (e_s, e_y, e_dx)    # (a bf16 rounding may flip where the statistics' last bit moved)
+
+
+# ---- the transformer denoisers (C++ plans of dit_plan.h: per-sample column sums, grouped weight gradients, fp32 residual stream) ----
+def _pixart_once(name):
+    from flash_diffusion_amd.dit import MiTransformer2DModel
+    from flash_diffusion_amd.flash import Draws, FlashDiffusion, FlashDiffusionConfig
+    from flash_diffusion_amd.schedulers import DPMSolverMultistepScheduler
+    from oracle.golden_cases import PIXART_STEP_CASES, PromptTableConditioner, build_pixart_step_inputs
+    from tests.golden_util import load_case
+    kw, step, _ = PIXART_STEP_CASES[name]
+    g = load_case(name)
+    cfg, t_o, s_o, head, batch = build_pixart_step_inputs()
+    teacher = MiTransformer2DModel(**cfg)
+    teacher.load_state_dict(t_o.state_dict())
+    teacher = teacher.cuda()
+    teacher.freeze()
+    student = MiTransformer2DModel(**cfg)
+    student.add_adapter(8)
+    student.load_state_dict({k.replace(".base_layer.", "."): v for k, v in s_o.state_dict().items()})
+    student = student.cuda()
+    m = FlashDiffusion(FlashDiffusionConfig(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                       teacher_noise_scheduler=DPMSolverMultistepScheduler(), conditioner=PromptTableConditioner(),
+                       discriminator=copy.deepcopy(head).cuda()).cuda()
+    m.draws = Draws(g["draws"])
+    out = m({k: (v.cuda() if torch.is_tensor(v) else v) for k, v in batch.items()}, step=step, device="cuda")
+    out["loss"][step].backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    return ({k: out[k].detach().clone() for k in ("teacher_output", "student_output")},
+            [out["loss"][i].detach().clone() if torch.is_tensor(out["loss"][i]) else out["loss"][i] for i in (0, 1)], grads)
+
+
+def _sd3_once(name):
+    from flash_diffusion_amd.dit import MiSD3Transformer2DModel
+    from flash_diffusion_amd.flash import Draws
+    from flash_diffusion_amd.flash_sd3 import FlashDiffusionSD3, FlashDiffusionSD3Config, FlowMatchEulerDiscreteScheduler
+    from oracle.flash_sd3_ref import EmbeddingPipeline
+    from oracle.golden_cases import SD3_MMDIT_CASES, build_sd3_mmdit_inputs
+    from tests.golden_util import load_case
+    kw, case, step, _ = SD3_MMDIT_CASES[name]
+    g = load_case(name)
+    cfg, t_o, s_o, head, pipe, batch = build_sd3_mmdit_inputs(case)
+    teacher = MiSD3Transformer2DModel(**cfg)
+    teacher.load_state_dict(t_o.state_dict())
+    teacher = teacher.cuda()
+    teacher.freeze()
+    student = MiSD3Transformer2DModel(**cfg)
+    student.add_adapter(8)
+    student.load_state_dict({k.replace(".base_layer.", "."): v for k, v in s_o.state_dict().items()})
+    student = student.cuda()
+    pipe = EmbeddingPipeline(pipe.e[0].cuda(), pipe.e[2].cuda(), pipe.e[1].cuda(), pipe.e[3].cuda())
+    m = FlashDiffusionSD3(FlashDiffusionSD3Config(**kw), student_denoiser=student, teacher_denoiser=teacher,
+                          teacher_noise_scheduler=FlowMatchEulerDiscreteScheduler(), discriminator=copy.deepcopy(head).cuda(),
+                          pipeline=pipe)
+    m.draws = Draws(g["draws"])
+    out = m({"image": batch["image"].cuda(), "text": batch["text"]}, step=step)
+    out["loss"][step].backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+    return ({k: out[k].detach().clone() for k in ("teacher_output", "student_output")},
+            [out["loss"][i].detach().clone() if torch.is_tensor(out["loss"][i]) else out["loss"][i] for i in (0, 1)], grads)
+
+
+def _dit_twice_body(kind, name):
+    ops.deterministic.set(True)
+    once = _pixart_once if kind == "pixart" else _sd3_once
+    a = once(name)
+    b = once(name)
+    n = _identical(a, b, name)
+    log(f"{kind} step {name}: two deterministic runs bit-identical ({n} gradient tensors)")
+
+
+@pytest.mark.parametrize("kind,name", [("pixart", "pixart_g_dmd_lsgan"), ("sd3", "sd3_mmdit_g_dmd_lsgan")])
+def test_two_runs_of_a_transformer_step_are_bit_identical(kind, name):
+    """the PixArt-alpha DiT (epsilon prediction, DPM-Solver++ teacher loop, masked T5 keys) and the SD3 MMDiT (flow matching) steps
+    with DMD + lsgan GAN through the C++ plans, generator step with every LoRA gradient"""
+    from tests.isolate import run_isolated
+    run_isolated(__name__, "_dit_twice_body", (kind, name), timeout=600)
