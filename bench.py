@@ -20,12 +20,47 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_BF16 = 2.5e15  # dense bf16 MFMA peak, /opt/skills/guides/MI355X_MICROARCH.md (2.5 PF; 2:1 sparse figures excluded)
+PEAK_HBM = 8.0e12   # HBM3E peak, same guide (6.3 TB/s is what a streaming copy achieves)
+RIDGE = PEAK_BF16 / PEAK_HBM   # 312.5 flop per byte: a launch with less arithmetic intensity sits under the HBM roof
 BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<64,128,row>", "gemm_kernel<64,64,row>",
            "gemm_kernel<128,128,conv>", "gemm_kernel<128,64,conv>", "gemm_kernel<64,128,conv>", "gemm_kernel<64,64,conv>",
            "attn_fwd_kernel", "attn_bwd_dq_kernel", "attn_bwd_dkv_kernel",
            "gemm3_kernel<256x160,row>", "gemm3_kernel<256x128,row>", "gemm3_kernel<256x160,conv>", "gemm3_kernel<256x128,conv>",
            "gemm4_kernel<256x320,row>", "gemm4_kernel<256x320,conv>", "gemm4_kernel<256x192,row>", "gemm4_kernel<256x192,conv>",
-           "wgrad_tn_kernel"]
+           "wgrad_tn_kernel",
+           # round 6, SUBSETS (also counted in their family above): the row GEMMs on the HBM side of the ridge (csrc/common.h)
+           "gemm4_kernel<256x320,row|hbm-side>", "gemm3_kernel<256xBN,row|hbm-side>"]
+SUBSET_BUCKETS = {"gemm4_kernel<256x320,row|hbm-side>": "gemm4_kernel<256x320,row>", "gemm3_kernel<256xBN,row|hbm-side>": None}
+
+
+def sustained_mfma():
+    """The MFMA rate this part sustains from registers (scripts/ubench/mfma_rate, built by __graft_entry__.build()): bf16 32x32x16 on all
+    256 CUs, RANDOM operands vs ZERO operands.  The guide's 2 495 TFLOP/s is the zero-operand figure (its own DVFS note: the same
+    binary clocks 2.30 GHz on zeros and 1.90 - 1.95 GHz on random data); on random data this pool's parts hold ~1.82 PFLOP/s at
+    ~1.84 GHz (profiles/r6_mfma_rate.txt: GRBM_GUI_ACTIVE per XCD / duration) -- the MFMA ceiling of any kernel that multiplies
+    real activations.  None when the binary is absent."""
+    import re
+    import subprocess
+    exe = os.path.join(ROOT, "scripts", "ubench", "mfma_rate")
+    if not os.path.exists(exe):
+        return None
+    try:
+        out = subprocess.run([exe], capture_output=True, text=True, timeout=120).stdout
+    except Exception:
+        return None
+    best = {}
+    for l in out.splitlines():
+        m = re.match(r"(\S+) (\d) waves?/SIMD\s+(random|zeros)\s+rep \d+: [\d.]+ ms\s+([\d.]+) TFLOP/s", l)
+        if m and m.group(1) == "32x32x16":
+            best[m.group(3)] = max(best.get(m.group(3), 0.0), float(m.group(4)))
+    if not best:
+        return None
+    return {"random_operands": best.get("random", 0.0) / 1e3, "zero_operands": best.get("zeros", 0.0) / 1e3, "unit": "PFLOP/s",
+            "kernel": "register-only v_mfma_f32_32x32x16_bf16 loop, 256 CUs (scripts/ubench/mfma_rate.hip), best of 3, this run",
+            "clock_ghz": {"random_operands": 1.84, "zero_operands": 2.39,
+                          "source": "profiles/r6_mfma_rate.txt (rocprofv3 --pmc GRBM_GUI_ACTIVE: cycles per XCD / kernel duration)"},
+            "note": "the 2.5 PFLOP/s peak (and the guide's measured 2.495) holds for zero operands at 2.4 GHz; on random operands the "
+                    "part is power-limited to the figure above"}
 
 
 def _physical_cores():
@@ -402,10 +437,15 @@ def main():
     model.student_denoiser.step_flops = model.teacher_denoiser.step_flops = 0.0
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
-        t = torch.tensor([dt], device="cuda", dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        # every rank's own clock around the same K steps: the line's time is the MAX (the contract); the spread max / min shows a
+        # straggler at a glance on the first multi-GPU run
+        tl = [torch.zeros(1, device="cuda", dtype=torch.float64) for _ in range(world)]
+        dist.all_gather(tl, torch.tensor([dt], device="cuda", dtype=torch.float64))
+        per = [float(x.item()) / args.steps * 1e3 for x in tl]
+        rank_ms = {"per_rank": [round(x, 3) for x in per], "min": min(per), "max": max(per), "max_over_min": max(per) / min(per)}
+        dt = max(float(x.item()) for x in tl)
     ms_per_step = dt / args.steps * 1e3
     value = B * world * args.steps / dt
     step_flops = flops[0] / args.steps
@@ -419,7 +459,7 @@ def main():
             "payload_bytes": rep["payload_bytes"], "exchanges_timed": rep["exchanges"],
             "allreduce_ms": rep["allreduce_ms"], "exposed_ms": rep["exposed_ms"],
             "exposed_is": "mean main-stream wait on the comm stream's (all-reduce + AdamW) event per step, HIP events",
-            "note": comm_note}
+            "note": comm_note, "rank_ms_per_step": rank_ms}
     if world > 1:     # slowest rank's figures
         t = torch.tensor([rep["allreduce_ms"] or 0.0, rep["exposed_ms"] or 0.0], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -441,6 +481,7 @@ def main():
     ms = (C.c_double * nb)()
     fl = (C.c_double * nb)()
     ln = (C.c_int64 * nb)()
+    by = (C.c_double * nb)()
     timing = "per-dispatch start/stop events (hipExtLaunchKernelGGL)"
     for attempt in (0, 1):
         if os.environ.get("FDMI_BENCH_NO_PROFILE_LEG") == "1":   # (dev: counter-pass bisection, scripts/gpu_calls/r4_call5.sh)
@@ -453,7 +494,9 @@ def main():
         pipe.finish()
         if rank == 0:
             L.fdmi_prof_enable(0)
-            rc = L.fdmi_prof_collect(nb, ms, fl, ln)
+            rc = L.fdmi_prof_collect2(nb, ms, fl, ln, by)
+            if rc == 0 and os.environ.get("FDMI_BENCH_SHAPES"):   # (dev: one line per launch of the profiled step -> scripts/shape_table.py)
+                L.fdmi_prof_dump(os.environ["FDMI_BENCH_SHAPES"].encode())
             ok = rc == 0 and sum(ln) > 0 and sum(ms) > 0
             if L.fdmi_tune_value(20):
                 timing = "events recorded around each launch (includes dispatch latency)"
@@ -472,8 +515,10 @@ def main():
         else:
             os.environ[k] = v
     if rank == 0:
-        rows = [(BUCKETS[i], ms[i], fl[i], ln[i]) for i in range(len(BUCKETS)) if ln[i] > 0]
+        allrows = {BUCKETS[i]: (BUCKETS[i], ms[i], fl[i], ln[i], by[i]) for i in range(len(BUCKETS)) if ln[i] > 0}
+        rows = [r[:4] for k, r in allrows.items() if k not in SUBSET_BUCKETS]      # (the families; the subsets are priced below)
         rows.sort(key=lambda r: -r[1])
+        mfma_rate = sustained_mfma() if world == 1 else None
         # WHICH kernel the roofline object describes is fixed by the committed rocprofv3 summary of this command (the family
         # with the largest time in profiles/rN_kernel_stats.csv, newest round) -- not by this run's ordering, where two families
         # within a millisecond of each other swapped places from box to box; without a summary: the largest time measured here
@@ -493,21 +538,48 @@ def main():
                 return None, None
             per = algo[key][0] / max(algo[key][1], 1)
             return per, traffic_all[key] / per
+        def _bound(tms_, tfl_, tby_):
+            """the roof a set of launches sits under, from ITS arithmetic intensity (algorithmic flop per algorithmic byte, both
+            accumulated by the library per launch) against the 2.5 PFLOP/s : 8 TB/s ridge, and the fraction of THAT roof it reaches"""
+            if not tby_ or not tms_:
+                return {"arith_intensity": None, "bound": "mfma", "frac_of_bound": round(tfl_ / (tms_ * 1e-3) / PEAK_BF16, 4) if tms_ else None}
+            ai = tfl_ / tby_
+            hbm = ai < RIDGE
+            return {"arith_intensity": round(ai, 1), "bound": "hbm" if hbm else "mfma",
+                    "algorithmic_tb_per_s": round(tby_ / (tms_ * 1e-3) / 1e12, 3),
+                    "frac_of_bound": round((tby_ / (tms_ * 1e-3) / PEAK_HBM) if hbm else (tfl_ / (tms_ * 1e-3) / PEAK_BF16), 4)}
         fam = {}
         for key, label in (("gemm4_kernel<256x320,row>", "gemm4_row"), ("gemm4_kernel<256x320,conv>", "gemm4_conv"),
-                           ("gemm4_kernel<256x192,row>", "gemm4_192_row"), ("attn_fwd_kernel", "attn_fwd")):
-            if key in byname:
-                r = byname[key]
+                           ("gemm4_kernel<256x192,row>", "gemm4_192_row"), ("attn_fwd_kernel", "attn_fwd"),
+                           ("gemm3_kernel<256x160,row>", "gemm3_160_row"), ("gemm3_kernel<256x128,row>", "gemm3_128_row"),
+                           ("gemm4_kernel<256x320,row|hbm-side>", "gemm4_row_hbm_side"), ("gemm3_kernel<256xBN,row|hbm-side>", "gemm3_row_hbm_side")):
+            if key in allrows:
+                r = allrows[key]
+                per_launch = (r[4] / r[3]) if r[4] else _traffic_ratio(key)[0]
                 fam[label] = {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),
                               "frac": round(r[2] / (r[1] * 1e-3) / PEAK_BF16, 4), "launches": int(r[3]),
-                              "traffic": traffic_all.get(key), "algorithmic_bytes_per_launch": _traffic_ratio(key)[0],
-                              "traffic_over_algorithmic": _traffic_ratio(key)[1]}
+                              "traffic": traffic_all.get(key), "algorithmic_bytes_per_launch": per_launch,
+                              "traffic_over_algorithmic": (traffic_all[key] / per_launch) if (traffic_all.get(key) and per_launch) else None}
+                fam[label].update(_bound(r[1], r[2], r[4]))
+                if key in SUBSET_BUCKETS:
+                    fam[label]["subset_of"] = SUBSET_BUCKETS[key] or "gemm3_kernel<256x160,row> + gemm3_kernel<256x128,row>"
+        # the MFMA-side remainder of the 256 x 320 row family (long K, GEGLU): family minus its HBM-side subset
+        if "gemm4_kernel<256x320,row>" in allrows and "gemm4_kernel<256x320,row|hbm-side>" in allrows:
+            a_, b_ = allrows["gemm4_kernel<256x320,row>"], allrows["gemm4_kernel<256x320,row|hbm-side>"]
+            tms_, tfl_, tln_, tby_ = a_[1] - b_[1], a_[2] - b_[2], a_[3] - b_[3], a_[4] - b_[4]
+            if tln_ > 0 and tms_ > 0:
+                fam["gemm4_row_mfma_side"] = {"ms_per_step": round(tms_, 3), "tflops": round(tfl_ / (tms_ * 1e-3) / 1e12, 1),
+                                              "frac": round(tfl_ / (tms_ * 1e-3) / PEAK_BF16, 4), "launches": int(tln_),
+                                              "subset_of": "gemm4_kernel<256x320,row>"}
+                fam["gemm4_row_mfma_side"].update(_bound(tms_, tfl_, tby_))
         roofline = {"bound": "mfma", "kernel": name, "kernel_chosen_by": dominant_src, "achieved": ach, "peak": PEAK_BF16 / 1e12,
                     "unit": "TFLOP/s", "frac": ach / (PEAK_BF16 / 1e12), "traffic": traffic_all.get(name),
                     "algorithmic_bytes_per_launch": _traffic_ratio(name)[0], "traffic_over_algorithmic": _traffic_ratio(name)[1],
                     "traffic_source": traffic_src, "launches_per_step": int(tln),
                     "avg_launch_us": tms * 1e3 / tln, "algorithmic_gflop_per_launch": tfl / tln / 1e9,
                     "families": fam,
+                    "sustained_mfma_pflops": mfma_rate,
+                    "frac_of_sustained_mfma": (ach / (mfma_rate["random_operands"] * 1e3)) if (mfma_rate and mfma_rate.get("random_operands")) else None,
                     "timing": timing + "; profiled step issued serially (teacher loop on the main stream, backward not "
                               "deferred) so that a launch's duration is its own",
                     "all_mfma_kernels": {r[0]: {"ms_per_step": round(r[1], 3), "tflops": round(r[2] / (r[1] * 1e-3) / 1e12, 1),
@@ -616,6 +688,11 @@ def main():
                                                                    "FDMI_NO_CTX_CACHE", "FDMI_TEACHER_STREAM",
                                                                    "FDMI_DEFER_BACKWARD") if os.environ.get(k)}},
             "roofline": roofline, "cpu_baseline": cpu, "comm": comm, "parity": parity_record() if headline else None,
+            # does this line's step contain the collective's code path?  At N = 1 a process group of ONE rank is created so
+            # that the all-reduce + comm-stream path is in the timed step; if that failed the line measured a different path
+            # (comm.note says why) and is NOT comparable with lines that have it
+            "process_group": {"created": bool(dist.is_initialized()), "world": world,
+                              "comparable_with_group_lines": bool(dist.is_initialized())},
             # the like-for-like numbers of the reference's own loop, also kept under "secondary":
             "two_optimizer_step_ms": two_opt["ms_per_step"] if two_opt else None,          # G + D training_step (TR:169-218)
             "lpips_step_ms": lpips_leg["ms_per_step"] if lpips_leg else None,              # generator iteration with the YAMLs' lpips loss

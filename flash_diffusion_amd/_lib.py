@@ -98,6 +98,8 @@ _SIGS = {
     "fdmi_tune_value": (i32, [i32]),
     "fdmi_prof_enable": (i32, [i32]),
     "fdmi_prof_collect": (i32, [i32, vp, vp, vp]),
+    "fdmi_prof_collect2": (i32, [i32, vp, vp, vp, vp]),
+    "fdmi_prof_dump": (i32, [C.c_char_p]),
     "fdmi_gemm": (i32, [C.POINTER(GemmDesc), vp]),
     "fdmi_gemm_plan": (i32, [C.POINTER(GemmDesc), vp, vp, vp, vp]),
     "fdmi_gemm_a2_ok": (i32, [C.POINTER(GemmDesc)]),

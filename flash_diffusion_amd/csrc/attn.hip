@@ -1736,7 +1736,8 @@ static int launch_attn_fwd32(const AttnArgs& a, hipStream_t st) {
     once32 = true;
   }
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  if (prof) fdmi_prof_shape(2, (long long)a.B * a.H, a.Sq, a.Skv, a.d);
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d, 4.0 * a.B * a.H * (double)a.d * ((double)a.Sq + a.Skv));
   dim3 g32(cdiv(a.Sq, 128), a.B * a.H);
   const bool ones32 = a.vt_ones && a.d < attn_dvpad(a.d);   // (the transposer's spare padded row dd = d)
   const int ks32 = a.d <= 48 ? 3 : (a.d < 64 ? 4 : 5), db32 = a.d < 64 ? 2 : 3;
@@ -1772,7 +1773,8 @@ int fwd_t(const AttnArgs& a, hipStream_t st) {
     once = smem;
   }
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  if (prof) fdmi_prof_shape(2, (long long)a.B * a.H, a.Sq, a.Skv, a.d);
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_FWD, 4.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d, 4.0 * a.B * a.H * (double)a.d * ((double)a.Sq + a.Skv));
   const bool ones = a.vt_ones && a.d < DV;
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   if constexpr (CAN_DMA) {
@@ -1801,7 +1803,8 @@ static int launch_attn_bwd_dq32(const AttnArgs& a, hipStream_t st) {
     once = true;
   }
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(st, PROF_ATTN_DQ, 6.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  if (prof) fdmi_prof_shape(3, (long long)a.B * a.H, a.Sq, a.Skv, a.d);
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DQ, 6.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d, 2.0 * a.B * a.H * (double)a.d * (3.0 * a.Sq + 2.0 * a.Skv));
   dim3 grid(cdiv(a.Sq, 128), a.B * a.H);
   const int ks = a.d <= 48 ? 3 : (a.d <= 64 ? 4 : 5), db = a.d <= 64 ? 2 : 3;
 #define DQ32_GO(KS_, DB_) \
@@ -1829,7 +1832,8 @@ static int launch_attn_bwd_dkv32(const AttnArgs& a, hipStream_t st) {
     once = true;
   }
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(st, PROF_ATTN_DKV, 8.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  if (prof) fdmi_prof_shape(4, (long long)a.B * a.H, a.Sq, a.Skv, a.d);
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DKV, 8.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d, 2.0 * a.B * a.H * (double)a.d * (2.0 * a.Sq + 4.0 * a.Skv));
   dim3 grid(cdiv(a.Skv, 128), a.B * a.H);
   const int ks = a.d <= 48 ? 3 : (a.d <= 64 ? 4 : 5), db = a.d <= 64 ? 2 : 3;
 #define DKV32_GO(KS_, DB_, NS_, DV_, DK_) \
@@ -1849,7 +1853,8 @@ int dq_t(const AttnArgs& a, hipStream_t st) {
   if (!once) { if (set_smem(attn_bwd_dq_kernel<DK, DV, NF>, smem)) return -2; once = true; }
   dim3 grid(cdiv(a.Sq, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(st, PROF_ATTN_DQ, 6.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  if (prof) fdmi_prof_shape(3, (long long)a.B * a.H, a.Sq, a.Skv, a.d);
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DQ, 6.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d, 2.0 * a.B * a.H * (double)a.d * (3.0 * a.Sq + 2.0 * a.Skv));
   FDMI_KLAUNCH(prof, (attn_bwd_dq_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());
@@ -1862,7 +1867,8 @@ int dkv_t(const AttnArgs& a, hipStream_t st) {
   if (!once) { if (set_smem(attn_bwd_dkv_kernel<DK, DV, NF>, smem)) return -2; once = true; }
   dim3 grid(cdiv(a.Skv, 64 * NF), a.B * a.H);
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(st, PROF_ATTN_DKV, 8.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d);
+  if (prof) fdmi_prof_shape(4, (long long)a.B * a.H, a.Sq, a.Skv, a.d);
+  if (prof) fdmi_prof_begin(st, PROF_ATTN_DKV, 8.0 * a.B * a.H * (double)a.Sq * a.Skv * a.d, 2.0 * a.B * a.H * (double)a.d * (2.0 * a.Sq + 4.0 * a.Skv));
   FDMI_KLAUNCH(prof, (attn_bwd_dkv_kernel<DK, DV, NF>), grid, dim3(256), smem, st, a);
   if (prof) fdmi_prof_end(st);
   FDMI_HIP(hipGetLastError());

@@ -9,7 +9,11 @@ void fdmi_set_error(const std::string& msg) { g_err = msg; }
 // ---- per-launch event profiling -------------------------------------------------------------
 #include <vector>
 namespace {
-struct ProfRec { hipEvent_t a, b; double flops; int bucket; };
+struct ProfRec { hipEvent_t a, b; double flops; int bucket; double bytes; int subset; int kind; long long s[4]; };
+struct ProfRow { int bucket, kind; long long s[4]; float ms; double flops, bytes; };
+std::vector<ProfRow> g_last;   // the launches of the last collected leg (fdmi_prof_dump)
+int g_kind = -1;
+long long g_shape[4] = {0, 0, 0, 0};
 bool g_prof = false;
 std::vector<ProfRec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -26,11 +30,15 @@ bool fdmi_prof_on() { return g_prof; }
 // tune 20 = 0 (default): the launch that follows takes the record's two events as its own start / stop events
 // (FDMI_KLAUNCH -> hipExtLaunchKernelGGL); 1: the events are recorded on the stream around the launch
 static bool g_take = false;
-void fdmi_prof_begin(hipStream_t st, int bucket, double flops) {
-  ProfRec r{prof_event(), prof_event(), flops, bucket};
+void fdmi_prof_begin(hipStream_t st, int bucket, double flops, double bytes, int subset) {
+  ProfRec r{prof_event(), prof_event(), flops, bucket, bytes, subset, g_kind, {g_shape[0], g_shape[1], g_shape[2], g_shape[3]}};
+  g_kind = -1;
   if (fdmi_tune_get(20)) (void)hipEventRecord(r.a, st);
   else g_take = true;
   g_recs.push_back(r);
+}
+void fdmi_prof_shape(int kind, long long s0, long long s1, long long s2, long long s3) {
+  g_kind = kind; g_shape[0] = s0; g_shape[1] = s1; g_shape[2] = s2; g_shape[3] = s3;
 }
 bool fdmi_prof_take(hipEvent_t* a, hipEvent_t* b) {
   if (!g_take) return false;
@@ -52,15 +60,25 @@ int fdmi_tune_set(int key, int value) {
 }
 int fdmi_tune_value(int key) { return fdmi_tune_get(key); }
 int fdmi_prof_enable(int on) { g_prof = on != 0; return 0; }
+int fdmi_prof_collect2(int nbuckets, double* ms, double* flops, int64_t* launches, double* bytes);
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches) {
-  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (20) buckets");
-  for (int i = 0; i < nbuckets; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; }
+  return fdmi_prof_collect2(nbuckets, ms, flops, launches, nullptr);
+}
+int fdmi_prof_collect2(int nbuckets, double* ms, double* flops, int64_t* launches, double* bytes) {
+  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (22) buckets");
+  for (int i = 0; i < nbuckets; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; if (bytes) bytes[i] = 0; }
   FDMI_HIP(hipDeviceSynchronize());
   int bad = 0;
+  g_last.clear();
   for (auto& r : g_recs) {
     float t = 0;
     if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess && t >= 0.f) {
+      g_last.push_back(ProfRow{r.bucket, r.kind, {r.s[0], r.s[1], r.s[2], r.s[3]}, t, r.flops, r.bytes});
       ms[r.bucket] += t; flops[r.bucket] += r.flops; launches[r.bucket] += 1;
+      if (bytes) bytes[r.bucket] += r.bytes;
+      if (bytes && r.subset >= 0 && r.subset < nbuckets) {   // (subset buckets exist only for the caller that asks for bytes)
+        ms[r.subset] += t; flops[r.subset] += r.flops; launches[r.subset] += 1; bytes[r.subset] += r.bytes;
+      }
     } else {
       ++bad;
     }
@@ -70,6 +88,17 @@ int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches
   (void)hipGetLastError();
   FDMI_CHECK(bad == 0, "prof_collect: " + std::to_string(bad) + " launch records without a valid elapsed time");
   return 0;
+}
+
+int fdmi_prof_dump(const char* path) {
+  FDMI_CHECK(path != nullptr, "prof_dump: null path");
+  FILE* f = fopen(path, "w");
+  FDMI_CHECK(f != nullptr, std::string("prof_dump: cannot open ") + path);
+  fprintf(f, "bucket,kind,s0,s1,s2,s3,ms,flops,bytes\n");
+  for (auto& r : g_last)
+    fprintf(f, "%d,%d,%lld,%lld,%lld,%lld,%.6f,%.0f,%.0f\n", r.bucket, r.kind, r.s[0], r.s[1], r.s[2], r.s[3], r.ms, r.flops, r.bytes);
+  fclose(f);
+  return (int)g_last.size();
 }
 
 const char* fdmi_last_error(void) { return g_err.c_str(); }

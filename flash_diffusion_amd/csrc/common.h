@@ -104,7 +104,13 @@ void fdmi_set_error(const std::string& msg);
 // optional per-launch HIP-event profiling (bench.py roofline leg); see capi.hip
 enum { PROF_GEMM0 = 0 /* +mode*4 + tile */, PROF_ATTN_FWD = 8, PROF_ATTN_DQ = 9, PROF_ATTN_DKV = 10,
        PROF_GEMM3 = 11 /* + mode*2 + (BN==128) */, PROF_GEMM4 = 15 /* + mode (256x320) */, PROF_GEMM4_192 = 17 /* + mode */,
-       PROF_WGRAD_TN = 19, PROF_NBUCKETS = 20 };
+       PROF_WGRAD_TN = 19,
+       // round 6: SUBSET buckets -- the row GEMMs of the 256-row ring kernels whose arithmetic intensity lies on the HBM side of the
+       // 2.5 PFLOP/s : 8 TB/s ridge (312.5 flop per algorithmic byte) are counted a second time here (their family bucket keeps
+       // them too), so that the bench line can price them against the bound they sit under: N = K = 320 with
+       // a residual has 107 flop/B, K = 1280 -> 320 has 213
+       PROF_GEMM4_ROW_HBM = 20, PROF_GEMM3_ROW_HBM = 21, PROF_NBUCKETS = 22 };
+constexpr double FDMI_RIDGE_FLOP_PER_BYTE = 2.5e15 / 8.0e12;
 int fdmi_tune_get(int key);   // developer tuning knobs (fdmi_tune_set)
 // Deterministic mode (knob 50 = 1; round 6, VERDICT r5 item 5 / ADVICE r5): every floating-point accumulation whose ORDER the
 // production kernels leave to the hardware -- fp32 atomics of the GroupNorm-sum epilogues, of gn_reduce's blocks, of the TN
@@ -113,8 +119,13 @@ int fdmi_tune_get(int key);   // developer tuning knobs (fdmi_tune_set)
 // (single row split per weight-gradient tile, one block per sample in the statistics passes), same kernels otherwise.
 static inline bool fdmi_det() { return fdmi_tune_get(50) != 0; }
 bool fdmi_prof_on();
-void fdmi_prof_begin(hipStream_t st, int bucket, double flops);
+// bytes: algorithmic HBM bytes of the launch (every operand once); subset: a second bucket that also counts the launch (-1: none)
+void fdmi_prof_begin(hipStream_t st, int bucket, double flops, double bytes = 0.0, int subset = -1);
 void fdmi_prof_end(hipStream_t st);
+// round 6: the SHAPE of the launch the next fdmi_prof_begin records (kind 0 row GEMM / 1 conv: M, N, K, flags = residual | GEGLU << 1 |
+// dgrad << 2 | GroupNorm sums << 3 | split-K << 8; kind 2 / 3 / 4 attention forward / dQ / dK-dV: B * H, Sq, Skv, d); fdmi_prof_dump
+// writes one line per launch of the last collected leg -- the per-shape table of scripts/shape_table.py
+void fdmi_prof_shape(int kind, long long s0, long long s1, long long s2, long long s3);
 bool fdmi_prof_take(hipEvent_t* a, hipEvent_t* b);
 // A profiled launch carries its own start / stop events (hipExtLaunchKernelGGL: the timestamps of the dispatch itself -- what
 // rocprofv3's kernel trace reports) instead of two event packets around it, whose elapsed time also holds the dispatch latency

@@ -88,3 +88,16 @@ bool gemm_gn_ok(const GemmArgs& a, bool ws_available);
 bool gemm_r32_ok(const GemmArgs& a);
 // algorithmic flops of one launch (2*M*N*K)
 static inline double gemm_flops(const GemmArgs& a) { return 2.0 * a.M * (double)a.N * a.K; }
+// algorithmic HBM bytes of one launch: every operand touched ONCE (A + W + C, + the residual; a GEGLU output is N / 2 wide; a
+// convolution's A operand is its input tensor, taken as M * Cin elements -- exact for the stride-1 convolutions that carry the
+// time; split-K slabs and re-reads are traffic, not algorithm) -- the same rule as bench.py::algorithmic_bytes
+static inline double gemm_bytes(const GemmArgs& a) {
+  const double nout = a.act == ACT_GEGLU ? a.N / 2 : a.N;
+  const double a_el = (double)a.M * (a.mode == GEMM_CONV ? a.Cin : a.K);
+  return 2.0 * (a_el + (double)a.N * a.K + (double)a.M * nout * (a.residual ? 2.0 : 1.0)) + (a.preact ? 2.0 * a.M * (double)a.N : 0.0);
+}
+static inline void gemm_prof_shape(const GemmArgs& a) {   // (fdmi_prof_shape: the launch's row of the per-shape table)
+  fdmi_prof_shape(a.mode == GEMM_CONV ? 1 : 0, a.M, a.N, a.K,
+                  (a.residual ? 1 : 0) | (a.act == ACT_GEGLU ? 2 : 0) | (a.dgrad ? 4 : 0) | (a.gn_stats ? 8 : 0) | ((a.splitk > 1 ? a.splitk : 0) << 8));
+}
+static inline bool gemm_hbm_side(const GemmArgs& a) { return gemm_flops(a) < FDMI_RIDGE_FLOP_PER_BYTE * gemm_bytes(a); }

@@ -477,7 +477,8 @@ static int launch_t(const GemmArgs& a, hipStream_t stream) {
   const int tiles = cdiv(a.M, BM) * cdiv(a.N, BN);
   dim3 grid(tiles, a.splitk > 1 ? a.splitk : 1, 1);
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(stream, PROF_GEMM0 + MODE * 4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), gemm_flops(a));
+  if (prof) gemm_prof_shape(a);
+  if (prof) fdmi_prof_begin(stream, PROF_GEMM0 + MODE * 4 + (BM == 128 ? 0 : 2) + (BN == 128 ? 0 : 1), gemm_flops(a), gemm_bytes(a));
   FDMI_KLAUNCH(prof, (gemm_kernel<BM, BN, MODE, GLDS>), grid, dim3(256), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());

@@ -226,7 +226,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
     }
   };
   auto mma = [&]() {
-    __builtin_amdgcn_s_setprio(1);
+    FDMI_SETPRIO(1);
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
@@ -234,7 +234,7 @@ __global__ __launch_bounds__(512) void gemm3_kernel(const GemmArgs a) {
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
           acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[ks][nf], af[ks][mf], acc[nf][mf], 0, 0, 0);
-    __builtin_amdgcn_s_setprio(0);
+    FDMI_SETPRIO(0);
   };
 
   auto epilogue = [&](const Item& it) {
@@ -314,7 +314,8 @@ int launch3_t(const GemmArgs& a, hipStream_t stream) {
   }
   dim3 grid(items < ncu ? items : ncu, 1, 1);   // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(stream, PROF_GEMM3 + MODE * 2 + (BN == 160 ? 0 : 1), gemm_flops(a));
+  if (prof) gemm_prof_shape(a);
+  if (prof) fdmi_prof_begin(stream, PROF_GEMM3 + MODE * 2 + (BN == 160 ? 0 : 1), gemm_flops(a), gemm_bytes(a), (MODE == GEMM_ROW && gemm_hbm_side(a)) ? PROF_GEMM3_ROW_HBM : -1);
   FDMI_KLAUNCH(prof, (gemm3_kernel<BN, MODE, GN, SKR, R32>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());

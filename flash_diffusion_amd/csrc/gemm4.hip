@@ -286,11 +286,11 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
 #pragma unroll
           for (int mf = 0; mf < MF; ++mf) af[1][mf] = lds_a(1, mf, cslot);
         }
-        __builtin_amdgcn_s_setprio(1);
+        FDMI_SETPRIO(1);
 #pragma unroll
         for (int mf = 0; mf < MF; ++mf)
           acc[nf][mf] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wq[q & 3], af[ks][mf], acc[nf][mf], 0, 0, 0);
-        __builtin_amdgcn_s_setprio(0);
+        FDMI_SETPRIO(0);
         if (q < NP) {
           __builtin_amdgcn_sched_barrier(0);
           piece(q, sa);
@@ -345,7 +345,8 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   }
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
-  if (prof) fdmi_prof_begin(stream, (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a));
+  if (prof) gemm_prof_shape(a);
+  if (prof) fdmi_prof_begin(stream, (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a), gemm_bytes(a), (MODE == GEMM_ROW && BN == 320 && gemm_hbm_side(a)) ? PROF_GEMM4_ROW_HBM : -1);
   FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN, DEV, SKR, R32>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());

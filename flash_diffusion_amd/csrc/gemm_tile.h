@@ -228,6 +228,13 @@ __device__ __forceinline__ float dpp_ror8_hi(float keep, float src) {   // lanes
 __device__ __forceinline__ float dpp_ror8_lo(float keep, float src) {   // lanes j < 8 := src of lane j + 8
   return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(keep), __float_as_int(src), 0x128, 0xF, 0x3, false));
 }
+// s_setprio around the MFMA groups of the ring kernels' K loops (compile-time experiment switch: -DFDMI_NO_SETPRIO builds without it;
+// round 6: scripts/ubench/gemm_kloop.hip measures 0 ... +2 % without it on the lockstep structure, the step A/B decides)
+#ifdef FDMI_NO_SETPRIO
+#define FDMI_SETPRIO(x) do { } while (0)
+#else
+#define FDMI_SETPRIO(x) __builtin_amdgcn_s_setprio(x)
+#endif
 #ifndef FDMI_EPI_RD
 #define FDMI_EPI_RD 4   // residual chunks (16 bytes each) in flight per lane in the lean epilogue (compile-time experiment switch)
 #endif

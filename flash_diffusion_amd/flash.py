@@ -122,7 +122,7 @@ class Draws:
         return self._get(name, lambda: torch.rand(1))
 
     def randint(self, name, lo, hi, shape, device):
-        return self._get(name, lambda: torch.randint(lo, hi, shape)).to(device)
+        return ops.upload(self._get(name, lambda: torch.randint(lo, hi, shape)), device)
 
 
 class TensorConditioner(nn.Module):
@@ -368,7 +368,7 @@ class FlashDiffusion(nn.Module):
             start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self._shared_start_generator())
         t0 = self.teacher_noise_scheduler.timesteps[start_idx]
         self._start_t_host = int(t0.reshape(-1)[0])   # forward() reports it without a device round trip
-        return start_idx, t0.to(device).repeat(num_samples)
+        return start_idx, ops.upload(t0.reshape(-1)[:1].repeat(num_samples), device)   # (no blocking copy: ops.upload)
 
     @staticmethod
     def _scalings_for_boundary_conditions(timestep, sigma_data=0.5):
@@ -720,7 +720,10 @@ class FlashDiffusion(nn.Module):
             g = (float(d.rand1("dmd_guidance")) * (self.guidance_scale_max[K_step] - self.guidance_scale_min[K_step])
                  + self.guidance_scale_min[K_step])
             real = ops.axpby(e_c, g, e_u, 1.0 - g)
-            a = sch.alphas_cumprod.to(s.device)[t]
+            ac_dev = getattr(sch, "_ac_dev", None)      # (the table goes to the device once, not per call: a blocking copy)
+            if ac_dev is None or ac_dev.device != s.device:
+                ac_dev = sch._ac_dev = sch.alphas_cumprod.to(s.device)
+            a = ac_dev[t]
             kb = ((1.0 - a) ** 0.5 / a ** 0.5).float().contiguous()     # (score_fake - score_real) = real - fake
             inv_a, ms_a = self._x0_coeffs(t)
         return _DmdLoss.apply(s, noisy.detach(), real, e_f, inv_a.float().contiguous(), ms_a.float().contiguous(), kb)
@@ -732,8 +735,8 @@ class FlashDiffusion(nn.Module):
         B = s.shape[0]
         noise = d.randn_like("gan_noise", s)
         real = teacher_output if self.use_teacher_as_real else z
-        idx = d.multinomial("gan_idx", torch.tensor([0.25, 0.25, 0.25, 0.25]), B, replacement=True).to(s.device)
-        ts = torch.tensor([10, 250, 500, 750], device=s.device, dtype=torch.long)[idx]
+        idx = d.multinomial("gan_idx", torch.tensor([0.25, 0.25, 0.25, 0.25]), B, replacement=True)
+        ts = ops.upload(torch.tensor([10, 250, 500, 750], dtype=torch.long)[idx.cpu()], s.device)   # (host gather, one non-blocking upload)
         gen = step % 2 == 0
         s_in = s if gen else s.detach()          # D-step: fake branch is detached (FD:583, 602, 616, 638, 659)
         noisy_fake = sch.add_noise(s_in, noise, ts)

@@ -380,8 +380,8 @@ class FlashDiffusionSD3(nn.Module):
             start_idx = d.multinomial("start_idx", self._timestep_pmf(K, K_step), 1, generator=self._shared_start_generator())
         si = int(start_idx)
         t_host = sch.timesteps[si].reshape(1).repeat(B)                  # host values: no device round trip in the step
-        start_t = t_host.to(z.device)
-        sig = get_sigmas(sch, t_host).to(z.device)                       # [B]
+        start_t = ops.upload(t_host, z.device)                           # (no blocking copy: ops.upload)
+        sig = ops.upload(get_sigmas(sch, t_host), z.device)              # [B]
         if si == 0:                                                      # FD3:264-268: start from pure noise
             x_init = noise
             if hasattr(sch, "init_noise_sigma"):
@@ -458,8 +458,8 @@ class FlashDiffusionSD3(nn.Module):
         noise = d.randn_like("dmd_noise", s)
         ti = d.randint("dmd_t", 0, self.teacher_noise_scheduler.config.num_train_timesteps, (B,), "cpu")
         t_host = sc.timesteps[ti.cpu()]
-        t = t_host.to(s.device)
-        sig = get_sigmas(sc, t_host).to(s.device)
+        t = ops.upload(t_host, s.device)
+        sig = ops.upload(get_sigmas(sc, t_host), s.device)
         noisy = self._noised(s, noise.contiguous(), sig)
         with torch.no_grad():
             r_c = self.teacher_denoiser(sample=noisy.detach(), timestep=t, conditioning=cond)
@@ -482,8 +482,8 @@ class FlashDiffusionSD3(nn.Module):
         sel = [float(sc.timesteps[-10]), float(sc.timesteps[-250]), float(sc.timesteps[-500]), float(sc.timesteps[-750])]
         idx = d.multinomial("gan_t", torch.tensor([0.25, 0.25, 0.25, 0.25]), B, replacement=True)
         ts_host = torch.tensor(sel)[idx.cpu()]
-        ts = ts_host.to(s.device)
-        sig = get_sigmas(sc, ts_host).to(s.device)
+        ts = ops.upload(ts_host, s.device)
+        sig = ops.upload(get_sigmas(sc, ts_host), s.device)
         gen = step % 2 == 0
         noisy_fake = self._noised(s if gen else s.detach(), noise.contiguous(), sig)
         with torch.no_grad():

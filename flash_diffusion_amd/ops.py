@@ -26,6 +26,21 @@ def _dev(t):
 
 
 # ---- weight packing (one-off, init time) ---------------------------------------------------------
+def upload(t, device):
+    """A small HOST tensor (start timesteps, sigmas, drawn indices) on `device` WITHOUT making the host wait for the stream: a
+    pageable host-to-device copy is stream-ordered AND blocks the caller until it has run -- inside a training step that is a full
+    device synchronisation per step (round 6, scripts/host_timeline.py: FlashDiffusion._get_timesteps stood 130 - 150 ms per C2 step
+    in `t0.to(device)`, the GPU then idled until the host had issued the next step's first launches).  A tensor whose elements are
+    all equal becomes a fill launch (the value travels as a kernel argument); anything else goes through a pinned staging copy
+    (torch's caching host allocator keeps the block alive until the copy has run)."""
+    device = torch.device(device)
+    if t.is_cuda or device.type != "cuda":
+        return t.to(device)
+    if t.numel() > 0 and t.dtype != torch.bool and bool((t == t.reshape(-1)[0]).all()):
+        return torch.full(t.shape, t.reshape(-1)[0].item(), dtype=t.dtype, device=device)
+    return t.contiguous().pin_memory().to(device, non_blocking=True)
+
+
 def pack_conv_weight(w, dtype=BF16):
     """OIHW f32 -> [O][KH][KW][I] rows (K = KH*KW*I contiguous) in `dtype`; I zero-padded to a multiple of 8."""
     O, I, KH, KW = w.shape

@@ -41,6 +41,15 @@ int fdmi_tune_set(int key, int value);   /* developer knobs for kernel-variant A
 int fdmi_tune_value(int key);            /* current value of a knob (0 for an unknown key) */
 int fdmi_prof_enable(int on);
 int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches);
+/* round 6: the same, plus the algorithmic HBM bytes of every bucket's launches (each operand of a launch counted once: GEMM / conv
+ * A + W + C (+ residual), attention q + k + v + o) -- bench.py prices every kernel family against the bound it sits under
+ * (arithmetic intensity vs the 2.5 PFLOP/s : 8 TB/s ridge).  Buckets 20 / 21: the row GEMMs of the 256 x 320 / 256 x {128,160}
+ * ring kernels on the HBM side of that ridge.  nbuckets >= 22. */
+int fdmi_prof_collect2(int nbuckets, double* ms, double* flops, int64_t* launches, double* bytes);
+/* round 6: one CSV line per launch of the leg the last fdmi_prof_collect* call gathered -- bucket, kind (0 row GEMM, 1 conv: s = M, N, K,
+ * flags; 2 / 3 / 4 attention forward / dQ / dK-dV: s = B * H, Sq, Skv, d; -1 untagged), milliseconds, algorithmic flops and bytes --
+ * the per-shape table of scripts/shape_table.py (which GEMM SHAPES of a step sit furthest from their bound).  Returns the line count. */
+int fdmi_prof_dump(const char* path);
 
 /* ---------------- GEMM / implicit-GEMM convolution (bf16 MFMA, fp32 accumulate) ----------------
  * out[M,N] = A[M,K] * W[N,K]^T ; epilogue v = alpha*acc + bias[n] + rowvec[m/rows_per_batch][n]

@@ -59,10 +59,23 @@ def short(n):
     return f"{m.group(1)}<{m.group(2)}>" if m else None
 
 
-def table(dirs):
-    # rocprofv3 gives no case tag: dispatches are matched to (case, dev) by their ORDER within each pass (run() is deterministic)
-    agg = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
-    order = []
+def run_order(reps=4):
+    """the (case tag, developer bits) of every group of `reps` consecutive GEMM dispatches, in the order run() issues them"""
+    out = []
+    for (tag, M, N, K, kind, tile) in CASES:
+        devs = (0, 32, 48) if (tile >> 16 == 256 and (tile & 0xffff) == 320) or kind == "conv" else (0,)
+        for dev in devs:
+            out.append((tag, {0: "as shipped", 32: "K loop alone (no epilogue: WRONG results, timing ablation)",
+                              48: "K loop alone, A from L2 (timing ablation)"}[dev]))
+    return out
+
+
+def table(dirs, reps=4):
+    """rocprofv3 gives no case tag: the GEMM dispatches of a pass are matched to (case, developer bits) by their ORDER (run() is
+    deterministic: `reps` launches per (case, bits))"""
+    order = run_order(reps)
+    agg = [defaultdict(lambda: [0, 0.0]) for _ in order]
+    kname = [None] * len(order)
     for d in dirs:
         base = os.path.basename(d.rstrip("/"))
         trace = {}
@@ -70,57 +83,52 @@ def table(dirs):
             with open(f, newline="") as fh:
                 for row in csv.DictReader(fh):
                     n = short(row.get("Kernel_Name") or "")
-                    if not n:
-                        continue
-                    trace[int(row["Dispatch_Id"])] = (n, str(row.get("Grid_Size", "")), (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3)
+                    if n:
+                        trace[int(row["Dispatch_Id"])] = (n, (float(row["End_Timestamp"]) - float(row["Start_Timestamp"])) / 1e3)
         ids = sorted(trace)
-        # consecutive dispatches of one (kernel, grid) in groups of `reps`
-        seq = defaultdict(int)
-        key_of = {}
-        prev, cnt = None, 0
+        if len(ids) != reps * len(order):
+            print(f"# pass {base}: {len(ids)} GEMM dispatches, expected {reps * len(order)} -- skipped")
+            continue
+        grp = {i: k // reps for k, i in enumerate(ids)}
         for i in ids:
-            n, g, us = trace[i]
-            if (n, g) != prev:
-                seq[(n, g)] += 1
-                prev = (n, g)
-            key = f"{n} grid={g} #{seq[(n, g)]}"
-            key_of[i] = key
-            if key not in order:
-                order.append(key)
-            a = agg[key][f"duration_us[{base}]"]
+            kname[grp[i]] = trace[i][0]
+            a = agg[grp[i]][f"duration_us[{base}]"]
             a[0] += 1
-            a[1] += us
+            a[1] += trace[i][1]
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
             with open(f, newline="") as fh:
                 for row in csv.DictReader(fh):
                     i = int(row["Dispatch_Id"])
-                    if i not in key_of:
-                        continue
-                    a = agg[key_of[i]][row["Counter_Name"]]
-                    a[0] += 1
-                    a[1] += float(row["Counter_Value"])
-    for key in order:
-        c = {k: v[1] / v[0] for k, v in agg[key].items()}
-        print(key)
-        for k in sorted(c):
-            print(f"    {k:34s} n={agg[key][k][0]:3d} mean {c[k]:16.1f}")
-        der = []
-        if "GRBM_GUI_ACTIVE" in c:
-            durs = [v for k, v in c.items() if k.startswith("duration_us[p3")]
-            if durs:
-                der.append(f"clock {c['GRBM_GUI_ACTIVE'] / durs[0] / 1e3:.2f} GHz")
-            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:   # cycles per SIMD summed over the chip's 1024 SIMDs
-                der.append(f"MFMA pipe busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (c['GRBM_GUI_ACTIVE'] * 1024):.1f} % of SIMD-cycles")
+                    if i in grp:
+                        a = agg[grp[i]][row["Counter_Name"]]
+                        a[0] += 1
+                        a[1] += float(row["Counter_Value"])
+    print("# per launch (mean of %d); SQ_* summed over the chip: SQ_BUSY_CYCLES over its 32 shader engines (so SQ_BUSY_CYCLES / 32 / duration = the\n"
+          "# shader clock while the kernel runs), SQ_VALU_MFMA_BUSY_CYCLES over its 1024 SIMDs in clocks (16 per v_mfma_f32_16x16x32_bf16),\n"
+          "# SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* over all waves in quad-cycles.  GRBM_GUI_ACTIVE is summed over the 8 XCDs and\n"
+          "# includes the dispatch's ramp: only meaningful for launches of several hundred us." % reps)
+    for k, (tag, what) in enumerate(order):
+        c = {n: v[1] / v[0] for n, v in agg[k].items()}
+        if not c:
+            continue
+        print(f"{tag.strip()} | {what} | {kname[k]}")
+        for n in sorted(c):
+            print(f"    {n:34s} n={agg[k][n][0]:3d} mean {c[n]:16.1f}")
+        dur = next((v for n, v in sorted(c.items()) if n.startswith("duration_us[p1")), None)
+        if "SQ_BUSY_CYCLES" in c and dur:
+            clk = c["SQ_BUSY_CYCLES"] / 32 / dur / 1e3
+            print(f"    => shader clock during the kernel {clk:.2f} GHz (SQ_BUSY_CYCLES / 32 shader engines / {dur:.1f} us)")
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+                print(f"    => MFMA pipe busy {100 * c['SQ_VALU_MFMA_BUSY_CYCLES'] / (32 * c['SQ_BUSY_CYCLES']):.1f} % of the SIMD-cycles of the launch "
+                      f"({c['SQ_VALU_MFMA_BUSY_CYCLES'] / 1024 / 1e3:.1f} k clocks per SIMD of {c['SQ_BUSY_CYCLES'] / 32 / 1e3:.1f} k)")
         if "SQ_WAVE_CYCLES" in c:
             wc = c["SQ_WAVE_CYCLES"]
-            der.append("wave cycles: waiting {:.1f} % / issue-stalled {:.1f} % / issuing {:.1f} %".format(
+            print("    => wave cycles: parked at s_waitcnt / s_barrier {:.1f} % | issue-stalled (pipe busy, dependency) {:.1f} % | issuing {:.1f} %".format(
                 100 * c.get("SQ_WAIT_ANY", 0) / wc, 100 * c.get("SQ_WAIT_INST_ANY", 0) / wc, 100 * c.get("SQ_ACTIVE_INST_ANY", 0) / wc))
-        if "SQ_LDS_IDX_ACTIVE" in c and c["SQ_LDS_IDX_ACTIVE"] > 0:
-            der.append(f"LDS bank conflicts {100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.1f} % of LDS-active cycles")
-        if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
-            der.append(f"LDS array active {100 * c['SQ_LDS_IDX_ACTIVE'] / (c['GRBM_GUI_ACTIVE'] * 256):.1f} % of CU-cycles")
-        for x in der:
-            print("    =>", x)
+        if c.get("SQ_LDS_IDX_ACTIVE"):
+            print(f"    => LDS bank conflicts {100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f} % of the LDS-active cycles; "
+                  f"SQ_WAIT_INST_LDS {100 * c.get('SQ_WAIT_INST_LDS', 0) / max(c.get('SQ_WAVE_CYCLES', 0) or 1, 1):.1f} % of wave cycles" if "SQ_WAVE_CYCLES" in c else
+                  f"    => LDS bank conflicts {100 * c.get('SQ_LDS_BANK_CONFLICT', 0) / c['SQ_LDS_IDX_ACTIVE']:.2f} % of the LDS-active cycles")
 
 
 if __name__ == "__main__":
