@@ -29,8 +29,11 @@ BUCKETS = ["gemm_kernel<128,128,row>", "gemm_kernel<128,64,row>", "gemm_kernel<6
            "gemm4_kernel<256x320,row>", "gemm4_kernel<256x320,conv>", "gemm4_kernel<256x192,row>", "gemm4_kernel<256x192,conv>",
            "wgrad_tn_kernel",
            # round 6, SUBSETS (also counted in their family above): the row GEMMs on the HBM side of the ridge (csrc/common.h)
-           "gemm4_kernel<256x320,row|hbm-side>", "gemm3_kernel<256xBN,row|hbm-side>"]
-SUBSET_BUCKETS = {"gemm4_kernel<256x320,row|hbm-side>": "gemm4_kernel<256x320,row>", "gemm3_kernel<256xBN,row|hbm-side>": None}
+           "gemm4_kernel<256x320,row|hbm-side>", "gemm3_kernel<256xBN,row|hbm-side>",
+           # the 128 x 320 two-blocks-per-CU row kernel (csrc/gemm5.hip: a measured experiment, force_tile only -- empty in the product step)
+           "gemm5_kernel<128x320,row>", "gemm5_kernel<128x320,row|hbm-side>"]
+SUBSET_BUCKETS = {"gemm4_kernel<256x320,row|hbm-side>": "gemm4_kernel<256x320,row>", "gemm3_kernel<256xBN,row|hbm-side>": None,
+                  "gemm5_kernel<128x320,row|hbm-side>": "gemm5_kernel<128x320,row>"}
 
 
 def sustained_mfma():

@@ -65,7 +65,7 @@ int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches
   return fdmi_prof_collect2(nbuckets, ms, flops, launches, nullptr);
 }
 int fdmi_prof_collect2(int nbuckets, double* ms, double* flops, int64_t* launches, double* bytes) {
-  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (22) buckets");
+  FDMI_CHECK(nbuckets >= PROF_NBUCKETS, "prof_collect: need >= PROF_NBUCKETS (24) buckets");
   for (int i = 0; i < nbuckets; ++i) { ms[i] = 0; flops[i] = 0; launches[i] = 0; if (bytes) bytes[i] = 0; }
   FDMI_HIP(hipDeviceSynchronize());
   int bad = 0;

@@ -512,7 +512,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   if (a.force_tile) {
     p.BM = a.force_tile >> 16;
     p.BN = a.force_tile & 0xffff;
-    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : 0;
+    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : ((p.BM == 128 && p.BN == 320) ? 3 : 0);
     p.splitk = a.splitk > 0 ? a.splitk : 1;
     return p;
   }
@@ -611,19 +611,42 @@ __device__ int g_sk_tickets[SK_STREAMS * SK_TICKETS];
 std::mutex g_sk_mu;
 hipStream_t g_sk_stream[SK_STREAMS];
 int g_sk_nstreams = 0;
-int* g_sk_base = nullptr;
+//  a __device__ symbol has one address PER DEVICE: the cache is keyed by the current device, and the persistent kernels'
+// grid (one block per CU, a multiple of 8) is read from the device the launch goes to -- the bound on the tiles one block may
+// collect (SkList: 12) is computed from THAT grid, not from an assumed 248 resident blocks
+constexpr int SK_MAX_DEVICES = 16;
+int* g_sk_base[SK_MAX_DEVICES] = {};
+int g_sk_ncu[SK_MAX_DEVICES] = {};
+int sk_current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return -1; }
+  return (dev >= 0 && dev < SK_MAX_DEVICES) ? dev : -1;
+}
+int sk_persistent_grid(int64_t items) {   // grid of gemm3 / gemm4 for `items` work items on the current device
+  const int dev = sk_current_device();
+  if (dev < 0) return 0;
+  if (!g_sk_ncu[dev]) {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    int n = prop.multiProcessorCount > 0 ? (prop.multiProcessorCount & ~7) : 256;
+    g_sk_ncu[dev] = n < 8 ? 8 : n;
+  }
+  return items < g_sk_ncu[dev] ? (int)items : g_sk_ncu[dev];
+}
 int* sk_ticket_region(hipStream_t st) {
   std::lock_guard<std::mutex> lk(g_sk_mu);
-  if (!g_sk_base && hipGetSymbolAddress((void**)&g_sk_base, HIP_SYMBOL(g_sk_tickets)) != hipSuccess) {
+  const int dev = sk_current_device();
+  if (dev < 0) return nullptr;
+  if (!g_sk_base[dev] && hipGetSymbolAddress((void**)&g_sk_base[dev], HIP_SYMBOL(g_sk_tickets)) != hipSuccess) {
     (void)hipGetLastError();
-    g_sk_base = nullptr;
+    g_sk_base[dev] = nullptr;
     return nullptr;
   }
   for (int i = 0; i < g_sk_nstreams; ++i)
-    if (g_sk_stream[i] == st) return g_sk_base + i * SK_TICKETS;
+    if (g_sk_stream[i] == st) return g_sk_base[dev] + i * SK_TICKETS;   // (a stream belongs to one device)
   if (g_sk_nstreams == SK_STREAMS) return nullptr;
   g_sk_stream[g_sk_nstreams] = st;
-  return g_sk_base + (g_sk_nstreams++) * SK_TICKETS;
+  return g_sk_base[dev] + (g_sk_nstreams++) * SK_TICKETS;
 }
 }  // namespace
 
@@ -651,6 +674,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.A2) FDMI_CHECK(p.big != 0, "gemm: a second A segment is read by the LDS-DMA kernels only (forced tile?)");
   if (p.big == 1) FDMI_CHECK(gemm3_eligible(a) && (p.BN == 128 || p.BN == 160), "gemm: 256-row tile not applicable to this problem");
   if (p.big == 2) FDMI_CHECK(gemm4_eligible(a, p.BN), "gemm: 256x320 / 256x192 tile not applicable to this problem");
+  if (p.big == 3) FDMI_CHECK(p.splitk <= 1 && gemm5_eligible(a), "gemm: 128x320 tile not applicable to this problem");
   a.splitk = p.splitk;
   if (a.accum_atomic && fdmi_det()) a.splitk = 1;   // deterministic mode: one contributor per element of the atomic accumulation
   {  // every split must own at least one K tile (slabs of empty splits would stay uninitialised)
@@ -669,18 +693,22 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   a.sk_tickets = nullptr;
   {
     const int sk_max = fdmi_tune_get(48) > 0 ? fdmi_tune_get(48) : 0;
-    const int tiles = p.big ? cdiv(a.M, 256) * cdiv(a.N, p.BN) : 0;
+    const int tiles = (p.big == 1 || p.big == 2) ? cdiv(a.M, 256) * cdiv(a.N, p.BN) : 0;
     const int64_t items = (int64_t)tiles * a.splitk;     // (a block of the persistent kernels takes ceil(items / 256) of them)
-    if (p.big && a.splitk > 1 && a.splitk <= sk_max && !a.accum_atomic && a.act != ACT_GEGLU && !(a.dev & (16 | 32 | 0x800)) &&
+    if ((p.big == 1 || p.big == 2) && a.splitk > 1 && a.splitk <= sk_max && !a.accum_atomic && a.act != ACT_GEGLU && !(a.dev & (16 | 32 | 0x800)) &&
         !a.residual32 && !a.C32 &&
-        tiles <= SK_TICKETS && (items + 247) / 248 <= 12)
-      a.sk_tickets = sk_ticket_region(stream);
+        tiles <= SK_TICKETS) {
+      const int grid = sk_persistent_grid(items);
+      if (grid > 0 && (items + grid - 1) / grid <= 12) a.sk_tickets = sk_ticket_region(stream);
+    }
   }
   if (g_gemm_log.on)
     ++g_gemm_log.n[std::make_tuple(a.mode, a.M, a.N, a.K, a.act, (a.residual ? 1 : 0) | (a.preact ? 2 : 0) | (a.accum_atomic ? 4 : 0) | (a.out_f32 ? 8 : 0) | (a.dgrad ? 16 : 0),
                                    p.big ? p.big * 1000 + p.BN : p.BM * 1000 + p.BN, a.splitk)];
   int rc;
-  if (p.big == 2)
+  if (p.big == 3)
+    rc = launch_gemm5(a, stream);
+  else if (p.big == 2)
     rc = launch_gemm4(a, stream, p.BN);
   else if (p.big)
     rc = launch_gemm3(a, p.BN, stream);

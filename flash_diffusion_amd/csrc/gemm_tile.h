@@ -476,11 +476,15 @@ __device__ __forceinline__ void tile_epilogue_fast_geglu(const GemmArgs& a, int 
         pk.x = pack2bf(gate[0], gate[1]); pk.y = pack2bf(gate[2], gate[3]); pk.z = pack2bf(gate[4], gate[5]); pk.w = pack2bf(gate[6], gate[7]);
         *(uint4*)(pp + mf * pstep + 64 * t + 16) = pk;
       }
-      uint4 o;
-      o.x = pack2bf(val[0] * gelu_f(gate[0]), val[1] * gelu_f(gate[1]));
-      o.y = pack2bf(val[2] * gelu_f(gate[2]), val[3] * gelu_f(gate[3]));
-      o.z = pack2bf(val[4] * gelu_f(gate[4]), val[5] * gelu_f(gate[5]));
-      o.w = pack2bf(val[6] * gelu_f(gate[6]), val[7] * gelu_f(gate[7]));
+      uint4 o;   // (two gates per gelu_f2: packed fp32 arithmetic, bit-identical to gelu_f per component)
+      const fdmi_f2 o0 = (fdmi_f2){val[0], val[1]} * gelu_f2((fdmi_f2){gate[0], gate[1]});
+      const fdmi_f2 o1 = (fdmi_f2){val[2], val[3]} * gelu_f2((fdmi_f2){gate[2], gate[3]});
+      const fdmi_f2 o2 = (fdmi_f2){val[4], val[5]} * gelu_f2((fdmi_f2){gate[4], gate[5]});
+      const fdmi_f2 o3 = (fdmi_f2){val[6], val[7]} * gelu_f2((fdmi_f2){gate[6], gate[7]});
+      o.x = pack2bf(o0.x, o0.y);
+      o.y = pack2bf(o1.x, o1.y);
+      o.z = pack2bf(o2.x, o2.y);
+      o.w = pack2bf(o3.x, o3.y);
       *(uint4*)(cp + mf * cstep + 32 * t) = o;
     }
   }
@@ -503,8 +507,10 @@ __device__ __forceinline__ void tile_epilogue_fast_geglu(const GemmArgs& a, int 
         *(uint2*)(pq + mf * pstep + 16) = pk;
       }
       uint2 o;
-      o.x = pack2bf(val[0] * gelu_f(gate[0]), val[1] * gelu_f(gate[1]));
-      o.y = pack2bf(val[2] * gelu_f(gate[2]), val[3] * gelu_f(gate[3]));
+      const fdmi_f2 o0 = (fdmi_f2){val[0], val[1]} * gelu_f2((fdmi_f2){gate[0], gate[1]});
+      const fdmi_f2 o1 = (fdmi_f2){val[2], val[3]} * gelu_f2((fdmi_f2){gate[2], gate[3]});
+      o.x = pack2bf(o0.x, o0.y);
+      o.y = pack2bf(o1.x, o1.y);
       *(uint2*)(cq + mf * cstep) = o;
     }
   }
@@ -539,6 +545,7 @@ __device__ __forceinline__ void splitk_arrive(const GemmArgs& a, int tile, int m
       __hip_atomic_store(a.sk_tickets + tile, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // for the next launch on this stream
       volatile SkList* l = (volatile SkList*)lds;
       const int k = l->n;
+      if (k >= 12) __builtin_trap();   // (launch_gemm bounds the items per block by the list's size from the actual grid: unreachable)
       l->m0[k] = m0;
       l->n0[k] = n0;
       l->n = k + 1;

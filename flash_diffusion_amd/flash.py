@@ -125,6 +125,17 @@ class Draws:
         return ops.upload(self._get(name, lambda: torch.randint(lo, hi, shape)), device)
 
 
+def shared_start_seed_for(seed: int, step: int) -> int:
+    """seed of the per-forward start-index generator of data-parallel training: a splitmix64-style hash of (the seed every rank
+    shares, the step counter) -- consecutive integers do not go into the Mersenne twister as they are"""
+    m = (1 << 64) - 1
+    z = (int(seed) * 0x9E3779B97F4A7C15 + int(step) + 0x632BE59BD9B4E019) & m
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & m
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & m
+    return (z ^ (z >> 31)) & ((1 << 62) - 1)
+
+
+
 class TensorConditioner(nn.Module):
     """Stand-in for ConditionerWrapper (embedders/conditioners_wrapper.py:39-91) when the batch already
     carries the embeddings (`crossattn` [B,L,D], optional `vector`, `concat`).  Keys listed in `ucg_keys`
@@ -323,16 +334,21 @@ class FlashDiffusion(nn.Module):
         for the rank that drew the longest teacher loop.  With a host generator seeded IDENTICALLY on every rank (the trainer
         broadcasts rank 0's seed once) all ranks draw the same index from the same pmf at every step -- no communication in the
         step, and each rank's marginal distribution of start indices is the reference's.  Noise, guidance scale and GAN draws
-        stay per rank.  seed=None switches back to per-rank draws.  The generator of a forward is derived from (seed, the model's
-        forward counter FD:181) and holds no state between forwards, so a rank-local extra draw (validation or sample logging on
-        rank 0 only) cannot make the ranks drift apart.  DEVIATION from the reference, on by default in
+        stay per rank.  seed=None switches back to per-rank draws.  The generator of a forward holds no state between forwards: it
+        is seeded with a hash of (seed, step), where `step` is `self.shared_start_step` when the trainer sets it -- TrainingPipeline
+        sets its own count of training_step calls before every forward, a counter a rank-local forward (validation or sample
+        logging through the model on rank 0 only, a retried batch) does not advance -- and otherwise the model's forward counter
+        (FD:181), which such a forward DOES advance: without a trainer-owned counter the ranks then draw different indices from that
+        point on and every step waits for the longest teacher loop, with no error raised.  Neither counter is part of
+        a checkpoint; a resumed job restarts the sequence on all ranks alike.  DEVIATION from the reference, on by default in
         TrainingPipeline when world > 1: the global batch of an optimizer step sees ONE start timestep instead of `world`."""
         self.shared_start_seed = None if seed is None else int(seed)
 
     def _shared_start_generator(self):
         if getattr(self, "shared_start_seed", None) is None:
             return None
-        return torch.Generator().manual_seed((self.shared_start_seed * 1000003 + int(self.iter_steps)) % (2 ** 62))
+        step = getattr(self, "shared_start_step", None)
+        return torch.Generator().manual_seed(shared_start_seed_for(self.shared_start_seed, self.iter_steps if step is None else step))
 
     def freeze(self):
         self.eval()
@@ -520,7 +536,8 @@ class FlashDiffusion(nn.Module):
         if st is None:
             st = self._side_streams = {}
         if like.device not in st:
-            st[like.device] = torch.cuda.Stream(device=like.device)
+            # (dev A/B: FDMI_TEACHER_PRIORITY = -1 gives the loop's queue the higher hardware priority, 0 = default)
+            st[like.device] = torch.cuda.Stream(device=like.device, priority=int(os.environ.get("FDMI_TEACHER_PRIORITY", "0")))
         return st[like.device]
 
     def _teacher_cfg(self, x, tt, cond, uncond, cfg_cond, *args, ctx_cache=None, res=None, **kwargs):

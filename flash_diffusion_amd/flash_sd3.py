@@ -196,7 +196,9 @@ class FlashDiffusionSD3(nn.Module):
     def _shared_start_generator(self):
         if self.shared_start_seed is None:
             return None
-        return torch.Generator().manual_seed((self.shared_start_seed * 1000003 + int(self.iter_steps)) % (2 ** 62))
+        from .flash import shared_start_seed_for
+        step = getattr(self, "shared_start_step", None)
+        return torch.Generator().manual_seed(shared_start_seed_for(self.shared_start_seed, self.iter_steps if step is None else step))
 
     def freeze(self):
         self.eval()

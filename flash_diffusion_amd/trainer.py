@@ -186,6 +186,7 @@ class TrainingPipeline(nn.Module):
             if self.distributed and self.world > 1:
                 torch.distributed.broadcast_object_list(seed, src=0)
             model.share_start_idx(seed[0])
+        self.global_step = 0      # training_step calls: the counter the shared start-index draw is derived from (flash.share_start_idx)
 
     @property
     def device(self):
@@ -394,6 +395,9 @@ class TrainingPipeline(nn.Module):
     def training_step(self, train_batch: Dict[str, Any], batch_idx: int = 0) -> dict:
         if not self.optims:
             self.configure_optimizers()
+        if self.share_start_idx:
+            self.model.shared_start_step = self.global_step   # (a rank-local forward outside training_step does not advance it)
+        self.global_step += 1
         if not getattr(self.model, "calls_before_student", False):
             # a model whose forward never calls the before_student hook would read parameters the deferred step is
             # still writing: wait here instead (FlashDiffusion / FlashDiffusionSD3 call the hook after their teacher loop)

@@ -44,7 +44,8 @@ int fdmi_prof_collect(int nbuckets, double* ms, double* flops, int64_t* launches
 /* round 6: the same, plus the algorithmic HBM bytes of every bucket's launches (each operand of a launch counted once: GEMM / conv
  * A + W + C (+ residual), attention q + k + v + o) -- bench.py prices every kernel family against the bound it sits under
  * (arithmetic intensity vs the 2.5 PFLOP/s : 8 TB/s ridge).  Buckets 20 / 21: the row GEMMs of the 256 x 320 / 256 x {128,160}
- * ring kernels on the HBM side of that ridge.  nbuckets >= 22. */
+ * ring kernels on the HBM side of that ridge; 22 / 23: the 128 x 320 two-blocks-per-CU row kernel and its HBM-side subset.
+ * nbuckets >= 24. */
 int fdmi_prof_collect2(int nbuckets, double* ms, double* flops, int64_t* launches, double* bytes);
 /* round 6: one CSV line per launch of the leg the last fdmi_prof_collect* call gathered -- bucket, kind (0 row GEMM, 1 conv: s = M, N, K,
  * flags; 2 / 3 / 4 attention forward / dQ / dK-dV: s = B * H, Sq, Skv, d; -1 untagged), milliseconds, algorithmic flops and bytes --

@@ -498,18 +498,28 @@ FULLSTEP4_CASES = {
 FULLSTEP4_B = 2
 FULLSTEP4_HW = {"step4_sdxl": 64, "step4_pixart": 64, "step4_sd3": 64}
 FULLSTEP4_KEY_LENS = (100, 57)          # PixArt: per-sample T5 prefix lengths of the conditional prompts
-FULLSTEP_CASES_ALL = dict(FULLSTEP_CASES, **FULLSTEP4_CASES)
+# ---- round 6 (VERDICT r5 missing 5): the four-step loop at the BENCHMARKED latent size, 128x128 (4096 tokens), B = 1 -- what fits the
+# authoring container's host memory (the B = 2 tape of the GAN term does not, see above); the examples' own heads, unmodified (they
+# are sized for 128x128).  Same recipes, own seeds.  Names = the 64x64 case + "_hw128".
+FULLSTEP4_HW128_CASES = {
+    "step4_sdxl_hw128": ("fd", dict(_FS4, guidance_scale_min=3.0, guidance_scale_max=13.0), 91),
+    "step4_pixart_hw128": ("fd", dict(_FS4, guidance_scale_min=2.0, guidance_scale_max=9.0, ucg_keys=["text"], use_empty_prompt=True), 92),
+    "step4_sd3_hw128": ("fd3", dict(_FS4, guidance_scale_min=3.0, guidance_scale_max=7.0), 93),
+}
+FULLSTEP4_HW.update({k: 128 for k in FULLSTEP4_HW128_CASES})
+FULLSTEP4_BS = dict({k: FULLSTEP4_B for k in FULLSTEP4_CASES}, **{k: 1 for k in FULLSTEP4_HW128_CASES})
+FULLSTEP_CASES_ALL = dict(FULLSTEP_CASES, **FULLSTEP4_CASES, **FULLSTEP4_HW128_CASES)
 
 
 def _fs_base(name):
-    return name.replace("step4_", "step_")
+    return name.replace("_hw128", "").replace("step4_", "step_")
 
 
 def fullstep_head(name):
     """the PatchGAN head of the example: SDXL on the teacher's mid-block features [B, 1280, 32, 32] (train_flash_sdxl.py:238-267),
     PixArt / SD3 on the prediction itself (train_flash_pixart.py:277-325: five strided stages; train_flash_sd3.py:145-183: four)"""
     nn = torch.nn
-    four = name.startswith("step4_")
+    small = name.startswith("step4_") and FULLSTEP4_HW[name] == 64
     name = _fs_base(name)
     if name == "step_sdxl":
         c, f, n = 1280, 256, 3
@@ -517,10 +527,9 @@ def fullstep_head(name):
         c, f, n = 4, 64, 5
     else:
         c, f, n = 16, 64, 4
-    if four and name != "step_sd3":
+    if small and name != "step_sd3":
         # 64x64 latents (FULLSTEP4_HW): the examples' heads are sized for 128x128 -- their last 4x4 / stride-1 convolution would
         # meet a 2x2 map -- so the SDXL and PixArt heads drop their last strided stage (same widths otherwise; SD3's fits as is)
-        assert FULLSTEP4_HW["step4_" + name[5:]] == 64
         n -= 1
     layers = [nn.Conv2d(c, f, 4, 2, 1, bias=False), nn.SiLU(True)]
     for i in range(1, n):
@@ -570,7 +579,7 @@ def fullstep_inputs(name, device="cpu", B=None, hw=None):
     the fixture's batch to the benchmarked one)."""
     from .flash_ref import TensorConditioner
     four = name.startswith("step4_")
-    B = B or (FULLSTEP4_B if four else 1)
+    B = B or (FULLSTEP4_BS[name] if four else 1)
     hw = hw or (FULLSTEP4_HW[name] if four else 128)
     name = _fs_base(name)
     if name == "step_sdxl":

@@ -55,7 +55,7 @@ def audit(text):
 
 
 def main():
-    objs = sys.argv[1:] or [os.path.join(ROOT, "flash_diffusion_amd", "csrc", f) for f in ("gemm3.o", "gemm4.o")]
+    objs = sys.argv[1:] or [os.path.join(ROOT, "flash_diffusion_amd", "csrc", f) for f in ("gemm3.o", "gemm4.o", "gemm5.o")]
     bad = 0
     for o in objs:
         res = audit(device_disassembly(o))

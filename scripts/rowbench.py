@@ -1,6 +1,6 @@
 """Short-K row GEMMs of the C2 step under each kernel geometry (dev tool; run on the GPU box):
   python scripts/rowbench.py [reps]
-per problem: the 256x320 one-block-per-CU kernel, the 128x160 two-blocks-per-CU geometry (round 3), the 256x160 ring kernel and
+per problem: the 256x320 one-block-per-CU kernel, the 128x320 two-blocks-per-CU kernel (round 6, gemm5.hip; its output must equal the 256x320 kernel's bit for bit), the 256x160 ring kernel and
 the 128x128 tile -- us per launch, algorithmic TB/s (every operand once) and TFLOP/s.  Operands rotate over several buffer sets
 so that a launch does not find its inputs in the 256 MB Infinity Cache."""
 import os
@@ -10,7 +10,7 @@ import torch
 from flash_diffusion_amd import ops
 
 BF = torch.bfloat16
-TILES = {"g4 256x320": (256 << 16) | 320, "g5 128x160": (128 << 16) | 160, "g3 256x160": (256 << 16) | 160, "t 128x128": (128 << 16) | 128}
+TILES = {"g4 256x320": (256 << 16) | 320, "g5 128x320": (128 << 16) | 320, "g3 256x160": (256 << 16) | 160, "t 128x128": (128 << 16) | 128}
 
 
 def bench(fns, reps):
@@ -103,7 +103,9 @@ def main():
         (131072, 320, 320, True, False), (131072, 320, 320, False, False), (131072, 960, 320, False, False),
         (65536, 320, 320, True, False), (65536, 320, 128, True, False), (131072, 2560, 320, False, True),
         (32768, 640, 640, True, False), (32768, 1920, 640, False, False), (32768, 5120, 640, False, True),
-        (131072, 320, 1280, True, False), (32768, 640, 2560, True, False), (8192, 1280, 1280, True, False)]
+        (131072, 320, 1280, True, False), (32768, 640, 2560, True, False), (8192, 1280, 1280, True, False),
+        (65536, 2560, 320, False, True), (32768, 640, 640, False, False), (65536, 320, 320, False, False), (8192, 10240, 1280, False, True),
+        (8192, 3840, 1280, False, False), (16384, 640, 640, True, False)]
     for (M, N, K, res, geglu) in cases:
         Nout = N // 2 if geglu else N
         nset = max(2, int(600e6 // (2 * M * (K + Nout * (2 if res else 1)))) + 1)
@@ -125,7 +127,15 @@ def main():
                 fns = [(lambda A=A, W=W, out=out, R=R: ops.gemm(A, W, bias=bias, residual=R, out=out, force_tile=tile,
                                                                  act=ops.ACT_GEGLU if geglu else ops.ACT_NONE)) for (A, W, out, R) in sets]
                 us = bench(fns, reps)
-                line += f" {name}: {us:7.1f} us {by / us / 1e6:5.2f} TB/s {fl / us / 1e6:6.0f} TF |"
+                tag = ""
+                sets[0][2].zero_()
+                fns[0]()
+                torch.cuda.synchronize()
+                if name == "g4 256x320":
+                    ref = sets[0][2].clone()
+                elif name == "g5 128x320" and not torch.equal(sets[0][2], ref):
+                    tag = f" MISMATCH({float((sets[0][2].float() - ref.float()).abs().max()):.3g})"
+                line += f" {name}: {us:7.1f} us {by / us / 1e6:5.2f} TB/s {fl / us / 1e6:6.0f} TF{tag} |"
             except RuntimeError as e:
                 line += f" {name}: n/a |"
         print(line, flush=True)

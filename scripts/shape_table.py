@@ -7,7 +7,7 @@ from collections import defaultdict
 BUCKETS = {0: "gemm128x128 row", 1: "gemm128x64 row", 2: "gemm64x128 row", 3: "gemm64x64 row", 4: "gemm128x128 conv", 5: "gemm128x64 conv",
            6: "gemm64x128 conv", 7: "gemm64x64 conv", 8: "attn fwd", 9: "attn dQ", 10: "attn dKV", 11: "g3 256x160 row", 12: "g3 256x128 row",
            13: "g3 256x160 conv", 14: "g3 256x128 conv", 15: "g4 256x320 row", 16: "g4 256x320 conv", 17: "g4 256x192 row", 18: "g4 256x192 conv",
-           19: "wgrad_tn"}
+           19: "wgrad_tn", 22: "g5 128x320 row"}
 PEAK, HBM = 2.5e15, 8.0e12
 agg = defaultdict(lambda: [0, 0.0, 0.0, 0.0])
 for r in csv.DictReader(open(sys.argv[1])):

@@ -73,7 +73,9 @@ def pytest_collection_modifyitems(config, items):
 # declares more -- `@pytest.mark.gpu_mem(gib)` -- or all of them (`gpu_exclusive`: the full-width steps at the benchmarked batch).
 # Taking slots: under the turnstile lock, try-lock any k free slot files; whoever cannot get its k keeps the turnstile while it
 # waits, so no new test enters, the running ones drain, and a large request cannot starve.  No hold-and-wait: no deadlock.
-_LOCK_DIR = os.environ.get("FDMI_TEST_LOCK_DIR", "/tmp")
+# (a per-user directory -- lock files in a shared /tmp collide across users / containers of one host)
+_LOCK_DIR = os.environ.get("FDMI_TEST_LOCK_DIR") or os.path.join("/tmp", f"fdmi-test-locks-{os.getuid()}")
+os.makedirs(_LOCK_DIR, exist_ok=True)
 _SLOTS, _SLOT_GIB = 8, 34
 
 

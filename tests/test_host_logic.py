@@ -222,7 +222,14 @@ def _start_idx_worker(rank, world, port, q, share):
             # a rank-LOCAL extra draw (sample logging / validation on rank 0 only): the shared index is a function of (seed,
             # forward counter) and holds no generator state, so the ranks cannot drift apart
             m._get_timesteps(Draws(), 2, 8, 0, "cpu")
-    q.put((rank, idx))
+    # round 6: a rank-local FORWARD advances the model's forward counter -- with the counter the trainer owns
+    # (TrainingPipeline.training_step sets model.shared_start_step) the ranks still agree
+    idx2 = []
+    for i in range(12):
+        m.shared_start_step = 100 + i                           # what training_step does before the forward
+        m.iter_steps += 1 + (rank == 0 and i % 3 == 1)          # rank 0 ran an extra forward (validation) in between
+        idx2.append(int(m._get_timesteps(Draws(), 2, 8, 0, "cpu")[0]))
+    q.put((rank, idx + [-1] + idx2))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -242,7 +249,11 @@ def test_ranks_share_the_start_index_by_default(share):
     res = dict(q.get(timeout=180) for _ in range(2))
     for p in procs:
         p.join(60)
+    tail = {r: v[v.index(-1) + 1:] for r, v in res.items()}     # the draws under the trainer-owned step counter
+    res = {r: v[:v.index(-1)] for r, v in res.items()}
     assert all(0 <= i < 8 for i in res[0] + res[1]) and len(set(res[0])) >= 4
+    if share is None:
+        assert tail[0] == tail[1] and len(set(tail[0])) >= 3, (tail[0], tail[1])
     if share is None:
         assert res[0] == res[1], (res[0], res[1])
     else:

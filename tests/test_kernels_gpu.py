@@ -566,6 +566,54 @@ def test_gemm4_many_items_per_block():
 
 
 # ---- two-segment A operand (GemmArgs::A2): [A | A2] W^T without materialising the concatenation ---------------------------------
+# ---- 128 x 320 x 32 tile kernel, two blocks per CU (gemm5, round 6: a measured experiment, reached through force_tile only) ----------
+T5 = (128 << 16) | 320
+
+
+@pytest.mark.parametrize("shape", [(128, 320, 64), (256, 320, 64), (640, 640, 320), (1024, 320, 1280), (8192, 960, 448), (2176, 1280, 192)])
+def test_gemm5_row_equals_gemm4_bit_for_bit(shape):
+    """same wave tile, same accumulation order along K, same epilogue code: the 128-row kernel's output IS the 256-row kernel's
+    (where that one applies: M % 256 == 0); against fp32 otherwise.  Covers one and several items per block, the persistent loop's
+    hand-over, bias / residual operand sets"""
+    ops = _ops()
+    M, N, K = shape
+    A, W = b16(rnd(M, K, seed=1)), b16(rnd(N, K, seed=2, scale=K ** -0.5))
+    bias, res = rnd(N, seed=3), b16(rnd(M, N, seed=5))
+    ref = A.float() @ W.float().t()
+    out = ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=T5)
+    close(f"gemm5_row{shape}", out, ref + bias + res.float())
+    plain = ops.gemm(A.cuda(), W.cuda(), force_tile=T5)
+    close(f"gemm5_plain{shape}", plain, ref)
+    if M % 256 == 0:
+        assert torch.equal(out, ops.gemm(A.cuda(), W.cuda(), bias=bias.cuda(), residual=res.cuda(), force_tile=T4))
+        assert torch.equal(plain, ops.gemm(A.cuda(), W.cuda(), force_tile=T4))
+
+
+def test_gemm5_geglu_and_two_segment_a():
+    ops = _ops()
+    M, K, Fh = 512, 192, 640
+    A = b16(rnd(M, K, seed=1))
+    W = b16(rnd(2 * Fh, K, seed=2, scale=K ** -0.5))
+    bias = rnd(2 * Fh, seed=3)
+    perm = ops.geglu_perm(Fh)
+    pre = torch.empty(M, 2 * Fh, dtype=torch.bfloat16, device="cuda")
+    pre4 = torch.empty_like(pre)
+    Wp, bp = W[perm].contiguous().cuda(), bias[perm].contiguous().cuda()
+    out = ops.gemm(A.cuda(), Wp, bias=bp, act=ops.ACT_GEGLU, preact=pre, force_tile=T5)
+    ref4 = ops.gemm(A.cuda(), Wp, bias=bp, act=ops.ACT_GEGLU, preact=pre4, force_tile=T4)
+    h = A.float() @ W.float().t() + bias
+    close("gemm5_geglu", out, h[:, :Fh] * F.gelu(h[:, Fh:]))
+    assert torch.equal(out, ref4) and torch.equal(pre, pre4)
+    # two-segment A (the LoRA up-projection as extra K tiles): the seam at a 64-multiple inside the 32-deep tile sequence
+    M, N, K1, K2 = 1024, 320, 320, 128
+    A1, A2 = b16(rnd(M, K1, seed=1)), b16(rnd(M, K2, seed=2))
+    W = b16(rnd(N, K1 + K2, seed=3, scale=(K1 + K2) ** -0.5))
+    res = b16(rnd(M, N, seed=5))
+    out = ops.gemm(A1.cuda(), W.cuda(), A2=A2.cuda(), residual=res.cuda(), force_tile=T5)
+    close("gemm5_a2", out, torch.cat([A1, A2], 1).float() @ W.float().t() + res.float())
+    assert torch.equal(out, ops.gemm(A1.cuda(), W.cuda(), A2=A2.cuda(), residual=res.cuda(), force_tile=T4))
+
+
 A2_SHAPES = [(512, 640, 320, 128), (1024, 1920, 1280, 640), (768, 320, 64, 64), (2048, 960, 320, 384)]
 A2_CASES = [(t, sh) for t in (T4, (256 << 16) | 160, (256 << 16) | 128, (256 << 16) | 192, 0) for sh in A2_SHAPES
             if not t or sh[1] % (t & 0xffff) == 0]          # (a forced tile must divide N)
@@ -841,3 +889,15 @@ def _inlaunch_conv_two_streams(ops):
     torch.cuda.synchronize()
     for o1, o2 in outs:
         assert torch.equal(o1, want) and torch.equal(o2, want_c)
+
+
+def test_upload_of_small_host_tensors_keeps_values_and_dtypes():
+    """ops.upload (round 6): the step's start timesteps / sigmas / drawn indices reach the device through a fill launch (all elements
+    equal) or a pinned non-blocking copy -- never through a pageable copy, which blocks the host until the stream has drained"""
+    ops = _ops()
+    for t in (torch.full((16,), 999, dtype=torch.long), torch.tensor([10, 250, 500, 750, 10]), torch.tensor([0.25, 0.5]),
+              torch.full((4,), 0.7071, dtype=torch.float32), torch.zeros(0), torch.tensor([True, False])):
+        d = ops.upload(t, "cuda")
+        assert d.is_cuda and d.dtype == t.dtype and d.shape == t.shape and torch.equal(d.cpu(), t)
+    on = torch.arange(4, device="cuda")
+    assert ops.upload(on, "cuda") is on

@@ -9,14 +9,14 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "scripts"))
 
 
-@pytest.mark.parametrize("obj", ["gemm3.o", "gemm4.o"])
+@pytest.mark.parametrize("obj", ["gemm3.o", "gemm4.o", "gemm5.o"])
 def test_no_scratch_instruction_inside_a_k_loop(obj):
     import kloop_spill_audit as A
     path = os.path.join(ROOT, "flash_diffusion_amd", "csrc", obj)
     if not os.path.exists(path) or not os.path.exists(A.OBJDUMP):
         pytest.skip("needs the built object and llvm-objdump (python __graft_entry__.py)")
     res = A.audit(A.device_disassembly(path))
-    assert len(res) >= 7                                           # every instantiation was looked at
+    assert len(res) >= (2 if obj == "gemm5.o" else 7)              # every instantiation was looked at
     bad = {k: v[0] for k, v in res.items() if v[0]}
     assert not bad, bad
 

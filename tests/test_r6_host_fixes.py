@@ -82,13 +82,15 @@ def _bench():
 def test_bench_ridge_and_bucket_tables():
     b = _bench()
     assert abs(b.RIDGE - 312.5) < 1e-9 and b.PEAK_HBM == 8.0e12 and b.PEAK_BF16 == 2.5e15
-    # the library's bucket enumeration (csrc/common.h) and bench.py's names must stay in step: 22 buckets, the two subsets last
+    # the library's bucket enumeration (csrc/common.h) and bench.py's names must stay in step: 24 buckets
     hdr = open(os.path.join(ROOT, "flash_diffusion_amd", "csrc", "common.h")).read()
     m = re.search(r"PROF_NBUCKETS = (\d+)", hdr)
-    assert m and int(m.group(1)) == len(b.BUCKETS) == 22
+    assert m and int(m.group(1)) == len(b.BUCKETS) == 24
     assert int(re.search(r"PROF_GEMM4_ROW_HBM = (\d+)", hdr).group(1)) == b.BUCKETS.index("gemm4_kernel<256x320,row|hbm-side>")
     assert int(re.search(r"PROF_GEMM3_ROW_HBM = (\d+)", hdr).group(1)) == b.BUCKETS.index("gemm3_kernel<256xBN,row|hbm-side>")
-    assert set(b.SUBSET_BUCKETS) == set(b.BUCKETS[20:])
+    assert int(re.search(r"PROF_GEMM5 = (\d+)", hdr).group(1)) == b.BUCKETS.index("gemm5_kernel<128x320,row>")
+    assert int(re.search(r"PROF_GEMM5_HBM = (\d+)", hdr).group(1)) == b.BUCKETS.index("gemm5_kernel<128x320,row|hbm-side>")
+    assert set(b.SUBSET_BUCKETS) == {n for n in b.BUCKETS if n.endswith("|hbm-side>")}
     # which side of the ridge the step's row GEMMs sit on (2 M N K flop over 2 (M K + N K + M N (1 + residual)) bytes)
     def ai(M, N, K, res, nout=None):
         nout = N if nout is None else nout
