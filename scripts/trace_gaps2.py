@@ -21,7 +21,7 @@ import sys
 
 
 def short(n):
-    n = re.sub(r"^void ", "", n)
+    n = re.sub(r"^void ", "", n).replace("(anonymous namespace)::", "")
     n = re.sub(r"\(.*$", "", n)
     return n[:56]
 

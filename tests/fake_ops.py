@@ -15,6 +15,10 @@ def _dev(t):
     return t
 
 
+def upload(t, device):   # ops.upload: a small host tensor on `device` without a blocking copy (on CPU: the tensor itself)
+    return t.to(device)
+
+
 def gemm(A, W, *, bias=None, residual=None, act=ACT_NONE, preact=None, out=None, out_f32=False, alpha=1.0, splitk=1,
          accum_atomic=False, rowvec=None, rows_per_batch=1, rowvec_mul=False, **kw):
     assert A.dtype == BF16 and W.dtype == BF16 and A.shape[1] == W.shape[1] and A.shape[1] % 8 == 0, (A.shape, W.shape)
