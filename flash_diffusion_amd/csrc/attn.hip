@@ -87,10 +87,22 @@ template <int DK>
 __device__ __forceinline__ bf16x8 row_frag(const char* lds, int f, int ks, int g, int j) {
   return *(const bf16x8*)(lds + (16 * f + j) * RowTile<DK>::ROWB + (4 * ks + g) * 16);
 }
+// One 8-byte LDS read that stays ONE `ds_read_b64` (round 6).  hipcc's load/store optimizer pairs plain 8-byte reads off one base
+// into `ds_read2_b64` / `ds_read2st64_b64`; on gfx950 the paired form moves 128 B/clk instead of 256 and banks modulo 32 instead of
+// 64 (MI355X_MICROARCH.md, LDS table), which turns the V^T fragment layouts below -- conflict-free for `ds_read_b64` -- into 2-way
+// conflicts: the d = 64 forward spent 40 % of its LDS-active cycles in bank conflicts (profiles/r6_attn.txt).  A relaxed
+// wavefront-scope atomic load is the same instruction with the same waitcnt bookkeeping, but not a pairing candidate.
+__device__ __forceinline__ uint2 lds_read8(const char* p) {
+#ifdef FDMI_PAIRED_LDS_READS   // (A/B build switch: the plain load hipcc pairs; scripts/build_variant.sh)
+  return *(const uint2*)p;
+#endif
+  const unsigned long long v = __hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+  return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
 __device__ __forceinline__ bf16x8 tr_frag(const char* lds, int df, int s2, int g, int j) {
   const char* p = lds + (16 * df + j) * TROWB + (32 * s2 + 4 * g) * 2;
-  const uint2 lo = *(const uint2*)p;
-  const uint2 hi = *(const uint2*)(p + 32);
+  const uint2 lo = lds_read8(p);
+  const uint2 hi = lds_read8(p + 32);
   union { uint4 u; bf16x8 v; } t;
   t.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return t.v;
@@ -190,8 +202,8 @@ __device__ __forceinline__ bf16x8 row_frag_sw(const char* lds, int f, int ks, in
 __device__ __forceinline__ bf16x8 tr_frag_sw(const char* lds, int df, int s2, int g, int j) {
   const int sw = (j >> 1) & 7, c0 = 4 * s2 + (g >> 1);
   const char* row = lds + (16 * df + j) * 128 + (g & 1) * 8;
-  const uint2 lo = *(const uint2*)(row + ((c0 ^ sw) * 16));
-  const uint2 hi = *(const uint2*)(row + (((c0 + 2) ^ sw) * 16));
+  const uint2 lo = lds_read8(row + ((c0 ^ sw) * 16));
+  const uint2 hi = lds_read8(row + (((c0 + 2) ^ sw) * 16));
   union { uint4 u; bf16x8 v; } t;
   t.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return t.v;
@@ -361,7 +373,7 @@ __global__ __launch_bounds__(256, (DK <= 96 ? 2 : 1)) void attn_fwd_kernel(const
 #pragma unroll
       for (int df = 0; df < DF; ++df) {
         if (DMA) {
-          const uint2 lo = *(const uint2*)(sV + vofs[s2][0] + df * 2048), hi = *(const uint2*)(sV + vofs[s2][1] + df * 2048);
+          const uint2 lo = lds_read8(sV + vofs[s2][0] + df * 2048), hi = lds_read8(sV + vofs[s2][1] + df * 2048);
           union { uint4 u; bf16x8 v; } tt;
           tt.u = make_uint4(lo.x, lo.y, hi.x, hi.y);
           vfr[s2][df] = tt.v;

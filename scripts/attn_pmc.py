@@ -11,7 +11,7 @@ def run():
     from flash_diffusion_amd import ops, _lib
     L = _lib.lib()
     BF = torch.bfloat16
-    for (B, S, H, d) in [(32, 4096, 8, 40), (8, 4096, 10, 64)]:
+    for (B, S, H, d) in [(32, 4096, 8, 40), (8, 4096, 10, 64), (16, 4096, 16, 72)]:
         q, k, v = (torch.randn(B, S, H * d, device="cuda").to(BF) for _ in range(3))
         for knob in (0, 1):
             L.fdmi_tune_set(26, knob)
