@@ -69,14 +69,14 @@ struct GemmArgs {
 int launch_gemm(const GemmArgs& a, hipStream_t stream);
 int launch_gemm32(const GemmArgs& a, hipStream_t stream);   // a.f32 == 1 (launch_gemm forwards to it)
 // kernel / tile / split-K selection (shared by the launcher and by callers that must size `ws`)
-struct GemmPlan { int big = 0;  /* 0: gemm.hip tiles, 1: gemm3 (256 x BN), 2: gemm4 (256 x BN, BN = 320 | 192), 3: gemm5 (128 x 320, two blocks per CU) */ int BM = 128, BN = 128, splitk = 1; };
+struct GemmPlan { int big = 0;  /* 0: gemm.hip tiles, 1: gemm3 (256 x BN), 2: gemm4 (256 x BN, BN = 320 | 192 | 384), 3: gemm5 (128 x 320, two blocks per CU) */ int BM = 128, BN = 128, splitk = 1; };
 GemmPlan plan_gemm(const GemmArgs& a, bool ws_available);
 // bytes of fp32 workspace the auto split-K plan wants for this problem (0 = no split)
 size_t gemm_ws_bytes(const GemmArgs& a);
 bool gemm3_eligible(const GemmArgs& a);
 int gemm3_pick_bn(const GemmArgs& a);
 int launch_gemm3(const GemmArgs& a, int BN, hipStream_t stream);
-bool gemm4_eligible(const GemmArgs& a, int BN = 320);   // 256 x {320, 192} tile (gemm4.hip)
+bool gemm4_eligible(const GemmArgs& a, int BN = 320);   // 256 x {320, 192, 384} tile (gemm4.hip)
 bool gemm5_eligible(const GemmArgs& a);                 // 128 x 320 row tile, two blocks per CU (gemm5.hip)
 int launch_gemm5(const GemmArgs& a, hipStream_t stream);
 int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN = 320);

@@ -512,7 +512,7 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   if (a.force_tile) {
     p.BM = a.force_tile >> 16;
     p.BN = a.force_tile & 0xffff;
-    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192) ? 2 : 1) : ((p.BM == 128 && p.BN == 320) ? 3 : 0);
+    p.big = p.BM == 256 ? ((p.BN == 320 || p.BN == 192 || p.BN == 384) ? 2 : 1) : ((p.BM == 128 && p.BN == 320) ? 3 : 0);
     p.splitk = a.splitk > 0 ? a.splitk : 1;
     return p;
   }
@@ -539,6 +539,9 @@ GemmPlan plan_gemm(const GemmArgs& a, bool ws_available) {
   // 256 x 192 (the widths of the transformer denoisers, which 320 does not divide): measured -6.6 % on the C4 step against the
   // 256 x 128 ring kernel it displaces (profiles/r2_knob12_c4.txt); A/B switch 12 = 1 takes it out of the planner
   if (!fdmi_tune_get(12) && gemm4_eligible(a, 192)) consider(2, 256, 192, 256, 3.9);
+  // 256 x 384 (round 6): the wide tile for the same widths -- +9 ... +16 % per K loop over 256 x 192 in the micro-benchmark
+  // (profiles/r6_kloop_dit_widths.txt); A/B switch 51 = 1 takes it out of the planner
+  if (!fdmi_tune_get(12) && !fdmi_tune_get(51) && gemm4_eligible(a, 384)) consider(2, 256, 384, 256, 4.4);
   const bool geglu = a.act == ACT_GEGLU;
   if (a.A2) return p;   // a two-segment A operand: only the LDS-DMA kernels above read it (gemm_a2_ok)
   consider(0, 128, 128, 512, 1.05);
@@ -695,7 +698,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
     const int sk_max = fdmi_tune_get(48) > 0 ? fdmi_tune_get(48) : 0;
     const int tiles = (p.big == 1 || p.big == 2) ? cdiv(a.M, 256) * cdiv(a.N, p.BN) : 0;
     const int64_t items = (int64_t)tiles * a.splitk;     // (a block of the persistent kernels takes ceil(items / 256) of them)
-    if ((p.big == 1 || p.big == 2) && a.splitk > 1 && a.splitk <= sk_max && !a.accum_atomic && a.act != ACT_GEGLU && !(a.dev & (16 | 32 | 0x800)) &&
+    if ((p.big == 1 || p.big == 2) && p.BN != 384 && a.splitk > 1 && a.splitk <= sk_max && !a.accum_atomic && a.act != ACT_GEGLU && !(a.dev & (16 | 32 | 0x800)) &&
         !a.residual32 && !a.C32 &&
         tiles <= SK_TICKETS) {
       const int grid = sk_persistent_grid(items);

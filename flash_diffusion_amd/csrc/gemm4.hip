@@ -18,8 +18,25 @@
 
 namespace {
 
+// LDS-DMA piece with a wave-uniform 64-bit base (SGPR pair) + a 32-bit lane offset (the 256 x 384 instantiations: their 192 accumulator
+// registers leave no room for two 64-bit per-lane pointers plus a 64-bit temporary per piece; the bases advance on the scalar unit)
+__device__ __forceinline__ void glds16_s(const void* sbase, unsigned voff, unsigned lds_addr) {
+  const uint64_t pv = (uint64_t)(uintptr_t)sbase;
+  const uint32_t plo = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)pv), phi = (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(pv >> 32));
+  sbase = (const void*)(uintptr_t)(((uint64_t)phi << 32) | (uint64_t)plo);
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(voff), "s"(sbase), "s"(lds_addr));
+}
+
 // BN = 320 is the tile described above.  BN = 192 is the same pipeline for widths that 320 does not divide but 192 does --
 // the transformer denoisers' 1152 / 1536 / 4608 / 6144 (PixArt, SD3): 56 KB per tile, 110 flop/B, wave tile 64 x 96.
+// BN = 384 (round 6; row problems only) is the wide tile for the same widths: 80 KB per tile -- the ring takes the CU's whole 160 KB --,
+// 154 flop/B, wave tile 64 x 192 = 192 accumulator registers of the 256 a wave has at two per SIMD (the compiler keeps a handful of
+// loop-invariant values in scratch OUTSIDE the K loop: scripts/kloop_spill_audit.py).  scripts/ubench/gemm_kloop.hip (mode 4): +9 ... +16 % over
+// the 256 x 192 structure on the SD3 / PixArt widths (profiles/r6_kloop_dit_widths.txt); 256 x 256 quantises worse than 192 and loses.
 // GN: the epilogue also accumulates the consumer's GroupNorm statistics (GemmArgs::gn_stats); a separate instantiation, so the
 // default kernels are instruction-identical with and without the feature
 // DEV: developer instantiation (scripts/rowbench.py, scripts/kbench.py through knob 40 = GemmArgs::dev) -- timing ablations with
@@ -94,6 +111,13 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   int akpos = 0, arow = 0;     // ROW with a second A segment (GemmArgs::A2): k of the tile to issue next, this thread's row
   const bf16_t* wbase = zero;  // W row n0+lr; piece i is 64*i rows further
   int64_t wstep = 0;
+  // WIDE (BN = 384, row problems without a second A segment): uniform bases + 32-bit lane offsets instead of the per-lane pointers above
+  constexpr bool WIDE = BN == 384;
+  const char* asb = (const char*)zero;   // A row m0, column kbeg of the tile to issue next (uniform)
+  const char* wsb = (const char*)zero;   // W row n0, column kbeg (uniform)
+  unsigned aoff = 0u, woff = 0u;         // this lane's row / chunk inside a 64-row group (bytes); 0 while parked: every lane reads the zero page
+  const unsigned astepb = WIDE ? (unsigned)(128 * a.lda) : 0u, wstepb = WIDE ? (unsigned)(128 * a.ldw) : 0u;   // 64 rows further (bytes; uniform: added to the BASE on the scalar unit)
+  unsigned pmask = 0u;                   // 0 while parked
   auto retap = [&]() {
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
@@ -123,6 +147,14 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
     }
   };
   auto setup_issue = [&](const Item& it) {
+    if (WIDE) {
+      asb = (const char*)(a.A + (int64_t)it.m0 * a.lda + it.kbeg);
+      wsb = (const char*)(a.W + (int64_t)it.n0 * a.ldw + it.kbeg);
+      aoff = (unsigned)((lr * a.lda + c8) * 2);
+      woff = (unsigned)((lr * a.ldw + c8) * 2);
+      pmask = ~0u;
+      return;
+    }
     if (MODE == GEMM_ROW) {
       if (a.A2 && it.kbeg >= a.K1) {   // (a k-split that starts behind the seam)
         abase = a.A2 + (int64_t)(it.m0 + lr) * a.lda2 + (it.kbeg - a.K1) + c8;
@@ -184,6 +216,12 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
     return true;
   };
   auto park_issue = [&]() {  // past the last tile: the pieces read a zero page (keeps one instruction stream)
+    if (WIDE) {
+      asb = wsb = (const char*)zero;
+      aoff = woff = 0u;
+      pmask = 0u;
+      return;
+    }
     abase = zero; astep = 0;
     wbase = zero; wstep = 0;
     aok = 0;
@@ -192,6 +230,11 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
   };
   auto slot_base = [&]() { return (unsigned)__builtin_amdgcn_readfirstlane(lds0 + islot * STAGE + wave * 1024); };
   auto piece = [&](int i, unsigned sa) {
+    if (WIDE) {
+      if (i < AR) glds16_s(asb + (size_t)(i * (astepb & pmask)), aoff, sa + 512 * 16 * i);
+      else glds16_s(wsb + (size_t)((i - AR) * (wstepb & pmask)), woff, sa + BM * 128 + 512 * 16 * (i - AR));
+      return;
+    }
     if (i < AR) {
       if (MODE == GEMM_ROW) {
         glds16(abase + i * astep, sa + 512 * 16 * i);
@@ -204,6 +247,13 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
     }
   };
   auto issue_finish = [&]() {
+    if (WIDE) {
+      asb += pmask & 128u;
+      wsb += pmask & 128u;
+      islot ^= 1;
+      ++ikt;
+      return;
+    }
     if (MODE == GEMM_ROW) {
       abase += astep ? 64 : 0;
       akpos += 64;
@@ -302,7 +352,7 @@ __global__ __launch_bounds__(512) void gemm4_kernel(const GemmArgs a) {
     }
     // the next item's first tile is landing meanwhile
     if constexpr (R32)
-      tile_epilogue_r32<NF, MF>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
+      tile_epilogue_r32<NF, MF, BN == 384>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);
     else if (!(DEV && (a.dev & 32)))   // (timing ablation of scripts/rowbench.py: the K loop alone)
       tile_epilogue<NF, MF, GEGLU ? 1 : 0, GN, true, MODE == GEMM_ROW>(a, it.m0 + wm * 64, it.n0 + wn * (BN / 2), it.z, acc, g, j);   // (whole tiles only)
     if constexpr (SKR)   // in-launch split-K reduction: this item's slab is stored -- hand off (gemm_tile.h)
@@ -346,7 +396,7 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
   dim3 grid(items < ncu ? items : ncu, 1, 1);  // persistent: one 8-wave block per CU
   const bool prof = fdmi_prof_on();
   if (prof) gemm_prof_shape(a);
-  if (prof) fdmi_prof_begin(stream, (BN == 192 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a), gemm_bytes(a), (MODE == GEMM_ROW && BN == 320 && gemm_hbm_side(a)) ? PROF_GEMM4_ROW_HBM : -1);
+  if (prof) fdmi_prof_begin(stream, (BN != 320 ? PROF_GEMM4_192 : PROF_GEMM4) + MODE, gemm_flops(a), gemm_bytes(a), (MODE == GEMM_ROW && BN == 320 && gemm_hbm_side(a)) ? PROF_GEMM4_ROW_HBM : -1);
   FDMI_KLAUNCH(prof, (gemm4_kernel<MODE, GEGLU, BN, GN, DEV, SKR, R32>), grid, dim3(512), smem, stream, a);
   if (prof) fdmi_prof_end(stream);
   FDMI_HIP(hipGetLastError());
@@ -356,18 +406,28 @@ int launch4_t(const GemmArgs& a, hipStream_t stream) {
 }  // namespace
 
 bool gemm4_eligible(const GemmArgs& a, int BN) {
-  if (BN != 320 && BN != 192) return false;
+  if (BN != 320 && BN != 192 && BN != 384) return false;
   if ((a.K & 63) != 0 || (a.M & 255) != 0 || (a.N % BN) != 0) return false;
-  if (BN == 192 && a.act == ACT_GEGLU) return false;
+  if (BN != 320 && a.act == ACT_GEGLU) return false;
+  if (BN == 384) {   // the wide tile: ONE A operand, and what its only epilogue (tile_epilogue_r32 + a run-time tanh-GELU) serves
+    if (a.mode != GEMM_ROW || a.A2 || (a.act != ACT_NONE && a.act != ACT_GELU_TANH)) return false;
+    GemmArgs b = a;
+    b.act = ACT_NONE;
+    if (!gemm_r32_ok(b)) return false;
+  }
   if (a.mode == GEMM_CONV && ((a.Cin & 63) != 0 || a.Hout > 2048 || a.Wout > 2048)) return false;
   if (a.act == ACT_GEGLU && (a.mode != GEMM_ROW || a.accum_atomic || fdmi_tune_get(9))) return false;
-  if ((a.residual32 || a.C32) && BN != 192) return false;   // (the fp32 residual stream: the transformer denoisers' 256 x 192 tile only)
+  if ((a.residual32 || a.C32) && BN == 320) return false;   // (the fp32 residual stream: the transformer denoisers' 256 x 192 / 256 x 384 tiles only)
   return true;
 }
 int launch_gemm4(const GemmArgs& a, hipStream_t stream, int BN) {
-  FDMI_CHECK((a.M & 255) == 0 && (a.N % BN) == 0 && (a.K & 63) == 0, "gemm4: whole 256 x BN x 64 tiles only (its epilogue has no bounds checks)");
+  FDMI_CHECK((BN == 320 || BN == 192 || BN == 384) && (a.M & 255) == 0 && (a.N % BN) == 0 && (a.K & 63) == 0, "gemm4: whole 256 x BN x 64 tiles only (its epilogue has no bounds checks)");
+  if (BN == 384) {   // the wide tile has ONE instantiation (the fp32-residual-stream epilogue, which also serves plain problems and tanh-GELU)
+    FDMI_CHECK(gemm4_eligible(a, 384) && !a.sk_tickets, "gemm4: the 256 x 384 tile takes row problems with one A operand, no activation but tanh-GELU, bf16 output");
+    return launch4_t<GEMM_ROW, false, 384, false, false, false, true>(a, stream);
+  }
   if (a.residual32 || a.C32) {   // the fp32 residual stream: its own instantiation
-    FDMI_CHECK(BN == 192 && a.mode == GEMM_ROW && !a.sk_tickets, "gemm4: the fp32 residual stream runs on the 256 x 192 row kernel");
+    FDMI_CHECK(BN == 192 && a.mode == GEMM_ROW && !a.sk_tickets, "gemm4: the fp32 residual stream runs on the 256 x 192 / 256 x 384 row kernels");
     return launch4_t<GEMM_ROW, false, 192, false, false, false, true>(a, stream);
   }
   if (a.sk_tickets) {   // in-launch split-K reduction: the SKR instantiations (launch_gemm sets the tickets only for plain problems)

@@ -590,7 +590,9 @@ __device__ __forceinline__ void splitk_sum_slabs(const GemmArgs& a, int mw, int 
 // ---- epilogue of the fp32-residual-stream GEMMs (GemmArgs::residual32 / C32; the R32 instantiations of gemm3 / gemm4) --------------
 // v = (alpha acc + bias) (* | +) rowvec + residual (bf16) + residual32 (fp32); C32 <- v (fp32), C <- bf16(v).  8 columns per lane
 // after the fragment-pair swap (16-byte bf16 stores, 2 x 16-byte fp32 loads / stores), bounds-checked; split-K slabs as usual.
-template <int NF, int MF>
+// ACTRT (the 256 x 384 tile, whose ONLY epilogue this is -- the general one's live ranges do not fit beside its 192 accumulators): a run-time
+// tanh-GELU (GemmArgs::act == ACT_GELU_TANH, uniform) after every additive term, where the general epilogue applies it
+template <int NF, int MF, bool ACTRT = false>
 __device__ __forceinline__ void tile_epilogue_r32(const GemmArgs& a, int mw, int nw, int z, f32x4 (&acc)[NF][MF], int g, int j) {
   if (a.splitk > 1) {
     float* slab = a.ws + (int64_t)z * a.M * a.N;
@@ -633,6 +635,12 @@ __device__ __forceinline__ void tile_epilogue_r32(const GemmArgs& a, int mw, int
     if (a.residual32) {
       const float4 t0 = *(const float4*)(a.residual32 + m * a.ldr32 + n), t1 = *(const float4*)(a.residual32 + m * a.ldr32 + n + 4);
       v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w; v[4] += t1.x; v[5] += t1.y; v[6] += t1.z; v[7] += t1.w;
+    }
+    if constexpr (ACTRT) {
+      if (a.act == ACT_GELU_TANH) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) v[r] = gelu_tanh_fast(v[r]);
+      }
     }
     if (a.C32) {
       float* c = a.C32 + m * a.ldc32 + n;

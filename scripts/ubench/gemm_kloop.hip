@@ -541,7 +541,10 @@ int main(int argc, char** argv) {
   const int fill = argc > 2 ? atoi(argv[2]) : 0;   // 0: uniform random; 1: zeros; 2: constant 1.0 / 0.05 (no toggling, non-zero)
   struct Shape { int M, N, K; };
   const int only32 = argc > 3 ? atoi(argv[3]) : 0;   // 1: only the product structure and the 32-deep ring variants
-  const Shape shapes[] = {{16384, 3840, 4096}, {131072, 320, 2880}, {32768, 1920, 1152}, {131072, 320, 320}, {131072, 2560, 320}, {131072, 320, 1280}};   // long-K square-ish, conv-like, DiT-like, short-K
+  const Shape shapes0[] = {{16384, 3840, 4096}, {131072, 320, 2880}, {32768, 1920, 1152}, {131072, 320, 320}, {131072, 2560, 320}, {131072, 320, 1280}};   // long-K square-ish, conv-like, DiT-like, short-K
+  // only32 == 4: the transformer denoisers' own widths (SD3-medium D = 1536 at 4096 + 333 tokens x B = 4 ... 8, PixArt D = 1152): which N tile?
+  const Shape shapes4[] = {{16384, 4608, 1536}, {16384, 1536, 1536}, {16384, 6144, 1536}, {16384, 1536, 6144}, {32768, 4608, 1152}, {32768, 1152, 4608}, {32768, 3456, 1152}};
+  std::vector<Shape> shapes(only32 == 4 ? std::begin(shapes4) : std::begin(shapes0), only32 == 4 ? std::end(shapes4) : std::end(shapes0));
   for (const Shape& s : shapes) {
     std::vector<bf16_t> hA((size_t)s.M * s.K), hW((size_t)s.N * s.K);
     srand(1);
@@ -554,6 +557,13 @@ int main(int argc, char** argv) {
     a.M = s.M; a.N = s.N; a.K = s.K;
     printf("M=%d N=%d K=%d fill=%d\n", s.M, s.N, s.K, fill);
     for (int round = 0; round < 2; ++round) {   // interleaved rounds (run-to-run noise, clock state)
+      if (only32 == 4) {   // N tile of the product structure for widths 320 does not divide
+        run<4, 2, 192, 0>("V8 256x192 (product structure)", a, hA, hW, reps);
+        run<4, 2, 256, 0>("V8 256x256 (product structure)", a, hA, hW, reps);
+        run<4, 2, 128, 0>("V8 256x128 (product structure)", a, hA, hW, reps);
+        run<4, 2, 384, 0>("V8 256x384 (product structure)", a, hA, hW, reps);
+        continue;
+      }
       run<4, 2, 320, 0>("V8 256x320 (product structure)", a, hA, hW, reps);
       if (only32 == 3) {   // cache policy of the LDS-DMA pieces
         run<4, 2, 320, 256>("V8 256x320 A pieces nt", a, hA, hW, reps);

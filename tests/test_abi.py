@@ -76,9 +76,20 @@ def test_gemm_planner_choices_for_the_benchmark_shapes():
     tiles the per-sample-vector GEMMs; LoRA weight gradients (long contraction, tiny output) are split 16 ways"""
     assert _plan(65536, 320, 320)[:3] == (2, 256, 320) and _plan(65536, 2560, 320)[:3] == (2, 256, 320)   # SD1.5 level 0
     assert _plan(16384, 640, 640)[0] == 1 and _plan(4096, 1280, 1280)[0] == 1
-    for shape in [(32768, 1152, 1152), (65536, 1152, 1152), (32768, 4608, 1152), (32768, 1152, 4608),     # PixArt C4
-                  (16384, 1536, 1536), (16384, 6144, 1536), (16384, 1536, 6144)]:                         # SD3 C5
-        assert _plan(*shape)[:3] == (2, 256, 192), shape
+    # round 6: the wide 256 x 384 tile where it quantises at least as well (its K loop is 9 - 16 % faster: profiles/r6_kloop_dit_widths.txt);
+    # N = 1152 at 32 768 rows is 384 tiles = 1.5 rounds of 256 CUs against 3 full rounds of 256 x 192 tiles: the narrow tile stays
+    from flash_diffusion_amd import _lib
+    wide = {(32768, 4608, 1152), (32768, 3456, 1152), (16384, 1536, 1536), (16384, 4608, 1536), (16384, 6144, 1536), (16384, 1536, 6144)}
+    narrow = {(32768, 1152, 1152), (32768, 1152, 4608)}
+    for shape in sorted(wide | narrow):
+        assert _plan(*shape)[:3] == (2, 256, 384 if shape in wide else 192), shape
+    assert _plan(32768, 4608, 1152, act=5)[:3] == (2, 256, 384) and _plan(32768, 4608, 1152, act=1)[:3] == (2, 256, 192)   # tanh-GELU yes, SiLU no
+    _lib.lib().fdmi_tune_set(51, 1)                               # A/B switch: the planner without the wide tile
+    try:
+        for shape in sorted(wide | narrow):
+            assert _plan(*shape)[:3] == (2, 256, 192), shape
+    finally:
+        _lib.lib().fdmi_tune_set(51, 0)
     assert _plan(8, 6912, 1152)[0] == 0 and _plan(32768, 32, 1152)[0] == 0
     k, bm, bn, sk = _plan(1152, 64, 32768, splitk=0, accum_atomic=1, out_f32=1)
     assert sk == 16 and k == 0
@@ -87,7 +98,7 @@ def test_gemm_planner_choices_for_the_benchmark_shapes():
 def test_planner_offers_the_256x192_tile_for_the_transformer_widths():
     from flash_diffusion_amd import _lib
     L = _lib.lib()
-    assert _plan(32768, 1152, 1152)[:3] == (2, 256, 192) and _plan(16384, 6144, 1536)[:3] == (2, 256, 192)
+    assert _plan(32768, 1152, 1152)[:3] == (2, 256, 192) and _plan(16384, 6144, 1536)[:3] == (2, 256, 384)
     assert _plan(65536, 320, 320)[:3] == (2, 256, 320)            # widths that 320 divides keep the larger tile
     L.fdmi_tune_set(12, 1)                                        # A/B switch: the planner without the tile
     try:

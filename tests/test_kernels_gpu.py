@@ -566,6 +566,60 @@ def test_gemm4_many_items_per_block():
 
 
 # ---- two-segment A operand (GemmArgs::A2): [A | A2] W^T without materialising the concatenation ---------------------------------
+# ---- 256 x 384 tile (gemm4, round 6): the wide tile for the transformer denoisers' widths -- same K order, same MFMA sequence per output
+# element as the 256 x 192 tile, so the results must be bit-identical on every epilogue both serve ---------------------------------------
+T384, T192 = (256 << 16) | 384, (256 << 16) | 192
+
+
+@pytest.mark.parametrize("shape", [(256, 384, 64), (512, 1536, 1536), (768, 4608, 1152), (1024, 1152, 4608), (512, 6144, 1536), (2304, 3456, 1152)])
+def test_gemm4_384_tile_matches_the_192_tile(shape):
+    """the wide tile has ONE epilogue (the fp32-residual-stream one + a run-time tanh-GELU); the 256 x 192 tile serves the same problems
+    through the general / lean epilogues: plain products are bit-identical, the others agree to an fp32 rounding before the bf16 one"""
+    ops = _ops()
+    M, N, K = shape
+    rpb = 64
+    A, W = b16(rnd(M, K, seed=1)).cuda(), b16(rnd(N, K, seed=2, scale=K ** -0.5)).cuda()
+    bias, res = rnd(N, seed=3).cuda(), b16(rnd(M, N, seed=4)).cuda()
+    gate = b16(rnd(M // rpb, N, seed=5)).cuda()
+    h = A.float().cpu() @ W.float().cpu().t() + bias.cpu()
+
+    def same(name, x, y, ref):
+        close(f"gemm4_384_{name}{shape}", x, ref)
+        d = (x.float() - y.float()).abs()
+        assert float((d > 0).float().mean()) < 1e-3 and float(d.max()) <= 2.0 ** -6 * float(ref.abs().max()), name   # (a rare bf16 tie)
+
+    assert torch.equal(ops.gemm(A, W, force_tile=T384), ops.gemm(A, W, force_tile=T192))
+    same("bias_res", ops.gemm(A, W, bias=bias, residual=res, force_tile=T384), ops.gemm(A, W, bias=bias, residual=res, force_tile=T192),
+         h + res.float().cpu())
+    kw = dict(bias=bias, rowvec=gate, rows_per_batch=rpb, rowvec_mul=True, residual=res)
+    same("gate", ops.gemm(A, W, force_tile=T384, **kw), ops.gemm(A, W, force_tile=T192, **kw),
+         h * gate.float().cpu().repeat_interleave(rpb, 0) + res.float().cpu())
+    same("gelu_tanh", ops.gemm(A, W, bias=bias, act=ops.ACT_GELU_TANH, force_tile=T384),
+         ops.gemm(A, W, bias=bias, act=ops.ACT_GELU_TANH, force_tile=T192), F.gelu(h, approximate="tanh"))
+    if K >= 1152:   # slab split-K: the finalize kernel sums the same slabs and applies the same epilogue
+        assert torch.equal(ops.gemm(A, W, bias=bias, act=ops.ACT_GELU_TANH, force_tile=T384, splitk=3),
+                           ops.gemm(A, W, bias=bias, act=ops.ACT_GELU_TANH, force_tile=T192, splitk=3))
+    if K >= 128:    # a two-segment A operand [A1 | A2] (the folded LoRA up-projection) is NOT the wide tile's: the planner keeps 256 x 192
+        K1 = K - 64
+        A1, A2 = A[:, :K1].contiguous(), A[:, K1:].contiguous()
+        assert torch.equal(ops.gemm(A1, W, A2=A2, residual=res), ops.gemm(A, W, residual=res, force_tile=T192))
+
+
+def test_the_planner_takes_the_384_tile_for_the_transformer_widths_and_switch_51_removes_it():
+    ops = _ops()
+    from flash_diffusion_amd import _lib
+    for (M, N, K) in [(32768, 4608, 1152), (16384, 1536, 6144), (16384, 6144, 1536)]:
+        p = ops.gemm_plan(M, N, K)
+        assert p[:3] == (2, 256, 384), p
+        _lib.lib().fdmi_tune_set(51, 1)
+        try:
+            q = ops.gemm_plan(M, N, K)
+        finally:
+            _lib.lib().fdmi_tune_set(51, 0)
+        assert q[:3] == (2, 256, 192), q
+    assert ops.gemm_plan(32768, 1280, 1280)[2] in (320, 160, 128)   # (384 does not divide the UNets' widths)
+
+
 # ---- 128 x 320 x 32 tile kernel, two blocks per CU (gemm5, round 6: a measured experiment, reached through force_tile only) ----------
 T5 = (128 << 16) | 320
 
