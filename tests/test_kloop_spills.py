@@ -28,3 +28,15 @@ def test_audit_sees_a_spill_between_mfmas():
                       "0000000000002000 <k2>:", "  scratch_load_dword v5, off, off", "  v_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]"])
     r = A.audit(text)
     assert len(r["k1"][0]) == 1 and r["k1"][1] == 1 and r["k1"][2] == 2 and r["k2"][0] == [] and r["k2"][1] == 1
+
+
+def test_audit_sees_a_stray_vmcnt_wait_behind_the_first_piece_of_a_gemm4_tile():
+    """round 6: a value reloaded at an item's setup made hipcc wait vmcnt(0) in front of the first W piece of EVERY K tile of the 256 x 384
+    kernel (its pieces issued since the tile's head included); a wait in front of the tile's first piece is harmless and not counted"""
+    import kloop_spill_audit as A
+    mf = "  v_mfma_f32_16x16x32_bf16 v[0:3], v[4:7], v[8:11], v[0:3]"
+    text = "\n".join(["0000000000001000 <gemm4_kernel_x>:", mf, "  s_waitcnt vmcnt(0)", "  global_load_lds_dwordx4 v1, s[2:3]", mf,
+                      "  s_waitcnt vmcnt(0)", "  global_load_lds_dwordx4 v2, s[4:5]", mf,
+                      "0000000000002000 <gemm3_kernel_x>:", mf, "  global_load_lds_dwordx4 v1, s[2:3]", "  s_waitcnt vmcnt(2)", mf])
+    r = A.audit(text)
+    assert len(r["gemm4_kernel_x"][0]) == 1 and r["gemm3_kernel_x"][0] == []
