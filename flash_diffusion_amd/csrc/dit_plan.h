@@ -320,7 +320,7 @@ static T* dit_linear_gelu(Exec& E, T* x, LinearW& L, bool need_dx = true) {
   return f ? dit_act(E, f, DIT_GELU_TANH) : nullptr;
 }
 
-static T* dit_linear_gate_res(Exec& E, T* x, LinearW& L, T* mod, int gate_col, T* res, int rpb, bool mod_grad) {
+static T* dit_linear_gate_res(Exec& E, T* x, LinearW& L, T* mod, int gate_col, T* res, int rpb, bool mod_grad, bool shadow = true) {
   if (dit_fusable(E, L)) {
     T* y = E.R.mk(x->rows, L.w.N);
     DIT_NULL(!y);
@@ -333,6 +333,7 @@ static T* dit_linear_gate_res(Exec& E, T* x, LinearW& L, T* mod, int gate_col, T
       DIT_NULL(!E.R.mk32(y));
       a.residual = nullptr; a.residual32 = res->p32; a.ldr32 = res->cols;
       a.C32 = y->p32; a.ldc32 = L.w.N;
+      if (!shadow && !fdmi_tune_get(53)) a.C = nullptr;   // (the consumer is a LayerNorm: it reads the fp32 master; Exec::linear)
     }
     DIT_NULL(E.gemm(a));
     return y;
@@ -614,13 +615,13 @@ int run_dit(fdmi_unet* U, Run& R, const DitIn& in, int flags) {
       FAIL_IF_NULL(q); FAIL_IF_NULL(k); FAIL_IF_NULL(v);
       o = dit_cross_attention(E, q, k, v, B, heads, Tn, L, in.lens);
       FAIL_IF_NULL(o);
-      hid = E.linear(o, blk.at.a2.o, hid);
+      hid = E.linear(o, blk.at.a2.o, hid, false);          // (consumer: the LayerNorm below)
       FAIL_IF_NULL(hid);
       T* n2 = dit_ln_mod(E, hid, mod, 3 * D, 4 * D, Tn, c.norm_eps, modg);
       FAIL_IF_NULL(n2);
       T* ff = dit_linear_gelu(E, n2, blk.ff1);
       FAIL_IF_NULL(ff);
-      hid = dit_linear_gate_res(E, ff, blk.ff2, mod, 5 * D, hid, Tn, modg);
+      hid = dit_linear_gate_res(E, ff, blk.ff2, mod, 5 * D, hid, Tn, modg, false);   // (consumer: the next block's / the final LayerNorm)
       FAIL_IF_NULL(hid);
       RET_IF(pp.leave());
     }
@@ -698,13 +699,13 @@ int run_dit(fdmi_unet* U, Run& R, const DitIn& in, int flags) {
       FAIL_IF_NULL(o);
       RET_IF(dit_split(E, o, B, Tn, L, !blk.pre_only, &ox, &oc));
       }
-      hid = dit_linear_gate_res(E, ox, blk.x.a1.o, m, 2 * D, hid, Tn, modg);
+      hid = dit_linear_gate_res(E, ox, blk.x.a1.o, m, 2 * D, hid, Tn, modg, false);
       FAIL_IF_NULL(hid);
       T* n2 = dit_ln_mod(E, hid, m, 3 * D, 4 * D, Tn, eps, modg);
       FAIL_IF_NULL(n2);
       T* ff = dit_linear_gelu(E, n2, blk.ff1);
       FAIL_IF_NULL(ff);
-      hid = dit_linear_gate_res(E, ff, blk.ff2, m, 5 * D, hid, Tn, modg);
+      hid = dit_linear_gate_res(E, ff, blk.ff2, m, 5 * D, hid, Tn, modg, false);
       FAIL_IF_NULL(hid);
       if (!blk.pre_only) {
         ctx = dit_linear_gate_res(E, oc, blk.c.a1.o, mc, 2 * D, ctx, L, modg);

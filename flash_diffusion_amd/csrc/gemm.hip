@@ -61,6 +61,7 @@ __device__ __forceinline__ void epi_store(const GemmArgs& a, int act, int64_t m,
     v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
   }
   if (a.C32) *(float4*)(a.C32 + m * a.ldc32 + nout) = make_float4(v[0], v[1], v[2], v[3]);
+  if (!a.C) return;   // (an fp32-stream output without its bf16 shadow: gemm_r32_ok problems only -- no activation, bf16 C)
   if (act == ACT_SILU) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) v[r] = silu_f(v[r]);
@@ -672,6 +673,7 @@ int launch_gemm(const GemmArgs& a_in, hipStream_t stream) {
   if (a.act == ACT_GEGLU) FDMI_CHECK((a.N % 32) == 0, "geglu: N must be a multiple of 32");
   if (a.rowvec_mul) FDMI_CHECK(a.rowvec != nullptr && a.act != ACT_GEGLU, "gemm: rowvec_mul needs a row vector and is not available with GEGLU");
   if (a.accum_atomic) FDMI_CHECK(a.out_f32, "accum_atomic needs f32 C");
+  FDMI_CHECK(a.C || a.C32, "gemm: no output");
   if (a.residual32 || a.C32) FDMI_CHECK(gemm_r32_ok(a), "gemm: the fp32 residual stream (residual32 / C32) needs a plain row GEMM, ACT_NONE, bf16 C, 8-aligned N and leading dims");
   const GemmPlan p = plan_gemm(a, a.ws != nullptr || a.accum_atomic);
   if (a.A2) FDMI_CHECK(p.big != 0, "gemm: a second A segment is read by the LDS-DMA kernels only (forced tile?)");

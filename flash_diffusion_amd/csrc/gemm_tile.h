@@ -647,9 +647,11 @@ __device__ __forceinline__ void tile_epilogue_r32(const GemmArgs& a, int mw, int
       *(float4*)c = make_float4(v[0], v[1], v[2], v[3]);
       *(float4*)(c + 4) = make_float4(v[4], v[5], v[6], v[7]);
     }
-    uint4 pk;
-    pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
-    *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
+    if (a.C) {   // (nullptr: nobody reads the bf16 shadow of this fp32-stream output -- its consumer is a LayerNorm, which reads C32)
+      uint4 pk;
+      pk.x = pack2bf(v[0], v[1]); pk.y = pack2bf(v[2], v[3]); pk.z = pack2bf(v[4], v[5]); pk.w = pack2bf(v[6], v[7]);
+      *(uint4*)((bf16_t*)a.C + m * a.ldc + n) = pk;
+    }
   };
   auto finish = [&](int64_t m, int n, float* v, int nc) {   // the odd fragment: 4 consecutive columns n .. of row m
     for (int r = 0; r < nc; ++r) v[r] *= a.alpha;
@@ -674,6 +676,7 @@ __device__ __forceinline__ void tile_epilogue_r32(const GemmArgs& a, int mw, int
       float* c = a.C32 + m * a.ldc32 + n;
       for (int r = 0; r < nc; r += 4) *(float4*)(c + r) = make_float4(v[r], v[r + 1], v[r + 2], v[r + 3]);
     }
+    if (!a.C) return;
     bf16_t* c = (bf16_t*)a.C + m * a.ldc + n;
     for (int r = 0; r < nc; r += 4) {
       uint2 pk;

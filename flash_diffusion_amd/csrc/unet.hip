@@ -957,11 +957,13 @@ struct Exec {
   }
 
   // y = x W^T + b (+ residual) (+ LoRA)
-  T* linear(T* x, LinearW& L, T* residual = nullptr) { return linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr); }
+  // shadow = false: nobody reads the bf16 value of this fp32-stream output (its consumer is a LayerNorm reading the fp32 master): a run
+  // without a tape then skips the bf16 store (2 of every 10 bytes of such a launch, which is HBM-bound)
+  T* linear(T* x, LinearW& L, T* residual = nullptr, bool shadow = true) { return linear_w(x, L.w, residual, L.lora.on ? &L.lora : nullptr, true, 0, false, shadow); }
   // gn_rows > 0: the output feeds a GroupNorm over samples of gn_rows rows (want_gn)
   // out32 / a residual that carries an fp32 master (T::p32): the output gets one too -- v = ... + residual32 in fp32, stored to
   // y->p32 beside the bf16 y->p (GemmArgs::residual32 / C32: the transformer denoisers' residual stream)
-  T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true, int gn_rows = 0, bool out32 = false) {
+  T* linear_w(T* x, Weight& w, T* residual = nullptr, Lora* lo = nullptr, bool need_dx = true, int gn_rows = 0, bool out32 = false, bool shadow = true) {
     T* y = R.mk(x->rows, w.N, x->B, x->H, x->W);
     if (!y) return nullptr;
     const bool r32 = !f32() && (out32 || (residual && residual->p32));
@@ -992,6 +994,7 @@ struct Exec {
       if (r32) {
         a.C32 = y->p32; a.ldc32 = w.N;
         if (residual && residual->p32) { a.residual = nullptr; a.residual32 = residual->p32; a.ldr32 = residual->cols; }
+        if (!shadow && !R.save && !lo && !fdmi_tune_get(53)) a.C = nullptr;   // (A/B switch 53 = 1: always store the shadow)
       }
       NULL_IF(gemm(a));
       y->gn = a.gn_stats;
